@@ -1,0 +1,210 @@
+// TEST INFRASTRUCTURE - NOT PART OF THE PRODUCT (see hml_oracle.hpp).
+// extern "C" surface of the CPU restatement for the Python tests (ctypes), plus probes for
+// the math/RNG/distribution building blocks.
+#include <chrono>
+#include <cmath>
+#include <cstring>
+#include <random>
+
+#include "../hammlet_amd/csrc/hml_synth_host.hpp"
+#include "hml_oracle.hpp"
+
+using namespace hml_oracle;
+
+static thread_local std::string g_err;
+
+#define ORC_TRY try {
+#define ORC_END                                      \
+    }                                                \
+    catch (std::exception & e) {                     \
+        g_err = e.what();                            \
+        return 1;                                    \
+    }                                                \
+    return 0;
+
+extern "C" {
+
+const char* orc_last_error() { return g_err.c_str(); }
+
+void* orc_create(int K, float e_var, float e_p, float t_off, float t_diag, float pi_alpha, int self_trans,
+                 float weight_mult, uint64_t seed, uint32_t chain, int rng, int math, int reduce) {
+    try {
+        Config c;
+        c.K = K; c.e_var = e_var; c.e_p = e_p; c.t_off = t_off; c.t_diag = t_diag; c.pi_alpha = pi_alpha;
+        c.self_trans = self_trans != 0; c.weight_mult = weight_mult; c.seed = seed; c.chain = chain;
+        c.rng = rng; c.math = math; c.reduce = reduce;
+        return new Oracle(c);
+    } catch (std::exception& e) { g_err = e.what(); return nullptr; }
+}
+void orc_destroy(void* h) { delete (Oracle*)h; }
+
+int orc_load(void* h, const float* x, uint64_t T, int build_pointers) {
+    ORC_TRY ((Oracle*)h)->load(x, T, build_pointers != 0); ORC_END
+}
+int orc_autoprior(void* h, float out4[4]) {
+    ORC_TRY Oracle* o = (Oracle*)h; o->autoprior(); memcpy(out4, o->nig_prior, 16); ORC_END
+}
+int orc_set_prior(void* h, const float p[4]) { ORC_TRY ((Oracle*)h)->set_nig_prior(p); ORC_END }
+int orc_init_model(void* h) { ORC_TRY ((Oracle*)h)->init_model(); ORC_END }
+int orc_token(void* h, char tok) {
+    ORC_TRY Oracle* o = (Oracle*)h;
+    if (tok == 'P') o->token_P(); else if (tok == 'S') o->token_S(); else if (tok == 'D') o->token_D(); else o->token_begin();
+    ORC_END
+}
+int orc_set_record(void* h, int marg, int seq, int blocks, int params, int compr) {
+    Oracle* o = (Oracle*)h;
+    o->rec_marginals = marg; o->rec_sequences = seq; o->rec_blocks = blocks; o->rec_params = params; o->rec_compression = compr;
+    return 0;
+}
+int orc_set_probes(void* h, int on) { ((Oracle*)h)->keep_probes = on != 0; return 0; }
+int orc_iterate(void* h, char method, uint64_t iters, uint64_t thin) {
+    ORC_TRY Oracle* o = (Oracle*)h;
+    o->token_begin();
+    for (uint64_t i = 0; i < iters; ++i) o->sweep(method, thin > 0 && ((i + 1) % thin == 0));
+    ORC_END
+}
+int orc_enumerate_blocks(void* h, float thr) { ORC_TRY ((Oracle*)h)->enumerate_blocks(thr); ORC_END }
+
+uint64_t orc_T(void* h) { return ((Oracle*)h)->T; }
+double orc_sigma_hat(void* h) { return ((Oracle*)h)->sigma_hat; }
+float orc_threshold(void* h) { return ((Oracle*)h)->thr; }
+uint64_t orc_nblocks(void* h) { Oracle* o = (Oracle*)h; return o->starts.empty() ? 0 : o->starts.size() - 1; }
+uint64_t orc_total_blocks(void* h) { return ((Oracle*)h)->total_blocks; }
+uint64_t orc_warn_uniform(void* h) { return ((Oracle*)h)->warn_uniform; }
+uint64_t orc_n_recorded(void* h) { return ((Oracle*)h)->n_recorded; }
+
+void orc_get_coeffs(void* h, float* out) { Oracle* o = (Oracle*)h; memcpy(out, o->coeffs.data(), o->T * 4); }
+void orc_get_weights(void* h, float* out) { Oracle* o = (Oracle*)h; memcpy(out, o->w.data(), o->T * 4); }
+void orc_get_integral(void* h, float* s, float* q) {
+    Oracle* o = (Oracle*)h; memcpy(s, o->ia_s.data(), (o->T + 1) * 4); memcpy(q, o->ia_q.data(), (o->T + 1) * 4);
+}
+void orc_get_blocks(void* h, uint32_t* starts) { Oracle* o = (Oracle*)h; memcpy(starts, o->starts.data(), o->starts.size() * 4); }
+void orc_get_block_stats(void* h, float* s, float* q) {
+    Oracle* o = (Oracle*)h; size_t B = o->starts.size() - 1;
+    memcpy(s, o->bs_s.data(), B * 4); memcpy(q, o->bs_q.data(), B * 4);
+}
+void orc_get_states(void* h, int16_t* q) { Oracle* o = (Oracle*)h; memcpy(q, o->q.data(), o->q.size() * 2); }
+void orc_get_theta(void* h, float* mean_var) {
+    Oracle* o = (Oracle*)h;
+    for (int k = 0; k < o->cfg.K; ++k) { mean_var[2 * k] = o->mu[k]; mean_var[2 * k + 1] = o->var[k]; }
+}
+void orc_get_A(void* h, float* A) { Oracle* o = (Oracle*)h; memcpy(A, o->A.data(), o->A.size() * 4); }
+void orc_get_pi(void* h, float* pi) { Oracle* o = (Oracle*)h; memcpy(pi, o->pi.data(), o->pi.size() * 4); }
+void orc_set_params(void* h, const float* mean_var, const float* A, const float* pi) {
+    Oracle* o = (Oracle*)h; const int K = o->cfg.K;
+    for (int k = 0; k < K; ++k) o->set_theta(k, mean_var[2 * k], mean_var[2 * k + 1]);
+    memcpy(o->A.data(), A, (size_t)K * K * 4); memcpy(o->pi.data(), pi, K * 4);
+    o->sample_prior_pending = false;
+}
+void orc_get_loglik(void* h, float* E) { Oracle* o = (Oracle*)h; memcpy(E, o->lastE.data(), o->lastE.size() * 4); }
+void orc_get_forward_rows(void* h, float* rows) { Oracle* o = (Oracle*)h; memcpy(rows, o->fwd_rows.data(), o->fwd_rows.size() * 4); }
+void orc_get_counts(void* h, uint64_t* trans, uint64_t* occ, float* sum_s, float* sum_q, uint64_t* nterms) {
+    Oracle* o = (Oracle*)h; const int K = o->cfg.K;
+    memcpy(trans, o->last_trans.data(), (size_t)K * K * 8); memcpy(occ, o->last_occ.data(), K * 8);
+    memcpy(sum_s, o->last_sum_s.data(), K * 4); memcpy(sum_q, o->last_sum_q.data(), K * 4);
+    memcpy(nterms, o->last_nterms.data(), K * 8);
+}
+void orc_get_posterior(void* h, float* nig4K, float* dirA, float* dirPi) {
+    Oracle* o = (Oracle*)h; const int K = o->cfg.K;
+    for (int k = 0; k < K; ++k) { nig4K[4 * k] = o->post_alpha[k]; nig4K[4 * k + 1] = o->post_beta[k]; nig4K[4 * k + 2] = o->post_mu0[k]; nig4K[4 * k + 3] = o->post_nu[k]; }
+    memcpy(dirA, o->dirA.data(), (size_t)K * K * 4); memcpy(dirPi, o->dirPi.data(), K * 4);
+}
+int orc_marginals_dense(void* h, int32_t* out) {
+    ORC_TRY Oracle* o = (Oracle*)h; std::vector<int32_t> v; o->marginals_dense(v); memcpy(out, v.data(), v.size() * 4); ORC_END
+}
+// text outputs: which = 0 marginals, 1 sequences, 2 blocks, 3 parameters, 4 compression
+uint64_t orc_text(void* h, int which, char* buf, uint64_t cap) {
+    Oracle* o = (Oracle*)h;
+    std::string s = which == 0 ? o->marginals_text() : which == 1 ? o->out_sequences : which == 2 ? o->out_blocks
+                    : which == 3 ? o->out_params : o->out_compression;
+    if (buf && cap >= s.size()) memcpy(buf, s.data(), s.size());
+    return s.size();
+}
+
+// --------------------------------------------------------------------- building-block probes
+void orc_philox(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t out[4]) {
+    hml_u32x4 o = hml_philox4x32_10(c0, c1, c2, c3, k0, k1);
+    memcpy(out, o.v, 16);
+}
+void orc_expf_dev(const float* x, float* y, uint64_t n) { for (uint64_t i = 0; i < n; ++i) y[i] = hml_expf(x[i]); }
+void orc_expf_libm(const float* x, float* y, uint64_t n) { for (uint64_t i = 0; i < n; ++i) y[i] = std::exp(x[i]); }
+void orc_logf_dev(const float* x, float* y, uint64_t n) { for (uint64_t i = 0; i < n; ++i) y[i] = hml_logf(x[i]); }
+void orc_logf_libm(const float* x, float* y, uint64_t n) { for (uint64_t i = 0; i < n; ++i) y[i] = std::log(x[i]); }
+void orc_powf_dev(const float* u, const float* p, float* y, uint64_t n) { for (uint64_t i = 0; i < n; ++i) y[i] = hml_powf_unit(u[i], p[i]); }
+void orc_powf_libm(const float* u, const float* p, float* y, uint64_t n) { for (uint64_t i = 0; i < n; ++i) y[i] = std::pow(u[i], p[i]); }
+// number of float bit patterns in [lo, hi] (as uint32 ranges of the bit pattern) on which hml_expf != expf
+uint64_t orc_expf_mismatches(uint32_t lo, uint32_t hi, uint32_t* first_bad) {
+    uint64_t bad = 0;
+    for (uint64_t u = lo; u <= hi; ++u) {
+        float x = hml_u2f((uint32_t)u);
+        float a = hml_expf(x), b = std::exp(x);
+        if (hml_f2u(a) != hml_f2u(b) && !(a != a && b != b)) { if (!bad && first_bad) *first_bad = (uint32_t)u; bad++; }
+    }
+    return bad;
+}
+
+// restated distributions vs libstdc++ on the same mt19937 stream; returns number of mismatches
+uint64_t orc_check_gamma(uint32_t seed, uint64_t n, float alpha, float beta) {
+    std::mt19937 a(seed), b(seed);
+    EngineSrc<std::mt19937> src(b);
+    uint64_t bad = 0;
+    for (uint64_t i = 0; i < n; ++i) {
+        std::gamma_distribution<float> d(alpha, beta);
+        float x = d(a);
+        float y = hml_gamma_f32<libm_math>(src, alpha, beta);
+        if (hml_f2u(x) != hml_f2u(y)) bad++;
+    }
+    if (a() != b()) bad++;  // engines must have consumed the same number of words
+    return bad;
+}
+uint64_t orc_check_normal(uint32_t seed, uint64_t n, float mean, float sd) {
+    std::mt19937 a(seed), b(seed);
+    EngineSrc<std::mt19937> src(b);
+    uint64_t bad = 0;
+    for (uint64_t i = 0; i < n; ++i) {
+        std::normal_distribution<float> d(mean, sd);
+        float x = d(a);
+        hml_normal_f32<libm_math> nd;
+        float y = nd.draw(src, mean, sd);
+        if (hml_f2u(x) != hml_f2u(y)) bad++;
+    }
+    if (a() != b()) bad++;
+    return bad;
+}
+uint64_t orc_check_categorical(uint32_t seed, uint64_t n, int K, int zero_every) {
+    std::mt19937 a(seed), b(seed), g(seed ^ 0x1234567u);
+    uint64_t bad = 0;
+    std::vector<float> w(K);
+    for (uint64_t i = 0; i < n; ++i) {
+        for (int k = 0; k < K; ++k) {
+            float u = (float)(g() >> 8) / 16777216.0f;
+            int mode = (int)(g() % 4);
+            w[k] = mode == 0 ? u : mode == 1 ? u * 1e-30f : mode == 2 ? 0.0f : u * u * u;
+        }
+        if (zero_every && (i % zero_every) == 0) for (int k = 0; k < K; ++k) w[k] = 0.0f;
+        std::discrete_distribution<size_t> d(w.begin(), w.end());
+        size_t x = d(a);
+        uint32_t r0 = (uint32_t)b(), r1 = (uint32_t)b();
+        int y = hml_categorical(w.data(), K, hml_canonical_f64(r0, r1));
+        if ((int)x != y) bad++;
+    }
+    return bad;
+}
+
+// synthetic trace (product generator, exposed here so oracle-only tests need no GPU library)
+void orc_synth_gauss(float* x, int16_t* states, uint64_t T, int K, const float* mu, float sigma, double dwell,
+                     uint64_t seed, int nthreads) {
+    hml_synth_gauss_trace(x, states, T, K, mu, sigma, dwell, seed, nthreads);
+}
+
+// timed run for bench.py's cpu_baseline: returns seconds spent in `iters` sweeps
+double orc_time_sweeps(void* h, char method, uint64_t iters) {
+    Oracle* o = (Oracle*)h;
+    o->token_begin();
+    auto t0 = std::chrono::steady_clock::now();
+    for (uint64_t i = 0; i < iters; ++i) o->sweep(method, false);
+    auto t1 = std::chrono::steady_clock::now();
+    return std::chrono::duration<double>(t1 - t0).count();
+}
+
+}  // extern "C"
