@@ -1,0 +1,328 @@
+"""ctypes binding of include/hml.h (libhammlet_hip.so) - the Python-side mirror of the C ABI.
+
+There is no CPU fallback: constructing a Chain without the compiled gfx950 library or without a
+GPU raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import build as _build
+
+_lib = None
+
+
+class HmlError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(msg)
+        self.code = code
+
+
+class HmlStats(C.Structure):
+    _fields_ = [("sweeps", C.c_uint64), ("block_updates", C.c_uint64), ("uniform_fallbacks", C.c_uint64),
+                ("forward_refits", C.c_uint64), ("forward_serial", C.c_uint64)]
+
+
+RECORD_CB = C.CFUNCTYPE(None, C.c_void_p, C.c_uint64, C.c_void_p)
+
+# name -> (restype, argtypes); every symbol include/hml.h declares
+_P = C.c_void_p
+SIGNATURES = {
+    "hml_last_error": (C.c_char_p, []),
+    "hml_abi_version": (C.c_uint32, []),
+    "hml_device_arch": (C.c_char_p, []),
+    "hml_create": (C.c_int, [C.POINTER(_P), C.c_int, C.c_uint64, C.c_uint32, _P]),
+    "hml_destroy": (None, [_P]),
+    "hml_load_observations": (C.c_int, [_P, _P, C.c_uint64]),
+    "hml_load_observations_device": (C.c_int, [_P, _P, C.c_uint64]),
+    "hml_noise_sigma": (C.c_int, [_P, C.POINTER(C.c_double)]),
+    "hml_scale_weights": (C.c_int, [_P, C.c_float]),
+    "hml_autoprior": (C.c_int, [_P, C.c_float, C.c_float, _P]),
+    "hml_set_model": (C.c_int, [_P, C.c_int, _P, C.c_float, C.c_float, C.c_float, C.c_int]),
+    "hml_sample_prior": (C.c_int, [_P]),
+    "hml_set_static_blocks": (C.c_int, [_P]),
+    "hml_set_dynamic": (C.c_int, [_P, C.c_int]),
+    "hml_create_blocks": (C.c_int, [_P, C.c_float]),
+    "hml_iterate": (C.c_int, [_P, C.c_char, C.c_uint64, C.c_uint64]),
+    "hml_set_recording": (C.c_int, [_P, C.c_int, RECORD_CB, _P]),
+    "hml_sync": (C.c_int, [_P]),
+    "hml_get_num_blocks": (C.c_int, [_P, C.POINTER(C.c_uint64)]),
+    "hml_get_blocks": (C.c_int, [_P, _P]),
+    "hml_get_block_stats": (C.c_int, [_P, _P, _P]),
+    "hml_get_states": (C.c_int, [_P, _P]),
+    "hml_get_theta": (C.c_int, [_P, _P]),
+    "hml_get_transitions": (C.c_int, [_P, _P, _P]),
+    "hml_set_parameters": (C.c_int, [_P, _P, _P, _P]),
+    "hml_get_threshold": (C.c_int, [_P, C.POINTER(C.c_float)]),
+    "hml_enable_probes": (C.c_int, [_P, C.c_int]),
+    "hml_get_block_loglik": (C.c_int, [_P, _P]),
+    "hml_get_forward_rows": (C.c_int, [_P, _P]),
+    "hml_get_counts": (C.c_int, [_P, _P, _P, _P, _P, _P]),
+    "hml_get_weights": (C.c_int, [_P, _P]),
+    "hml_get_coefficients": (C.c_int, [_P, _P]),
+    "hml_get_integral_array": (C.c_int, [_P, _P, _P]),
+    "hml_marginals_rle": (C.c_int, [_P, C.POINTER(C.c_uint64), C.POINTER(C.c_int), _P, _P]),
+    "hml_marginals_dense_device": (C.c_int, [_P, _P, _P]),
+    "hml_recorded_sweeps": (C.c_int, [_P, C.POINTER(C.c_uint64)]),
+    "hml_get_stats": (C.c_int, [_P, C.POINTER(HmlStats)]),
+    "hml_profile_enable": (C.c_int, [_P, C.c_int]),
+    "hml_profile_get": (C.c_int, [_P, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
+    "hml_debug_eval": (C.c_int, [C.c_int, C.c_int, _P, _P, _P, C.c_uint64, C.c_uint64]),
+    "hml_synth_gauss": (C.c_int, [_P, _P, C.c_uint64, C.c_int, _P, C.c_float, C.c_double, C.c_uint64, C.c_int]),
+}
+
+
+def load_library(path=None):
+    """dlopen libhammlet_hip.so and attach the signatures of include/hml.h.  Fails loudly."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    path = path or _build.LIB_PATH
+    if not os.path.exists(path):
+        raise HmlError(-1, "%s is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                           "(hipcc --offload-arch=gfx950); there is no CPU fallback" % path)
+    lib = C.CDLL(path, mode=C.RTLD_GLOBAL)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the library does not export a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def _check(rc):
+    if rc != 0:
+        raise HmlError(rc, load_library().hml_last_error().decode())
+
+
+def synth_gauss(T, K, mu, sigma, dwell, seed, nthreads=8, with_states=False):
+    lib = load_library()
+    x = np.empty(T, np.float32)
+    mu = np.ascontiguousarray(mu, np.float32)
+    st = np.empty(T, np.int16) if with_states else None
+    _check(lib.hml_synth_gauss(x.ctypes.data, st.ctypes.data if with_states else None, T, K, mu.ctypes.data, sigma,
+                               dwell, seed, nthreads))
+    return (x, st) if with_states else x
+
+
+def debug_eval(fn, a, b=None, seed=0, device=0):
+    lib = load_library()
+    a = np.ascontiguousarray(a, np.float32)
+    out = np.empty_like(a)
+    if b is not None:
+        b = np.ascontiguousarray(b, np.float32)
+    _check(lib.hml_debug_eval(device, fn, a.ctypes.data, b.ctypes.data if b is not None else None, out.ctypes.data, a.size, seed))
+    return out
+
+
+class Chain:
+    """One Gibbs chain on one GPU: the Python mirror of hml_ctx (see include/hml.h for the reference
+    interfaces each call stands for)."""
+
+    def __init__(self, device=0, seed=0, chain_id=0, stream=None):
+        self.lib = load_library()
+        h = _P()
+        _check(self.lib.hml_create(C.byref(h), device, seed, chain_id, stream))
+        self.h = h
+        self.K = None
+        self.T = None
+        self._cb = None
+
+    def close(self):
+        if self.h:
+            self.lib.hml_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- construction -------------------------------------------------------------------
+    def load(self, x):
+        x = np.ascontiguousarray(x, np.float32)
+        self.T = int(x.size)
+        _check(self.lib.hml_load_observations(self.h, x.ctypes.data, x.size))
+
+    def load_device(self, ptr, T):
+        self.T = int(T)
+        _check(self.lib.hml_load_observations_device(self.h, ptr, T))
+
+    def noise_sigma(self):
+        v = C.c_double()
+        _check(self.lib.hml_noise_sigma(self.h, C.byref(v)))
+        return v.value
+
+    def scale_weights(self, m):
+        _check(self.lib.hml_scale_weights(self.h, m))
+
+    def autoprior(self, s2=0.2, p=0.9):
+        out = np.empty(4, np.float32)
+        _check(self.lib.hml_autoprior(self.h, s2, p, out.ctypes.data))
+        return out
+
+    def set_model(self, K, nig4, a_off=0.5, a_diag=0.5, pi_alpha=0.5, self_trans=True):
+        nig4 = np.ascontiguousarray(nig4, np.float32)
+        self.K = K
+        _check(self.lib.hml_set_model(self.h, K, nig4.ctypes.data, a_off, a_diag, pi_alpha, 1 if self_trans else 0))
+
+    def sample_prior(self):
+        _check(self.lib.hml_sample_prior(self.h))
+
+    def set_static_blocks(self):
+        _check(self.lib.hml_set_static_blocks(self.h))
+
+    def set_dynamic(self, on=True):
+        _check(self.lib.hml_set_dynamic(self.h, 1 if on else 0))
+
+    def create_blocks(self, thr):
+        _check(self.lib.hml_create_blocks(self.h, thr))
+
+    def iterate(self, method, iterations, thinning=0):
+        _check(self.lib.hml_iterate(self.h, method.encode()[0:1], iterations, thinning))
+
+    def set_recording(self, marginals=True, callback=None):
+        if callback is not None:
+            def tramp(_ctx, sweep, _user):
+                callback(self, sweep)
+            self._cb = RECORD_CB(tramp)
+        else:
+            self._cb = C.cast(None, RECORD_CB)
+        _check(self.lib.hml_set_recording(self.h, 1 if marginals else 0, self._cb, None))
+
+    def sync(self):
+        _check(self.lib.hml_sync(self.h))
+
+    # ---- probes -------------------------------------------------------------------------
+    def num_blocks(self):
+        v = C.c_uint64()
+        _check(self.lib.hml_get_num_blocks(self.h, C.byref(v)))
+        return v.value
+
+    def blocks(self):
+        B = self.num_blocks()
+        s = np.empty(B + 1, np.uint32)
+        _check(self.lib.hml_get_blocks(self.h, s.ctypes.data))
+        return s
+
+    def block_stats(self):
+        B = self.num_blocks()
+        a = np.empty(B, np.float32)
+        b = np.empty(B, np.float32)
+        _check(self.lib.hml_get_block_stats(self.h, a.ctypes.data, b.ctypes.data))
+        return a, b
+
+    def states(self):
+        B = self.num_blocks()
+        q = np.empty(B, np.int16)
+        _check(self.lib.hml_get_states(self.h, q.ctypes.data))
+        return q
+
+    def theta(self):
+        t = np.empty(2 * self.K, np.float32)
+        _check(self.lib.hml_get_theta(self.h, t.ctypes.data))
+        return t
+
+    def transitions(self):
+        A = np.empty((self.K, self.K), np.float32)
+        pi = np.empty(self.K, np.float32)
+        _check(self.lib.hml_get_transitions(self.h, A.ctypes.data, pi.ctypes.data))
+        return A, pi
+
+    def set_parameters(self, mean_var, A, pi):
+        mv = np.ascontiguousarray(mean_var, np.float32)
+        A = np.ascontiguousarray(A, np.float32)
+        pi = np.ascontiguousarray(pi, np.float32)
+        _check(self.lib.hml_set_parameters(self.h, mv.ctypes.data, A.ctypes.data, pi.ctypes.data))
+
+    def threshold(self):
+        v = C.c_float()
+        _check(self.lib.hml_get_threshold(self.h, C.byref(v)))
+        return v.value
+
+    def enable_probes(self, on=True):
+        _check(self.lib.hml_enable_probes(self.h, 1 if on else 0))
+
+    def block_loglik(self):
+        B = self.num_blocks()
+        E = np.empty((B, self.K), np.float32)
+        _check(self.lib.hml_get_block_loglik(self.h, E.ctypes.data))
+        return E
+
+    def forward_rows(self):
+        B = self.num_blocks()
+        r = np.empty((B + 1, self.K), np.float32)
+        _check(self.lib.hml_get_forward_rows(self.h, r.ctypes.data))
+        return r
+
+    def counts(self):
+        K = self.K
+        trans = np.empty((K, K), np.uint64)
+        occ = np.empty(K, np.uint64)
+        s = np.empty(K, np.float32)
+        q = np.empty(K, np.float32)
+        n = np.empty(K, np.uint64)
+        _check(self.lib.hml_get_counts(self.h, trans.ctypes.data, occ.ctypes.data, s.ctypes.data, q.ctypes.data, n.ctypes.data))
+        return trans, occ, s, q, n
+
+    def weights(self):
+        w = np.empty(self.T, np.float32)
+        _check(self.lib.hml_get_weights(self.h, w.ctypes.data))
+        return w
+
+    def coefficients(self):
+        w = np.empty(self.T, np.float32)
+        _check(self.lib.hml_get_coefficients(self.h, w.ctypes.data))
+        return w
+
+    def integral_array(self):
+        a = np.empty(self.T + 1, np.float32)
+        b = np.empty(self.T + 1, np.float32)
+        _check(self.lib.hml_get_integral_array(self.h, a.ctypes.data, b.ctypes.data))
+        return a, b
+
+    # ---- results ------------------------------------------------------------------------
+    def recorded_sweeps(self):
+        v = C.c_uint64()
+        _check(self.lib.hml_recorded_sweeps(self.h, C.byref(v)))
+        return v.value
+
+    def marginals_rle(self):
+        n = C.c_uint64()
+        k = C.c_int()
+        _check(self.lib.hml_marginals_rle(self.h, C.byref(n), C.byref(k), None, None))
+        seg = np.empty(n.value, np.uint64)
+        cnt = np.empty((n.value, max(k.value, 0)), np.int32)
+        _check(self.lib.hml_marginals_rle(self.h, C.byref(n), C.byref(k), seg.ctypes.data, cnt.ctypes.data if k.value else None))
+        return seg, cnt
+
+    def marginals_dense_device(self, out_ptr, perm=None):
+        p = None
+        if perm is not None:
+            perm = np.ascontiguousarray(perm, np.int32)
+            p = perm.ctypes.data
+        _check(self.lib.hml_marginals_dense_device(self.h, out_ptr, p))
+
+    def stats(self):
+        s = HmlStats()
+        _check(self.lib.hml_get_stats(self.h, C.byref(s)))
+        return {f: getattr(s, f) for f, _ in HmlStats._fields_}
+
+    def profile_enable(self, on=True):
+        _check(self.lib.hml_profile_enable(self.h, 1 if on else 0))
+
+    def profile_get(self, name):
+        ms = C.c_double()
+        n = C.c_uint64()
+        _check(self.lib.hml_profile_get(self.h, name.encode(), C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+
+def marginals_text(seg, cnt):
+    """StateMarginals::save format (reference src/StateMarginals.hpp:268-310)."""
+    lines = []
+    for i in range(len(seg)):
+        lines.append("\t".join([str(int(seg[i]))] + [str(int(v)) for v in cnt[i]]))
+    return "\n".join(lines) + "\n"

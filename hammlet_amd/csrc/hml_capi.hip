@@ -1,0 +1,949 @@
+// libhammlet_hip.so - C ABI (include/hml.h) over the gfx950 kernels.  Host side only orchestrates:
+// allocation, launches on the context's stream, and the few inherently sequential one-time steps of
+// the reference's driver (noise estimate src/main.cpp:303-311, autoPrior src/AutoPriors.hpp:86-110).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/hml.h"
+#include "hml_k_backward.h"
+#include "hml_k_blocks.h"
+#include "hml_k_build.h"
+#include "hml_k_forward.h"
+#include "hml_k_marginals.h"
+#include "hml_k_params.h"
+#include "hml_state.h"
+#include "hml_synth_host.hpp"
+
+static thread_local std::string g_err;
+static int set_err(int code, const std::string& msg) { g_err = msg; return code; }
+
+#define HIPCHK(call)                                                                                  \
+    do {                                                                                              \
+        hipError_t e_ = (call);                                                                       \
+        if (e_ != hipSuccess)                                                                         \
+            return set_err(HML_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_));           \
+    } while (0)
+
+#define KLAUNCH_CHECK() HIPCHK(hipGetLastError())
+
+#define HML_DISPATCH_K(KV, ...)                                                   \
+    switch (KV) {                                                                 \
+        case 2: { constexpr int KK = 2; __VA_ARGS__; } break;                     \
+        case 3: { constexpr int KK = 3; __VA_ARGS__; } break;                     \
+        case 4: { constexpr int KK = 4; __VA_ARGS__; } break;                     \
+        case 5: { constexpr int KK = 5; __VA_ARGS__; } break;                     \
+        case 6: { constexpr int KK = 6; __VA_ARGS__; } break;                     \
+        case 7: { constexpr int KK = 7; __VA_ARGS__; } break;                     \
+        case 8: { constexpr int KK = 8; __VA_ARGS__; } break;                     \
+        case 9: { constexpr int KK = 9; __VA_ARGS__; } break;                     \
+        case 10: { constexpr int KK = 10; __VA_ARGS__; } break;                   \
+        case 11: { constexpr int KK = 11; __VA_ARGS__; } break;                   \
+        case 12: { constexpr int KK = 12; __VA_ARGS__; } break;                   \
+        case 13: { constexpr int KK = 13; __VA_ARGS__; } break;                   \
+        case 14: { constexpr int KK = 14; __VA_ARGS__; } break;                   \
+        case 15: { constexpr int KK = 15; __VA_ARGS__; } break;                   \
+        case 16: { constexpr int KK = 16; __VA_ARGS__; } break;                   \
+        default: return set_err(HML_ERR_ARG, "number of states must be in [2,16]"); \
+    }
+
+struct ProfAcc { double ms = 0; uint64_t n = 0; std::vector<std::pair<hipEvent_t, hipEvent_t>> pending; };
+
+struct hml_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    uint64_t seed = 0;
+    uint32_t chain = 0;
+    uint64_t T = 0;
+    int K = 0;
+    bool loaded = false, model_set = false;
+    bool dynamic = true;
+    bool blocks_valid = false;     // starts/bstat describe the current threshold
+    double sigma = 0;
+    // construction
+    float* d_w = nullptr;
+    float* d_coeff = nullptr;
+    float2* d_ia = nullptr;
+    // block structure
+    uint16_t* d_stage = nullptr;
+    uint32_t *d_span_count = nullptr, *d_span_offset = nullptr, *d_starts = nullptr;
+    float2* d_bstat = nullptr;
+    uint32_t n_spans = 0;
+    // sweep buffers (allocated by set_model)
+    float *d_em = nullptr, *d_gsc = nullptr, *d_rows = nullptr, *d_eprobe = nullptr, *d_aprobe = nullptr;
+    float *d_entry = nullptr, *d_exitA = nullptr, *d_exitB = nullptr;
+    uint32_t* d_fb = nullptr;
+    unsigned long long *d_smap = nullptr, *d_cmap = nullptr;
+    uint8_t* d_bentry = nullptr;
+    int16_t* d_q = nullptr;
+    double* d_partial = nullptr;
+    int32_t* d_diff = nullptr;
+    uint32_t* d_boundary = nullptr;
+    hml_model* d_mdl = nullptr;
+    uint32_t* h_B = nullptr;        // pinned: last block count copied back (grid sizing hint)
+    uint32_t B_hint = 0;
+    // forward geometry
+    int fwdL = 16, fwdW = 32, fwdRounds = 1;
+    bool probes = false;
+    bool rec_marginals = true;
+    hml_record_cb cb = nullptr;
+    void* cb_user = nullptr;
+    bool profiling = false;
+    std::map<std::string, ProfAcc> prof;
+    std::vector<hipEvent_t> ev_pool;
+};
+
+// ------------------------------------------------------------------------------------------------
+static int ctx_bind(hml_ctx* c) {
+    HIPCHK(hipSetDevice(c->device));
+    return 0;
+}
+
+static hipEvent_t ev_get(hml_ctx* c) {
+    if (!c->ev_pool.empty()) { hipEvent_t e = c->ev_pool.back(); c->ev_pool.pop_back(); return e; }
+    hipEvent_t e;
+    hipEventCreate(&e);
+    return e;
+}
+
+struct ProfScope {
+    hml_ctx* c; const char* name; hipEvent_t a = nullptr, b = nullptr;
+    ProfScope(hml_ctx* c_, const char* n) : c(c_), name(n) {
+        if (c->profiling) { a = ev_get(c); b = ev_get(c); hipEventRecord(a, c->stream); }
+    }
+    ~ProfScope() {
+        if (c->profiling) { hipEventRecord(b, c->stream); c->prof[name].pending.push_back({a, b}); }
+    }
+};
+
+static int grid_for(uint64_t items, int per_block, int lo, int hi) {
+    uint64_t g = (items + per_block - 1) / per_block;
+    if (g < (uint64_t)lo) g = lo;
+    if (g > (uint64_t)hi) g = hi;
+    return (int)g;
+}
+
+static const char* deverr_text(uint32_t code, float v, char* buf, size_t n) {
+    switch (code) {
+        case HML_DEVERR_IP_NOT_FINITE: snprintf(buf, n, "Result of Normal inner product is not finite!"); break;
+        case HML_DEVERR_NEG_BACKWARD: snprintf(buf, n, "Negative backward variable!"); break;
+        case HML_DEVERR_NEG_SUMSQ: snprintf(buf, n, "Sum of squares is negative (%s)!", std::to_string(v).c_str()); break;
+        case HML_DEVERR_NIG_ALPHA: snprintf(buf, n, "Alpha (%s) must be positive!", std::to_string(v).c_str()); break;
+        case HML_DEVERR_NIG_BETA: snprintf(buf, n, "Beta (%s) must be positive!", std::to_string(v).c_str()); break;
+        case HML_DEVERR_NIG_NU: snprintf(buf, n, "Nu (%s)must be positive!", std::to_string(v).c_str()); break;
+        case HML_DEVERR_NIG_MU0: snprintf(buf, n, "Mu0 (%s)  must be finite!", std::to_string(v).c_str()); break;
+        case HML_DEVERR_MEAN_NOT_FINITE: snprintf(buf, n, "Mean (%s) must be set to a finite value!", std::to_string(v).c_str()); break;
+        case HML_DEVERR_VAR_NOT_FINITE: snprintf(buf, n, "Variance(%s) must be set to a finite value!", std::to_string(v).c_str()); break;
+        case HML_DEVERR_VAR_NOT_POSITIVE: snprintf(buf, n, "Variance (%s) must be positive!", std::to_string(v).c_str()); break;
+        case HML_DEVERR_TOO_MANY_RECORDS: snprintf(buf, n, "Too many recorded iterations for the marginal counters!"); break;
+        default: snprintf(buf, n, "device error %u", code);
+    }
+    return buf;
+}
+
+static int fetch_model(hml_ctx* c, hml_model* out) {
+    HIPCHK(hipMemcpyAsync(out, c->d_mdl, sizeof(hml_model), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+static int check_device_error(hml_ctx* c) {
+    hml_model m;
+    if (int r = fetch_model(c, &m)) return r;
+    if (m.err_code != 0) {
+        char buf[256];
+        return set_err(HML_ERR_MODEL, deverr_text(m.err_code, m.err_value, buf, sizeof buf));
+    }
+    return 0;
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// hml_debug_eval: evaluates one of the shared host/device functions on the GPU (parity probe for
+// hml_math.h / hml_dist.h: the tests compare with the same function compiled by gcc).
+__global__ void hml_k_debug_eval(int fn, const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out,
+                                 uint64_t n, uint64_t seed) {
+    if (fn == 24) {   // gamma draw with ONE active lane per wavefront (divergence-free control)
+        const uint64_t nw = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+        if ((threadIdx.x & 63) != 0) return;
+        for (uint64_t i = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6; i < n; i += nw) {
+            hml_dev_src src;
+            src.s = hml_stream_open(hml_make_key(seed, 0), HML_KIND_THETA, seed, (uint32_t)i);
+            out[i] = hml_gamma_f32<hml_devmath>(src, a[i], b[i]);
+        }
+        return;
+    }
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const float x = a[i], y = b ? b[i] : 0.0f;
+        float r = 0.0f;
+        switch (fn) {
+            case 0: r = hml_expf(x); break;
+            case 1: r = hml_logf(x); break;
+            case 2: r = hml_powf_unit(x, y); break;
+            case 3: r = HML_SQRTF(x); break;
+            case 4: r = x / y; break;
+            case 5: {   // gamma(alpha = x, beta = y) from sub-stream (THETA, epoch = seed, index = i)
+                hml_dev_src src;
+                src.s = hml_stream_open(hml_make_key(seed, 0), HML_KIND_THETA, seed, (uint32_t)i);
+                r = hml_gamma_f32<hml_devmath>(src, x, y);
+            } break;
+            case 6: {   // normal(mean = x, sd = y)
+                hml_dev_src src;
+                src.s = hml_stream_open(hml_make_key(seed, 0), HML_KIND_PI, seed, (uint32_t)i);
+                hml_normal_f32<hml_devmath> nd;
+                r = nd.draw(src, x, y);
+            } break;
+            case 7: r = (float)hml_log((double)x); break;
+            case 8: r = (float)hml_exp_nonpos((double)x); break;
+            case 9: r = (float)((double)x / (double)y); break;
+            case 10: r = (float)(1.0 / (double)x); break;
+            case 12: case 13: case 14: case 15: case 16: case 17: case 18: case 19: case 20: case 21: case 22: case 23: {
+                hml_dev_src src; src.s = hml_stream_open(hml_make_key(seed, 0), HML_KIND_THETA, seed, (uint32_t)i);
+                const float alpha = x, beta = y; (void)beta;
+                const float malpha = alpha < 1.0f ? alpha + 1.0f : alpha;
+                const float a1 = malpha - 1.0f / 3.0f;
+                const float a2 = 1.0f / hml_devmath::sqrtf_(9.0f * a1);
+                hml_normal_f32<hml_devmath> nd;
+                float n = nd.draw(src, 0.0f, 1.0f);
+                float v = 1.0f + a2 * n;
+                float v3 = v * v * v;
+                float u = hml_canonical_f32(src);
+                const bool c1 = (double)u > (double)1.0f - 0.0331 * (double)n * (double)n * (double)n * (double)n;
+                const bool c2 = ((double)hml_devmath::logf_(u) > (0.5 * (double)n * (double)n + (double)a1 * ((1.0 - (double)v3) + (double)hml_devmath::logf_(v3))));
+                float n2 = nd.draw(src, 0.0f, 1.0f);
+                float vb = 1.0f + a2 * n2;
+                float vb3 = vb * vb * vb;
+                float ub = hml_canonical_f32(src);
+                const bool d1 = (double)ub > (double)1.0f - 0.0331 * (double)n2 * (double)n2 * (double)n2 * (double)n2;
+                const bool d2 = ((double)hml_devmath::logf_(ub) > (0.5 * (double)n2 * (double)n2 + (double)a1 * ((1.0 - (double)vb3) + (double)hml_devmath::logf_(vb3))));
+                r = fn == 12 ? n : fn == 13 ? v3 : fn == 14 ? u : fn == 15 ? (float)(c1 ? 1 : 0) + 2.0f * (c2 ? 1 : 0) : fn == 16 ? n2 : fn == 17 ? a2
+                    : fn == 18 ? vb3 : fn == 19 ? ub : fn == 20 ? (float)(d1 ? 1 : 0) + 2.0f * (d2 ? 1 : 0) : fn == 21 ? (float)src.s.n : 0.0f;
+                if (fn == 22) r = nd.draw(src, 0.0f, 1.0f);   // third normal (fresh pair)
+                if (fn == 23) { hml_normal_f32<hml_devmath> nf; r = nf.draw(src, 0.0f, 1.0f); r = nf.draw(src, 0.0f, 1.0f); }  // saved of the fresh pair
+            } break;
+            case 11: { const double d = HML_SQRT((double)x * 1.0000001); r = (float)((d - (double)(float)d) * 1e9); } break;
+        }
+        out[i] = r;
+    }
+}
+
+extern "C" {
+
+const char* hml_last_error(void) { return g_err.c_str(); }
+uint32_t hml_abi_version(void) { return 1; }
+const char* hml_device_arch(void) { return "gfx950"; }
+
+int hml_create(hml_ctx** out, int device, uint64_t seed, uint32_t chain_id, void* stream) {
+    if (!out) return set_err(HML_ERR_ARG, "null output pointer");
+    int n = 0;
+    HIPCHK(hipGetDeviceCount(&n));
+    if (n <= 0) return set_err(HML_ERR_HIP, "no HIP device available: the MI355X kernels cannot run (there is no CPU fallback)");
+    if (device < 0 || device >= n) return set_err(HML_ERR_ARG, "device index out of range");
+    hml_ctx* c = new hml_ctx();
+    c->device = device; c->seed = seed; c->chain = chain_id;
+    HIPCHK(hipSetDevice(device));
+    if (stream) { c->stream = (hipStream_t)stream; c->own_stream = false; }
+    else { HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)); c->own_stream = true; }
+    HIPCHK(hipMalloc(&c->d_mdl, sizeof(hml_model)));
+    HIPCHK(hipMemsetAsync(c->d_mdl, 0, sizeof(hml_model), c->stream));
+    HIPCHK(hipHostMalloc(&c->h_B, sizeof(uint32_t)));
+    *c->h_B = 0;
+    if (const char* e = getenv("HML_FWD_CHUNK")) c->fwdL = std::max(1, atoi(e));
+    if (const char* e = getenv("HML_FWD_WARMUP")) c->fwdW = std::max(0, atoi(e));
+    if (const char* e = getenv("HML_FWD_ROUNDS")) c->fwdRounds = std::max(0, atoi(e));
+    *out = c;
+    return 0;
+}
+
+static void free_all(hml_ctx* c) {
+    void* ptrs[] = {c->d_w, c->d_coeff, c->d_ia, c->d_stage, c->d_span_count, c->d_span_offset, c->d_starts, c->d_bstat,
+                    c->d_em, c->d_gsc, c->d_rows, c->d_eprobe, c->d_aprobe, c->d_entry, c->d_exitA, c->d_exitB, c->d_fb,
+                    c->d_smap, c->d_cmap, c->d_bentry, c->d_q, c->d_partial, c->d_diff, c->d_boundary, c->d_mdl};
+    for (void* p : ptrs) if (p) hipFree(p);
+    if (c->h_B) hipHostFree(c->h_B);
+}
+
+void hml_destroy(hml_ctx* c) {
+    if (!c) return;
+    hipSetDevice(c->device);
+    hipStreamSynchronize(c->stream);
+    for (auto& kv : c->prof) for (auto& p : kv.second.pending) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
+    for (auto e : c->ev_pool) hipEventDestroy(e);
+    free_all(c);
+    if (c->own_stream) hipStreamDestroy(c->stream);
+    delete c;
+}
+
+// ---------------------------------------------------------------------------------------- load
+static int build_from_device_x(hml_ctx* c, const float* d_x, const float* h_x) {
+    const uint64_t T = c->T;
+    // noise estimate (src/main.cpp:303-311): f64 accumulation, in index order, of the finest-level
+    // maxlet coefficients c[t] = sqrt2half * |x[t-1] - x[t]| at odd t (wavelet.hpp:139-150, level 1)
+    {
+        const float sqrt2 = (float)std::sqrt(2.0);
+        const float sqrt2half = (float)(sqrt2 / 2.0);
+        double acc = 0; uint64_t cnt = 0;
+        for (uint64_t i = 1; i < T; i += 2) {
+            const float d = std::abs(h_x[i - 1] - h_x[i]);
+            const float cf = sqrt2half * d;
+            acc += (0.0f < cf) ? cf : 0.0f;
+            cnt++;
+        }
+        acc /= cnt;
+        acc /= 0.797884560802865355879892119868763736951717262329869315331;
+        c->sigma = acc;
+    }
+    HIPCHK(hipMalloc(&c->d_w, T * sizeof(float)));
+    HIPCHK(hipMalloc(&c->d_coeff, T * sizeof(float)));
+    HIPCHK(hipMalloc(&c->d_ia, (T + 1) * sizeof(float2)));
+    // K1: levels 10 at a time
+    {
+        float h_norm[64];
+        const float sqrt2 = (float)std::sqrt(2.0);
+        const float sqrt2half = (float)(sqrt2 / 2.0);
+        h_norm[0] = 1.0f;
+        float nrm = sqrt2half;
+        for (int l = 1; l < 64; ++l) { h_norm[l] = nrm; nrm *= sqrt2half; }
+        float* d_norm = nullptr;
+        HIPCHK(hipMalloc(&d_norm, sizeof h_norm));
+        HIPCHK(hipMemcpyAsync(d_norm, h_norm, sizeof h_norm, hipMemcpyHostToDevice, c->stream));
+        uint64_t n = T;
+        int base = 0;
+        const float* in = d_x;
+        float *bufA = nullptr, *bufB = nullptr;
+        const uint64_t n1 = T >> HML_MAXLET_LOG_TILE;
+        HIPCHK(hipMalloc(&bufA, std::max<uint64_t>(n1, 1) * sizeof(float)));
+        HIPCHK(hipMalloc(&bufB, std::max<uint64_t>(n1 >> HML_MAXLET_LOG_TILE, 1) * sizeof(float)));
+        float* outb = bufA;
+        while (true) {
+            const uint64_t tiles = (n + HML_MAXLET_TILE - 1) / HML_MAXLET_TILE;
+            hipLaunchKernelGGL(hml_k_maxlet, dim3((unsigned)tiles), dim3(256), 0, c->stream, in, n, base, c->d_coeff, T, outb, d_norm);
+            KLAUNCH_CHECK();
+            base += HML_MAXLET_LOG_TILE;
+            if (base >= 40 || (1ull << base) >= T) break;   // no discontinuity position left below T
+            n = T >> base;                                   // complete elements of the next level (>= 1)
+            in = outb;
+            outb = (outb == bufA) ? bufB : bufA;
+        }
+        HIPCHK(hipStreamSynchronize(c->stream));
+        hipFree(bufA); hipFree(bufB); hipFree(d_norm);
+    }
+    hipLaunchKernelGGL(hml_k_weights, dim3(grid_for(T, 256, 1, 65536)), dim3(256), 0, c->stream, c->d_coeff, c->d_w, T, 1.0f);
+    KLAUNCH_CHECK();
+    {
+        const uint64_t cells = (T + 1 + HML_CELLSIZE - 1) / HML_CELLSIZE;
+        hipLaunchKernelGGL(hml_k_integral, dim3((unsigned)((cells + 3) / 4)), dim3(256), 0, c->stream, d_x, c->d_ia, T);
+        KLAUNCH_CHECK();
+    }
+    // block-structure buffers
+    c->n_spans = (uint32_t)((T + HML_SPAN - 1) / HML_SPAN);
+    HIPCHK(hipMalloc(&c->d_stage, (uint64_t)c->n_spans * HML_SPAN * sizeof(uint16_t)));
+    HIPCHK(hipMalloc(&c->d_span_count, c->n_spans * sizeof(uint32_t)));
+    HIPCHK(hipMalloc(&c->d_span_offset, c->n_spans * sizeof(uint32_t)));
+    HIPCHK(hipMalloc(&c->d_starts, (T + 1) * sizeof(uint32_t)));
+    HIPCHK(hipMalloc(&c->d_bstat, T * sizeof(float2)));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    c->loaded = true;
+    return 0;
+}
+
+int hml_load_observations(hml_ctx* c, const float* x, uint64_t T) {
+    if (!c || !x) return set_err(HML_ERR_ARG, "null argument");
+    if (T == 0) return set_err(HML_ERR_ARG, "Input vector for breakpoint weights is empty!");
+    if (T >= 0xffffffffull) return set_err(HML_ERR_ARG, "at most 2^32-2 positions are supported");
+    if (c->loaded) return set_err(HML_ERR_ARG, "observations already loaded");
+    if (int r = ctx_bind(c)) return r;
+    c->T = T;
+    float* d_x = nullptr;
+    HIPCHK(hipMalloc(&d_x, T * sizeof(float)));
+    HIPCHK(hipMemcpyAsync(d_x, x, T * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    int r = build_from_device_x(c, d_x, x);
+    hipFree(d_x);
+    return r;
+}
+
+int hml_load_observations_device(hml_ctx* c, const void* x_dev, uint64_t T) {
+    if (!c || !x_dev) return set_err(HML_ERR_ARG, "null argument");
+    if (T == 0) return set_err(HML_ERR_ARG, "Input vector for breakpoint weights is empty!");
+    if (T >= 0xffffffffull) return set_err(HML_ERR_ARG, "at most 2^32-2 positions are supported");
+    if (c->loaded) return set_err(HML_ERR_ARG, "observations already loaded");
+    if (int r = ctx_bind(c)) return r;
+    c->T = T;
+    std::vector<float> h(T);
+    HIPCHK(hipMemcpy(h.data(), x_dev, T * sizeof(float), hipMemcpyDeviceToHost));
+    return build_from_device_x(c, (const float*)x_dev, h.data());
+}
+
+int hml_noise_sigma(hml_ctx* c, double* sigma) {
+    if (!c || !c->loaded) return set_err(HML_ERR_ARG, "no observations loaded");
+    *sigma = c->sigma;
+    return 0;
+}
+
+int hml_scale_weights(hml_ctx* c, float mult) {
+    if (!c || !c->loaded) return set_err(HML_ERR_ARG, "no observations loaded");
+    if (int r = ctx_bind(c)) return r;
+    hipLaunchKernelGGL(hml_k_scale, dim3(grid_for(c->T, 256, 1, 65536)), dim3(256), 0, c->stream, c->d_w, c->T, mult);
+    KLAUNCH_CHECK();
+    c->blocks_valid = false;
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------- blocks
+static int launch_compact(hml_ctx* c, bool use_override, float thr) {
+    const uint32_t T = (uint32_t)c->T;
+    {
+        ProfScope ps(c, "blocks_compact");
+        hipLaunchKernelGGL(hml_k_compact_scan, dim3((c->n_spans + 3) / 4), dim3(256), 0, c->stream, c->d_w, T, c->d_mdl, thr,
+                           use_override ? 1 : 0, c->d_stage, c->d_span_count);
+    }
+    KLAUNCH_CHECK();
+    {
+        ProfScope ps(c, "blocks_offsets");
+        hipLaunchKernelGGL(hml_k_compact_offsets, dim3(1), dim3(1024), 0, c->stream, c->d_span_count, c->d_span_offset,
+                           c->n_spans, c->d_mdl, c->d_starts, T);
+        hipLaunchKernelGGL(hml_k_compact_scatter, dim3((c->n_spans + 3) / 4), dim3(256), 0, c->stream, c->d_stage,
+                           c->d_span_count, c->d_span_offset, c->n_spans, c->d_starts);
+    }
+    KLAUNCH_CHECK();
+    HIPCHK(hipMemcpyAsync(c->h_B, &c->d_mdl->B, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    {
+        ProfScope ps(c, "block_stats");
+        const uint32_t hint = c->B_hint ? c->B_hint : (uint32_t)std::min<uint64_t>(c->T, 1u << 20);
+        hipLaunchKernelGGL(hml_k_block_stats, dim3(grid_for(hint, 256, 64, 16384)), dim3(256), 0, c->stream, c->d_ia,
+                           c->d_starts, c->d_mdl, c->d_bstat);
+    }
+    KLAUNCH_CHECK();
+    return 0;
+}
+
+static void refresh_hint(hml_ctx* c) {
+    const uint32_t b = *(volatile uint32_t*)c->h_B;
+    if (b) c->B_hint = b + b / 4 + 1024;
+}
+
+int hml_create_blocks(hml_ctx* c, float threshold) {
+    if (!c || !c->loaded) return set_err(HML_ERR_ARG, "no observations loaded");
+    if (int r = ctx_bind(c)) return r;
+    if (int r = launch_compact(c, true, threshold)) return r;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    refresh_hint(c);
+    c->blocks_valid = false;   // an explicit threshold is not the model's threshold
+    return 0;
+}
+
+int hml_autoprior(hml_ctx* c, float s2, float p, float out4[4]) {
+    if (!c || !c->loaded) return set_err(HML_ERR_ARG, "no observations loaded");
+    if (int r = ctx_bind(c)) return r;
+    // y.createBlocks( sqrt(2*log((double)T)) * noiseStdev )   (AutoPriors.hpp:95-96)
+    const float thr0 = (float)(std::sqrt(2 * std::log((double)c->T)) * c->sigma);
+    if (int r = launch_compact(c, true, thr0)) return r;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    refresh_hint(c);
+    const uint32_t B = *c->h_B;
+    std::vector<uint32_t> st(B + 1);
+    std::vector<float2> bs(B);
+    HIPCHK(hipMemcpy(st.data(), c->d_starts, (B + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(bs.data(), c->d_bstat, B * sizeof(float2), hipMemcpyDeviceToHost));
+    // block means in block order, float accumulation (SufficientStatistics<Normal>::addObs)
+    float muSum = 0, muSq = 0;
+    for (uint32_t b = 0; b < B; ++b) {
+        const float m = bs[b].x / (float)(st[b + 1] - st[b]);
+        muSum += m;
+        muSq += m * m;
+    }
+    const double n = (double)B;
+    const double blocksMean = (double)(float)(muSum / n);
+    const double avg = (double)(float)(muSum / n);
+    const double blocksVar = (double)(float)(muSq / n - (avg * avg));
+    const float dataMean = (float)blocksMean, dataVar = (float)blocksVar;
+    if (p < 0 || p > 1) return set_err(HML_ERR_MODEL, "Parameter p for automatic priors is a probability and must be in [0,1]!");
+    if (s2 <= 0) return set_err(HML_ERR_MODEL, "Parameter s2  for automatic priors is a variance and must be positive!");
+    if (dataVar <= 0) return set_err(HML_ERR_MODEL, "Data variance provided to autoprior must be positive!");
+    const float M1 = 0.3361, M2 = -0.0042, M3 = -0.0201;
+    const float b = -std::log(p);
+    const float alpha = 2.0;
+    const float beta = s2 * ((2.0 * std::sqrt(b)) / (M1 * std::sqrt(b) + std::sqrt(2.0) * (M2 * b * std::exp(M3 * std::sqrt(b)) + 1)) + b);
+    const float mu0 = dataMean;
+    const float nu = beta / dataVar;
+    if (beta <= 0) return set_err(HML_ERR_MODEL, "Autoprior yields non-positive beta!");
+    if (nu <= 0) return set_err(HML_ERR_MODEL, "Autoprior yields non-positive nu!");
+    if (!std::isfinite(beta)) return set_err(HML_ERR_MODEL, "Autoprior yields non-finite beta!");
+    if (!std::isfinite(mu0)) return set_err(HML_ERR_MODEL, "Autoprior yields non-finite mu0!");
+    if (!std::isfinite(nu)) return set_err(HML_ERR_MODEL, "Autoprior yields non-finite nu!");
+    out4[0] = alpha; out4[1] = beta; out4[2] = mu0; out4[3] = nu;
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------- model
+int hml_set_model(hml_ctx* c, int K, const float nig4[4], float a_off, float a_diag, float pi_alpha, int self_trans) {
+    if (!c || !c->loaded) return set_err(HML_ERR_ARG, "no observations loaded");
+    if (K < 2) return set_err(HML_ERR_MODEL, "Requested parameters would yield an HMM with less than 2 states!");
+    if (K > HML_MAX_K) return set_err(HML_ERR_ARG, "number of states must be in [2,16]");
+    if (c->model_set) return set_err(HML_ERR_ARG, "model already set");
+    if (!(nig4[0] > 0)) return set_err(HML_ERR_MODEL, "Alpha (" + std::to_string(nig4[0]) + ") must be positive!");
+    if (!(nig4[1] > 0)) return set_err(HML_ERR_MODEL, "Beta (" + std::to_string(nig4[1]) + ") must be positive!");
+    if (!(nig4[3] > 0)) return set_err(HML_ERR_MODEL, "Nu (" + std::to_string(nig4[3]) + ")must be positive!");
+    if (int r = ctx_bind(c)) return r;
+    c->K = K;
+    const uint64_t T = c->T;
+    HIPCHK(hipMalloc(&c->d_em, T * K * sizeof(float)));
+    HIPCHK(hipMalloc(&c->d_gsc, T * K * sizeof(float)));
+    HIPCHK(hipMalloc(&c->d_rows, (T + 1) * K * sizeof(float)));
+    const uint64_t maxChunks = (T + c->fwdL - 1) / c->fwdL + 1;
+    HIPCHK(hipMalloc(&c->d_entry, maxChunks * K * sizeof(float)));
+    HIPCHK(hipMalloc(&c->d_exitA, maxChunks * K * sizeof(float)));
+    HIPCHK(hipMalloc(&c->d_exitB, maxChunks * K * sizeof(float)));
+    HIPCHK(hipMalloc(&c->d_fb, maxChunks * sizeof(uint32_t)));
+    HIPCHK(hipMalloc(&c->d_smap, (T + 2) * sizeof(unsigned long long)));
+    const uint64_t bchunks = (T + HML_BWD_CHUNK - 1) / HML_BWD_CHUNK + 1;
+    HIPCHK(hipMalloc(&c->d_cmap, bchunks * sizeof(unsigned long long)));
+    HIPCHK(hipMalloc(&c->d_bentry, bchunks));
+    HIPCHK(hipMalloc(&c->d_q, T * sizeof(int16_t)));
+    HIPCHK(hipMalloc(&c->d_partial, (uint64_t)HML_REDUCE_GROUPS * K * 2 * sizeof(double)));
+    HIPCHK(hipMemsetAsync(c->d_partial, 0, (uint64_t)HML_REDUCE_GROUPS * K * 2 * sizeof(double), c->stream));
+
+    hml_model m;
+    memset(&m, 0, sizeof m);
+    m.K = K; m.self_trans = self_trans ? 1 : 0; m.dynamic = 1; m.T = (uint32_t)T;
+    for (int i = 0; i < 4; ++i) m.nig_prior[i] = nig4[i];
+    m.a_off = a_off; m.a_diag = a_diag; m.pi_alpha = pi_alpha;
+    m.key = hml_make_key(c->seed, c->chain);
+    for (int k = 0; k < K; ++k) {
+        for (int i = 0; i < 4; ++i) m.nig_post[k][i] = nig4[i];
+        m.dirPi[k] = pi_alpha;
+        m.pi[k] = 1.0f / K;
+        for (int j = 0; j < K; ++j) { m.dirA[k * K + j] = (k == j) ? a_diag : a_off; m.A[k * K + j] = 1.0f / K; }
+    }
+    m.max_state_recorded = -1;
+    m.n_spans = c->n_spans;
+    // keep the block count of an earlier enumeration (autoprior) out of the model: B = 0
+    HIPCHK(hipMemcpyAsync(c->d_mdl, &m, sizeof m, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    c->model_set = true;
+    c->dynamic = true;
+    // Theta's constructor samples once from the prior (src/Theta.hpp:126-127)
+    HML_DISPATCH_K(K, hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_params<KK>), dim3(1), dim3(1024), 0, c->stream, c->d_mdl, c->d_partial, 2));
+    KLAUNCH_CHECK();
+    return 0;
+}
+
+int hml_sample_prior(hml_ctx* c) {
+    if (!c || !c->model_set) return set_err(HML_ERR_ARG, "model not set");
+    if (int r = ctx_bind(c)) return r;
+    HML_DISPATCH_K(c->K, hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_params<KK>), dim3(1), dim3(1024), 0, c->stream, c->d_mdl, c->d_partial, 1));
+    KLAUNCH_CHECK();
+    if (c->dynamic) c->blocks_valid = false;
+    return 0;
+}
+
+int hml_set_static_blocks(hml_ctx* c) {
+    if (!c || !c->model_set) return set_err(HML_ERR_ARG, "model not set");
+    if (int r = ctx_bind(c)) return r;
+    hipLaunchKernelGGL(hml_k_set_dynamic, dim3(1), dim3(64), 0, c->stream, c->d_mdl, 0, 1);
+    KLAUNCH_CHECK();
+    c->dynamic = false;
+    if (int r = launch_compact(c, false, 0.0f)) return r;
+    c->blocks_valid = true;
+    return 0;
+}
+
+int hml_set_dynamic(hml_ctx* c, int on) {
+    if (!c || !c->model_set) return set_err(HML_ERR_ARG, "model not set");
+    if (int r = ctx_bind(c)) return r;
+    hipLaunchKernelGGL(hml_k_set_dynamic, dim3(1), dim3(64), 0, c->stream, c->d_mdl, on ? 1 : 0, on ? 1 : 0);
+    KLAUNCH_CHECK();
+    c->dynamic = on != 0;
+    if (on) c->blocks_valid = false;
+    return 0;
+}
+
+int hml_set_recording(hml_ctx* c, int marginals, hml_record_cb cb, void* user) {
+    if (!c) return set_err(HML_ERR_ARG, "null context");
+    c->rec_marginals = marginals != 0;
+    c->cb = cb; c->cb_user = user;
+    return 0;
+}
+
+int hml_enable_probes(hml_ctx* c, int on) {
+    if (!c || !c->model_set) return set_err(HML_ERR_ARG, "model not set");
+    if (int r = ctx_bind(c)) return r;
+    if (on && !c->d_eprobe) {
+        HIPCHK(hipMalloc(&c->d_eprobe, c->T * c->K * sizeof(float)));
+        HIPCHK(hipMalloc(&c->d_aprobe, (c->T + 1) * c->K * sizeof(float)));
+    }
+    c->probes = on != 0;
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------- sweeps
+static int ensure_marginal_buffers(hml_ctx* c) {
+    if (c->d_diff) return 0;
+    const uint64_t n = (uint64_t)c->K * (c->T + 1);
+    HIPCHK(hipMalloc(&c->d_diff, n * sizeof(int32_t)));
+    HIPCHK(hipMemsetAsync(c->d_diff, 0, n * sizeof(int32_t), c->stream));
+    const uint64_t words = (c->T + 1 + 31) / 32 + 1;
+    HIPCHK(hipMalloc(&c->d_boundary, words * sizeof(uint32_t)));
+    HIPCHK(hipMemsetAsync(c->d_boundary, 0, words * sizeof(uint32_t), c->stream));
+    return 0;
+}
+
+}  // extern "C"
+
+template <int KK>
+static int sweep_k(hml_ctx* c, char method, bool record) {
+    hipStream_t s = c->stream;
+    if (c->dynamic) {
+        if (int r = launch_compact(c, false, 0.0f)) return r;
+    } else if (!c->blocks_valid) {
+        if (int r = launch_compact(c, false, 0.0f)) return r;
+        c->blocks_valid = true;
+    }
+    refresh_hint(c);
+    const uint32_t hint = c->B_hint ? c->B_hint : (uint32_t)std::min<uint64_t>(c->T, 1u << 20);
+    const int gB = grid_for(hint, 256, 64, 16384);
+    const bool mix = (method == HML_METHOD_MIXTURE);
+    {
+        ProfScope ps(c, "emission");
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_emission<KK>), dim3(gB), dim3(256), 0, s, c->d_bstat, c->d_starts, c->d_mdl,
+                           c->d_em, c->d_gsc, c->probes ? c->d_eprobe : nullptr, mix ? 1 : 0);
+    }
+    if (!mix) {
+        const int L = c->fwdL, W = c->fwdW;
+        const uint64_t chunks = ((uint64_t)hint + L - 1) / L;
+        const int gF = grid_for(chunks * HML_FWD_GROUP, 256, 16, 1 << 20);
+        {
+            ProfScope ps(c, "forward");
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_forward<KK, 0>), dim3(gF), dim3(256), 0, s, c->d_em, c->d_gsc, c->d_mdl,
+                               c->d_rows, c->probes ? c->d_aprobe : nullptr, c->d_entry, (const float*)nullptr, c->d_exitA,
+                               c->d_fb, L, W);
+            float* ein = c->d_exitA; float* eout = c->d_exitB;
+            for (int r = 0; r < c->fwdRounds; ++r) {
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_forward<KK, 1>), dim3(gF), dim3(256), 0, s, c->d_em, c->d_gsc, c->d_mdl,
+                                   c->d_rows, c->probes ? c->d_aprobe : nullptr, c->d_entry, (const float*)ein, eout, c->d_fb,
+                                   L, W);
+                std::swap(ein, eout);
+            }
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_forward_serial<KK>), dim3(1), dim3(256), 0, s, c->d_em, c->d_gsc, c->d_mdl,
+                               c->d_rows, c->probes ? c->d_aprobe : nullptr, c->d_entry, ein, c->d_fb, L, W);
+        }
+        {
+            ProfScope ps(c, "backward");
+            const uint64_t bch = ((uint64_t)hint + HML_BWD_CHUNK - 1) / HML_BWD_CHUNK;
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_backward_maps<KK>), dim3(grid_for(bch * 64, 256, 16, 1 << 18)), dim3(256), 0,
+                               s, c->d_rows, c->d_mdl, c->d_smap, c->d_cmap);
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_backward_chain<KK>), dim3(1), dim3(1024), 0, s, c->d_cmap, c->d_mdl,
+                               c->d_bentry);
+            hipLaunchKernelGGL(hml_k_backward_apply, dim3(gB), dim3(256), 0, s, c->d_smap, c->d_bentry, c->d_mdl, c->d_q);
+        }
+    } else {
+        ProfScope ps(c, "backward");
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_mixture<KK>), dim3(gB), dim3(256), 0, s, c->d_em, c->d_mdl, c->d_q);
+    }
+    {
+        ProfScope ps(c, "counts");
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_counts<KK>), dim3(HML_REDUCE_GROUPS), dim3(256), 0, s, c->d_q, c->d_starts,
+                           c->d_bstat, c->d_mdl, c->d_partial);
+    }
+    if (record && c->rec_marginals) {
+        if (int r = ensure_marginal_buffers(c)) return r;
+        ProfScope ps(c, "marginals");
+        hipLaunchKernelGGL(hml_k_record, dim3(gB), dim3(256), 0, s, c->d_q, c->d_starts, c->d_mdl, c->d_diff, c->d_boundary);
+    }
+    {
+        ProfScope ps(c, "params");
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_params<KK>), dim3(1), dim3(1024), 0, s, c->d_mdl, c->d_partial, 0);
+    }
+    KLAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" {
+
+int hml_iterate(hml_ctx* c, char method, uint64_t iterations, uint64_t thinning) {
+    if (!c || !c->model_set) return set_err(HML_ERR_ARG, "model not set");
+    if (method != HML_METHOD_FB && method != HML_METHOD_MIXTURE)
+        return set_err(HML_ERR_ARG, std::string("Unknown sampling type ") + method + "!");
+    if (int r = ctx_bind(c)) return r;
+    for (uint64_t i = 0; i < iterations; ++i) {
+        const bool record = thinning > 0 && ((i + 1) % thinning == 0);
+        HML_DISPATCH_K(c->K, if (int r = sweep_k<KK>(c, method, record)) return r);
+        if (record && c->cb) {
+            HIPCHK(hipStreamSynchronize(c->stream));
+            if (int r = check_device_error(c)) return r;
+            c->cb(c, i, c->cb_user);
+        }
+    }
+    return 0;
+}
+
+int hml_sync(hml_ctx* c) {
+    if (!c) return set_err(HML_ERR_ARG, "null context");
+    if (int r = ctx_bind(c)) return r;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (c->model_set) return check_device_error(c);
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------- probes
+#define NEED_MODEL() if (!c || !c->model_set) return set_err(HML_ERR_ARG, "model not set"); if (int r_ = ctx_bind(c)) return r_
+#define NEED_LOADED() if (!c || !c->loaded) return set_err(HML_ERR_ARG, "no observations loaded"); if (int r_ = ctx_bind(c)) return r_
+
+static int current_B(hml_ctx* c, uint32_t* B) {
+    HIPCHK(hipMemcpyAsync(c->h_B, &c->d_mdl->B, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    *B = *c->h_B;
+    return 0;
+}
+
+int hml_get_num_blocks(hml_ctx* c, uint64_t* B) {
+    NEED_LOADED();
+    uint32_t b; if (int r = current_B(c, &b)) return r;
+    *B = b; return 0;
+}
+int hml_get_blocks(hml_ctx* c, uint32_t* starts) {
+    NEED_LOADED();
+    uint32_t b; if (int r = current_B(c, &b)) return r;
+    HIPCHK(hipMemcpy(starts, c->d_starts, ((uint64_t)b + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    return 0;
+}
+int hml_get_block_stats(hml_ctx* c, float* sum, float* sum_sq) {
+    NEED_LOADED();
+    uint32_t b; if (int r = current_B(c, &b)) return r;
+    std::vector<float2> v(b);
+    HIPCHK(hipMemcpy(v.data(), c->d_bstat, (uint64_t)b * sizeof(float2), hipMemcpyDeviceToHost));
+    for (uint32_t i = 0; i < b; ++i) { sum[i] = v[i].x; sum_sq[i] = v[i].y; }
+    return 0;
+}
+int hml_get_states(hml_ctx* c, int16_t* q) {
+    NEED_MODEL();
+    uint32_t b; if (int r = current_B(c, &b)) return r;
+    HIPCHK(hipMemcpy(q, c->d_q, (uint64_t)b * sizeof(int16_t), hipMemcpyDeviceToHost));
+    return 0;
+}
+int hml_get_theta(hml_ctx* c, float* mean_var) {
+    NEED_MODEL();
+    hml_model m; if (int r = fetch_model(c, &m)) return r;
+    for (int k = 0; k < c->K; ++k) { mean_var[2 * k] = m.mu[k]; mean_var[2 * k + 1] = m.var[k]; }
+    return 0;
+}
+int hml_get_transitions(hml_ctx* c, float* A, float* pi) {
+    NEED_MODEL();
+    hml_model m; if (int r = fetch_model(c, &m)) return r;
+    if (A) memcpy(A, m.A, (size_t)c->K * c->K * sizeof(float));
+    if (pi) memcpy(pi, m.pi, (size_t)c->K * sizeof(float));
+    return 0;
+}
+int hml_set_parameters(hml_ctx* c, const float* mean_var, const float* A, const float* pi) {
+    NEED_MODEL();
+    hml_model m; if (int r = fetch_model(c, &m)) return r;
+    const int K = c->K;
+    for (int k = 0; k < K; ++k) {
+        const float mean = mean_var[2 * k], var = mean_var[2 * k + 1];
+        if (!std::isfinite(mean)) return set_err(HML_ERR_MODEL, "Mean (" + std::to_string(mean) + ") must be set to a finite value!");
+        if (!std::isfinite(var)) return set_err(HML_ERR_MODEL, "Variance(" + std::to_string(var) + ") must be set to a finite value!");
+        if (var <= 0) return set_err(HML_ERR_MODEL, "Variance (" + std::to_string(var) + ") must be positive!");
+        m.mu[k] = mean; m.var[k] = var; m.sd[k] = sqrtf(var);
+    }
+    memcpy(m.A, A, (size_t)K * K * sizeof(float));
+    memcpy(m.pi, pi, (size_t)K * sizeof(float));
+    HIPCHK(hipMemcpyAsync(c->d_mdl, &m, sizeof m, hipMemcpyHostToDevice, c->stream));
+    HML_DISPATCH_K(K, hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_derive<KK>), dim3(1), dim3(64), 0, c->stream, c->d_mdl));
+    KLAUNCH_CHECK();
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (c->dynamic) c->blocks_valid = false;
+    return 0;
+}
+int hml_get_threshold(hml_ctx* c, float* thr) {
+    NEED_MODEL();
+    hml_model m; if (int r = fetch_model(c, &m)) return r;
+    *thr = m.thr; return 0;
+}
+int hml_get_block_loglik(hml_ctx* c, float* E) {
+    NEED_MODEL();
+    if (!c->probes) return set_err(HML_ERR_ARG, "probes are not enabled");
+    uint32_t b; if (int r = current_B(c, &b)) return r;
+    HIPCHK(hipMemcpy(E, c->d_eprobe, (uint64_t)b * c->K * sizeof(float), hipMemcpyDeviceToHost));
+    return 0;
+}
+int hml_get_forward_rows(hml_ctx* c, float* rows) {
+    NEED_MODEL();
+    if (!c->probes) return set_err(HML_ERR_ARG, "probes are not enabled");
+    uint32_t b; if (int r = current_B(c, &b)) return r;
+    HIPCHK(hipMemcpy(rows, c->d_aprobe, ((uint64_t)b + 1) * c->K * sizeof(float), hipMemcpyDeviceToHost));
+    return 0;
+}
+int hml_get_counts(hml_ctx* c, uint64_t* trans, uint64_t* occ, float* sum, float* sum_sq, uint64_t* nterms) {
+    NEED_MODEL();
+    hml_model m; if (int r = fetch_model(c, &m)) return r;
+    const int K = c->K;
+    for (int i = 0; i < K * K; ++i) trans[i] = m.last_trans[i];
+    for (int k = 0; k < K; ++k) { occ[k] = m.last_occ[k]; nterms[k] = m.last_occ[k]; sum[k] = m.last_sum[k]; sum_sq[k] = m.last_sumsq[k]; }
+    return 0;
+}
+int hml_get_weights(hml_ctx* c, float* w) {
+    NEED_LOADED();
+    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipMemcpy(w, c->d_w, c->T * sizeof(float), hipMemcpyDeviceToHost));
+    return 0;
+}
+int hml_get_coefficients(hml_ctx* c, float* cf) {
+    NEED_LOADED();
+    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipMemcpy(cf, c->d_coeff, c->T * sizeof(float), hipMemcpyDeviceToHost));
+    return 0;
+}
+int hml_get_integral_array(hml_ctx* c, float* sum, float* sum_sq) {
+    NEED_LOADED();
+    HIPCHK(hipStreamSynchronize(c->stream));
+    std::vector<float2> v(c->T + 1);
+    HIPCHK(hipMemcpy(v.data(), c->d_ia, (c->T + 1) * sizeof(float2), hipMemcpyDeviceToHost));
+    for (uint64_t i = 0; i <= c->T; ++i) { sum[i] = v[i].x; sum_sq[i] = v[i].y; }
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------- results
+int hml_recorded_sweeps(hml_ctx* c, uint64_t* n) {
+    NEED_MODEL();
+    hml_model m; if (int r = fetch_model(c, &m)) return r;
+    *n = m.n_recorded; return 0;
+}
+
+int hml_marginals_rle(hml_ctx* c, uint64_t* n_segments, int* n_columns, uint64_t* seg_len, int32_t* counts) {
+    NEED_MODEL();
+    hml_model m; if (int r = fetch_model(c, &m)) return r;
+    if (m.err_code) { char buf[256]; return set_err(HML_ERR_MODEL, deverr_text(m.err_code, m.err_value, buf, sizeof buf)); }
+    const uint32_t T = (uint32_t)c->T;
+    const int K = c->K;
+    const int ncol = m.max_state_recorded + 1;
+    if (!c->d_diff || m.n_recorded == 0) {   // nothing recorded: one segment, no count columns
+        *n_segments = 1; *n_columns = 0;
+        if (seg_len) seg_len[0] = T;
+        return 0;
+    }
+    uint32_t *d_cnt = nullptr, *d_off = nullptr, *d_seg = nullptr;
+    int32_t* d_g = nullptr;
+    HIPCHK(hipMalloc(&d_cnt, c->n_spans * sizeof(uint32_t)));
+    HIPCHK(hipMalloc(&d_off, c->n_spans * sizeof(uint32_t)));
+    hipLaunchKernelGGL(hml_k_marg_count, dim3((c->n_spans + 3) / 4), dim3(256), 0, c->stream, c->d_boundary, T, d_cnt);
+    // reuse the span-offset scan; it writes the total into mdl->B, so save and restore B
+    std::vector<uint32_t> h_cnt(c->n_spans);
+    HIPCHK(hipMemcpyAsync(h_cnt.data(), d_cnt, c->n_spans * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    std::vector<uint32_t> h_off(c->n_spans);
+    uint64_t M = 0;
+    for (uint32_t i = 0; i < c->n_spans; ++i) { h_off[i] = (uint32_t)M; M += h_cnt[i]; }
+    *n_segments = M; *n_columns = ncol;
+    if (!seg_len) { hipFree(d_cnt); hipFree(d_off); return 0; }
+    HIPCHK(hipMemcpyAsync(d_off, h_off.data(), c->n_spans * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMalloc(&d_seg, (M + 1) * sizeof(uint32_t)));
+    HIPCHK(hipMalloc(&d_g, M * K * sizeof(int32_t)));
+    hipLaunchKernelGGL(hml_k_marg_scatter, dim3((c->n_spans + 3) / 4), dim3(256), 0, c->stream, c->d_boundary, T, d_off, d_seg);
+    hipLaunchKernelGGL(hml_k_marg_gather, dim3(grid_for(M, 256, 1, 16384)), dim3(256), 0, c->stream, c->d_diff, T, K, d_seg,
+                       (uint32_t)M, d_g);
+    KLAUNCH_CHECK();
+    std::vector<uint32_t> h_seg(M);
+    std::vector<int32_t> h_g(M * K);
+    HIPCHK(hipMemcpyAsync(h_seg.data(), d_seg, M * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(h_g.data(), d_g, M * K * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    hipFree(d_cnt); hipFree(d_off); hipFree(d_seg); hipFree(d_g);
+    // running sums over segments: counts of a segment = sum of the differences at all boundaries up to it
+    std::vector<int32_t> cur(K, 0);
+    for (uint64_t i = 0; i < M; ++i) {
+        for (int s = 0; s < K; ++s) cur[s] += h_g[i * K + s];
+        seg_len[i] = (uint64_t)((i + 1 < M ? h_seg[i + 1] : T) - h_seg[i]);
+        if (counts) for (int s = 0; s < ncol; ++s) counts[i * ncol + s] = cur[s];
+    }
+    return 0;
+}
+
+int hml_marginals_dense_device(hml_ctx* c, void* out_dev, const int32_t* perm) {
+    NEED_MODEL();
+    const uint32_t T = (uint32_t)c->T;
+    const int K = c->K;
+    int32_t* out = (int32_t*)out_dev;
+    if (!c->d_diff) {
+        HIPCHK(hipMemsetAsync(out, 0, (uint64_t)(K + 1) * T * sizeof(int32_t), c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        return 0;
+    }
+    const uint32_t n_chunks = c->n_spans;
+    int32_t *d_cs = nullptr, *d_perm = nullptr;
+    HIPCHK(hipMalloc(&d_cs, (uint64_t)K * n_chunks * sizeof(int32_t)));
+    if (perm) {
+        HIPCHK(hipMalloc(&d_perm, K * sizeof(int32_t)));
+        HIPCHK(hipMemcpyAsync(d_perm, perm, K * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+    }
+    hipLaunchKernelGGL(hml_k_dense_partial, dim3(n_chunks, K), dim3(256), 0, c->stream, c->d_diff, T, K, d_cs, n_chunks);
+    hipLaunchKernelGGL(hml_k_dense_chunkscan, dim3(K), dim3(1024), 0, c->stream, d_cs, n_chunks);
+    hipLaunchKernelGGL(hml_k_dense_final, dim3(n_chunks, K), dim3(256), 0, c->stream, c->d_diff, T, K, d_cs, n_chunks, d_perm, out);
+    hipLaunchKernelGGL(hml_k_dense_boundary, dim3(grid_for(T, 256, 1, 65536)), dim3(256), 0, c->stream, c->d_boundary, T,
+                       out + (uint64_t)K * T);
+    KLAUNCH_CHECK();
+    HIPCHK(hipStreamSynchronize(c->stream));
+    hipFree(d_cs);
+    if (d_perm) hipFree(d_perm);
+    return 0;
+}
+
+int hml_get_stats(hml_ctx* c, hml_stats* out) {
+    NEED_MODEL();
+    hml_model m; if (int r = fetch_model(c, &m)) return r;
+    out->sweeps = m.sweeps; out->block_updates = m.block_updates; out->uniform_fallbacks = m.uniform_fallbacks;
+    out->forward_refits = m.forward_refits; out->forward_serial = m.forward_serial;
+    return 0;
+}
+
+int hml_profile_enable(hml_ctx* c, int on) {
+    if (!c) return set_err(HML_ERR_ARG, "null context");
+    c->profiling = on != 0;
+    return 0;
+}
+
+int hml_profile_get(hml_ctx* c, const char* name, double* total_ms, uint64_t* launches) {
+    if (!c) return set_err(HML_ERR_ARG, "null context");
+    if (int r = ctx_bind(c)) return r;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    auto& acc = c->prof[name];
+    for (auto& p : acc.pending) {
+        float ms = 0;
+        hipEventElapsedTime(&ms, p.first, p.second);
+        acc.ms += ms; acc.n++;
+        c->ev_pool.push_back(p.first); c->ev_pool.push_back(p.second);
+    }
+    acc.pending.clear();
+    if (total_ms) *total_ms = acc.ms;
+    if (launches) *launches = acc.n;
+    return 0;
+}
+
+int hml_debug_eval(int device, int fn, const float* a, const float* b, float* out, uint64_t n, uint64_t seed) {
+    HIPCHK(hipSetDevice(device));
+    float *d_a = nullptr, *d_b = nullptr, *d_o = nullptr;
+    HIPCHK(hipMalloc(&d_a, n * 4)); HIPCHK(hipMalloc(&d_o, n * 4));
+    HIPCHK(hipMemcpy(d_a, a, n * 4, hipMemcpyHostToDevice));
+    if (b) { HIPCHK(hipMalloc(&d_b, n * 4)); HIPCHK(hipMemcpy(d_b, b, n * 4, hipMemcpyHostToDevice)); }
+    hipLaunchKernelGGL(hml_k_debug_eval, dim3(1024), dim3(256), 0, 0, fn, d_a, d_b, d_o, n, seed);
+    KLAUNCH_CHECK();
+    HIPCHK(hipMemcpy(out, d_o, n * 4, hipMemcpyDeviceToHost));
+    hipFree(d_a); hipFree(d_o); if (d_b) hipFree(d_b);
+    return 0;
+}
+
+int hml_synth_gauss(float* x, int16_t* states, uint64_t T, int K, const float* mu, float sigma, double mean_dwell,
+                    uint64_t seed, int nthreads) {
+    if (!x || !mu || K < 1) return set_err(HML_ERR_ARG, "invalid argument");
+    hml_synth_gauss_trace(x, states, T, K, mu, sigma, mean_dwell, seed, nthreads);
+    return 0;
+}
+
+}  // extern "C"

@@ -92,25 +92,51 @@ struct hml_normal_f32 {
 };
 
 // gamma_distribution<float>(alpha, beta)(urng) with a fresh distribution object.
+// libstdc++ nests three do-while loops (polar pair / v <= 0 / squeeze-and-log rejection) around a
+// normal_distribution member that caches the pair's second variate.  The same sequence of draws and
+// tests is written here as ONE loop with explicit state: hipcc (ROCm 7.2, -O3) mis-executes the
+// nested form on gfx950 when the lanes of a wavefront leave the loops at different trip counts
+// (tests/test_gpu_parity.py::test_gamma_lanes_independent keeps watch).
 template <class M, class Src>
 HML_HD float hml_gamma_f32(Src& src, float alpha, float beta) {
     const float malpha = alpha < 1.0f ? alpha + 1.0f : alpha;
     const float a1 = malpha - 1.0f / 3.0f;
     const float a2 = 1.0f / M::sqrtf_(9.0f * a1);
-    hml_normal_f32<M> nd;
-    float u, v, n;
-    do {
-        do {
-            n = nd.draw(src, 0.0f, 1.0f);
-            v = 1.0f + a2 * n;
-        } while (v <= 0.0f);
-        v = v * v * v;
-        u = hml_canonical_f32(src);
-    } while ((double)u > (double)1.0f - 0.0331 * (double)n * (double)n * (double)n * (double)n &&
-             ((double)M::logf_(u) > (0.5 * (double)n * (double)n +
-                                     (double)a1 * ((1.0 - (double)v) + (double)M::logf_(v)))));
+    float saved = 0.0f;     // normal_distribution::_M_saved
+    bool have = false;      // normal_distribution::_M_saved_available
+    float v = 0.0f;
+    bool accepted = false;
+    while (!accepted) {
+        float n;
+        if (have) {
+            have = false;
+            n = saved;
+        } else {
+            float x = 0.0f, y = 0.0f, r2 = 2.0f;
+            while (r2 > 1.0f || r2 == 0.0f) {
+                x = (float)((double)(2.0f * hml_canonical_f32(src)) - 1.0);
+                y = (float)((double)(2.0f * hml_canonical_f32(src)) - 1.0);
+                r2 = x * x + y * y;
+            }
+            const float mult = M::sqrtf_(-2 * M::logf_(r2) / r2);
+            saved = x * mult;
+            have = true;
+            n = y * mult;
+        }
+        n = n * 1.0f + 0.0f;                 // __ret * stddev() + mean() of the (0,1) member
+        const float vv = 1.0f + a2 * n;
+        if (!(vv <= 0.0f)) {                 // `while (__v <= 0.0)` draws another n
+            v = vv * vv * vv;
+            const float u = hml_canonical_f32(src);
+            const bool c1 = (double)u > (double)1.0f - 0.0331 * (double)n * (double)n * (double)n * (double)n;
+            const bool c2 = (double)M::logf_(u) >
+                            (0.5 * (double)n * (double)n + (double)a1 * ((1.0 - (double)v) + (double)M::logf_(v)));
+            accepted = !(c1 && c2);
+        }
+    }
     if (alpha == malpha) return a1 * v * beta;
-    do u = hml_canonical_f32(src); while (u == 0.0f);
+    float u = hml_canonical_f32(src);
+    while (u == 0.0f) u = hml_canonical_f32(src);
     return M::powf_(u, 1.0f / alpha) * a1 * v * beta;
 }
 

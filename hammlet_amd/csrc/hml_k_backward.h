@@ -1,0 +1,290 @@
+// Backward categorical sampling, mixture sampling, and the count pass.
+#ifndef HML_K_BACKWARD_H
+#define HML_K_BACKWARD_H
+
+#include "hml_dist.h"
+#include "hml_k_forward.h"
+#include "hml_philox.h"
+#include "hml_state.h"
+
+#define HML_MAP_IDENTITY 0xfedcba9876543210ull
+
+// (f o g)(x) = f(g(x)) on maps [K]->[K] packed 4 bits per entry
+template <int K>
+__device__ __forceinline__ unsigned long long hml_map_compose(unsigned long long f, unsigned long long g) {
+    unsigned long long r = 0ull;   // entries x >= K are never read
+#pragma unroll
+    for (int x = 0; x < K; ++x) {
+        const unsigned y = (unsigned)(g >> (4 * x)) & 15u;
+        const unsigned long long z = (f >> (4 * y)) & 15ull;
+        r |= z << (4 * x);
+    }
+    return r;
+}
+
+__device__ __forceinline__ unsigned long long hml_shfl_down_u64(unsigned long long v, int d) {
+    const unsigned lo = (unsigned)v, hi = (unsigned)(v >> 32);
+    const unsigned lo2 = __shfl_down(lo, d), hi2 = __shfl_down(hi, d);
+    return ((unsigned long long)hi2 << 32) | lo2;
+}
+
+// std::discrete_distribution draw (hml_dist.h) over K register-resident weights
+template <int K>
+__device__ __forceinline__ int hml_categorical_k(const float (&w)[K], double u) {
+    double sum = 0.0;
+#pragma unroll
+    for (int i = 0; i < K; ++i) sum += (double)w[i];
+    double cp = 0.0;
+    int res = K - 1;
+    bool done = false;
+#pragma unroll
+    for (int i = 0; i < K; ++i) {
+        cp += (double)w[i] / sum;
+        const double c = (i == K - 1) ? 1.0 : cp;
+        if (!done && !(c < u)) { res = i; done = true; }
+    }
+    return res;
+}
+
+// ------------------------------------------------------------------------------------------
+// K7a backward_maps - backward sampling (reference src/StateSequence/ForwardBackward.hpp:133-162,
+// Trellis::sample src/Trellis.hpp:61-66):  q_B ~ Cat(r_B),  q_t ~ Cat(r_t[i] * A(i, q_{t+1})).
+// Row t's uniform u_t comes from Philox sub-stream (CAT, epoch, t), so for every possible
+// successor state x the draw cand_t(x) is known in advance: row t is a MAP [K]->[K].  The state
+// sequence is the composition of those maps applied from the last row down - associative, hence a
+// scan.  One wavefront owns 64 consecutive rows: lane l evaluates row t = 64c + l + 1, then a
+// suffix scan over the wavefront yields S_t = cand_t o ... o cand_{64c+64} for each row and the
+// chunk's map S_{64c+1}.
+// ------------------------------------------------------------------------------------------
+template <int K>
+__global__ __launch_bounds__(256) void hml_k_backward_maps(const float* __restrict__ rows, hml_model* __restrict__ mdl,
+                                                           unsigned long long* __restrict__ smap,
+                                                           unsigned long long* __restrict__ cmap) {
+    const uint32_t B = mdl->B;
+    const uint32_t nchunks = (B + HML_BWD_CHUNK - 1u) / HML_BWD_CHUNK;
+    const int lane = threadIdx.x & 63;
+    const uint32_t wave_global = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
+    const unsigned long long epoch = mdl->epoch;
+    const hml_key key = mdl->key;
+    for (uint32_t c = wave_global; c < nchunks; c += nwaves) {
+        const uint32_t t = c * HML_BWD_CHUNK + (uint32_t)lane + 1u;
+        unsigned long long map = HML_MAP_IDENTITY;
+        if (t <= B) {
+            const hml_u32x4 o = hml_stream4(key, HML_KIND_CAT, epoch, t, 0);
+            const double u = hml_canonical_f64(o.v[0], o.v[1]);
+            float r[K];
+#pragma unroll
+            for (int i = 0; i < K; ++i) r[i] = rows[(uint64_t)t * K + i];
+            map = 0ull;
+            if (t == B) {
+                const unsigned long long st = (unsigned long long)hml_categorical_k<K>(r, u);
+#pragma unroll
+                for (int x = 0; x < K; ++x) map |= st << (4 * x);
+            } else {
+#pragma unroll
+                for (int x = 0; x < K; ++x) {
+                    float w[K];
+#pragma unroll
+                    for (int i = 0; i < K; ++i) {
+                        w[i] = r[i] * mdl->A[i * K + x];
+                        if (w[i] < 0.0f) hml_raise(mdl, HML_DEVERR_NEG_BACKWARD, w[i]);
+                    }
+                    map |= (unsigned long long)hml_categorical_k<K>(w, u) << (4 * x);
+                }
+            }
+        }
+        // suffix scan of map composition across the wavefront
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            unsigned long long o = hml_shfl_down_u64(map, d);
+            if (lane + d >= 64) o = HML_MAP_IDENTITY;
+            map = hml_map_compose<K>(map, o);
+        }
+        if (t <= B) smap[t] = map;
+        if (lane == 0) cmap[c] = map;
+    }
+}
+
+// K7b backward_chain - compose the chunk maps from the last chunk down: entry[c] = state of the first
+// row of chunk c+1 (entry of the last chunk is a dummy 0: its map is constant).  One workgroup.
+template <int K>
+__global__ __launch_bounds__(1024) void hml_k_backward_chain(const unsigned long long* __restrict__ cmap,
+                                                             const hml_model* __restrict__ mdl,
+                                                             uint8_t* __restrict__ entry) {
+    __shared__ unsigned long long P[1024];
+    const uint32_t B = mdl->B;
+    const uint32_t NC = (B + HML_BWD_CHUNK - 1u) / HML_BWD_CHUNK;
+    const int tid = threadIdx.x;
+    const uint32_t per = (NC + 1023u) / 1024u;
+    const uint32_t a = (uint32_t)tid * per < NC ? (uint32_t)tid * per : NC;
+    const uint32_t b = (a + per < NC) ? a + per : NC;
+    // product of this thread's maps: cmap[a] o cmap[a+1] o ... o cmap[b-1]
+    unsigned long long prod = HML_MAP_IDENTITY;
+    for (uint32_t c = b; c > a; --c) prod = hml_map_compose<K>(cmap[c - 1], prod);
+    P[tid] = prod;
+    __syncthreads();
+    // suffix scan: Q[tid] = P[tid] o P[tid+1] o ... o P[1023]
+    for (int d = 1; d < 1024; d <<= 1) {
+        const unsigned long long o = (tid + d < 1024) ? P[tid + d] : HML_MAP_IDENTITY;
+        __syncthreads();
+        P[tid] = hml_map_compose<K>(P[tid], o);
+        __syncthreads();
+    }
+    if (a >= b) return;
+    // state entering this thread's last chunk = (composition of all later chunks)(dummy 0)
+    const unsigned long long later = (tid + 1 < 1024) ? P[tid + 1] : HML_MAP_IDENTITY;
+    unsigned x = (unsigned)(later & 15ull);
+    for (uint32_t c = b; c > a; --c) {
+        entry[c - 1] = (uint8_t)x;
+        x = (unsigned)(cmap[c - 1] >> (4 * x)) & 15u;
+    }
+}
+
+// K7c backward_apply - q_b = S_{b+1}(entry[chunk])
+__global__ __launch_bounds__(256) void hml_k_backward_apply(const unsigned long long* __restrict__ smap,
+                                                            const uint8_t* __restrict__ entry,
+                                                            const hml_model* __restrict__ mdl, int16_t* __restrict__ q) {
+    const uint32_t B = mdl->B;
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t b = blockIdx.x * blockDim.x + threadIdx.x; b < B; b += stride) {
+        const unsigned x = entry[b / HML_BWD_CHUNK];
+        q[b] = (int16_t)((smap[b + 1] >> (4 * x)) & 15ull);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// K6m mixture - StateSequence<Mixture>::sample (reference src/StateSequence/Mixture.hpp:90-129):
+// q_b ~ Cat(expf(E_s - max E)) independently per block, uniform from sub-stream (MIX, epoch, b).
+// `em` holds the weights written by the emission kernel in mixture mode.
+// ------------------------------------------------------------------------------------------
+template <int K>
+__global__ __launch_bounds__(256) void hml_k_mixture(const float* __restrict__ em, const hml_model* __restrict__ mdl,
+                                                     int16_t* __restrict__ q) {
+    const uint32_t B = mdl->B;
+    const unsigned long long epoch = mdl->epoch;
+    const hml_key key = mdl->key;
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t b = blockIdx.x * blockDim.x + threadIdx.x; b < B; b += stride) {
+        float w[K];
+#pragma unroll
+        for (int s = 0; s < K; ++s) w[s] = em[(uint64_t)b * K + s];
+        const hml_u32x4 o = hml_stream4(key, HML_KIND_MIX, epoch, b, 0);
+        q[b] = (int16_t)hml_categorical_k<K>(w, hml_canonical_f64(o.v[0], o.v[1]));
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// K8 state_reduce - the count pass (reference src/StateSequence/ForwardBackward.hpp:170-200,
+// Mixture.hpp:113-128): K x K transition counts ([s][s] += N-1, [prev][s] += 1, prev_0 = 0),
+// occupancies, per-state (sum x, sum x^2, n).  Counts are exact integers (device atomics).  The
+// floating-point sums use a FIXED tree so that the result does not depend on scheduling:
+//   chunk (256 blocks, one workgroup pass) = 4 wavefront butterflies added in wavefront order,
+//   group g accumulates chunks g, g+1024, ... in order, the parameter kernel adds the 1024 groups
+//   in a pairwise tree.  Doubles throughout; the CPU checker mirrors the same tree.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ double hml_shfl_xor_f64(double v, int m) {
+    const unsigned long long u = hml_d2u(v);
+    const unsigned lo = __shfl_xor((unsigned)u, m), hi = __shfl_xor((unsigned)(u >> 32), m);
+    return hml_u2d(((unsigned long long)hi << 32) | lo);
+}
+
+template <int K>
+__global__ __launch_bounds__(256) void hml_k_counts(const int16_t* __restrict__ q, const uint32_t* __restrict__ starts,
+                                                    const float2* __restrict__ bstat, hml_model* __restrict__ mdl,
+                                                    double* __restrict__ partial /*[GROUPS][K][2]*/) {
+    __shared__ unsigned long long h_trans[K * K];
+    __shared__ unsigned long long h_occ[K];
+    __shared__ double wsum[4][K][2];
+    const uint32_t B = mdl->B;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t g = blockIdx.x;
+    for (int i = tid; i < K * K; i += 256) h_trans[i] = 0ull;
+    if (tid < K) h_occ[tid] = 0ull;
+    __syncthreads();
+    double acc_s[K], acc_q[K];   // only thread 0 uses them
+#pragma unroll
+    for (int s = 0; s < K; ++s) { acc_s[s] = 0.0; acc_q[s] = 0.0; }
+    const uint32_t nchunks = (B + HML_REDUCE_CHUNK - 1u) / HML_REDUCE_CHUNK;
+    for (uint32_t c = g; c < nchunks; c += HML_REDUCE_GROUPS) {
+        const uint32_t b = c * HML_REDUCE_CHUNK + (uint32_t)tid;
+        int st = -1;
+        double vx = 0.0, vq = 0.0;
+        if (b < B) {
+            st = q[b];
+            const uint32_t n = starts[b + 1] - starts[b];
+            const int prev = (b == 0) ? 0 : (int)q[b - 1];
+            const float2 v = bstat[b];
+            vx = (double)v.x; vq = (double)v.y;
+            atomicAdd(&h_trans[st * K + st], (unsigned long long)(n - 1u));
+            atomicAdd(&h_trans[prev * K + st], 1ull);
+            atomicAdd(&h_occ[st], (unsigned long long)n);
+        }
+#pragma unroll
+        for (int s = 0; s < K; ++s) {
+            double a = (st == s) ? vx : 0.0, d = (st == s) ? vq : 0.0;
+#pragma unroll
+            for (int m = 1; m < 64; m <<= 1) {
+                a = a + hml_shfl_xor_f64(a, m);
+                d = d + hml_shfl_xor_f64(d, m);
+            }
+            if (lane == 0) { wsum[wave][s][0] = a; wsum[wave][s][1] = d; }
+        }
+        __syncthreads();
+        if (tid == 0) {
+#pragma unroll
+            for (int s = 0; s < K; ++s) {
+                double cs = 0.0, cq = 0.0;
+#pragma unroll
+                for (int wv = 0; wv < 4; ++wv) { cs = cs + wsum[wv][s][0]; cq = cq + wsum[wv][s][1]; }
+                acc_s[s] = acc_s[s] + cs;
+                acc_q[s] = acc_q[s] + cq;
+            }
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+#pragma unroll
+        for (int s = 0; s < K; ++s) {
+            partial[((uint64_t)g * K + s) * 2 + 0] = acc_s[s];
+            partial[((uint64_t)g * K + s) * 2 + 1] = acc_q[s];
+        }
+    }
+    for (int i = tid; i < K * K; i += 256)
+        if (h_trans[i]) atomicAdd(&mdl->trans[i], h_trans[i]);
+    if (tid < K && h_occ[tid]) atomicAdd(&mdl->occ[tid], h_occ[tid]);
+}
+
+// ------------------------------------------------------------------------------------------
+// K10 marginals_accumulate - Records::record(state, N) + StateMarginals::addRecord (reference
+// src/Records.hpp:155-235, src/StateMarginals.hpp:51-137).  Adjacent blocks in the same state form
+// one segment; every segment adds one count for its state to all of its positions, and the
+// marginals file is cut wherever any recorded sweep had a segment boundary.  Device form: +1/-1
+// into a per-state difference array at segment starts and a boundary bit; one thread per block.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void hml_k_record(const int16_t* __restrict__ q, const uint32_t* __restrict__ starts,
+                                                    hml_model* __restrict__ mdl, int32_t* __restrict__ diff,
+                                                    uint32_t* __restrict__ boundary) {
+    const uint32_t B = mdl->B;
+    const uint64_t T1 = (uint64_t)mdl->T + 1u;
+    const uint32_t stride = gridDim.x * blockDim.x;
+    int mx = -1;
+    for (uint32_t b = blockIdx.x * blockDim.x + threadIdx.x; b < B; b += stride) {
+        const int st = q[b];
+        const int prev = (b == 0) ? -1 : (int)q[b - 1];
+        if (st != prev) {
+            const uint32_t t = starts[b];
+            atomicAdd(&diff[(uint64_t)st * T1 + t], 1);
+            if (prev >= 0) atomicAdd(&diff[(uint64_t)prev * T1 + t], -1);
+            atomicOr(&boundary[t >> 5], 1u << (t & 31u));
+            mx = st > mx ? st : mx;
+        }
+    }
+    if (mx >= 0) atomicMax(&mdl->max_state_recorded, mx);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        const unsigned long long n = atomicAdd(&mdl->n_recorded, 1ull);
+        if (n >= 0x7fffffffull) hml_raise(mdl, HML_DEVERR_TOO_MANY_RECORDS, 0.0f);
+    }
+}
+
+#endif

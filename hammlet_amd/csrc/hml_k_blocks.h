@@ -1,0 +1,172 @@
+// Per-sweep block structure: threshold scan + compaction (the HBM-bound kernel) and block statistics.
+#ifndef HML_K_BLOCKS_H
+#define HML_K_BLOCKS_H
+
+#include "hml_state.h"
+
+// ------------------------------------------------------------------------------------------
+// K4 blocks_compact - Blocks<BreakpointArray>::next (reference src/Blocks/BreakpointArray.hpp:216-235).
+//
+// The reference walks uint16 "next larger weight" pointers; the set of block starts it visits is
+// exactly {0} u {t >= 1 : !(w[t] < thr)}.  On the GPU that is a flat scan of w[0..T) - 4 bytes
+// per position, nothing else - followed by an ordered compaction:
+//   (a) scan:    one wavefront per span of 4096 positions, 16 x (64 lanes x float4) coalesced loads
+//                issued up-front; flagged positions are written, in order, as 16-bit offsets into
+//                the span's slot of a staging array; the span's count goes to span_count[].
+//   (b) offsets: exclusive scan of span_count (one workgroup) -> span_offset[], B.
+//   (c) scatter: staged offsets -> starts[], starts[B] = T.
+// Nothing but flagged positions is ever written, so at typical compression (1 start per ~500
+// positions) the kernel's traffic is the 4*T bytes of w.
+// ------------------------------------------------------------------------------------------
+
+typedef float hml_f4 __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(256) void hml_k_compact_scan(const float* __restrict__ w, uint32_t T,
+                                                          const hml_model* __restrict__ mdl, float thr_override,
+                                                          int use_override, uint16_t* __restrict__ stage,
+                                                          uint32_t* __restrict__ span_count) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint32_t span = blockIdx.x * 4u + (uint32_t)wave;
+    const uint64_t base = (uint64_t)span * HML_SPAN;
+    if (base >= T) return;
+    const float thr = use_override ? thr_override : mdl->thr;
+    uint32_t running = 0;
+    uint16_t* __restrict__ out = stage + base;
+    if (base + HML_SPAN <= T) {
+        // full span: 16 independent 16-byte loads per lane
+        hml_f4 v[16];
+        const hml_f4* __restrict__ p = reinterpret_cast<const hml_f4*>(w + base) + lane;
+#pragma unroll
+        for (int it = 0; it < 16; ++it) v[it] = __builtin_nontemporal_load(p + it * 64);
+#pragma unroll
+        for (int it = 0; it < 16; ++it) {
+            bool f0 = !(v[it].x < thr), f1 = !(v[it].y < thr), f2 = !(v[it].z < thr), f3 = !(v[it].w < thr);
+            if (span == 0 && it == 0 && lane == 0) f0 = true;   // position 0 always starts a block
+            const bool any = f0 | f1 | f2 | f3;
+            if (__ballot(any) == 0ull) continue;   // wave-uniform
+            const unsigned long long m0 = __ballot(f0), m1 = __ballot(f1), m2 = __ballot(f2), m3 = __ballot(f3);
+            const unsigned long long lt = (1ull << lane) - 1ull;
+            uint32_t pos = running + __popcll(m0 & lt) + __popcll(m1 & lt) + __popcll(m2 & lt) + __popcll(m3 & lt);
+            const uint32_t off = (uint32_t)it * 256u + (uint32_t)lane * 4u;
+            if (f0) out[pos++] = (uint16_t)(off);
+            if (f1) out[pos++] = (uint16_t)(off + 1);
+            if (f2) out[pos++] = (uint16_t)(off + 2);
+            if (f3) out[pos++] = (uint16_t)(off + 3);
+            running += __popcll(m0) + __popcll(m1) + __popcll(m2) + __popcll(m3);
+        }
+    } else {
+        // tail span: guarded scalar loads
+        for (int it = 0; it < 16; ++it) {
+            bool f[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint64_t t = base + (uint64_t)it * 256u + (uint64_t)lane * 4u + j;
+                f[j] = (t < T) ? (t == 0 || !(w[t] < thr)) : false;
+            }
+            const unsigned long long m0 = __ballot(f[0]), m1 = __ballot(f[1]), m2 = __ballot(f[2]), m3 = __ballot(f[3]);
+            if ((m0 | m1 | m2 | m3) == 0ull) continue;
+            const unsigned long long lt = (1ull << lane) - 1ull;
+            uint32_t pos = running + __popcll(m0 & lt) + __popcll(m1 & lt) + __popcll(m2 & lt) + __popcll(m3 & lt);
+            const uint32_t off = (uint32_t)it * 256u + (uint32_t)lane * 4u;
+            if (f[0]) out[pos++] = (uint16_t)(off);
+            if (f[1]) out[pos++] = (uint16_t)(off + 1);
+            if (f[2]) out[pos++] = (uint16_t)(off + 2);
+            if (f[3]) out[pos++] = (uint16_t)(off + 3);
+            running += __popcll(m0) + __popcll(m1) + __popcll(m2) + __popcll(m3);
+        }
+    }
+    if (lane == 0) span_count[span] = running;
+}
+
+// exclusive scan of span_count[0..n_spans) -> span_offset, total -> mdl->B (one workgroup of 1024)
+__global__ __launch_bounds__(1024) void hml_k_compact_offsets(const uint32_t* __restrict__ span_count,
+                                                              uint32_t* __restrict__ span_offset, uint32_t n_spans,
+                                                              hml_model* __restrict__ mdl, uint32_t* __restrict__ starts,
+                                                              uint32_t T) {
+    __shared__ uint32_t part[1024];
+    const int tid = threadIdx.x;
+    const uint32_t per = (n_spans + 1023u) / 1024u;
+    const uint32_t a = (uint32_t)tid * per;
+    const uint32_t b = (a + per < n_spans) ? a + per : n_spans;
+    uint32_t sum = 0;
+    for (uint32_t i = a; i < b; ++i) sum += span_count[i];
+    part[tid] = sum;
+    __syncthreads();
+    // Hillis-Steele inclusive scan over the 1024 partials
+    for (int d = 1; d < 1024; d <<= 1) {
+        uint32_t v = (tid >= d) ? part[tid - d] : 0u;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    uint32_t run = part[tid] - sum;   // exclusive prefix of this thread's range
+    for (uint32_t i = a; i < b; ++i) {
+        span_offset[i] = run;
+        run += span_count[i];
+    }
+    if (tid == 1023) {
+        const uint32_t B = part[1023];
+        mdl->B = B;
+        starts[B] = T;
+    }
+}
+
+__global__ __launch_bounds__(256) void hml_k_compact_scatter(const uint16_t* __restrict__ stage,
+                                                             const uint32_t* __restrict__ span_count,
+                                                             const uint32_t* __restrict__ span_offset, uint32_t n_spans,
+                                                             uint32_t* __restrict__ starts) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint32_t span = blockIdx.x * 4u + (uint32_t)wave;
+    if (span >= n_spans) return;
+    const uint32_t cnt = span_count[span];
+    const uint32_t off = span_offset[span];
+    const uint32_t base = span * (uint32_t)HML_SPAN;
+    const uint16_t* __restrict__ in = stage + (uint64_t)base;
+    for (uint32_t k = lane; k < cnt; k += 64) starts[off + k] = base + (uint32_t)in[k];
+}
+
+// ------------------------------------------------------------------------------------------
+// K5 block_stats - Statistics<IntegralArray,Normal>::addBlockStats / setStats (reference
+// src/Statistics/IntegralArray.hpp:104-124,198-212) with KahanAggregator (src/KahanAggregator.hpp:26-45):
+//   pos = Kahan(IA[start], IA[c] for every cell boundary c in (start,end));  neg = IA[end] unless
+//   end % 65535 == 0;  (sum x, sum x^2) = pos - neg.      Same operations, same order, float.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void hml_block_stats_one(const float2* __restrict__ ia, uint32_t start, uint32_t end,
+                                                    float& s, float& q) {
+    float ps = 0.0f, pq = 0.0f, es = 0.0f, eq = 0.0f;
+    {
+        const float2 v = ia[start];
+        const float y = v.x - es, t = ps + y; es = (t - ps) - y; ps = t;
+        const float y2 = v.y - eq, t2 = pq + y2; eq = (t2 - pq) - y2; pq = t2;
+    }
+    for (uint64_t c = ((uint64_t)start + HML_CELLSIZE) / HML_CELLSIZE * HML_CELLSIZE; c < end; c += HML_CELLSIZE) {
+        const float2 v = ia[c];
+        const float y = v.x - es, t = ps + y; es = (t - ps) - y; ps = t;
+        const float y2 = v.y - eq, t2 = pq + y2; eq = (t2 - pq) - y2; pq = t2;
+    }
+    float ns = 0.0f, nq = 0.0f;
+    if (end % HML_CELLSIZE != 0) {
+        const float2 v = ia[end];
+        // KahanAggregator::subtract on a fresh aggregator: y = x - 0; temp = 0 + y
+        const float y = v.x - 0.0f; ns = 0.0f + y;
+        const float y2 = v.y - 0.0f; nq = 0.0f + y2;
+    }
+    s = ps - ns;
+    q = pq - nq;
+}
+
+__global__ __launch_bounds__(256) void hml_k_block_stats(const float2* __restrict__ ia,
+                                                         const uint32_t* __restrict__ starts,
+                                                         const hml_model* __restrict__ mdl,
+                                                         float2* __restrict__ bstat) {
+    const uint32_t B = mdl->B;
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t b = blockIdx.x * blockDim.x + threadIdx.x; b < B; b += stride) {
+        const uint32_t s = starts[b], e = starts[b + 1];
+        float sx, sq;
+        hml_block_stats_one(ia, s, e, sx, sq);
+        bstat[b] = make_float2(sx, sq);
+    }
+}
+
+#endif

@@ -1,0 +1,187 @@
+// Conjugate parameter resampling: the K-sized step between two sweeps.
+#ifndef HML_K_PARAMS_H
+#define HML_K_PARAMS_H
+
+#include "hml_dist.h"
+#include "hml_k_backward.h"
+#include "hml_state.h"
+
+struct hml_dev_src {
+    hml_stream s;
+    __device__ __forceinline__ uint32_t next() { return hml_stream_next(&s); }
+};
+
+// logNormalizer / logA / threshold from the current parameters (EFD.hpp:35-38,
+// ForwardBackward.hpp:47-52, BreakpointArray.hpp:196-199 + Theta.hpp:227-234)
+template <int K>
+__device__ __forceinline__ void hml_derive(hml_model* mdl, int tid) {
+    if (tid < K) {
+        const float m = mdl->mu[tid], v = mdl->var[tid], sd = mdl->sd[tid];
+        mdl->logN[tid] = hml_logf(sd) + m * m / (2 * v);
+        mdl->logA[tid] = hml_logf(mdl->A[tid * K + tid]);
+    }
+    if (tid == 0) {
+        float mv = HML_INF_F;
+#pragma unroll
+        for (int k = 0; k < K; ++k) { const float v = mdl->var[k]; mv = (v < mv) ? v : mv; }   // std::min(result, var)
+        const float l = hml_logf((float)mdl->T);
+        const float arg = 2 * l * mv;
+        const float t = HML_SQRTF(arg);
+        mdl->thr_theta = t;
+        if (mdl->dynamic) mdl->thr = t;
+    }
+}
+
+template <int K>
+__global__ __launch_bounds__(64) void hml_k_derive(hml_model* mdl) { hml_derive<K>(mdl, threadIdx.x); }
+
+__global__ __launch_bounds__(64) void hml_k_set_dynamic(hml_model* mdl, int on, int take_threshold) {
+    if (threadIdx.x == 0) {
+        mdl->dynamic = on;
+        if (take_threshold) mdl->thr = mdl->thr_theta;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// K9 params_resample - posterior updates and draws (reference src/Conjugate.hpp:121-168,178-205;
+// src/Distribution.hpp:77-87,116-178; Theta::sample src/Theta.hpp:203-211; Initial::sample
+// src/Initial.hpp:34-40; Transitions::sample src/Transitions.hpp:75-79), then posteriors reset to
+// the priors.  mode 0: after a sweep (also finishes the count pass's fixed summation tree);
+// mode 1: draw from the priors (src/main.cpp:393-401); mode 2: Theta's constructor draw (theta only).
+// One workgroup of 1024: wavefront 0 draws theta, wavefront 1 pi, wavefronts 2.. the K*K entries
+// of A, every variate from its own Philox sub-stream.
+// ------------------------------------------------------------------------------------------
+template <int K>
+__global__ __launch_bounds__(1024) void hml_k_params(hml_model* __restrict__ mdl, const double* __restrict__ partial,
+                                                     int mode) {
+    __shared__ double wp[16][K][2];
+    __shared__ float fin[K][2];
+    __shared__ float graw[K * K];
+    __shared__ float praw[K];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const unsigned long long epoch = mdl->epoch;
+    const hml_key key = mdl->key;
+
+    if (mode == 0) {
+        // finish the fixed tree over the 1024 group partials: butterfly inside each wavefront ...
+#pragma unroll
+        for (int s = 0; s < K; ++s) {
+            double a = partial[((uint64_t)tid * K + s) * 2 + 0], d = partial[((uint64_t)tid * K + s) * 2 + 1];
+#pragma unroll
+            for (int m = 1; m < 64; m <<= 1) {
+                a = a + hml_shfl_xor_f64(a, m);
+                d = d + hml_shfl_xor_f64(d, m);
+            }
+            if (lane == 0) { wp[wave][s][0] = a; wp[wave][s][1] = d; }
+        }
+        __syncthreads();
+        // ... then a pairwise tree over the 16 wavefront sums
+        if (tid < 2 * K) {
+            const int s = tid >> 1, c = tid & 1;
+            double v[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) v[i] = wp[i][s][c];
+#pragma unroll
+            for (int st = 1; st < 16; st <<= 1)
+#pragma unroll
+                for (int i = 0; i < 16; i += 2 * st) v[i] = v[i] + v[i + st];
+            fin[s][c] = (float)v[0];
+        }
+        __syncthreads();
+    }
+
+    if (wave == 0 && lane < K) {
+        const int k = lane;
+        float alpha = mdl->nig_post[k][0], beta = mdl->nig_post[k][1], mu0 = mdl->nig_post[k][2], nu = mdl->nig_post[k][3];
+        const unsigned long long cnt = (mode == 0) ? mdl->occ[k] : 0ull;   // n_s == occupancy (exact integers)
+        if (mode == 0) { mdl->last_sum[k] = fin[k][0]; mdl->last_sumsq[k] = fin[k][1]; }
+        if (cnt > 0ull) {
+            // Conjugate<NormalInverseGammaParam>::addObservation (Conjugate.hpp:121-168)
+            const float sum = fin[k][0], sumSq = fin[k][1];
+            if (sumSq < 0.0f) hml_raise(mdl, HML_DEVERR_NEG_SUMSQ, sumSq);
+            const double N = (double)cnt;
+            const float xbar = (float)((double)sum / N);
+            float ssN = (float)((double)(sum * sum) / N);
+            if (ssN > sumSq) ssN = sumSq;
+            const float na = (float)((double)alpha + N / 2.0);
+            const float dxm = (xbar - mu0) * (xbar - mu0);
+            const float nb = (float)((double)beta +
+                                     (((double)sumSq + (N * (double)nu / (N + (double)nu)) * (double)dxm) - (double)ssN) / 2.0);
+            const float nm = (float)((double)(nu * mu0 + sum) / ((double)nu + N));
+            const float nn = (float)((double)nu + N);
+            if (na <= 0.0f) hml_raise(mdl, HML_DEVERR_NIG_ALPHA, na);
+            if (nb <= 0.0f) hml_raise(mdl, HML_DEVERR_NIG_BETA, nb);
+            if (nn <= 0.0f) hml_raise(mdl, HML_DEVERR_NIG_NU, nn);
+            if (!hml_isfinite(nm)) hml_raise(mdl, HML_DEVERR_NIG_MU0, nm);
+            alpha = na; beta = nb; mu0 = nm; nu = nn;
+        }
+        // Distribution<NormalInverseGamma>::resample (Distribution.hpp:77-87)
+        hml_dev_src src;
+        src.s = hml_stream_open(key, HML_KIND_THETA, epoch, (uint32_t)k);
+        const float g = hml_gamma_f32<hml_devmath>(src, alpha, (float)(1.0 / (double)beta));
+        const float v = (float)(1.0 / (double)g);
+        hml_normal_f32<hml_devmath> nd;
+        const float m = nd.draw(src, mu0, HML_SQRTF(v / nu));
+        if (!hml_isfinite(m)) hml_raise(mdl, HML_DEVERR_MEAN_NOT_FINITE, m);
+        if (!hml_isfinite(v)) hml_raise(mdl, HML_DEVERR_VAR_NOT_FINITE, v);
+        else if (v <= 0.0f) hml_raise(mdl, HML_DEVERR_VAR_NOT_POSITIVE, v);
+        mdl->mu[k] = m; mdl->var[k] = v; mdl->sd[k] = HML_SQRTF(v);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) mdl->nig_post[k][i] = mdl->nig_prior[i];
+    }
+    if (mode != 2) {
+        if (wave == 1 && lane < K) {
+            const int k = lane;
+            const float al = mdl->dirPi[k] + (float)mdl->occ[k];
+            hml_dev_src src;
+            src.s = hml_stream_open(key, HML_KIND_PI, epoch, (uint32_t)k);
+            praw[k] = hml_gamma_f32<hml_devmath>(src, al, 1.0f);
+        }
+        if (tid >= 128 && tid < 128 + K * K) {
+            const int e = tid - 128;
+            const float al = mdl->dirA[e] + (float)mdl->trans[e];
+            hml_dev_src src;
+            src.s = hml_stream_open(key, HML_KIND_TRANS, epoch, (uint32_t)e);
+            graw[e] = hml_gamma_f32<hml_devmath>(src, al, 1.0f);
+        }
+    }
+    __syncthreads();
+    if (mode != 2) {
+        // dirichlet_sample's normalisation (Distribution.hpp:116-139): float sum in index order
+        if (tid < K) {
+            float sum = 0.0f;
+#pragma unroll
+            for (int d = 0; d < K; ++d) sum += graw[tid * K + d];
+#pragma unroll
+            for (int d = 0; d < K; ++d) mdl->A[tid * K + d] = graw[tid * K + d] / sum;
+        }
+        if (tid == 64) {
+            float sum = 0.0f;
+#pragma unroll
+            for (int d = 0; d < K; ++d) sum += praw[d];
+#pragma unroll
+            for (int d = 0; d < K; ++d) mdl->pi[d] = praw[d] / sum;
+        }
+        // reset Dirichlet posteriors and the sweep's accumulators
+        if (tid >= 128 && tid < 128 + K * K) {
+            const int e = tid - 128;
+            mdl->dirA[e] = (e / K == e % K) ? mdl->a_diag : mdl->a_off;
+            mdl->last_trans[e] = mdl->trans[e];
+            mdl->trans[e] = 0ull;
+        }
+        if (tid >= 512 && tid < 512 + K) {
+            const int k = tid - 512;
+            mdl->dirPi[k] = mdl->pi_alpha;
+            mdl->last_occ[k] = mdl->occ[k]; mdl->occ[k] = 0ull;
+        }
+    }
+    __threadfence_block();
+    __syncthreads();
+    hml_derive<K>(mdl, tid);
+    if (tid == 1023) {
+        mdl->epoch = epoch + 1ull;
+        if (mode == 0) { mdl->sweeps += 1ull; mdl->block_updates += (unsigned long long)mdl->B; }
+    }
+}
+
+#endif

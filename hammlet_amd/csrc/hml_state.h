@@ -1,0 +1,75 @@
+// Device-resident state of one Gibbs chain and the fixed geometry shared by the kernels.
+#ifndef HML_STATE_H
+#define HML_STATE_H
+
+#include "hml_common.h"
+#include "hml_philox.h"
+
+// ---- fixed geometry (the CPU checker mirrors these numbers) ----
+#define HML_SPAN 4096          // positions scanned by one wavefront in blocks_compact
+#define HML_REDUCE_CHUNK 256   // blocks per reduction chunk (one workgroup)
+#define HML_REDUCE_GROUPS 1024 // chunk c is accumulated by group c % HML_REDUCE_GROUPS
+#define HML_BWD_CHUNK 64       // trellis rows per backward map chunk (one wavefront)
+#define HML_FWD_GROUP 16       // lanes cooperating on one forward chunk (>= HML_MAX_K)
+
+// error codes raised on the device (first one wins); mirrored into messages by the host
+enum {
+    HML_DEVERR_NONE = 0,
+    HML_DEVERR_IP_NOT_FINITE = 1,     // EFD.hpp:28-30
+    HML_DEVERR_NEG_BACKWARD = 2,      // ForwardBackward.hpp:147-149
+    HML_DEVERR_NEG_SUMSQ = 3,         // Conjugate.hpp:137-139
+    HML_DEVERR_NIG_ALPHA = 4,         // Observation.hpp:374-385
+    HML_DEVERR_NIG_BETA = 5,
+    HML_DEVERR_NIG_NU = 6,
+    HML_DEVERR_NIG_MU0 = 7,
+    HML_DEVERR_MEAN_NOT_FINITE = 8,   // Observation.hpp:148-160
+    HML_DEVERR_VAR_NOT_FINITE = 9,
+    HML_DEVERR_VAR_NOT_POSITIVE = 10,
+    HML_DEVERR_TOO_MANY_RECORDS = 11
+};
+
+struct hml_model {
+    // ---- configuration ----
+    int32_t K;
+    int32_t self_trans;
+    int32_t dynamic;
+    uint32_t T;
+    float nig_prior[4];          // alpha, beta, mu0, nu (same tuple for every state, main.cpp:348-352)
+    float a_off, a_diag, pi_alpha;
+    hml_key key;
+    // ---- current parameters ----
+    float mu[HML_MAX_K], var[HML_MAX_K], sd[HML_MAX_K];
+    float logN[HML_MAX_K];       // theta.logNormalizer(s)          (EFD.hpp:35-38)
+    float logA[HML_MAX_K];       // log A(s,s)                       (ForwardBackward.hpp:47-52)
+    float A[HML_MAX_K * HML_MAX_K];   // row-major, stride K
+    float pi[HML_MAX_K];
+    float thr;                   // current wavelet threshold
+    float thr_theta;             // threshold implied by the current theta (createBlocks(theta))
+    // ---- posteriors (reset to the priors after every draw) ----
+    float nig_post[HML_MAX_K][4];
+    float dirA[HML_MAX_K * HML_MAX_K];
+    float dirPi[HML_MAX_K];
+    // ---- block structure ----
+    uint32_t B;                  // number of blocks
+    uint32_t n_spans;
+    // ---- per-sweep accumulators (zeroed by the parameter kernel) ----
+    unsigned long long trans[HML_MAX_K * HML_MAX_K];
+    unsigned long long occ[HML_MAX_K];
+    // copies of the last sweep's sufficient statistics (probe)
+    unsigned long long last_trans[HML_MAX_K * HML_MAX_K];
+    unsigned long long last_occ[HML_MAX_K];
+    float last_sum[HML_MAX_K], last_sumsq[HML_MAX_K];
+    // ---- counters ----
+    unsigned long long epoch;
+    unsigned long long sweeps, block_updates, uniform_fallbacks, forward_refits, forward_serial;
+    unsigned long long n_recorded;
+    int32_t max_state_recorded;
+    // ---- errors ----
+    uint32_t err_code;
+    float err_value;
+    unsigned long long err_count;
+    // ---- scratch for the forward fix-up ----
+    uint32_t fwd_mismatch;       // set by a verification round that found a stale chunk
+};
+
+#endif

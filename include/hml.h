@@ -1,0 +1,164 @@
+/* hml.h - C ABI of the MI355X-native HaMMLET hot path (libhammlet_hip.so).
+ *
+ * The reference (wiedenhoeft/HaMMLET) is one header-only C++ program with no FFI seam; the
+ * types it instantiates in src/main.cpp:338-362,437,444 are what a drop-in has to stand behind.
+ * Every entry point below names the reference interface it replaces (file:line relative to the
+ * reference's repository root).  INTEGRATION.md shows the reference-side binding.
+ *
+ * Conventions: plain pointers and sizes only; every function returns 0 on success and a non-zero
+ * code on failure, with the message available from hml_last_error() (the text of the
+ * std::runtime_error the reference would have thrown, where one exists).  A context owns all
+ * device memory of one chain on one GPU and is not thread-safe (the reference is single-threaded
+ * with one shared RNG, src/main.cpp:108).  All work is enqueued on the context's HIP stream;
+ * functions that return data to the host synchronise that stream.
+ */
+#ifndef HML_H
+#define HML_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct hml_ctx hml_ctx;
+
+/* sampling methods of hml_iterate (src/main.cpp:432-445: "F" and "M" scheme tokens) */
+#define HML_METHOD_FB 'F'
+#define HML_METHOD_MIXTURE 'M'
+
+/* error codes */
+#define HML_OK 0
+#define HML_ERR_ARG 1      /* invalid argument / call order                                  */
+#define HML_ERR_HIP 2      /* HIP runtime failure                                            */
+#define HML_ERR_MODEL 3    /* a model invariant the reference enforces by throwing was hit   */
+
+const char* hml_last_error(void);
+
+/* Library/ABI version and the GPU architecture the kernels were compiled for ("gfx950"). */
+uint32_t hml_abi_version(void);
+const char* hml_device_arch(void);
+
+/* rng_t RNG(seed) (src/main.cpp:107-108) + one chain's device state.  `stream` may be NULL
+ * (a private stream is created) or a hipStream_t owned by the caller. */
+int hml_create(hml_ctx** out, int device, uint64_t seed, uint32_t chain_id, void* stream);
+void hml_destroy(hml_ctx* ctx);
+
+/* MaxletTransform + noise estimate + HaarBreakpointWeights + Statistics<IntegralArray,Normal> +
+ * Blocks<BreakpointArray> constructors (src/wavelet.hpp:68-188, src/main.cpp:303-318,340-341,
+ * src/Statistics/IntegralArray.hpp:136-191, src/Blocks/BreakpointArray.hpp:130-184).
+ * x: T host floats (hml_load_observations) or T device floats (hml_load_observations_device;
+ * sigma-hat is then computed from a host copy made internally). */
+int hml_load_observations(hml_ctx* ctx, const float* x, uint64_t T);
+int hml_load_observations_device(hml_ctx* ctx, const void* x_dev, uint64_t T);
+
+/* stdEstimate of src/main.cpp:303-311 */
+int hml_noise_sigma(hml_ctx* ctx, double* sigma);
+
+/* `for (auto& w : inputValues) w *= weightMultiplier` (src/main.cpp:332-334) */
+int hml_scale_weights(hml_ctx* ctx, float multiplier);
+
+/* autoPrior (src/AutoPriors.hpp:86-110, :18-80): s2 = VAR and p = P of "-e normal VAR P".
+ * out4 = {alpha, beta, mu0, nu}.  Leaves the universal threshold as the current threshold. */
+int hml_autoprior(hml_ctx* ctx, float s2, float p, float out4[4]);
+
+/* Mapping/Transitions/Initial/TransitionHyperParam/InitialHyperParam/ThetaHyperParam/Theta
+ * construction (src/main.cpp:133-166,354-362).  nig4 = {alpha,beta,mu0,nu} shared by all K
+ * emission parameters; a_off/a_diag = "-t" tokens; pi_alpha = "-I"; self_trans = !"-S".
+ * Like Theta's constructor (src/Theta.hpp:126-127) this draws theta once from the prior. */
+int hml_set_model(hml_ctx* ctx, int K, const float nig4[4], float a_off, float a_diag, float pi_alpha,
+                  int self_trans);
+
+/* theta.sample(tau_theta); pi.sample(tau_pi); A.sample(tau_A) from the priors
+ * (src/main.cpp:393-401, and again after a "P" token). */
+int hml_sample_prior(hml_ctx* ctx);
+
+/* "S" token: y.createBlocks(theta); dynamic = false (src/main.cpp:407-414).
+ * "D" token: dynamic = true (src/main.cpp:415-421). */
+int hml_set_static_blocks(hml_ctx* ctx);
+int hml_set_dynamic(hml_ctx* ctx, int on);
+
+/* Emissions::createBlocks(real_t) (src/Emissions.hpp:49-51) + a full enumeration with block
+ * statistics (Emissions::next, src/Emissions.hpp:88-95): parity probe for block structures. */
+int hml_create_blocks(hml_ctx* ctx, float threshold);
+
+/* sampleHMM (src/HMM.hpp:60-125) with StateSequence<ForwardBackward> or <Mixture>
+ * (src/StateSequence/ForwardBackward.hpp:16-213, Mixture.hpp:31-144): `iterations` Gibbs sweeps,
+ * recording when thinning > 0 && (i+1) % thinning == 0.  Device-resident; returns after the
+ * sweeps are enqueued unless per-sweep side files were requested with hml_set_recording. */
+int hml_iterate(hml_ctx* ctx, char method, uint64_t iterations, uint64_t thinning);
+
+/* Records::setRecord* (src/Records.hpp:121-144).  marginals: accumulate state marginals on the
+ * device.  The other four make hml_iterate call `cb` after every recorded sweep (with the stream
+ * synchronised) so the host can pull blocks/states/theta and append its files
+ * (src/Records.hpp:147-235). */
+typedef void (*hml_record_cb)(hml_ctx* ctx, uint64_t sweep_in_call, void* user);
+int hml_set_recording(hml_ctx* ctx, int marginals, hml_record_cb cb, void* user);
+
+/* wait for all enqueued work; surfaces model errors raised on the device */
+int hml_sync(hml_ctx* ctx);
+
+/* ---- probes: state of the last sweep (y.start()/end()/blockSize()/suffStat(), q.states(),
+ * theta/A/pi values; src/Emissions.hpp:66-99, src/StateSequence.hpp:71-74) ---- */
+int hml_get_num_blocks(hml_ctx* ctx, uint64_t* B);
+int hml_get_blocks(hml_ctx* ctx, uint32_t* starts /* B+1, last = T */);
+int hml_get_block_stats(hml_ctx* ctx, float* sum /*B*/, float* sum_sq /*B*/);
+int hml_get_states(hml_ctx* ctx, int16_t* q /*B*/);
+int hml_get_theta(hml_ctx* ctx, float* mean_var /*2K: mean0,var0,mean1,...*/);
+int hml_get_transitions(hml_ctx* ctx, float* A /*K*K row-major*/, float* pi /*K*/);
+int hml_set_parameters(hml_ctx* ctx, const float* mean_var, const float* A, const float* pi);
+int hml_get_threshold(hml_ctx* ctx, float* thr);
+/* E_s of src/StateSequence/ForwardBackward.hpp:74-81 for every block of the last sweep and the
+ * normalised forward rows alpha_t (row 0 = pi); only filled when probes are enabled. */
+int hml_enable_probes(hml_ctx* ctx, int on);
+int hml_get_block_loglik(hml_ctx* ctx, float* E /*B*K*/);
+int hml_get_forward_rows(hml_ctx* ctx, float* rows /*(B+1)*K*/);
+/* sufficient statistics of the last sweep's count pass (ForwardBackward.hpp:170-200) */
+int hml_get_counts(hml_ctx* ctx, uint64_t* trans /*K*K*/, uint64_t* occ /*K*/, float* sum /*K*/,
+                   float* sum_sq /*K*/, uint64_t* nterms /*K*/);
+/* construction probes */
+int hml_get_weights(hml_ctx* ctx, float* w /*T*/);
+int hml_get_coefficients(hml_ctx* ctx, float* c /*T*/);   /* maxlet coefficients (before weights) */
+int hml_get_integral_array(hml_ctx* ctx, float* sum /*T+1*/, float* sum_sq /*T+1*/);
+
+/* ---- results ---- */
+/* StateMarginals (src/StateMarginals.hpp:51-137,268-310): run-length form.  Call with
+ * seg_len == NULL to obtain the number of segments and of printed state columns. */
+int hml_marginals_rle(hml_ctx* ctx, uint64_t* n_segments, int* n_columns, uint64_t* seg_len /*n_segments*/,
+                      int32_t* counts /*n_segments * n_columns*/);
+/* dense per-position counts, [K+1][T] int32 on the DEVICE (row K = 1 at segment boundaries), with
+ * the state rows permuted by `perm` (perm[new] = old; NULL = identity): the buffer that the
+ * chain-parallel pooling all-reduces over RCCL. */
+int hml_marginals_dense_device(hml_ctx* ctx, void* out_dev, const int32_t* perm);
+int hml_recorded_sweeps(hml_ctx* ctx, uint64_t* n);
+
+/* ---- counters for measurement ---- */
+typedef struct {
+    uint64_t sweeps;            /* Gibbs sweeps executed                                   */
+    uint64_t block_updates;     /* sum over sweeps of the number of blocks                 */
+    uint64_t uniform_fallbacks; /* "[WARNING] Uniform sampling of forward variables!" count */
+    uint64_t forward_refits;    /* chunks whose speculative forward pass had to be redone  */
+    uint64_t forward_serial;    /* chunks finished by the sequential fallback              */
+} hml_stats;
+int hml_get_stats(hml_ctx* ctx, hml_stats* out);
+
+/* HIP-event timing of one named kernel family accumulated since the last reset (milliseconds and
+ * launches); name is one of "blocks_compact", "block_stats", "emission", "forward", "backward",
+ * "counts", "params", "marginals".  Only collected while profiling is enabled. */
+int hml_profile_enable(hml_ctx* ctx, int on);
+int hml_profile_get(hml_ctx* ctx, const char* name, double* total_ms, uint64_t* launches);
+
+/* parity probe for the arithmetic shared between the kernels and the CPU checker (hml_math.h, hml_dist.h):
+ * evaluates function `fn` elementwise on the GPU (0 expf, 1 logf, 2 pow(a,b) on (0,1], 3 sqrtf, 4 a/b,
+ * 5 gamma(alpha=a, beta=b) draw, 6 normal(mean=a, sd=b) draw, 7-10 double-precision kernels). */
+int hml_debug_eval(int device, int fn, const float* a, const float* b_or_null, float* out, uint64_t n, uint64_t seed);
+
+/* synthetic piecewise-constant Gaussian trace, host buffer */
+int hml_synth_gauss(float* x, int16_t* states_or_null, uint64_t T, int K, const float* mu, float sigma,
+                    double mean_dwell, uint64_t seed, int nthreads);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -191,6 +191,53 @@ uint64_t orc_check_categorical(uint32_t seed, uint64_t n, int K, int zero_every)
     return bad;
 }
 
+// host evaluation of the functions hml_debug_eval runs on the GPU
+void orc_debug_eval(int fn, const float* a, const float* b, float* out, uint64_t n, uint64_t seed) {
+    for (uint64_t i = 0; i < n; ++i) {
+        const float x = a[i], y = b ? b[i] : 0.0f;
+        float r = 0.0f;
+        switch (fn) {
+            case 0: r = hml_expf(x); break;
+            case 1: r = hml_logf(x); break;
+            case 2: r = hml_powf_unit(x, y); break;
+            case 3: r = HML_SQRTF(x); break;
+            case 4: r = x / y; break;
+            case 5: { StreamSrc src(hml_stream_open(hml_make_key(seed, 0), HML_KIND_THETA, seed, (uint32_t)i)); r = hml_gamma_f32<hml_devmath>(src, x, y); } break;
+            case 6: { StreamSrc src(hml_stream_open(hml_make_key(seed, 0), HML_KIND_PI, seed, (uint32_t)i)); hml_normal_f32<hml_devmath> nd; r = nd.draw(src, x, y); } break;
+            case 7: r = (float)hml_log((double)x); break;
+            case 8: r = (float)hml_exp_nonpos((double)x); break;
+            case 9: r = (float)((double)x / (double)y); break;
+            case 10: r = (float)(1.0 / (double)x); break;
+            case 12: case 13: case 14: case 15: case 16: case 17: case 18: case 19: case 20: case 21: case 22: case 23: {
+                StreamSrc src(hml_stream_open(hml_make_key(seed, 0), HML_KIND_THETA, seed, (uint32_t)i));
+                const float alpha = x, beta = y; (void)beta;
+                const float malpha = alpha < 1.0f ? alpha + 1.0f : alpha;
+                const float a1 = malpha - 1.0f / 3.0f;
+                const float a2 = 1.0f / hml_devmath::sqrtf_(9.0f * a1);
+                hml_normal_f32<hml_devmath> nd;
+                float n = nd.draw(src, 0.0f, 1.0f);
+                float v = 1.0f + a2 * n;
+                float v3 = v * v * v;
+                float u = hml_canonical_f32(src);
+                const bool c1 = (double)u > (double)1.0f - 0.0331 * (double)n * (double)n * (double)n * (double)n;
+                const bool c2 = ((double)hml_devmath::logf_(u) > (0.5 * (double)n * (double)n + (double)a1 * ((1.0 - (double)v3) + (double)hml_devmath::logf_(v3))));
+                float n2 = nd.draw(src, 0.0f, 1.0f);
+                float vb = 1.0f + a2 * n2;
+                float vb3 = vb * vb * vb;
+                float ub = hml_canonical_f32(src);
+                const bool d1 = (double)ub > (double)1.0f - 0.0331 * (double)n2 * (double)n2 * (double)n2 * (double)n2;
+                const bool d2 = ((double)hml_devmath::logf_(ub) > (0.5 * (double)n2 * (double)n2 + (double)a1 * ((1.0 - (double)vb3) + (double)hml_devmath::logf_(vb3))));
+                r = fn == 12 ? n : fn == 13 ? v3 : fn == 14 ? u : fn == 15 ? (float)(c1 ? 1 : 0) + 2.0f * (c2 ? 1 : 0) : fn == 16 ? n2 : fn == 17 ? a2
+                    : fn == 18 ? vb3 : fn == 19 ? ub : fn == 20 ? (float)(d1 ? 1 : 0) + 2.0f * (d2 ? 1 : 0) : fn == 21 ? (float)src.s.n : 0.0f;
+                if (fn == 22) r = nd.draw(src, 0.0f, 1.0f);   // third normal (fresh pair)
+                if (fn == 23) { hml_normal_f32<hml_devmath> nf; r = nf.draw(src, 0.0f, 1.0f); r = nf.draw(src, 0.0f, 1.0f); }  // saved of the fresh pair
+            } break;
+            case 11: { const double d = HML_SQRT((double)x * 1.0000001); r = (float)((d - (double)(float)d) * 1e9); } break;
+        }
+        out[i] = r;
+    }
+}
+
 // synthetic trace (product generator, exposed here so oracle-only tests need no GPU library)
 void orc_synth_gauss(float* x, int16_t* states, uint64_t T, int K, const float* mu, float sigma, double dwell,
                      uint64_t seed, int nthreads) {

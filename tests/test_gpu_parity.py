@@ -1,0 +1,195 @@
+"""GPU parity: the HIP path (through the C ABI) against the CPU checker in device mode, bit for bit."""
+import numpy as np
+import pytest
+
+from tests import oracle_lib as ol
+
+pytestmark = pytest.mark.gpu
+
+
+def bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+def make_pair(hml, T, K, data_seed, seed, chain=0, x=None, **kw):
+    x = ol.trace(T, K, data_seed) if x is None else x
+    o = ol.OracleChain(K=K, seed=seed, chain=chain, rng=ol.RNG_CTR, math=ol.MATH_DEV, reduce=ol.REDUCE_DEV, **kw)
+    o.load(x)
+    g = hml.Chain(device=0, seed=seed, chain_id=chain)
+    g.load(x)
+    if kw.get("weight_mult", 1.0) != 1.0:
+        g.scale_weights(kw["weight_mult"])
+    return x, o, g
+
+
+def setup_model(o, g, K, **kw):
+    po = o.autoprior()
+    pg = g.autoprior(kw.get("e_var", 0.2), kw.get("e_p", 0.9))
+    assert np.array_equal(bits(po), bits(pg)), (po, pg)
+    o.init_model()
+    g.set_model(K, pg, kw.get("t_off", 0.5), kw.get("t_diag", 0.5), kw.get("pi_alpha", 0.5), kw.get("self_trans", True))
+    return pg
+
+
+@pytest.mark.parametrize("T", [1, 2, 13, 16, 1000, 4096, 65534, 65535, 65536, 100000, 131071, 262144 + 3])
+def test_construction_bit_exact(hml, T):
+    """K1-K3 against MaxletTransform / HaarBreakpointWeights / IntegralArray (wavelet.hpp, IntegralArray.hpp)."""
+    rng = np.random.default_rng(T)
+    x = (rng.standard_normal(T) * 0.3 + np.repeat(rng.integers(-2, 3, (T + 499) // 500), 500)[:T]).astype(np.float32)
+    o = ol.OracleChain(K=3)
+    o.load(x)
+    g = hml.Chain()
+    g.load(x)
+    assert np.array_equal(bits(o.coeffs()), bits(g.coefficients()))
+    assert np.array_equal(bits(o.weights()), bits(g.weights()))
+    a, b = o.integral()
+    c, d = g.integral_array()
+    assert np.array_equal(bits(a), bits(c)) and np.array_equal(bits(b), bits(d))
+    if T > 2:
+        assert o.sigma_hat() == g.noise_sigma()
+
+
+@pytest.mark.parametrize("T,K", [(100000, 3), (300007, 5)])
+def test_blocks_and_stats_bit_exact(hml, T, K):
+    """K4/K5 against Blocks::next and addBlockStats for several thresholds, incl. B = T and B = 1-ish."""
+    x, o, g = make_pair(hml, T, K, 5, 1)
+    for thr in [0.0, 0.3, 1.0, 2.5, 1e9]:
+        o.enumerate_blocks(thr)
+        g.create_blocks(thr)
+        assert np.array_equal(o.blocks(), g.blocks()), thr
+        a, b = o.block_stats()
+        c, d = g.block_stats()
+        assert np.array_equal(bits(a), bits(c)) and np.array_equal(bits(b), bits(d)), thr
+
+
+def test_scaled_weights(hml):
+    x, o, g = make_pair(hml, 50000, 3, 6, 1, weight_mult=0.37)
+    assert np.array_equal(bits(o.weights()), bits(g.weights()))
+
+
+def run_both(o, g, scheme):
+    for tok in scheme:
+        if tok in ("P", "S", "D"):
+            o.token(tok)
+            # the reference draws the pending prior at the start of every token (main.cpp:393-406)
+            if g._pending_prior:
+                g.sample_prior()
+                g._pending_prior = False
+            if tok == "P":
+                g._pending_prior = True
+            elif tok == "S":
+                g.set_static_blocks()
+            else:
+                g.set_dynamic(True)
+        else:
+            m, n, t = tok
+            if g._pending_prior:
+                g.sample_prior()
+                g._pending_prior = False
+            o.iterate(m, n, t)
+            g.iterate(m, n, t)
+    g.sync()
+
+
+def compare_state(o, g, what=""):
+    assert np.array_equal(o.blocks(), g.blocks()), what
+    assert np.array_equal(o.states(), g.states()), what
+    assert np.array_equal(bits(o.theta()), bits(g.theta())), what
+    Ao, po = o.transitions()
+    Ag, pg = g.transitions()
+    assert np.array_equal(bits(Ao), bits(Ag)) and np.array_equal(bits(po), bits(pg)), what
+
+
+@pytest.mark.parametrize("T,K,scheme", [
+    (100000, 3, [("F", 1, 0)]),
+    (100000, 3, [("F", 30, 1)]),
+    (100000, 3, [("M", 20, 0), "S", "P", ("F", 10, 0), ("F", 15, 3)]),
+    (20000, 4, [("M", 10, 5), "D", ("F", 20, 2), "P", ("M", 5, 1), "S", ("F", 10, 1)]),
+    (200000, 5, [("F", 25, 5)]),
+    (50000, 2, [("F", 10, 1)]),
+    (50000, 10, [("F", 10, 2)]),
+    (30000, 16, [("F", 6, 2)]),
+])
+def test_sweeps_match_checker(hml, T, K, scheme):
+    """Whole sweeps (a7-a17): blocks, states, parameters and marginals equal the checker's, bit for bit."""
+    x, o, g = make_pair(hml, T, K, 7, 42)
+    setup_model(o, g, K)
+    g._pending_prior = True
+    o.set_record(marginals=True)
+    run_both(o, g, scheme)
+    compare_state(o, g)
+    seg, cnt = g.marginals_rle()
+    assert hml.marginals_text(seg, cnt) == o.text("marginals")
+    st = g.stats()
+    # the serial finisher is a rare slow path (correct by construction); it must stay rare
+    assert st["forward_serial"] <= max(4, st["block_updates"] // 2000), st
+
+
+def test_first_sweep_probes(hml):
+    """Kernel-level probes: E_s bit-exact vs the checker in device-math mode, within 1e-6 relative of the
+    libm reference mode; forward rows bit-exact (the speculative chunked filter equals the sequential one)."""
+    T, K = 100000, 5
+    x, o, g = make_pair(hml, T, K, 9, 3)
+    setup_model(o, g, K)
+    o.token("F")
+    g.sample_prior()
+    o.set_probes(True)
+    g.enable_probes(True)
+    o.iterate("F", 1, 0)
+    g.iterate("F", 1, 0)
+    g.sync()
+    Eo, Eg = o.loglik(), g.block_loglik()
+    assert np.array_equal(bits(Eo), bits(Eg))
+    assert np.array_equal(bits(o.forward_rows()), bits(g.forward_rows()))
+    # reference-math checker on the same parameters
+    r = ol.OracleChain(K=K, seed=3, rng=ol.RNG_CTR, math=ol.MATH_LIBM, reduce=ol.REDUCE_REF)
+    r.load(x)
+    r.autoprior()
+    r.init_model()
+    r.token("F")
+    r.set_probes(True)
+    r.iterate("F", 1, 0)
+    Er = r.loglik()
+    if Er.shape == Eg.shape:
+        rel = np.abs(Er - Eg) / np.maximum(np.abs(Er), 1e-30)
+        assert rel.max() <= 1e-6
+
+
+@pytest.mark.parametrize("fn,name", [(0, "expf"), (1, "logf"), (2, "pow"), (3, "sqrtf"), (4, "div"), (5, "gamma"), (6, "normal"),
+                                     (7, "log64"), (8, "exp64"), (9, "div64"), (10, "rcp64"), (11, "sqrt64")])
+def test_shared_arithmetic_device_equals_host(hml, fn, name):
+    """hml_math.h / hml_dist.h compiled by hipcc for gfx950 and by gcc give the same bits."""
+    rng = np.random.default_rng(fn)
+    n = 1 << 20
+    if fn in (0, 8):
+        a = rng.uniform(-104, 0, n).astype(np.float32); b = None
+    elif fn in (1, 3, 7, 10, 11):
+        a = np.exp(rng.uniform(-80, 80, n)).astype(np.float32); b = None
+    elif fn == 2:
+        a = rng.uniform(0, 1, n).astype(np.float32); a[a == 0] = 0.5
+        b = rng.choice(np.array([2.0, 1.0 / 0.3, 1.7, 5.0, 20.0], np.float32), n)
+    elif fn in (4, 9):
+        a = np.exp(rng.uniform(-30, 30, n)).astype(np.float32); b = np.exp(rng.uniform(-30, 30, n)).astype(np.float32)
+    elif fn == 5:
+        a = rng.choice(np.array([0.5, 0.1, 0.9, 1.0, 1.5, 2.0, 2.5, 17.5, 1000.5, 123456.5], np.float32), n)
+        b = rng.choice(np.array([1.0, 0.37, 12.5], np.float32), n)
+    else:
+        a = rng.uniform(-3, 3, n).astype(np.float32); b = rng.uniform(0.01, 3, n).astype(np.float32)
+    dev = hml.debug_eval(fn, a, b, seed=77)
+    host = ol.debug_eval(fn, a, b, seed=77)
+    bad = np.flatnonzero(bits(dev) != bits(host))
+    assert bad.size == 0, (name, bad.size, a[bad[:5]], None if b is None else b[bad[:5]], dev[bad[:5]], host[bad[:5]])
+
+
+def test_gamma_lanes_independent(hml):
+    """Regression for a hipcc -O3 hazard: the nested-loop form of the gamma draw gave different results
+    when 64 lanes ran it together than when one lane ran it alone (see hml_dist.h)."""
+    rng = np.random.default_rng(5)
+    n = 1 << 18
+    a = rng.choice(np.array([0.5, 0.1, 0.9, 1.0, 1.5, 2.0, 2.5, 17.5], np.float32), n)
+    b = rng.choice(np.array([1.0, 0.37, 12.5], np.float32), n)
+    together = hml.debug_eval(5, a, b, seed=9)
+    alone = hml.debug_eval(24, a, b, seed=9)
+    host = ol.debug_eval(5, a, b, seed=9)
+    assert np.array_equal(bits(together), bits(alone))
+    assert np.array_equal(bits(together), bits(host))
