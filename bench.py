@@ -1,0 +1,184 @@
+#!/usr/bin/env python3
+"""Benchmark of the Forward-Backward Gibbs sweep over wavelet-compressed blocks on MI355X.
+
+A "step" is one Gibbs sweep (dynamic wavelet recompression, forward trellis, backward sampling,
+count pass, conjugate resampling) of one chain over a synthetic piecewise-constant Gaussian trace
+that is already resident in HBM.  Workload = BASELINE.json's headline configuration (10^8 positions,
+5 states, dynamic blocks).  With N GPUs every rank runs an independent chain on the same trace
+(weak scaling, no data-path collective); value = block updates of all ranks / max-over-ranks time.
+
+    python bench.py --gpus 1 --steps 200 --warmup 20
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6.3 TB/s is what a copy achieves
+
+WORKLOADS = {
+    # name: (T, K, levels, sigma, mean dwell, data seed)
+    "c3_1e8_k5_dynamic": (100_000_000, 5, [-2, -1, 0, 1, 2], 0.3, 5000.0, 3),
+    "c2_1e7_k5": (10_000_000, 5, [-2, -1, 0, 1, 2], 0.3, 5000.0, 2),
+    "c1_1e5_k3": (100_000, 3, [-1, 0, 1], 0.2, 2000.0, 1),
+    "c4_1e8_k10": (100_000_000, 10, [x - 4.5 for x in range(10)], 0.3, 5000.0, 4),
+}
+
+
+def cpu_baseline(x, K, seed, budget_s=20.0):
+    """The CPU restatement in reference mode (sequential mt19937, glibc math, pointer-jumping block
+    enumeration), timed on this box's host cores; one thread like the reference."""
+    from tests import oracle_lib as ol
+    o = ol.OracleChain(K=K, seed=seed, rng=ol.RNG_MT, math=ol.MATH_LIBM, reduce=ol.REDUCE_REF)
+    o.load(x)
+    o.autoprior()
+    o.init_model()
+    o.set_record(marginals=False)
+    # burn in a few sweeps so the timed ones see the compression level of a running chain
+    t = o.time_sweeps("F", 3)
+    per = max(t / 3, 1e-6)
+    n = int(max(3, min(200, budget_s / per)))
+    b0 = o.total_blocks()
+    t = o.time_sweeps("F", n)
+    blocks = o.total_blocks() - b0
+    o.close()
+    return {"value": blocks / t, "unit": "block-updates/s", "cores": 1, "kind": "port",
+            "sample": "%d sweeps of the same %d-position trace (reference-mode CPU restatement, %.1f ms/sweep)" % (n, x.size, 1e3 * t / n)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default="c3_1e8_k5_dynamic", choices=sorted(WORKLOADS))
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--breakdown", action="store_true", help="extra profiled pass: per-kernel-family times")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("WORLD_SIZE (%d) != --gpus (%d)" % (world, args.gpus))
+
+    import torch
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(local_rank)
+
+    import hammlet_amd
+    T, K, levels, sigma, dwell, data_seed = WORKLOADS[args.workload]
+    x = hammlet_amd.synth_gauss(T, K, levels, sigma, dwell, data_seed, nthreads=max(1, (os.cpu_count() or 8) // max(1, world)))
+
+    chain = hammlet_amd.Chain(device=local_rank, seed=args.seed, chain_id=rank)
+    chain.load(x)
+    prior = chain.autoprior(0.2, 0.9)
+    chain.set_model(K, prior)
+    chain.sample_prior()
+    chain.set_recording(marginals=False)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    chain.iterate("F", args.warmup, 0)
+    chain.sync()
+    st0 = chain.stats()
+    chain.profile_enable(1)   # HIP events around the dominant kernel only, on the chain's own stream
+    barrier()
+    t0 = time.perf_counter()
+    chain.iterate("F", args.steps, 0)
+    chain.sync()
+    barrier()
+    t1 = time.perf_counter()
+    chain.profile_enable(0)
+    st1 = chain.stats()
+    elapsed = t1 - t0
+    blocks = st1["block_updates"] - st0["block_updates"]
+    scan_ms, scan_n = chain.profile_get("blocks_compact")
+
+    if dist is not None:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+        bb = torch.tensor([blocks], dtype=torch.int64, device="cuda")
+        dist.all_reduce(bb, op=dist.ReduceOp.SUM)
+        blocks_all = int(bb.item())
+    else:
+        blocks_all = blocks
+
+    out = None
+    if rank == 0:
+        B_avg = blocks / max(1, args.steps)
+        scan_avg_s = (scan_ms / max(1, scan_n)) * 1e-3
+        # algorithmic bytes of one blocks_compact launch: the weight stream (4 B/position) + one 32-bit
+        # start per block (DESIGN.md "K4"); per sweep: 4*T + B*(36 + 8*K)  
+        scan_bytes = 4.0 * T + 4.0 * B_avg
+        achieved = scan_bytes / scan_avg_s / 1e9 if scan_avg_s > 0 else 0.0
+        sweep_bytes = 4.0 * T + B_avg * (36 + 8 * K)
+        out = {
+            "metric": "block-updates/sec (Gibbs sweep) + HBM GB/s, 10^8 pos / 5 states",
+            "value": blocks_all / elapsed,
+            "unit": "block-updates/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": args.workload, "positions": T, "states": K, "blocks_per_sweep": B_avg,
+                       "compression": T / max(B_avg, 1.0), "block_structure": "dynamic", "chains": world,
+                       "parallelism": "chain-parallel x%d" % world},
+            "roofline": {"bound": "hbm", "kernel": "hml_k_compact_scan (forward-trellis block scan)",
+                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": None, "kernel_avg_us": 1e6 * scan_avg_s, "launches": scan_n,
+                         "bytes_per_launch": scan_bytes,
+                         "sweep_frac": sweep_bytes / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS},
+            "forward_refits": st1["forward_refits"] - st0["forward_refits"],
+            "forward_serial": st1["forward_serial"] - st0["forward_serial"],
+        }
+
+    if args.breakdown and rank == 0:
+        names = ("blocks_compact", "blocks_offsets", "block_stats", "emission", "forward", "backward", "counts", "params")
+        before = {nm: chain.profile_get(nm) for nm in names}
+        chain.profile_enable(2)
+        chain.iterate("F", min(50, args.steps), 0)
+        chain.sync()
+        chain.profile_enable(0)
+        fam = {}
+        for nm in names:
+            ms, n = chain.profile_get(nm)
+            fam[nm] = round(1e3 * (ms - before[nm][0]) / max(1, n - before[nm][1]), 2)
+        out["kernel_us_per_sweep"] = fam
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(x, K, args.seed)
+    elif rank == 0:
+        out["cpu_baseline"] = None
+
+    if rank == 0:
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

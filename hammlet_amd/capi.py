@@ -310,8 +310,8 @@ class Chain:
         _check(self.lib.hml_get_stats(self.h, C.byref(s)))
         return {f: getattr(s, f) for f, _ in HmlStats._fields_}
 
-    def profile_enable(self, on=True):
-        _check(self.lib.hml_profile_enable(self.h, 1 if on else 0))
+    def profile_enable(self, level=2):
+        _check(self.lib.hml_profile_enable(self.h, int(level)))
 
     def profile_get(self, name):
         ms = C.c_double()

@@ -95,7 +95,7 @@ struct hml_ctx {
     bool rec_marginals = true;
     hml_record_cb cb = nullptr;
     void* cb_user = nullptr;
-    bool profiling = false;
+    int profiling = 0;             // 0 off, 1 dominant kernel only (blocks_compact), 2 every kernel family
     std::map<std::string, ProfAcc> prof;
     std::vector<hipEvent_t> ev_pool;
 };
@@ -115,11 +115,12 @@ static hipEvent_t ev_get(hml_ctx* c) {
 
 struct ProfScope {
     hml_ctx* c; const char* name; hipEvent_t a = nullptr, b = nullptr;
-    ProfScope(hml_ctx* c_, const char* n) : c(c_), name(n) {
-        if (c->profiling) { a = ev_get(c); b = ev_get(c); hipEventRecord(a, c->stream); }
+    bool on;
+    ProfScope(hml_ctx* c_, const char* n, int level = 2) : c(c_), name(n), on(c_->profiling >= level) {
+        if (on) { a = ev_get(c); b = ev_get(c); hipEventRecord(a, c->stream); }
     }
     ~ProfScope() {
-        if (c->profiling) { hipEventRecord(b, c->stream); c->prof[name].pending.push_back({a, b}); }
+        if (on) { hipEventRecord(b, c->stream); c->prof[name].pending.push_back({a, b}); }
     }
 };
 
@@ -401,7 +402,7 @@ int hml_scale_weights(hml_ctx* c, float mult) {
 static int launch_compact(hml_ctx* c, bool use_override, float thr) {
     const uint32_t T = (uint32_t)c->T;
     {
-        ProfScope ps(c, "blocks_compact");
+        ProfScope ps(c, "blocks_compact", 1);
         hipLaunchKernelGGL(hml_k_compact_scan, dim3((c->n_spans + 3) / 4), dim3(256), 0, c->stream, c->d_w, T, c->d_mdl, thr,
                            use_override ? 1 : 0, c->d_stage, c->d_span_count);
     }
@@ -905,7 +906,7 @@ int hml_get_stats(hml_ctx* c, hml_stats* out) {
 
 int hml_profile_enable(hml_ctx* c, int on) {
     if (!c) return set_err(HML_ERR_ARG, "null context");
-    c->profiling = on != 0;
+    c->profiling = on;
     return 0;
 }
 

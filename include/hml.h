@@ -145,8 +145,9 @@ int hml_get_stats(hml_ctx* ctx, hml_stats* out);
 
 /* HIP-event timing of one named kernel family accumulated since the last reset (milliseconds and
  * launches); name is one of "blocks_compact", "block_stats", "emission", "forward", "backward",
- * "counts", "params", "marginals".  Only collected while profiling is enabled. */
-int hml_profile_enable(hml_ctx* ctx, int on);
+ * "counts", "params", "marginals", "blocks_offsets".  level 0 = off, 1 = only the dominant kernel
+ * ("blocks_compact", two events per sweep), 2 = every family. */
+int hml_profile_enable(hml_ctx* ctx, int level);
 int hml_profile_get(hml_ctx* ctx, const char* name, double* total_ms, uint64_t* launches);
 
 /* parity probe for the arithmetic shared between the kernels and the CPU checker (hml_math.h, hml_dist.h):
