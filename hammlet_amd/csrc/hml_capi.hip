@@ -633,6 +633,8 @@ static int sweep_k(hml_ctx* c, char method, bool record) {
                                    L, W);
                 std::swap(ein, eout);
             }
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_forward<KK, 2>), dim3(gF), dim3(256), 0, s, c->d_em, c->d_gsc, c->d_mdl,
+                               c->d_rows, (float*)nullptr, c->d_entry, (const float*)ein, eout, c->d_fb, L, W);
             hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_forward_serial<KK>), dim3(1), dim3(256), 0, s, c->d_em, c->d_gsc, c->d_mdl,
                                c->d_rows, c->probes ? c->d_aprobe : nullptr, c->d_entry, ein, c->d_fb, L, W);
         }

@@ -250,9 +250,10 @@ __global__ __launch_bounds__(256) void hml_k_counts(const int16_t* __restrict__ 
             partial[((uint64_t)g * K + s) * 2 + 1] = acc_q[s];
         }
     }
+    const int slot = (int)(g % HML_CNT_SPLIT);
     for (int i = tid; i < K * K; i += 256)
-        if (h_trans[i]) atomicAdd(&mdl->trans[i], h_trans[i]);
-    if (tid < K && h_occ[tid]) atomicAdd(&mdl->occ[tid], h_occ[tid]);
+        if (h_trans[i]) atomicAdd(&mdl->trans[slot][i], h_trans[i]);
+    if (tid < K && h_occ[tid]) atomicAdd(&mdl->occ[slot][tid], h_occ[tid]);
 }
 
 // ------------------------------------------------------------------------------------------

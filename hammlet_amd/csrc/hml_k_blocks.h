@@ -78,36 +78,54 @@ __global__ __launch_bounds__(256) void hml_k_compact_scan(const float* __restric
     if (lane == 0) span_count[span] = running;
 }
 
-// exclusive scan of span_count[0..n_spans) -> span_offset, total -> mdl->B (one workgroup of 1024)
+// exclusive scan of span_count[0..n_spans) -> span_offset, total -> mdl->B.  One workgroup of 1024:
+// each wavefront owns a contiguous slice, reads it 64 entries at a time (coalesced), scans each
+// group of 64 with shuffles and carries a running total; the 16 slice totals are scanned in LDS and
+// added in a second coalesced sweep.
 __global__ __launch_bounds__(1024) void hml_k_compact_offsets(const uint32_t* __restrict__ span_count,
                                                               uint32_t* __restrict__ span_offset, uint32_t n_spans,
                                                               hml_model* __restrict__ mdl, uint32_t* __restrict__ starts,
                                                               uint32_t T) {
-    __shared__ uint32_t part[1024];
-    const int tid = threadIdx.x;
-    const uint32_t per = (n_spans + 1023u) / 1024u;
-    const uint32_t a = (uint32_t)tid * per;
-    const uint32_t b = (a + per < n_spans) ? a + per : n_spans;
-    uint32_t sum = 0;
-    for (uint32_t i = a; i < b; ++i) sum += span_count[i];
-    part[tid] = sum;
+    __shared__ uint32_t wtot[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t per_wave = ((n_spans + 15u) / 16u + 63u) / 64u * 64u;   // slice length, multiple of 64
+    const uint32_t a = (uint32_t)wave * per_wave;
+    const uint32_t b = (a + per_wave < n_spans) ? a + per_wave : n_spans;
+    uint32_t run = 0;
+    for (uint32_t i0 = a; i0 < b; i0 += 256u) {
+        // four groups of 64 per trip so that four loads are in flight
+        uint32_t v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t i = i0 + (uint32_t)k * 64u + (uint32_t)lane;
+            v[k] = (i < b) ? span_count[i] : 0u;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            uint32_t incl = v[k];
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint32_t o = __shfl_up(incl, d);
+                if (lane >= d) incl += o;
+            }
+            const uint32_t i = i0 + (uint32_t)k * 64u + (uint32_t)lane;
+            if (i < b) span_offset[i] = run + incl - v[k];
+            run += __shfl(incl, 63);
+        }
+    }
+    if (lane == 0) wtot[wave] = run;
     __syncthreads();
-    // Hillis-Steele inclusive scan over the 1024 partials
-    for (int d = 1; d < 1024; d <<= 1) {
-        uint32_t v = (tid >= d) ? part[tid - d] : 0u;
-        __syncthreads();
-        part[tid] += v;
-        __syncthreads();
+    uint32_t base = 0, total = 0;
+#pragma unroll
+    for (int w2 = 0; w2 < 16; ++w2) {
+        if (w2 < wave) base += wtot[w2];
+        total += wtot[w2];
     }
-    uint32_t run = part[tid] - sum;   // exclusive prefix of this thread's range
-    for (uint32_t i = a; i < b; ++i) {
-        span_offset[i] = run;
-        run += span_count[i];
-    }
-    if (tid == 1023) {
-        const uint32_t B = part[1023];
-        mdl->B = B;
-        starts[B] = T;
+    if (base != 0u)
+        for (uint32_t i = a + (uint32_t)lane; i < b; i += 64u) span_offset[i] += base;
+    if (tid == 0) {
+        mdl->B = total;
+        starts[total] = T;
     }
 }
 

@@ -104,6 +104,7 @@ __device__ __forceinline__ float hml_fwd_step(const hml_fwd_ctx<K>& c, float alp
 }
 
 // MODE 0: speculative main pass.  MODE 1: verify against exit_in and recompute stale chunks.
+// MODE 2: verify only - raise mdl->fwd_mismatch if any chunk is still inconsistent (the serial pass then runs).
 template <int K, int MODE>
 __global__ __launch_bounds__(256) void hml_k_forward(const float* __restrict__ em, const float* __restrict__ gsc,
                                                      hml_model* __restrict__ mdl, float* __restrict__ rows,
@@ -113,73 +114,85 @@ __global__ __launch_bounds__(256) void hml_k_forward(const float* __restrict__ e
     const uint32_t B = mdl->B;
     const uint32_t C = (B + (uint32_t)L - 1u) / (uint32_t)L;
     const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t c = gid / HML_FWD_GROUP;
+    const uint32_t ngroups = (gridDim.x * blockDim.x) / HML_FWD_GROUP;
     const int j = (int)(gid % HML_FWD_GROUP);
     const int lane = threadIdx.x & 63;
     const int grp_in_wave = lane / HML_FWD_GROUP;
-    const bool live = (c < C);
-    const bool act = live && (j < K);
+    const bool act = (j < K);
     hml_fwd_ctx<K> cx;
     cx.j = j; cx.B = B; cx.self = mdl->self_trans != 0;
     cx.invK = (float)(1.0 / (double)(float)K);
 #pragma unroll
     for (int i = 0; i < K; ++i) cx.Acol[i] = act ? mdl->A[i * K + j] : 0.0f;
-
-    const uint32_t first = live ? c * (uint32_t)L : 0u;
-    const uint32_t last = live ? ((first + (uint32_t)L < B) ? first + (uint32_t)L : B) : 0u;   // one past
-    const uint32_t ws = (first >= (uint32_t)W) ? first - (uint32_t)W : 0u;
-    const bool exact = (ws == 0u);
-    float alpha = 0.0f;
-    bool run = live;
-    if (MODE == 0) {
-        alpha = act ? (exact ? mdl->pi[j] : cx.invK) : 0.0f;
-        // warm-up over [ws, first)
-        for (uint32_t b = ws; b < first; ++b) {
-            const float e = act ? em[(uint64_t)b * K + j] : 0.0f;
-            bool fb;
-            alpha = hml_fwd_step<K>(cx, alpha, e, fb);
-        }
-        if (act) entry[(uint64_t)c * K + j] = alpha;
-    } else {
-        // verification: was the vector this chunk started from the one its predecessor really ended in?
-        bool same = true;
-        float truth = 0.0f;
-        if (act && !exact) {
-            truth = exit_in[(uint64_t)(c - 1) * K + j];
-            same = hml_f2u(truth) == hml_f2u(entry[(uint64_t)c * K + j]);
-        }
-        const unsigned long long bal = __ballot(same || !live);
-        const bool all_same = ((bal >> (grp_in_wave * HML_FWD_GROUP)) & 0xffffull) == 0xffffull;
-        if (live && (exact || all_same)) {
-            if (act) exit_out[(uint64_t)c * K + j] = exit_in[(uint64_t)c * K + j];
-            run = false;
-        } else if (live) {
-            alpha = truth;
-            if (act) entry[(uint64_t)c * K + j] = alpha;
-            if (j == 0) { atomicAdd(&mdl->forward_refits, 1ull); mdl->fwd_mismatch = 1u; }
-        }
-    }
-    // the chunk proper over [first, last); inactive groups run zero iterations
-    uint32_t nfb = 0;
-    const uint32_t bend = run ? last : first;
-    for (uint32_t b = first; b < bend; ++b) {
-        const float e = act ? em[(uint64_t)b * K + j] : 0.0f;
-        const float g = (act && cx.self) ? gsc[(uint64_t)b * K + j] : 1.0f;
-        bool fb;
-        alpha = hml_fwd_step<K>(cx, alpha, e, fb);
-        if (fb) nfb++;
-        if (act) {
-            const uint32_t t = b + 1u;
-            const float stored = (cx.self && t < B) ? alpha * g : alpha;
-            rows[(uint64_t)t * K + j] = stored;
-            if (aprobe) aprobe[(uint64_t)t * K + j] = alpha;
-        }
-    }
-    if (run && act) exit_out[(uint64_t)c * K + j] = alpha;
-    if (run && j == 0) fb_count[c] = nfb;
     if (MODE == 0 && gid < (uint32_t)K) {
         rows[gid] = mdl->pi[gid];
         if (aprobe) aprobe[gid] = mdl->pi[gid];
+    }
+
+    // grid-stride over chunks: correctness never depends on the launch size (B is only known on the device)
+    for (uint32_t c = gid / HML_FWD_GROUP; c < C; c += ngroups) {
+        const uint32_t first = c * (uint32_t)L;
+        const uint32_t last = (first + (uint32_t)L < B) ? first + (uint32_t)L : B;   // one past
+        const uint32_t ws = (first >= (uint32_t)W) ? first - (uint32_t)W : 0u;
+        const bool exact = (ws == 0u);
+        float alpha = 0.0f;
+        bool run = true;
+        if (MODE == 0) {
+            alpha = act ? (exact ? mdl->pi[j] : cx.invK) : 0.0f;
+            // warm-up over [ws, first)
+            for (uint32_t b = ws; b < first; ++b) {
+                const float e = act ? em[(uint64_t)b * K + j] : 0.0f;
+                bool fb;
+                alpha = hml_fwd_step<K>(cx, alpha, e, fb);
+            }
+            if (act) entry[(uint64_t)c * K + j] = alpha;
+        } else {
+            // verification: was the vector this chunk started from the one its predecessor really ended in?
+            bool same = true;
+            float truth = 0.0f;
+            if (act && !exact) {
+                truth = exit_in[(uint64_t)(c - 1) * K + j];
+                same = hml_f2u(truth) == hml_f2u(entry[(uint64_t)c * K + j]);
+            }
+            const unsigned long long bal = __ballot(same);
+            const bool all_same = ((bal >> (grp_in_wave * HML_FWD_GROUP)) & 0xffffull) == 0xffffull;
+            if (MODE == 2) {
+                if (!exact && !all_same && j == 0) mdl->fwd_mismatch = 1u;
+                continue;
+            }
+            if (exact || all_same) {
+                if (act) exit_out[(uint64_t)c * K + j] = exit_in[(uint64_t)c * K + j];
+                run = false;
+            } else {
+                alpha = truth;
+                if (act) entry[(uint64_t)c * K + j] = alpha;
+                if (j == 0) atomicAdd(&mdl->forward_refits, 1ull);
+            }
+        }
+        if (!run) continue;
+        // the chunk proper over [first, last)
+        uint32_t nfb = 0;
+        for (uint32_t b = first; b < last; ++b) {
+            const float e = act ? em[(uint64_t)b * K + j] : 0.0f;
+            const float g = (act && cx.self) ? gsc[(uint64_t)b * K + j] : 1.0f;
+            bool fb;
+            alpha = hml_fwd_step<K>(cx, alpha, e, fb);
+            if (fb) nfb++;
+            if (act) {
+                const uint32_t t = b + 1u;
+                const float stored = (cx.self && t < B) ? alpha * g : alpha;
+                rows[(uint64_t)t * K + j] = stored;
+                if (aprobe) aprobe[(uint64_t)t * K + j] = alpha;
+            }
+        }
+        if (act) exit_out[(uint64_t)c * K + j] = alpha;
+        if (j == 0) {
+            // "[WARNING] Uniform sampling of forward variables!" events: keep the global tally consistent
+            // when a chunk is recomputed (two's-complement delta on the unsigned counter)
+            const uint32_t old = (MODE == 0) ? 0u : fb_count[c];
+            fb_count[c] = nfb;
+            if (nfb != old) atomicAdd(&mdl->uniform_fallbacks, (unsigned long long)(long long)((int)nfb - (int)old));
+        }
     }
 }
 
@@ -194,11 +207,11 @@ __global__ __launch_bounds__(256) void hml_k_forward_serial(const float* __restr
                                                             float* __restrict__ exitv, uint32_t* __restrict__ fb_count,
                                                             int L, int W) {
     __shared__ uint32_t first_bad;
-    __shared__ unsigned long long fb_total;
+    if (mdl->fwd_mismatch == 0u) return;   // the verification pass found every chunk consistent
     const uint32_t B = mdl->B;
     const uint32_t C = (B + (uint32_t)L - 1u) / (uint32_t)L;
     const int tid = threadIdx.x;
-    if (tid == 0) { first_bad = 0xffffffffu; fb_total = 0ull; }
+    if (tid == 0) first_bad = 0xffffffffu;
     __syncthreads();
     for (uint32_t c = 1u + (uint32_t)tid; c < C; c += 256u) {
         const uint32_t first = c * (uint32_t)L;
@@ -247,16 +260,17 @@ __global__ __launch_bounds__(256) void hml_k_forward_serial(const float* __restr
                 }
             }
             if (act) exitv[(uint64_t)c * K + j] = alpha;
-            if (tid == 0) { fb_count[c] = nfb; atomicAdd(&mdl->forward_serial, 1ull); }
+            if (tid == 0) {
+                const uint32_t old = fb_count[c];
+                fb_count[c] = nfb;
+                if (nfb != old) atomicAdd(&mdl->uniform_fallbacks, (unsigned long long)(long long)((int)nfb - (int)old));
+                atomicAdd(&mdl->forward_serial, 1ull);
+            }
             __threadfence_block();
         }
     }
     __syncthreads();
-    unsigned long long loc = 0;
-    for (uint32_t c = (uint32_t)tid; c < C; c += 256u) loc += fb_count[c];
-    atomicAdd(&fb_total, loc);
-    __syncthreads();
-    if (tid == 0) { mdl->uniform_fallbacks += fb_total; mdl->fwd_mismatch = 0u; }
+    if (tid == 0) mdl->fwd_mismatch = 0u;
 }
 
 #endif

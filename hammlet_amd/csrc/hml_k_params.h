@@ -58,10 +58,30 @@ __global__ __launch_bounds__(1024) void hml_k_params(hml_model* __restrict__ mdl
     __shared__ float fin[K][2];
     __shared__ float graw[K * K];
     __shared__ float praw[K];
+    __shared__ unsigned long long s_trans[K * K];
+    __shared__ unsigned long long s_occ[K];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const unsigned long long epoch = mdl->epoch;
     const hml_key key = mdl->key;
 
+    // gather the split integer accumulators
+    if (tid >= 128 && tid < 128 + K * K) {
+        const int e = tid - 128;
+        unsigned long long t = 0ull;
+#pragma unroll
+        for (int sp = 0; sp < HML_CNT_SPLIT; ++sp) { t += mdl->trans[sp][e]; mdl->trans[sp][e] = 0ull; }
+        s_trans[e] = t;
+        mdl->last_trans[e] = t;
+    }
+    if (tid >= 512 && tid < 512 + K) {
+        const int k = tid - 512;
+        unsigned long long t = 0ull;
+#pragma unroll
+        for (int sp = 0; sp < HML_CNT_SPLIT; ++sp) { t += mdl->occ[sp][k]; mdl->occ[sp][k] = 0ull; }
+        s_occ[k] = t;
+        mdl->last_occ[k] = t;
+    }
+    if (mode != 0) __syncthreads();
     if (mode == 0) {
         // finish the fixed tree over the 1024 group partials: butterfly inside each wavefront ...
 #pragma unroll
@@ -93,7 +113,7 @@ __global__ __launch_bounds__(1024) void hml_k_params(hml_model* __restrict__ mdl
     if (wave == 0 && lane < K) {
         const int k = lane;
         float alpha = mdl->nig_post[k][0], beta = mdl->nig_post[k][1], mu0 = mdl->nig_post[k][2], nu = mdl->nig_post[k][3];
-        const unsigned long long cnt = (mode == 0) ? mdl->occ[k] : 0ull;   // n_s == occupancy (exact integers)
+        const unsigned long long cnt = (mode == 0) ? s_occ[k] : 0ull;   // n_s == occupancy (exact integers)
         if (mode == 0) { mdl->last_sum[k] = fin[k][0]; mdl->last_sumsq[k] = fin[k][1]; }
         if (cnt > 0ull) {
             // Conjugate<NormalInverseGammaParam>::addObservation (Conjugate.hpp:121-168)
@@ -132,14 +152,14 @@ __global__ __launch_bounds__(1024) void hml_k_params(hml_model* __restrict__ mdl
     if (mode != 2) {
         if (wave == 1 && lane < K) {
             const int k = lane;
-            const float al = mdl->dirPi[k] + (float)mdl->occ[k];
+            const float al = mdl->dirPi[k] + (float)s_occ[k];
             hml_dev_src src;
             src.s = hml_stream_open(key, HML_KIND_PI, epoch, (uint32_t)k);
             praw[k] = hml_gamma_f32<hml_devmath>(src, al, 1.0f);
         }
         if (tid >= 128 && tid < 128 + K * K) {
             const int e = tid - 128;
-            const float al = mdl->dirA[e] + (float)mdl->trans[e];
+            const float al = mdl->dirA[e] + (float)s_trans[e];
             hml_dev_src src;
             src.s = hml_stream_open(key, HML_KIND_TRANS, epoch, (uint32_t)e);
             graw[e] = hml_gamma_f32<hml_devmath>(src, al, 1.0f);
@@ -166,19 +186,17 @@ __global__ __launch_bounds__(1024) void hml_k_params(hml_model* __restrict__ mdl
         if (tid >= 128 && tid < 128 + K * K) {
             const int e = tid - 128;
             mdl->dirA[e] = (e / K == e % K) ? mdl->a_diag : mdl->a_off;
-            mdl->last_trans[e] = mdl->trans[e];
-            mdl->trans[e] = 0ull;
         }
         if (tid >= 512 && tid < 512 + K) {
             const int k = tid - 512;
             mdl->dirPi[k] = mdl->pi_alpha;
-            mdl->last_occ[k] = mdl->occ[k]; mdl->occ[k] = 0ull;
         }
     }
     __threadfence_block();
     __syncthreads();
     hml_derive<K>(mdl, tid);
     if (tid == 1023) {
+        mdl->fwd_mismatch = 0u;
         mdl->epoch = epoch + 1ull;
         if (mode == 0) { mdl->sweeps += 1ull; mdl->block_updates += (unsigned long long)mdl->B; }
     }

@@ -11,6 +11,7 @@
 #define HML_REDUCE_GROUPS 1024 // chunk c is accumulated by group c % HML_REDUCE_GROUPS
 #define HML_BWD_CHUNK 64       // trellis rows per backward map chunk (one wavefront)
 #define HML_FWD_GROUP 16       // lanes cooperating on one forward chunk (>= HML_MAX_K)
+#define HML_CNT_SPLIT 16       // the integer count accumulators are split 16 ways to spread atomic contention
 
 // error codes raised on the device (first one wins); mirrored into messages by the host
 enum {
@@ -53,8 +54,8 @@ struct hml_model {
     uint32_t B;                  // number of blocks
     uint32_t n_spans;
     // ---- per-sweep accumulators (zeroed by the parameter kernel) ----
-    unsigned long long trans[HML_MAX_K * HML_MAX_K];
-    unsigned long long occ[HML_MAX_K];
+    unsigned long long trans[HML_CNT_SPLIT][HML_MAX_K * HML_MAX_K];
+    unsigned long long occ[HML_CNT_SPLIT][HML_MAX_K];
     // copies of the last sweep's sufficient statistics (probe)
     unsigned long long last_trans[HML_MAX_K * HML_MAX_K];
     unsigned long long last_occ[HML_MAX_K];
