@@ -156,7 +156,7 @@ def main():
         }
 
     if args.breakdown and rank == 0:
-        names = ("blocks_compact", "blocks_offsets", "block_stats", "emission", "forward", "backward", "counts", "params")
+        names = ("blocks_compact", "blocks_scatter", "stats_emission", "forward", "forward_fix", "backward", "counts", "params")
         before = {nm: chain.profile_get(nm) for nm in names}
         chain.profile_enable(2)
         chain.iterate("F", min(50, args.steps), 0)

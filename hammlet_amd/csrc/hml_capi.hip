@@ -73,9 +73,10 @@ struct hml_ctx {
     float2* d_ia = nullptr;
     // block structure
     uint16_t* d_stage = nullptr;
-    uint32_t *d_span_count = nullptr, *d_span_offset = nullptr, *d_starts = nullptr;
+    uint32_t *d_span_count = nullptr, *d_starts = nullptr;
     float2* d_bstat = nullptr;
     uint32_t n_spans = 0;
+    uint32_t* d_coarse1 = nullptr;   // block count per group of 64 spans
     // sweep buffers (allocated by set_model)
     float *d_em = nullptr, *d_gsc = nullptr, *d_rows = nullptr, *d_eprobe = nullptr, *d_aprobe = nullptr;
     float *d_entry = nullptr, *d_exitA = nullptr, *d_exitB = nullptr;
@@ -87,7 +88,8 @@ struct hml_ctx {
     int32_t* d_diff = nullptr;
     uint32_t* d_boundary = nullptr;
     hml_model* d_mdl = nullptr;
-    uint32_t* h_B = nullptr;        // pinned: last block count copied back (grid sizing hint)
+    uint32_t* h_B = nullptr;        // pinned + mapped: the offsets kernel stores the block count here (grid sizing hint)
+    uint32_t* d_hB = nullptr;       // device view of h_B
     uint32_t B_hint = 0;
     // forward geometry
     int fwdL = 16, fwdW = 32, fwdRounds = 1;
@@ -255,8 +257,9 @@ int hml_create(hml_ctx** out, int device, uint64_t seed, uint32_t chain_id, void
     else { HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)); c->own_stream = true; }
     HIPCHK(hipMalloc(&c->d_mdl, sizeof(hml_model)));
     HIPCHK(hipMemsetAsync(c->d_mdl, 0, sizeof(hml_model), c->stream));
-    HIPCHK(hipHostMalloc(&c->h_B, sizeof(uint32_t)));
+    HIPCHK(hipHostMalloc(&c->h_B, sizeof(uint32_t), hipHostMallocMapped));
     *c->h_B = 0;
+    HIPCHK(hipHostGetDevicePointer((void**)&c->d_hB, c->h_B, 0));
     if (const char* e = getenv("HML_FWD_CHUNK")) c->fwdL = std::max(1, atoi(e));
     if (const char* e = getenv("HML_FWD_WARMUP")) c->fwdW = std::max(0, atoi(e));
     if (const char* e = getenv("HML_FWD_ROUNDS")) c->fwdRounds = std::max(0, atoi(e));
@@ -265,8 +268,8 @@ int hml_create(hml_ctx** out, int device, uint64_t seed, uint32_t chain_id, void
 }
 
 static void free_all(hml_ctx* c) {
-    void* ptrs[] = {c->d_w, c->d_coeff, c->d_ia, c->d_stage, c->d_span_count, c->d_span_offset, c->d_starts, c->d_bstat,
-                    c->d_em, c->d_gsc, c->d_rows, c->d_eprobe, c->d_aprobe, c->d_entry, c->d_exitA, c->d_exitB, c->d_fb,
+    void* ptrs[] = {c->d_w, c->d_coeff, c->d_ia, c->d_stage, c->d_span_count, c->d_starts, c->d_bstat,
+                    c->d_em, c->d_gsc, c->d_rows, c->d_eprobe, c->d_aprobe, c->d_entry, c->d_exitA, c->d_exitB, c->d_fb, c->d_coarse1,
                     c->d_smap, c->d_cmap, c->d_bentry, c->d_q, c->d_partial, c->d_diff, c->d_boundary, c->d_mdl};
     for (void* p : ptrs) if (p) hipFree(p);
     if (c->h_B) hipHostFree(c->h_B);
@@ -348,8 +351,8 @@ static int build_from_device_x(hml_ctx* c, const float* d_x, const float* h_x) {
     c->n_spans = (uint32_t)((T + HML_SPAN - 1) / HML_SPAN);
     HIPCHK(hipMalloc(&c->d_stage, (uint64_t)c->n_spans * HML_SPAN * sizeof(uint16_t)));
     HIPCHK(hipMalloc(&c->d_span_count, c->n_spans * sizeof(uint32_t)));
-    HIPCHK(hipMalloc(&c->d_span_offset, c->n_spans * sizeof(uint32_t)));
     HIPCHK(hipMalloc(&c->d_starts, (T + 1) * sizeof(uint32_t)));
+    HIPCHK(hipMalloc(&c->d_coarse1, (((c->n_spans + 63u) >> 6) + 1u) * sizeof(uint32_t)));
     HIPCHK(hipMalloc(&c->d_bstat, T * sizeof(float2)));
     HIPCHK(hipStreamSynchronize(c->stream));
     c->loaded = true;
@@ -399,23 +402,27 @@ int hml_scale_weights(hml_ctx* c, float mult) {
 }
 
 // ---------------------------------------------------------------------------------------- blocks
-static int launch_compact(hml_ctx* c, bool use_override, float thr) {
-    const uint32_t T = (uint32_t)c->T;
+// K4: scan (the HBM-bound kernel) + scatter with in-kernel offsets
+static void launch_compact_pair(hml_ctx* c, bool use_override, float thr) {
+    const uint32_t nwg = (c->n_spans + 3) / 4;
     {
         ProfScope ps(c, "blocks_compact", 1);
-        hipLaunchKernelGGL(hml_k_compact_scan, dim3((c->n_spans + 3) / 4), dim3(256), 0, c->stream, c->d_w, T, c->d_mdl, thr,
+        hipLaunchKernelGGL(hml_k_compact_scan, dim3(nwg), dim3(256), 0, c->stream, c->d_w, (uint32_t)c->T, c->d_mdl, thr,
                            use_override ? 1 : 0, c->d_stage, c->d_span_count);
     }
-    KLAUNCH_CHECK();
     {
-        ProfScope ps(c, "blocks_offsets");
-        hipLaunchKernelGGL(hml_k_compact_offsets, dim3(1), dim3(1024), 0, c->stream, c->d_span_count, c->d_span_offset,
-                           c->n_spans, c->d_mdl, c->d_starts, T);
-        hipLaunchKernelGGL(hml_k_compact_scatter, dim3((c->n_spans + 3) / 4), dim3(256), 0, c->stream, c->d_stage,
-                           c->d_span_count, c->d_span_offset, c->n_spans, c->d_starts);
+        ProfScope ps(c, "blocks_scatter");
+        const uint32_t n1 = (c->n_spans + 63u) >> 6;
+        hipLaunchKernelGGL(hml_k_group_totals, dim3((n1 + 3) / 4), dim3(256), 0, c->stream, c->d_span_count, c->n_spans,
+                           c->d_coarse1);
+        hipLaunchKernelGGL(hml_k_compact_scatter, dim3(nwg), dim3(256), 0, c->stream, c->d_stage, c->d_span_count,
+                           c->d_coarse1, c->n_spans, (uint32_t)c->T, c->d_mdl, c->d_starts, c->d_hB);
     }
+}
+
+static int launch_compact(hml_ctx* c, bool use_override, float thr) {
+    launch_compact_pair(c, use_override, thr);
     KLAUNCH_CHECK();
-    HIPCHK(hipMemcpyAsync(c->h_B, &c->d_mdl->B, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
     {
         ProfScope ps(c, "block_stats");
         const uint32_t hint = c->B_hint ? c->B_hint : (uint32_t)std::min<uint64_t>(c->T, 1u << 20);
@@ -602,17 +609,28 @@ static int ensure_marginal_buffers(hml_ctx* c) {
 template <int KK>
 static int sweep_k(hml_ctx* c, char method, bool record) {
     hipStream_t s = c->stream;
-    if (c->dynamic) {
-        if (int r = launch_compact(c, false, 0.0f)) return r;
-    } else if (!c->blocks_valid) {
-        if (int r = launch_compact(c, false, 0.0f)) return r;
-        c->blocks_valid = true;
+    const bool mix = (method == HML_METHOD_MIXTURE);
+    const uint32_t T = (uint32_t)c->T;
+    bool emitted = false;
+    if (c->dynamic || !c->blocks_valid) {
+        // K4 single-pass scan + compaction, then statistics and emission terms in one dense launch
+        launch_compact_pair(c, false, 0.0f);
+        {
+            refresh_hint(c);
+            const uint32_t h0 = c->B_hint ? c->B_hint : (uint32_t)std::min<uint64_t>(c->T, 1u << 20);
+            ProfScope ps(c, "stats_emission");
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_stats_emission<KK>), dim3(grid_for(h0, 256, 64, 16384)), dim3(256), 0, s,
+                               c->d_ia, c->d_starts, c->d_mdl, c->d_bstat, c->d_em, c->d_gsc, c->probes ? c->d_eprobe : nullptr,
+                               mix ? 1 : 0);
+        }
+        KLAUNCH_CHECK();
+        emitted = true;
+        if (!c->dynamic) c->blocks_valid = true;
     }
     refresh_hint(c);
     const uint32_t hint = c->B_hint ? c->B_hint : (uint32_t)std::min<uint64_t>(c->T, 1u << 20);
     const int gB = grid_for(hint, 256, 64, 16384);
-    const bool mix = (method == HML_METHOD_MIXTURE);
-    {
+    if (!emitted) {
         ProfScope ps(c, "emission");
         hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_emission<KK>), dim3(gB), dim3(256), 0, s, c->d_bstat, c->d_starts, c->d_mdl,
                            c->d_em, c->d_gsc, c->probes ? c->d_eprobe : nullptr, mix ? 1 : 0);
@@ -621,20 +639,24 @@ static int sweep_k(hml_ctx* c, char method, bool record) {
         const int L = c->fwdL, W = c->fwdW;
         const uint64_t chunks = ((uint64_t)hint + L - 1) / L;
         const int gF = grid_for(chunks * HML_FWD_GROUP, 256, 16, 1 << 20);
+        float* ein = c->d_exitA; float* eout = c->d_exitB;
         {
             ProfScope ps(c, "forward");
             hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_forward<KK, 0>), dim3(gF), dim3(256), 0, s, c->d_em, c->d_gsc, c->d_mdl,
                                c->d_rows, c->probes ? c->d_aprobe : nullptr, c->d_entry, (const float*)nullptr, c->d_exitA,
                                c->d_fb, L, W);
-            float* ein = c->d_exitA; float* eout = c->d_exitB;
+        }
+        {
+            ProfScope ps(c, "forward_fix");
             for (int r = 0; r < c->fwdRounds; ++r) {
                 hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_forward<KK, 1>), dim3(gF), dim3(256), 0, s, c->d_em, c->d_gsc, c->d_mdl,
                                    c->d_rows, c->probes ? c->d_aprobe : nullptr, c->d_entry, (const float*)ein, eout, c->d_fb,
                                    L, W);
                 std::swap(ein, eout);
             }
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_forward<KK, 2>), dim3(gF), dim3(256), 0, s, c->d_em, c->d_gsc, c->d_mdl,
-                               c->d_rows, (float*)nullptr, c->d_entry, (const float*)ein, eout, c->d_fb, L, W);
+            if (c->fwdRounds == 0)   // no repair round: a verify-only pass decides whether the serial pass must run
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_forward<KK, 2>), dim3(gF), dim3(256), 0, s, c->d_em, c->d_gsc, c->d_mdl,
+                                   c->d_rows, (float*)nullptr, c->d_entry, (const float*)ein, eout, c->d_fb, L, W);
             hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_forward_serial<KK>), dim3(1), dim3(256), 0, s, c->d_em, c->d_gsc, c->d_mdl,
                                c->d_rows, c->probes ? c->d_aprobe : nullptr, c->d_entry, ein, c->d_fb, L, W);
         }
@@ -645,16 +667,23 @@ static int sweep_k(hml_ctx* c, char method, bool record) {
                                s, c->d_rows, c->d_mdl, c->d_smap, c->d_cmap);
             hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_backward_chain<KK>), dim3(1), dim3(1024), 0, s, c->d_cmap, c->d_mdl,
                                c->d_bentry);
-            hipLaunchKernelGGL(hml_k_backward_apply, dim3(gB), dim3(256), 0, s, c->d_smap, c->d_bentry, c->d_mdl, c->d_q);
+        }
+        {
+            ProfScope ps(c, "counts");
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_counts<KK, true>), dim3(HML_REDUCE_GROUPS), dim3(256), 0, s, c->d_q,
+                               c->d_starts, c->d_bstat, c->d_mdl, c->d_partial, c->d_smap, c->d_bentry);
         }
     } else {
-        ProfScope ps(c, "backward");
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_mixture<KK>), dim3(gB), dim3(256), 0, s, c->d_em, c->d_mdl, c->d_q);
-    }
-    {
-        ProfScope ps(c, "counts");
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_counts<KK>), dim3(HML_REDUCE_GROUPS), dim3(256), 0, s, c->d_q, c->d_starts,
-                           c->d_bstat, c->d_mdl, c->d_partial);
+        {
+            ProfScope ps(c, "backward");
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_mixture<KK>), dim3(gB), dim3(256), 0, s, c->d_em, c->d_mdl, c->d_q);
+        }
+        {
+            ProfScope ps(c, "counts");
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_counts<KK, false>), dim3(HML_REDUCE_GROUPS), dim3(256), 0, s, c->d_q,
+                               c->d_starts, c->d_bstat, c->d_mdl, c->d_partial, (const unsigned long long*)nullptr,
+                               (const uint8_t*)nullptr);
+        }
     }
     if (record && c->rec_marginals) {
         if (int r = ensure_marginal_buffers(c)) return r;

@@ -189,10 +189,14 @@ __device__ __forceinline__ double hml_shfl_xor_f64(double v, int m) {
     return hml_u2d(((unsigned long long)hi << 32) | lo);
 }
 
-template <int K>
-__global__ __launch_bounds__(256) void hml_k_counts(const int16_t* __restrict__ q, const uint32_t* __restrict__ starts,
+// FB = true: the states come straight from the backward maps (q_b = S_{b+1}(entry[chunk]), K7c) and are
+// written to q[] on the way; FB = false (mixture sweeps): q[] was written by the mixture kernel.
+template <int K, bool FB>
+__global__ __launch_bounds__(256) void hml_k_counts(int16_t* __restrict__ q, const uint32_t* __restrict__ starts,
                                                     const float2* __restrict__ bstat, hml_model* __restrict__ mdl,
-                                                    double* __restrict__ partial /*[GROUPS][K][2]*/) {
+                                                    double* __restrict__ partial /*[GROUPS][K][2]*/,
+                                                    const unsigned long long* __restrict__ smap,
+                                                    const uint8_t* __restrict__ entry) {
     __shared__ unsigned long long h_trans[K * K];
     __shared__ unsigned long long h_occ[K];
     __shared__ double wsum[4][K][2];
@@ -211,9 +215,16 @@ __global__ __launch_bounds__(256) void hml_k_counts(const int16_t* __restrict__ 
         int st = -1;
         double vx = 0.0, vq = 0.0;
         if (b < B) {
-            st = q[b];
+            int prev;
+            if (FB) {
+                st = (int)((smap[b + 1] >> (4 * (unsigned)entry[b / HML_BWD_CHUNK])) & 15ull);
+                prev = (b == 0) ? 0 : (int)((smap[b] >> (4 * (unsigned)entry[(b - 1) / HML_BWD_CHUNK])) & 15ull);
+                q[b] = (int16_t)st;
+            } else {
+                st = q[b];
+                prev = (b == 0) ? 0 : (int)q[b - 1];
+            }
             const uint32_t n = starts[b + 1] - starts[b];
-            const int prev = (b == 0) ? 0 : (int)q[b - 1];
             const float2 v = bstat[b];
             vx = (double)v.x; vq = (double)v.y;
             atomicAdd(&h_trans[st * K + st], (unsigned long long)(n - 1u));

@@ -13,8 +13,12 @@
 //   (a) scan:    one wavefront per span of 4096 positions, 16 x (64 lanes x float4) coalesced loads
 //                issued up-front; flagged positions are written, in order, as 16-bit offsets into
 //                the span's slot of a staging array; the span's count goes to span_count[].
-//   (b) offsets: exclusive scan of span_count (one workgroup) -> span_offset[], B.
-//   (c) scatter: staged offsets -> starts[], starts[B] = T.
+//   (b) scatter: every span's wavefront derives its global offset from the totals of the 64-span groups
+//                before it (a tiny kernel sums them, one wavefront per group) plus the counts of the
+//                <= 63 spans before it in its own group - a handful of coalesced reads instead of a
+//                serial scan launch - and turns the staged offsets into starts[], starts[B] = T.
+//   A decoupled look-back single-pass version was measured and rejected: with ~8000 one-span tiles in
+//   flight its first generation serialises ~128 look-back windows (318 us vs 64 us for the scan alone).
 // Nothing but flagged positions is ever written, so at typical compression (1 start per ~500
 // positions) the kernel's traffic is the 4*T bytes of w.
 // ------------------------------------------------------------------------------------------
@@ -78,69 +82,58 @@ __global__ __launch_bounds__(256) void hml_k_compact_scan(const float* __restric
     if (lane == 0) span_count[span] = running;
 }
 
-// exclusive scan of span_count[0..n_spans) -> span_offset, total -> mdl->B.  One workgroup of 1024:
-// each wavefront owns a contiguous slice, reads it 64 entries at a time (coalesced), scans each
-// group of 64 with shuffles and carries a running total; the 16 slice totals are scanned in LDS and
-// added in a second coalesced sweep.
-__global__ __launch_bounds__(1024) void hml_k_compact_offsets(const uint32_t* __restrict__ span_count,
-                                                              uint32_t* __restrict__ span_offset, uint32_t n_spans,
-                                                              hml_model* __restrict__ mdl, uint32_t* __restrict__ starts,
-                                                              uint32_t T) {
-    __shared__ uint32_t wtot[16];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const uint32_t per_wave = ((n_spans + 15u) / 16u + 63u) / 64u * 64u;   // slice length, multiple of 64
-    const uint32_t a = (uint32_t)wave * per_wave;
-    const uint32_t b = (a + per_wave < n_spans) ? a + per_wave : n_spans;
-    uint32_t run = 0;
-    for (uint32_t i0 = a; i0 < b; i0 += 256u) {
-        // four groups of 64 per trip so that four loads are in flight
-        uint32_t v[4];
+__device__ __forceinline__ uint32_t hml_wave_sum_u32(uint32_t v) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const uint32_t i = i0 + (uint32_t)k * 64u + (uint32_t)lane;
-            v[k] = (i < b) ? span_count[i] : 0u;
-        }
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            uint32_t incl = v[k];
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) {
-                const uint32_t o = __shfl_up(incl, d);
-                if (lane >= d) incl += o;
-            }
-            const uint32_t i = i0 + (uint32_t)k * 64u + (uint32_t)lane;
-            if (i < b) span_offset[i] = run + incl - v[k];
-            run += __shfl(incl, 63);
-        }
-    }
-    if (lane == 0) wtot[wave] = run;
-    __syncthreads();
-    uint32_t base = 0, total = 0;
-#pragma unroll
-    for (int w2 = 0; w2 < 16; ++w2) {
-        if (w2 < wave) base += wtot[w2];
-        total += wtot[w2];
-    }
-    if (base != 0u)
-        for (uint32_t i = a + (uint32_t)lane; i < b; i += 64u) span_offset[i] += base;
-    if (tid == 0) {
-        mdl->B = total;
-        starts[total] = T;
-    }
+    for (int m = 1; m < 64; m <<= 1) v += __shfl_xor(v, m);
+    return v;
+}
+
+// block count of every group of 64 spans (one wavefront per group; plain stores, no atomics: atomics from
+// the scan kernel itself were measured to cost it 10-16 us)
+__global__ __launch_bounds__(256) void hml_k_group_totals(const uint32_t* __restrict__ span_count, uint32_t n_spans,
+                                                          uint32_t* __restrict__ coarse1) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint32_t g = blockIdx.x * 4u + (uint32_t)wave;
+    const uint32_t i = (g << 6) + (uint32_t)lane;
+    if ((g << 6) >= n_spans) return;
+    const uint32_t v = hml_wave_sum_u32(i < n_spans ? span_count[i] : 0u);
+    if (lane == 0) coarse1[g] = v;
+}
+
+// exclusive offset of `span`: totals of the 64-span groups before it + counts of the spans before it
+// inside its group (T = 10^8: 6 + 1 coalesced reads per lane)
+__device__ __forceinline__ uint32_t hml_span_offset(const uint32_t* __restrict__ span_count,
+                                                    const uint32_t* __restrict__ coarse1, uint32_t span, int lane) {
+    uint32_t acc = 0;
+    const uint32_t g1 = span >> 6;
+    for (uint32_t i = (uint32_t)lane; i < g1; i += 64u) acc += coarse1[i];
+    const uint32_t s_first = g1 << 6;
+    if (s_first + (uint32_t)lane < span) acc += span_count[s_first + (uint32_t)lane];
+    return hml_wave_sum_u32(acc);
 }
 
 __global__ __launch_bounds__(256) void hml_k_compact_scatter(const uint16_t* __restrict__ stage,
                                                              const uint32_t* __restrict__ span_count,
-                                                             const uint32_t* __restrict__ span_offset, uint32_t n_spans,
-                                                             uint32_t* __restrict__ starts) {
+                                                             const uint32_t* __restrict__ coarse1, uint32_t n_spans,
+                                                             uint32_t T, hml_model* __restrict__ mdl,
+                                                             uint32_t* __restrict__ starts, uint32_t* __restrict__ host_B) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const uint32_t span = blockIdx.x * 4u + (uint32_t)wave;
     if (span >= n_spans) return;
     const uint32_t cnt = span_count[span];
-    const uint32_t off = span_offset[span];
+    const bool is_last = (span == n_spans - 1u);
+    if (cnt == 0u && !is_last) return;
+    const uint32_t off = hml_span_offset(span_count, coarse1, span, lane);
     const uint32_t base = span * (uint32_t)HML_SPAN;
     const uint16_t* __restrict__ in = stage + (uint64_t)base;
     for (uint32_t k = lane; k < cnt; k += 64) starts[off + k] = base + (uint32_t)in[k];
+    if (is_last && lane == 0) {
+        const uint32_t B = off + cnt;
+        mdl->B = B;
+        starts[B] = T;
+        // host-mapped word: lets the host size later grids without a copy in the stream
+        if (host_B) __hip_atomic_store(host_B, B, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 }
 
 // ------------------------------------------------------------------------------------------

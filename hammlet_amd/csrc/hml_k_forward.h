@@ -2,6 +2,7 @@
 #ifndef HML_K_FORWARD_H
 #define HML_K_FORWARD_H
 
+#include "hml_k_blocks.h"
 #include "hml_math.h"
 #include "hml_state.h"
 
@@ -23,37 +24,75 @@ __device__ __forceinline__ bool hml_isfinite(float x) { return (hml_f2u(x) & 0x7
 // One thread per block; em/g are [B][K] floats.
 // ------------------------------------------------------------------------------------------
 template <int K>
+struct hml_emit_params {
+    float mu[K], var[K], logN[K], logA[K];
+    bool self;
+};
+
+template <int K>
+__device__ __forceinline__ void hml_emit_load(hml_emit_params<K>& p, const hml_model* mdl, int mixture) {
+#pragma unroll
+    for (int s = 0; s < K; ++s) { p.mu[s] = mdl->mu[s]; p.var[s] = mdl->var[s]; p.logN[s] = mdl->logN[s]; p.logA[s] = mdl->logA[s]; }
+    p.self = mdl->self_trans != 0 && !mixture;
+}
+
+template <int K>
+__device__ __forceinline__ void hml_emit_block(const hml_emit_params<K>& p, hml_model* mdl, uint32_t b, float sx, float sq,
+                                               float N, float* __restrict__ em, float* __restrict__ gsc,
+                                               float* __restrict__ eprobe, int mixture) {
+    float E[K];
+    float maxE = -3.40282346638528859812e+38f;   // numeric_limits<float>::lowest()
+#pragma unroll
+    for (int s = 0; s < K; ++s) {
+        const double ipd = (2.0 * (double)p.mu[s] * (double)sx - (double)sq) / (2.0 * (double)p.var[s]);
+        const float ip = (float)ipd;
+        if (!hml_isfinite(ip)) hml_raise(mdl, HML_DEVERR_IP_NOT_FINITE, ip);
+        float e = (0.0f + ip) - N * p.logN[s];
+        if (p.self) e += (N - 1.0f) * p.logA[s];
+        E[s] = e;
+        maxE = (e < maxE) ? maxE : e;   // std::max(E, maxE)
+    }
+#pragma unroll
+    for (int s = 0; s < K; ++s) {
+        if (eprobe) eprobe[(uint64_t)b * K + s] = E[s];
+        em[(uint64_t)b * K + s] = hml_expf(E[s] - maxE);
+        if (!mixture) gsc[(uint64_t)b * K + s] = p.self ? hml_expf((N - 1.0f) * p.logA[s]) : 1.0f;
+    }
+}
+
+template <int K>
 __global__ __launch_bounds__(256) void hml_k_emission(const float2* __restrict__ bstat,
                                                       const uint32_t* __restrict__ starts, hml_model* __restrict__ mdl,
                                                       float* __restrict__ em, float* __restrict__ gsc,
                                                       float* __restrict__ eprobe, int mixture) {
     const uint32_t B = mdl->B;
-    const bool self = mdl->self_trans != 0 && !mixture;
-    float mu[K], var[K], logN[K], logA[K];
-#pragma unroll
-    for (int s = 0; s < K; ++s) { mu[s] = mdl->mu[s]; var[s] = mdl->var[s]; logN[s] = mdl->logN[s]; logA[s] = mdl->logA[s]; }
+    hml_emit_params<K> p;
+    hml_emit_load<K>(p, mdl, mixture);
     const uint32_t stride = gridDim.x * blockDim.x;
     for (uint32_t b = blockIdx.x * blockDim.x + threadIdx.x; b < B; b += stride) {
         const float2 st = bstat[b];
         const float N = (float)(starts[b + 1] - starts[b]);
-        float E[K];
-        float maxE = -3.40282346638528859812e+38f;   // numeric_limits<float>::lowest()
-#pragma unroll
-        for (int s = 0; s < K; ++s) {
-            const double ipd = (2.0 * (double)mu[s] * (double)st.x - (double)st.y) / (2.0 * (double)var[s]);
-            const float ip = (float)ipd;
-            if (!hml_isfinite(ip)) hml_raise(mdl, HML_DEVERR_IP_NOT_FINITE, ip);
-            float e = (0.0f + ip) - N * logN[s];
-            if (self) e += (N - 1.0f) * logA[s];
-            E[s] = e;
-            maxE = (e < maxE) ? maxE : e;   // std::max(E, maxE)
-        }
-#pragma unroll
-        for (int s = 0; s < K; ++s) {
-            if (eprobe) eprobe[(uint64_t)b * K + s] = E[s];
-            em[(uint64_t)b * K + s] = hml_expf(E[s] - maxE);
-            if (!mixture) gsc[(uint64_t)b * K + s] = self ? hml_expf((N - 1.0f) * logA[s]) : 1.0f;
-        }
+        hml_emit_block<K>(p, mdl, b, st.x, st.y, N, em, gsc, eprobe, mixture);
+    }
+}
+
+// K5+K6a fused for the sweeps that rebuild the block structure: one thread per block gathers the block
+// statistics from the integral array and emits the per-state terms - one dense launch instead of two.
+template <int K>
+__global__ __launch_bounds__(256) void hml_k_stats_emission(const float2* __restrict__ ia, const uint32_t* __restrict__ starts,
+                                                            hml_model* __restrict__ mdl, float2* __restrict__ bstat,
+                                                            float* __restrict__ em, float* __restrict__ gsc,
+                                                            float* __restrict__ eprobe, int mixture) {
+    const uint32_t B = mdl->B;
+    hml_emit_params<K> p;
+    hml_emit_load<K>(p, mdl, mixture);
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t b = blockIdx.x * blockDim.x + threadIdx.x; b < B; b += stride) {
+        const uint32_t s = starts[b], e = starts[b + 1];
+        float sx, sq;
+        hml_block_stats_one(ia, s, e, sx, sq);
+        bstat[b] = make_float2(sx, sq);
+        hml_emit_block<K>(p, mdl, b, sx, sq, (float)(e - s), em, gsc, eprobe, mixture);
     }
 }
 
@@ -184,6 +223,13 @@ __global__ __launch_bounds__(256) void hml_k_forward(const float* __restrict__ e
                 rows[(uint64_t)t * K + j] = stored;
                 if (aprobe) aprobe[(uint64_t)t * K + j] = alpha;
             }
+        }
+        if (MODE == 1) {
+            // a recomputed chunk that ends in different bits leaves its successor inconsistent: only then
+            // does the serial pass have work
+            const bool unchanged = !act || hml_f2u(alpha) == hml_f2u(exit_in[(uint64_t)c * K + j]);
+            const unsigned long long bal2 = __ballot(unchanged);
+            if (((bal2 >> (grp_in_wave * HML_FWD_GROUP)) & 0xffffull) != 0xffffull && j == 0) mdl->fwd_mismatch = 1u;
         }
         if (act) exit_out[(uint64_t)c * K + j] = alpha;
         if (j == 0) {
