@@ -92,7 +92,8 @@ struct hml_ctx {
     uint32_t* d_hB = nullptr;       // device view of h_B
     uint32_t B_hint = 0;
     // forward geometry
-    int fwdL = 16, fwdW = 32, fwdRounds = 1;
+    int fwdL = 4, fwdW = 24, fwdRounds = 1;
+    hml_layout lay = {2, 0};
     bool probes = false;
     bool rec_marginals = true;
     hml_record_cb cb = nullptr;
@@ -260,7 +261,7 @@ int hml_create(hml_ctx** out, int device, uint64_t seed, uint32_t chain_id, void
     HIPCHK(hipHostMalloc(&c->h_B, sizeof(uint32_t), hipHostMallocMapped));
     *c->h_B = 0;
     HIPCHK(hipHostGetDevicePointer((void**)&c->d_hB, c->h_B, 0));
-    if (const char* e = getenv("HML_FWD_CHUNK")) c->fwdL = std::max(1, atoi(e));
+    if (const char* e = getenv("HML_FWD_CHUNK")) { int l = std::max(1, atoi(e)); int sh = 0; while ((1 << (sh + 1)) <= l && sh < 10) ++sh; c->fwdL = 1 << sh; }
     if (const char* e = getenv("HML_FWD_WARMUP")) c->fwdW = std::max(0, atoi(e));
     if (const char* e = getenv("HML_FWD_ROUNDS")) c->fwdRounds = std::max(0, atoi(e));
     *out = c;
@@ -503,10 +504,16 @@ int hml_set_model(hml_ctx* c, int K, const float nig4[4], float a_off, float a_d
     if (int r = ctx_bind(c)) return r;
     c->K = K;
     const uint64_t T = c->T;
-    HIPCHK(hipMalloc(&c->d_em, T * K * sizeof(float)));
-    HIPCHK(hipMalloc(&c->d_gsc, T * K * sizeof(float)));
-    HIPCHK(hipMalloc(&c->d_rows, (T + 1) * K * sizeof(float)));
     const uint64_t maxChunks = (T + c->fwdL - 1) / c->fwdL + 1;
+    {
+        int sh = 0; while ((1 << sh) < c->fwdL) ++sh;
+        c->lay.lshift = (uint32_t)sh;
+        c->lay.cstride = (uint32_t)((maxChunks + 63) / 64 * 64);
+    }
+    const uint64_t plane = (uint64_t)c->fwdL * K * c->lay.cstride;   // floats in one chunk-transposed [L][K][cstride] array
+    HIPCHK(hipMalloc(&c->d_em, plane * sizeof(float)));
+    HIPCHK(hipMalloc(&c->d_gsc, plane * sizeof(float)));
+    HIPCHK(hipMalloc(&c->d_rows, plane * sizeof(float)));
     HIPCHK(hipMalloc(&c->d_entry, maxChunks * K * sizeof(float)));
     HIPCHK(hipMalloc(&c->d_exitA, maxChunks * K * sizeof(float)));
     HIPCHK(hipMalloc(&c->d_exitB, maxChunks * K * sizeof(float)));
@@ -532,6 +539,7 @@ int hml_set_model(hml_ctx* c, int K, const float nig4[4], float a_off, float a_d
         for (int j = 0; j < K; ++j) { m.dirA[k * K + j] = (k == j) ? a_diag : a_off; m.A[k * K + j] = 1.0f / K; }
     }
     m.max_state_recorded = -1;
+    m.fwd_W = m.fwd_W0 = (uint32_t)c->fwdW;
     m.n_spans = c->n_spans;
     // keep the block count of an earlier enumeration (autoprior) out of the model: B = 0
     HIPCHK(hipMemcpyAsync(c->d_mdl, &m, sizeof m, hipMemcpyHostToDevice, c->stream));
@@ -621,7 +629,7 @@ static int sweep_k(hml_ctx* c, char method, bool record) {
             ProfScope ps(c, "stats_emission");
             hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_stats_emission<KK>), dim3(grid_for(h0, 256, 64, 16384)), dim3(256), 0, s,
                                c->d_ia, c->d_starts, c->d_mdl, c->d_bstat, c->d_em, c->d_gsc, c->probes ? c->d_eprobe : nullptr,
-                               mix ? 1 : 0);
+                               mix ? 1 : 0, c->lay);
         }
         KLAUNCH_CHECK();
         emitted = true;
@@ -633,38 +641,38 @@ static int sweep_k(hml_ctx* c, char method, bool record) {
     if (!emitted) {
         ProfScope ps(c, "emission");
         hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_emission<KK>), dim3(gB), dim3(256), 0, s, c->d_bstat, c->d_starts, c->d_mdl,
-                           c->d_em, c->d_gsc, c->probes ? c->d_eprobe : nullptr, mix ? 1 : 0);
+                           c->d_em, c->d_gsc, c->probes ? c->d_eprobe : nullptr, mix ? 1 : 0, c->lay);
     }
     if (!mix) {
         const int L = c->fwdL, W = c->fwdW;
         const uint64_t chunks = ((uint64_t)hint + L - 1) / L;
-        const int gF = grid_for(chunks * HML_FWD_GROUP, 256, 16, 1 << 20);
+        const int gF = grid_for(chunks, 256, 16, 1 << 20);
         float* ein = c->d_exitA; float* eout = c->d_exitB;
         {
             ProfScope ps(c, "forward");
             hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_forward<KK, 0>), dim3(gF), dim3(256), 0, s, c->d_em, c->d_gsc, c->d_mdl,
                                c->d_rows, c->probes ? c->d_aprobe : nullptr, c->d_entry, (const float*)nullptr, c->d_exitA,
-                               c->d_fb, L, W);
+                               c->d_fb, L, W, c->lay);
         }
         {
             ProfScope ps(c, "forward_fix");
             for (int r = 0; r < c->fwdRounds; ++r) {
                 hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_forward<KK, 1>), dim3(gF), dim3(256), 0, s, c->d_em, c->d_gsc, c->d_mdl,
                                    c->d_rows, c->probes ? c->d_aprobe : nullptr, c->d_entry, (const float*)ein, eout, c->d_fb,
-                                   L, W);
+                                   L, W, c->lay);
                 std::swap(ein, eout);
             }
             if (c->fwdRounds == 0)   // no repair round: a verify-only pass decides whether the serial pass must run
                 hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_forward<KK, 2>), dim3(gF), dim3(256), 0, s, c->d_em, c->d_gsc, c->d_mdl,
-                                   c->d_rows, (float*)nullptr, c->d_entry, (const float*)ein, eout, c->d_fb, L, W);
+                                   c->d_rows, (float*)nullptr, c->d_entry, (const float*)ein, eout, c->d_fb, L, W, c->lay);
             hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_forward_serial<KK>), dim3(1), dim3(256), 0, s, c->d_em, c->d_gsc, c->d_mdl,
-                               c->d_rows, c->probes ? c->d_aprobe : nullptr, c->d_entry, ein, c->d_fb, L, W);
+                               c->d_rows, c->probes ? c->d_aprobe : nullptr, c->d_entry, ein, c->d_fb, L, W, c->lay);
         }
         {
             ProfScope ps(c, "backward");
             const uint64_t bch = ((uint64_t)hint + HML_BWD_CHUNK - 1) / HML_BWD_CHUNK;
             hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_backward_maps<KK>), dim3(grid_for(bch * 64, 256, 16, 1 << 18)), dim3(256), 0,
-                               s, c->d_rows, c->d_mdl, c->d_smap, c->d_cmap);
+                               s, c->d_rows, c->d_mdl, c->d_smap, c->d_cmap, c->lay);
             hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_backward_chain<KK>), dim3(1), dim3(1024), 0, s, c->d_cmap, c->d_mdl,
                                c->d_bentry);
         }
@@ -676,7 +684,7 @@ static int sweep_k(hml_ctx* c, char method, bool record) {
     } else {
         {
             ProfScope ps(c, "backward");
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_mixture<KK>), dim3(gB), dim3(256), 0, s, c->d_em, c->d_mdl, c->d_q);
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_mixture<KK>), dim3(gB), dim3(256), 0, s, c->d_em, c->d_mdl, c->d_q, c->lay);
         }
         {
             ProfScope ps(c, "counts");

@@ -59,7 +59,7 @@ __device__ __forceinline__ int hml_categorical_k(const float (&w)[K], double u) 
 template <int K>
 __global__ __launch_bounds__(256) void hml_k_backward_maps(const float* __restrict__ rows, hml_model* __restrict__ mdl,
                                                            unsigned long long* __restrict__ smap,
-                                                           unsigned long long* __restrict__ cmap) {
+                                                           unsigned long long* __restrict__ cmap, const hml_layout lay) {
     const uint32_t B = mdl->B;
     const uint32_t nchunks = (B + HML_BWD_CHUNK - 1u) / HML_BWD_CHUNK;
     const int lane = threadIdx.x & 63;
@@ -75,7 +75,7 @@ __global__ __launch_bounds__(256) void hml_k_backward_maps(const float* __restri
             const double u = hml_canonical_f64(o.v[0], o.v[1]);
             float r[K];
 #pragma unroll
-            for (int i = 0; i < K; ++i) r[i] = rows[(uint64_t)t * K + i];
+            for (int i = 0; i < K; ++i) r[i] = rows[hml_bk(lay, t - 1u, K, i)];   // rows are stored by block b = t-1
             map = 0ull;
             if (t == B) {
                 const unsigned long long st = (unsigned long long)hml_categorical_k<K>(r, u);
@@ -160,7 +160,7 @@ __global__ __launch_bounds__(256) void hml_k_backward_apply(const unsigned long 
 // ------------------------------------------------------------------------------------------
 template <int K>
 __global__ __launch_bounds__(256) void hml_k_mixture(const float* __restrict__ em, const hml_model* __restrict__ mdl,
-                                                     int16_t* __restrict__ q) {
+                                                     int16_t* __restrict__ q, const hml_layout lay) {
     const uint32_t B = mdl->B;
     const unsigned long long epoch = mdl->epoch;
     const hml_key key = mdl->key;
@@ -168,7 +168,7 @@ __global__ __launch_bounds__(256) void hml_k_mixture(const float* __restrict__ e
     for (uint32_t b = blockIdx.x * blockDim.x + threadIdx.x; b < B; b += stride) {
         float w[K];
 #pragma unroll
-        for (int s = 0; s < K; ++s) w[s] = em[(uint64_t)b * K + s];
+        for (int s = 0; s < K; ++s) w[s] = em[hml_bk(lay, b, K, s)];
         const hml_u32x4 o = hml_stream4(key, HML_KIND_MIX, epoch, b, 0);
         q[b] = (int16_t)hml_categorical_k<K>(w, hml_canonical_f64(o.v[0], o.v[1]));
     }

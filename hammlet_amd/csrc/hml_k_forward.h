@@ -39,7 +39,7 @@ __device__ __forceinline__ void hml_emit_load(hml_emit_params<K>& p, const hml_m
 template <int K>
 __device__ __forceinline__ void hml_emit_block(const hml_emit_params<K>& p, hml_model* mdl, uint32_t b, float sx, float sq,
                                                float N, float* __restrict__ em, float* __restrict__ gsc,
-                                               float* __restrict__ eprobe, int mixture) {
+                                               float* __restrict__ eprobe, int mixture, const hml_layout lay) {
     float E[K];
     float maxE = -3.40282346638528859812e+38f;   // numeric_limits<float>::lowest()
 #pragma unroll
@@ -55,8 +55,8 @@ __device__ __forceinline__ void hml_emit_block(const hml_emit_params<K>& p, hml_
 #pragma unroll
     for (int s = 0; s < K; ++s) {
         if (eprobe) eprobe[(uint64_t)b * K + s] = E[s];
-        em[(uint64_t)b * K + s] = hml_expf(E[s] - maxE);
-        if (!mixture) gsc[(uint64_t)b * K + s] = p.self ? hml_expf((N - 1.0f) * p.logA[s]) : 1.0f;
+        em[hml_bk(lay, b, K, s)] = hml_expf(E[s] - maxE);
+        if (!mixture) gsc[hml_bk(lay, b, K, s)] = p.self ? hml_expf((N - 1.0f) * p.logA[s]) : 1.0f;
     }
 }
 
@@ -64,7 +64,7 @@ template <int K>
 __global__ __launch_bounds__(256) void hml_k_emission(const float2* __restrict__ bstat,
                                                       const uint32_t* __restrict__ starts, hml_model* __restrict__ mdl,
                                                       float* __restrict__ em, float* __restrict__ gsc,
-                                                      float* __restrict__ eprobe, int mixture) {
+                                                      float* __restrict__ eprobe, int mixture, const hml_layout lay) {
     const uint32_t B = mdl->B;
     hml_emit_params<K> p;
     hml_emit_load<K>(p, mdl, mixture);
@@ -72,7 +72,7 @@ __global__ __launch_bounds__(256) void hml_k_emission(const float2* __restrict__
     for (uint32_t b = blockIdx.x * blockDim.x + threadIdx.x; b < B; b += stride) {
         const float2 st = bstat[b];
         const float N = (float)(starts[b + 1] - starts[b]);
-        hml_emit_block<K>(p, mdl, b, st.x, st.y, N, em, gsc, eprobe, mixture);
+        hml_emit_block<K>(p, mdl, b, st.x, st.y, N, em, gsc, eprobe, mixture, lay);
     }
 }
 
@@ -82,7 +82,7 @@ template <int K>
 __global__ __launch_bounds__(256) void hml_k_stats_emission(const float2* __restrict__ ia, const uint32_t* __restrict__ starts,
                                                             hml_model* __restrict__ mdl, float2* __restrict__ bstat,
                                                             float* __restrict__ em, float* __restrict__ gsc,
-                                                            float* __restrict__ eprobe, int mixture) {
+                                                            float* __restrict__ eprobe, int mixture, const hml_layout lay) {
     const uint32_t B = mdl->B;
     hml_emit_params<K> p;
     hml_emit_load<K>(p, mdl, mixture);
@@ -92,7 +92,7 @@ __global__ __launch_bounds__(256) void hml_k_stats_emission(const float2* __rest
         float sx, sq;
         hml_block_stats_one(ia, s, e, sx, sq);
         bstat[b] = make_float2(sx, sq);
-        hml_emit_block<K>(p, mdl, b, sx, sq, (float)(e - s), em, gsc, eprobe, mixture);
+        hml_emit_block<K>(p, mdl, b, sx, sq, (float)(e - s), em, gsc, eprobe, mixture, lay);
     }
 }
 
@@ -113,33 +113,85 @@ __global__ __launch_bounds__(256) void hml_k_stats_emission(const float2* __rest
 // vector its predecessor really ended in, and recomputes stale chunks from the true vector; a final
 // serial pass finishes whatever is still inconsistent.  When every comparison passes, induction
 // from chunk 0 (which starts from pi itself) proves that the stored rows ARE the sequential ones.
-//
-// Geometry: 16 lanes per chunk, lane j owns state j; 4 chunks per wavefront.
 // ------------------------------------------------------------------------------------------
+// Geometry: ONE LANE per chunk - the lane carries the whole K-vector in registers, A comes from scalar
+// registers (it is the same for every lane), and nothing crosses lanes.  (A 16-lanes-per-chunk layout
+// with one state per lane was measured first: its 2K ds_bpermute round trips per step made a step cost
+// ~530 cycles and used 9x more wavefront-instructions per block.)
 template <int K>
 struct hml_fwd_ctx {
-    float Acol[K];     // A(i, j) for this lane's j
+    float A[K * K];
     float invK;
-    int j;
     bool self;
     uint32_t B;
 };
 
-// one step of the recursion for block b (row t = b+1); returns the new alpha_j
 template <int K>
-__device__ __forceinline__ float hml_fwd_step(const hml_fwd_ctx<K>& c, float alpha, float e, bool& fellback) {
-    float tt = 0.0f;
+__device__ __forceinline__ void hml_fwd_ctx_load(hml_fwd_ctx<K>& cx, const hml_model* mdl) {
 #pragma unroll
-    for (int i = 0; i < K; ++i) {
-        const float p = __shfl(alpha, i, HML_FWD_GROUP);
-        tt += p * c.Acol[i];
+    for (int i = 0; i < K * K; ++i) cx.A[i] = mdl->A[i];
+    cx.invK = (float)(1.0 / (double)(float)K);
+    cx.self = mdl->self_trans != 0;
+    cx.B = mdl->B;
+}
+
+// one step of the recursion (reference ForwardBackward.hpp:88-112); alpha is updated in place
+template <int K>
+__device__ __forceinline__ bool hml_fwd_step(const hml_fwd_ctx<K>& cx, float (&alpha)[K], const float (&e)[K]) {
+    float f[K];
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+        float tt = 0.0f;
+#pragma unroll
+        for (int i = 0; i < K; ++i) tt += alpha[i] * cx.A[i * K + j];
+        f[j] = e[j] * tt;
     }
-    const float f = e * tt;
     float Z = 0.0f;
 #pragma unroll
-    for (int i = 0; i < K; ++i) Z += __shfl(f, i, HML_FWD_GROUP);
-    fellback = !(Z != 0.0f);
-    return (Z != 0.0f) ? f / Z : c.invK;
+    for (int j = 0; j < K; ++j) Z += f[j];
+    const bool ok = (Z != 0.0f);
+#pragma unroll
+    for (int j = 0; j < K; ++j) alpha[j] = ok ? f[j] / Z : cx.invK;
+    return !ok;
+}
+
+// Runs the recursion over blocks [b0, b1) in batches so that the (recursion-independent) loads of the
+// emission terms are in flight together instead of one cache round trip per step.
+template <int K, bool STORE>
+__device__ __forceinline__ void hml_fwd_run(const hml_fwd_ctx<K>& cx, float (&alpha)[K], const float* __restrict__ em,
+                                            const float* __restrict__ gsc, float* __restrict__ rows,
+                                            float* __restrict__ aprobe, uint32_t b0, uint32_t b1, uint32_t& nfb,
+                                            const hml_layout lay) {
+    constexpr int BATCH = (K <= 6) ? 4 : 2;
+    for (uint32_t b = b0; b < b1; b += BATCH) {
+        float e[BATCH][K], g[BATCH][K];
+#pragma unroll
+        for (int i = 0; i < BATCH; ++i) {
+            const uint32_t bi = b + (uint32_t)i;
+            const bool ok = bi < b1;
+#pragma unroll
+            for (int s = 0; s < K; ++s) {
+                e[i][s] = ok ? em[hml_bk(lay, bi, K, s)] : 0.0f;
+                g[i][s] = (STORE && ok && cx.self) ? gsc[hml_bk(lay, bi, K, s)] : 1.0f;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < BATCH; ++i) {
+            const uint32_t bi = b + (uint32_t)i;
+            if (bi < b1) {
+                const bool fb = hml_fwd_step<K>(cx, alpha, e[i]);
+                if (STORE) {
+                    if (fb) nfb++;
+                    const uint32_t t = bi + 1u;
+#pragma unroll
+                    for (int s = 0; s < K; ++s) {
+                        rows[hml_bk(lay, bi, K, s)] = (cx.self && t < cx.B) ? alpha[s] * g[i][s] : alpha[s];
+                        if (aprobe) aprobe[(uint64_t)t * K + s] = alpha[s];
+                    }
+                }
+            }
+        }
+    }
 }
 
 // MODE 0: speculative main pass.  MODE 1: verify against exit_in and recompute stale chunks.
@@ -149,112 +201,88 @@ __global__ __launch_bounds__(256) void hml_k_forward(const float* __restrict__ e
                                                      hml_model* __restrict__ mdl, float* __restrict__ rows,
                                                      float* __restrict__ aprobe, float* __restrict__ entry,
                                                      const float* __restrict__ exit_in, float* __restrict__ exit_out,
-                                                     uint32_t* __restrict__ fb_count, int L, int W) {
-    const uint32_t B = mdl->B;
+                                                     uint32_t* __restrict__ fb_count, int L, int W_unused, const hml_layout lay) {
+    hml_fwd_ctx<K> cx;
+    hml_fwd_ctx_load<K>(cx, mdl);
+    const uint32_t B = cx.B;
+    const int W = (int)mdl->fwd_W;   // adaptive, device-resident
     const uint32_t C = (B + (uint32_t)L - 1u) / (uint32_t)L;
     const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t ngroups = (gridDim.x * blockDim.x) / HML_FWD_GROUP;
-    const int j = (int)(gid % HML_FWD_GROUP);
-    const int lane = threadIdx.x & 63;
-    const int grp_in_wave = lane / HML_FWD_GROUP;
-    const bool act = (j < K);
-    hml_fwd_ctx<K> cx;
-    cx.j = j; cx.B = B; cx.self = mdl->self_trans != 0;
-    cx.invK = (float)(1.0 / (double)(float)K);
-#pragma unroll
-    for (int i = 0; i < K; ++i) cx.Acol[i] = act ? mdl->A[i * K + j] : 0.0f;
-    if (MODE == 0 && gid < (uint32_t)K) {
-        rows[gid] = mdl->pi[gid];
-        if (aprobe) aprobe[gid] = mdl->pi[gid];
-    }
-
+    const uint32_t nthreads = gridDim.x * blockDim.x;
+    if (MODE == 0 && gid < (uint32_t)K && aprobe) aprobe[gid] = mdl->pi[gid];
     // grid-stride over chunks: correctness never depends on the launch size (B is only known on the device)
-    for (uint32_t c = gid / HML_FWD_GROUP; c < C; c += ngroups) {
+    for (uint32_t c = gid; c < C; c += nthreads) {
         const uint32_t first = c * (uint32_t)L;
         const uint32_t last = (first + (uint32_t)L < B) ? first + (uint32_t)L : B;   // one past
         const uint32_t ws = (first >= (uint32_t)W) ? first - (uint32_t)W : 0u;
         const bool exact = (ws == 0u);
-        float alpha = 0.0f;
-        bool run = true;
+        float alpha[K];
+        uint32_t nfb = 0;
         if (MODE == 0) {
-            alpha = act ? (exact ? mdl->pi[j] : cx.invK) : 0.0f;
-            // warm-up over [ws, first)
-            for (uint32_t b = ws; b < first; ++b) {
-                const float e = act ? em[(uint64_t)b * K + j] : 0.0f;
-                bool fb;
-                alpha = hml_fwd_step<K>(cx, alpha, e, fb);
-            }
-            if (act) entry[(uint64_t)c * K + j] = alpha;
+#pragma unroll
+            for (int s = 0; s < K; ++s) alpha[s] = exact ? mdl->pi[s] : cx.invK;
+            hml_fwd_run<K, false>(cx, alpha, em, gsc, rows, aprobe, ws, first, nfb, lay);   // warm-up, nothing stored
+#pragma unroll
+            for (int s = 0; s < K; ++s) entry[(uint64_t)c * K + s] = alpha[s];
         } else {
             // verification: was the vector this chunk started from the one its predecessor really ended in?
             bool same = true;
-            float truth = 0.0f;
-            if (act && !exact) {
-                truth = exit_in[(uint64_t)(c - 1) * K + j];
-                same = hml_f2u(truth) == hml_f2u(entry[(uint64_t)c * K + j]);
+            if (!exact) {
+#pragma unroll
+                for (int s = 0; s < K; ++s) {
+                    alpha[s] = exit_in[(uint64_t)(c - 1) * K + s];
+                    same = same && (hml_f2u(alpha[s]) == hml_f2u(entry[(uint64_t)c * K + s]));
+                }
             }
-            const unsigned long long bal = __ballot(same);
-            const bool all_same = ((bal >> (grp_in_wave * HML_FWD_GROUP)) & 0xffffull) == 0xffffull;
             if (MODE == 2) {
-                if (!exact && !all_same && j == 0) mdl->fwd_mismatch = 1u;
+                if (!same) mdl->fwd_mismatch = 1u;
                 continue;
             }
-            if (exact || all_same) {
-                if (act) exit_out[(uint64_t)c * K + j] = exit_in[(uint64_t)c * K + j];
-                run = false;
-            } else {
-                alpha = truth;
-                if (act) entry[(uint64_t)c * K + j] = alpha;
-                if (j == 0) atomicAdd(&mdl->forward_refits, 1ull);
+            if (exact || same) {
+#pragma unroll
+                for (int s = 0; s < K; ++s) exit_out[(uint64_t)c * K + s] = exit_in[(uint64_t)c * K + s];
+                continue;
             }
+#pragma unroll
+            for (int s = 0; s < K; ++s) entry[(uint64_t)c * K + s] = alpha[s];
+            atomicAdd(&mdl->forward_refits, 1ull);
         }
-        if (!run) continue;
         // the chunk proper over [first, last)
-        uint32_t nfb = 0;
-        for (uint32_t b = first; b < last; ++b) {
-            const float e = act ? em[(uint64_t)b * K + j] : 0.0f;
-            const float g = (act && cx.self) ? gsc[(uint64_t)b * K + j] : 1.0f;
-            bool fb;
-            alpha = hml_fwd_step<K>(cx, alpha, e, fb);
-            if (fb) nfb++;
-            if (act) {
-                const uint32_t t = b + 1u;
-                const float stored = (cx.self && t < B) ? alpha * g : alpha;
-                rows[(uint64_t)t * K + j] = stored;
-                if (aprobe) aprobe[(uint64_t)t * K + j] = alpha;
-            }
-        }
+        hml_fwd_run<K, true>(cx, alpha, em, gsc, rows, aprobe, first, last, nfb, lay);
         if (MODE == 1) {
             // a recomputed chunk that ends in different bits leaves its successor inconsistent: only then
             // does the serial pass have work
-            const bool unchanged = !act || hml_f2u(alpha) == hml_f2u(exit_in[(uint64_t)c * K + j]);
-            const unsigned long long bal2 = __ballot(unchanged);
-            if (((bal2 >> (grp_in_wave * HML_FWD_GROUP)) & 0xffffull) != 0xffffull && j == 0) mdl->fwd_mismatch = 1u;
+            bool unchanged = true;
+#pragma unroll
+            for (int s = 0; s < K; ++s) unchanged = unchanged && (hml_f2u(alpha[s]) == hml_f2u(exit_in[(uint64_t)c * K + s]));
+            if (!unchanged) mdl->fwd_mismatch = 1u;
         }
-        if (act) exit_out[(uint64_t)c * K + j] = alpha;
-        if (j == 0) {
-            // "[WARNING] Uniform sampling of forward variables!" events: keep the global tally consistent
-            // when a chunk is recomputed (two's-complement delta on the unsigned counter)
-            const uint32_t old = (MODE == 0) ? 0u : fb_count[c];
-            fb_count[c] = nfb;
-            if (nfb != old) atomicAdd(&mdl->uniform_fallbacks, (unsigned long long)(long long)((int)nfb - (int)old));
-        }
+#pragma unroll
+        for (int s = 0; s < K; ++s) exit_out[(uint64_t)c * K + s] = alpha[s];
+        // "[WARNING] Uniform sampling of forward variables!" events: keep the global tally consistent when a
+        // chunk is recomputed (two's-complement delta on the unsigned counter)
+        const uint32_t old = (MODE == 0) ? 0u : fb_count[c];
+        fb_count[c] = nfb;
+        if (nfb != old) atomicAdd(&mdl->uniform_fallbacks, (unsigned long long)(long long)((int)nfb - (int)old));
     }
 }
 
-// Final serial pass: find the first chunk whose start vector is not its predecessor's end vector;
-// if there is none (the normal case) just add up the fallback counters, otherwise walk the chain
-// from there and recompute every inconsistent chunk in order.  One workgroup; the walk is done by
-// its first 16 lanes.
+// Final serial pass, only when the repair round left an inconsistency (mdl->fwd_mismatch): find the first
+// chunk whose start vector is not its predecessor's end vector and walk the chain from there, recomputing
+// every inconsistent chunk in order.  One workgroup; the walk is done by one lane.
 template <int K>
 __global__ __launch_bounds__(256) void hml_k_forward_serial(const float* __restrict__ em, const float* __restrict__ gsc,
                                                             hml_model* __restrict__ mdl, float* __restrict__ rows,
                                                             float* __restrict__ aprobe, float* __restrict__ entry,
                                                             float* __restrict__ exitv, uint32_t* __restrict__ fb_count,
-                                                            int L, int W) {
+                                                            int L, int W_unused, const hml_layout lay) {
     __shared__ uint32_t first_bad;
-    if (mdl->fwd_mismatch == 0u) return;   // the verification pass found every chunk consistent
-    const uint32_t B = mdl->B;
+    if (mdl->fwd_mismatch == 0u) return;   // every chunk is consistent
+    hml_fwd_ctx<K> cx;
+    hml_fwd_ctx_load<K>(cx, mdl);
+    const uint32_t B = cx.B;
+    const int W = (int)mdl->fwd_W;
+    (void)W_unused;
     const uint32_t C = (B + (uint32_t)L - 1u) / (uint32_t)L;
     const int tid = threadIdx.x;
     if (tid == 0) first_bad = 0xffffffffu;
@@ -270,49 +298,29 @@ __global__ __launch_bounds__(256) void hml_k_forward_serial(const float* __restr
     }
     __syncthreads();
     const uint32_t fbad = first_bad;
-    if (fbad != 0xffffffffu && tid < 64) {
-        // serial repair by the first group of 16 lanes (the rest of the wavefront idles through the shuffles)
-        const int j = tid % HML_FWD_GROUP;
-        const bool act = (tid < HML_FWD_GROUP) && (j < K);
-        hml_fwd_ctx<K> cx;
-        cx.j = j; cx.B = B; cx.self = mdl->self_trans != 0;
-        cx.invK = (float)(1.0 / (double)(float)K);
-#pragma unroll
-        for (int i = 0; i < K; ++i) cx.Acol[i] = act ? mdl->A[i * K + j] : 0.0f;
+    if (fbad != 0xffffffffu && tid == 0) {
+        mdl->fwd_serial_ran = 1u;   // the parameter kernel lengthens the warm-up for the next sweeps
         for (uint32_t c = fbad; c < C; ++c) {
             const uint32_t first = c * (uint32_t)L;
             const uint32_t last = (first + (uint32_t)L < B) ? first + (uint32_t)L : B;
-            float truth = 0.0f;
+            float alpha[K];
             bool same = true;
-            if (act) {
-                truth = exitv[(uint64_t)(c - 1) * K + j];
-                same = hml_f2u(truth) == hml_f2u(entry[(uint64_t)c * K + j]);
+#pragma unroll
+            for (int s = 0; s < K; ++s) {
+                alpha[s] = exitv[(uint64_t)(c - 1) * K + s];
+                same = same && (hml_f2u(alpha[s]) == hml_f2u(entry[(uint64_t)c * K + s]));
             }
-            const unsigned long long bal = __ballot(same);
-            if ((bal & 0xffffull) == 0xffffull) continue;
-            float alpha = truth;
-            if (act) entry[(uint64_t)c * K + j] = alpha;
+            if (same) continue;
+#pragma unroll
+            for (int s = 0; s < K; ++s) entry[(uint64_t)c * K + s] = alpha[s];
             uint32_t nfb = 0;
-            for (uint32_t b = first; b < last; ++b) {
-                const float e = act ? em[(uint64_t)b * K + j] : 0.0f;
-                const float g = (act && cx.self) ? gsc[(uint64_t)b * K + j] : 1.0f;
-                bool fb;
-                alpha = hml_fwd_step<K>(cx, alpha, e, fb);
-                if (fb) nfb++;
-                if (act) {
-                    const uint32_t t = b + 1u;
-                    rows[(uint64_t)t * K + j] = (cx.self && t < B) ? alpha * g : alpha;
-                    if (aprobe) aprobe[(uint64_t)t * K + j] = alpha;
-                }
-            }
-            if (act) exitv[(uint64_t)c * K + j] = alpha;
-            if (tid == 0) {
-                const uint32_t old = fb_count[c];
-                fb_count[c] = nfb;
-                if (nfb != old) atomicAdd(&mdl->uniform_fallbacks, (unsigned long long)(long long)((int)nfb - (int)old));
-                atomicAdd(&mdl->forward_serial, 1ull);
-            }
-            __threadfence_block();
+            hml_fwd_run<K, true>(cx, alpha, em, gsc, rows, aprobe, first, last, nfb, lay);
+#pragma unroll
+            for (int s = 0; s < K; ++s) exitv[(uint64_t)c * K + s] = alpha[s];
+            const uint32_t old = fb_count[c];
+            fb_count[c] = nfb;
+            if (nfb != old) atomicAdd(&mdl->uniform_fallbacks, (unsigned long long)(long long)((int)nfb - (int)old));
+            atomicAdd(&mdl->forward_serial, 1ull);
         }
     }
     __syncthreads();

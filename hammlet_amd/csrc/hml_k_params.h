@@ -196,6 +196,18 @@ __global__ __launch_bounds__(1024) void hml_k_params(hml_model* __restrict__ mdl
     __syncthreads();
     hml_derive<K>(mdl, tid);
     if (tid == 1023) {
+        // adapt the forward warm-up: double it whenever the serial repair had to run, shrink it slowly
+        // after 32 sweeps without a single refit (speed only - the rows are bit-exact for every W)
+        if (mode == 0) {
+            uint32_t W = mdl->fwd_W;
+            if (mdl->fwd_serial_ran) { W = (2u * W < 1024u) ? 2u * W : 1024u; mdl->fwd_quiet = 0u; }
+            else if (mdl->forward_refits == mdl->fwd_refits_seen) {
+                if (++mdl->fwd_quiet >= 32u) { const uint32_t w2 = W - W / 4u; W = (w2 > mdl->fwd_W0) ? (w2 & ~7u) : mdl->fwd_W0; mdl->fwd_quiet = 0u; }
+            } else mdl->fwd_quiet = 0u;
+            mdl->fwd_W = W;
+            mdl->fwd_refits_seen = mdl->forward_refits;
+            mdl->fwd_serial_ran = 0u;
+        }
         mdl->fwd_mismatch = 0u;
         mdl->epoch = epoch + 1ull;
         if (mode == 0) { mdl->sweeps += 1ull; mdl->block_updates += (unsigned long long)mdl->B; }

@@ -11,6 +11,19 @@
 #define HML_REDUCE_GROUPS 1024 // chunk c is accumulated by group c % HML_REDUCE_GROUPS
 #define HML_BWD_CHUNK 64       // trellis rows per backward map chunk (one wavefront)
 #define HML_FWD_GROUP 16       // lanes cooperating on one forward chunk (>= HML_MAX_K)
+// Layout of the per-block K-vectors (emission terms, rescale factors, trellis rows): "chunk-transposed".
+// The forward kernel gives chunk c = b / L to one lane, so element (block b, state s) lives at
+//   ((b % L) * K + s) * cstride + b / L          (L a power of two, cstride >= number of chunks)
+// and the 64 lanes of a wavefront read 64 consecutive floats at every step.
+struct hml_layout {
+    uint32_t lshift;     // log2(L)
+    uint32_t cstride;    // floats between consecutive (row-in-chunk, state) planes
+};
+HML_HD uint64_t hml_bk(const hml_layout lay, uint32_t b, int K, int s) {
+    const uint32_t r = b & ((1u << lay.lshift) - 1u), c = b >> lay.lshift;
+    return ((uint64_t)r * (uint32_t)K + (uint32_t)s) * lay.cstride + c;
+}
+
 #define HML_CNT_SPLIT 16       // the integer count accumulators are split 16 ways to spread atomic contention
 
 // error codes raised on the device (first one wins); mirrored into messages by the host
@@ -71,6 +84,9 @@ struct hml_model {
     unsigned long long err_count;
     // ---- scratch for the forward fix-up ----
     uint32_t fwd_mismatch;       // set by a verification round that found a stale chunk
+    // adaptive warm-up length of the speculative forward pass (results never depend on it)
+    uint32_t fwd_W, fwd_W0, fwd_serial_ran, fwd_quiet;
+    unsigned long long fwd_refits_seen;
 };
 
 #endif
