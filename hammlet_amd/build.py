@@ -1,4 +1,4 @@
-"""Build helpers: compile the gfx950 shared library (and, for tests only, the CPU checker)."""
+"""Build helpers: compile the gfx950 shared library and the command-line driver."""
 import os
 import shutil
 import subprocess
@@ -57,9 +57,3 @@ def build_cli(force=False, verbose=False):
             print(" ".join(cmd))
         subprocess.run(cmd, check=True)
     return CLI_PATH
-
-
-def build_oracle(verbose=False):
-    """TEST INFRASTRUCTURE: the CPU restatement under oracle/ (and oracle/_ref when /root/reference exists)."""
-    subprocess.run(["make", "-C", os.path.join(REPO_DIR, "oracle"), "all"], check=True,
-                   stdout=None if verbose else subprocess.DEVNULL)

@@ -1,0 +1,69 @@
+#!/usr/bin/env python3
+"""Generates the golden output files under tests/golden/ by running the UNMODIFIED reference binary
+(oracle/_ref/hammlet, built by oracle/Makefile from /root/reference/src/main.cpp) on synthetic traces.
+
+Only runs where /root/reference exists (the build container).  The committed fixtures are data: the
+reference's output files for inputs that the tests regenerate from (T, K, data seed) with the
+repository's own deterministic generator (values are printed with %.9g, which round-trips float32
+through the reference's `istream >> float`).
+
+    python tests/golden/make_golden.py
+"""
+import json
+import os
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, REPO)
+from tests import oracle_lib as ol  # noqa: E402
+
+REF = os.path.join(REPO, "oracle", "_ref", "hammlet")
+
+# name -> (T, K, data_seed, flags, outputs)
+CASES = {
+    "c1_fb": (100000, 3, 1, "-s 3 -R 1 -i F 100 1", ["marginals", "sequences", "parameters", "blocks", "compression"]),
+    "c1_default_scheme": (100000, 3, 11, "-s 3 -R 11", ["marginals"]),
+    "k4_mixed_scheme": (20000, 4, 3, "-s 4 -R 3 -i M 50 5 D F 60 2 P M 10 1 S F 30 1",
+                        ["marginals", "sequences", "parameters", "compression"]),
+    "k3_no_self_transitions": (100000, 3, 1, "-s 3 -R 5 -S -i F 50 1", ["marginals", "parameters"]),
+    "k3_priors_multiplier": (100000, 3, 1, "-s 3 -R 7 -m 1.5 -t 1 10 -I 2 -e normal 0.1 0.8 -i M 20 1 F 50 1",
+                             ["marginals", "parameters", "compression"]),
+    "k6_static_then_dynamic": (100000, 3, 1, "-s 6 -R 8 -t 0.1 -i S F 50 1 P D F 20 1", ["marginals", "parameters"]),
+    "k2_thinning": (100000, 3, 1, "-s 2 -R 9 -i F 30 7 M 5 0 F 10 3", ["marginals", "sequences"]),
+    "k5_200k": (200000, 5, 7, "-s 5 -R 42 -i F 25 5", ["marginals", "parameters", "compression"]),
+}
+
+
+def main():
+    if not os.path.exists(REF):
+        raise SystemExit("reference binary missing: run `make -C oracle ref` in the build container")
+    manifest = {}
+    for name, (T, K, dseed, flags, outs) in CASES.items():
+        # the data K (levels of the trace) is the first case field; `-s` in flags is the model's K
+        x = ol.trace(T, K, dseed)
+        d = os.path.join(HERE, name)
+        os.makedirs(d, exist_ok=True)
+        with tempfile.TemporaryDirectory() as tmp:
+            inp = os.path.join(tmp, "in.txt")
+            np.savetxt(inp, x, fmt="%.9g")
+            cmd = [REF, "-f", inp, "-o", os.path.join(tmp, "ref-"), ".csv", "-w", "-a"] + flags.split() + ["-O"] + outs
+            r = subprocess.run(cmd, capture_output=True, text=True)
+            assert r.returncode == 0, r.stderr
+            for o in outs:
+                with open(os.path.join(tmp, "ref-%s.csv" % o)) as f, open(os.path.join(d, o + ".csv"), "w") as g:
+                    g.write(f.read())
+            with open(os.path.join(d, "stdout.txt"), "w") as g:
+                g.write(r.stdout)
+        manifest[name] = {"T": T, "trace_levels": K, "data_seed": dseed, "flags": flags, "outputs": outs}
+        print(name, "ok")
+    with open(os.path.join(HERE, "manifest.json"), "w") as f:
+        json.dump(manifest, f, indent=1, sort_keys=True)
+
+
+if __name__ == "__main__":
+    main()
