@@ -1,0 +1,130 @@
+// Records - the output files of a run (reference src/Records.hpp:20-243, src/StateMarginals.hpp:268-310):
+//   PREFIXmarginalsSUFFIX    one line per marginal segment: SIZE \t count_0 ... count_{Kmax}   (written at close)
+//   PREFIXsequencesSUFFIX    one line per recorded sweep: tab-separated SIZE:STATE segments
+//   PREFIXblocksSUFFIX       one line per recorded sweep: tab-separated block sizes
+//   PREFIXparametersSUFFIX   one line per recorded sweep: mean \t var per state
+//   PREFIXcompressionSUFFIX  one line per recorded sweep: T / #blocks
+//   PREFIXsegmentsSUFFIX     one line per recorded sweep: #marginal segments \t internal size (see note)
+// The marginal counts are accumulated on the device (difference arrays + boundary bitmap) and fetched in
+// run-length form at close(); the per-sweep files are appended from the device's block list and state
+// sequence after every recorded sweep.
+// Note on "segments": the reference's second column is the length of its internal count queue in the
+// middle of a rotation - an artefact of its data structure; this implementation writes the number of
+// count entries the finished structure would hold (documented as approximate in DESIGN.md).
+#ifndef HAMMLET_RECORDS_HPP
+#define HAMMLET_RECORDS_HPP
+
+#include <fstream>
+#include <set>
+#include <string>
+#include <vector>
+
+namespace hammlet {
+
+inline bool fileExists(const std::string& path) {
+    std::ifstream f(path.c_str());
+    return f.good();
+}
+
+class Records {
+    const size_t mSize;
+    std::string mPrefix, mSuffix;
+    hml_ctx* mCtx = nullptr;
+    bool mRecordMarginals = true, mRecordBlocks = false, mRecordCompression = false, mRecordSequences = false,
+         mRecordTheta = false, mRecordSegments = false;
+    std::ofstream mMarginalsFile, mSequenceFile, mBlocksFile, mThetaFile, mCompressionsFile, mSegmentFile;
+    bool mClosed = false;
+    std::set<uint32_t> mBoundaries;   // only maintained when the segments file is requested
+
+    void setRecordX(std::ofstream& file, const std::string& type, bool& member, bool flag, bool overwrite) {
+        member = flag;
+        if (member && !file.is_open()) {
+            const std::string filename = mPrefix + type + mSuffix;
+            if (fileExists(filename) && !overwrite)
+                throw std::runtime_error("File " + filename + " already exists! Use -w to allow overwrite!");
+            file.open(filename.c_str());
+            if (!file.is_open()) throw std::runtime_error("Cannot write to file " + filename + "!");
+        }
+    }
+
+public:
+    Records(const Records&) = delete;
+    Records(size_t T, std::string prefix, std::string suffix, const size_t /*nrStates*/)
+        : mSize(T), mPrefix(std::move(prefix)), mSuffix(std::move(suffix)) {}
+    ~Records() {
+        try { close(); } catch (...) {}
+    }
+    void attach(hml_ctx* ctx) { mCtx = ctx; }
+
+    void setRecordMarginals(bool b, bool overwrite = false) { setRecordX(mMarginalsFile, "marginals", mRecordMarginals, b, overwrite); }
+    void setRecordBlocks(bool b, bool overwrite = false) { setRecordX(mBlocksFile, "blocks", mRecordBlocks, b, overwrite); }
+    void setRecordCompression(bool b, bool overwrite = false) { setRecordX(mCompressionsFile, "compression", mRecordCompression, b, overwrite); }
+    void setRecordStateSequence(bool b, bool overwrite = false) { setRecordX(mSequenceFile, "sequences", mRecordSequences, b, overwrite); }
+    void setRecordTheta(bool b, bool overwrite = false) { setRecordX(mThetaFile, "parameters", mRecordTheta, b, overwrite); }
+    void setRecordSegments(bool b, bool overwrite = false) { setRecordX(mSegmentFile, "segments", mRecordSegments, b, overwrite); }
+
+    bool recordsMarginals() const { return mRecordMarginals; }
+    bool needsPerSweepData() const { return mRecordBlocks || mRecordCompression || mRecordSequences || mRecordTheta || mRecordSegments; }
+
+    // one recorded sweep: Records::record(state, N) for every block in order + Records::record(theta)
+    template <typename ThetaT>
+    void recordSweep(hml_ctx* ctx, const ThetaT& theta) {
+        uint64_t B = 0;
+        hml_check(hml_get_num_blocks(ctx, &B));
+        std::vector<uint32_t> starts(B + 1);
+        std::vector<int16_t> q(B);
+        hml_check(hml_get_blocks(ctx, starts.data()));
+        hml_check(hml_get_states(ctx, q.data()));
+        bool firstSeg = true;
+        size_t segStart = 0;
+        for (size_t b = 0; b < B; ++b) {
+            if (mRecordBlocks) mBlocksFile << (b ? "\t" : "") << (starts[b + 1] - starts[b]);
+            const bool last = (b + 1 == B);
+            if (last || q[b + 1] != q[b]) {
+                if (mRecordSequences) mSequenceFile << (firstSeg ? "" : "\t") << (starts[b + 1] - starts[segStart]) << ":" << (size_t)q[b];
+                if (mRecordSegments) mBoundaries.insert(starts[segStart]);
+                firstSeg = false;
+                segStart = b + 1;
+            }
+        }
+        if (mRecordBlocks) mBlocksFile << "\n";
+        if (mRecordSequences) mSequenceFile << "\n";
+        if (mRecordCompression) mCompressionsFile << ((double)mSize) / ((double)B) << std::endl;
+        if (mRecordSegments) mSegmentFile << mBoundaries.size() << "\t" << mBoundaries.size() * 2 << std::endl;
+        if (mRecordTheta) mThetaFile << theta.str() << std::endl;
+    }
+
+    void close() {
+        if (mClosed) return;
+        mClosed = true;
+        if (mRecordMarginals && mMarginalsFile.is_open()) {
+            if (mCtx) {
+                uint64_t n = 0;
+                int cols = 0;
+                hml_check(hml_marginals_rle(mCtx, &n, &cols, nullptr, nullptr));
+                std::vector<uint64_t> seg(n);
+                std::vector<int32_t> cnt((size_t)n * (cols > 0 ? cols : 1));
+                hml_check(hml_marginals_rle(mCtx, &n, &cols, seg.data(), cols > 0 ? cnt.data() : nullptr));
+                std::string out;
+                out.reserve((size_t)n * (8 + 4 * (cols > 0 ? cols : 0)));
+                for (uint64_t i = 0; i < n; ++i) {
+                    out += std::to_string(seg[i]);
+                    for (int s = 0; s < cols; ++s) { out += '\t'; out += std::to_string(cnt[i * cols + s]); }
+                    out += '\n';
+                }
+                mMarginalsFile << out;
+            } else {
+                mMarginalsFile << mSize << "\n";
+            }
+            mMarginalsFile.close();
+        }
+        if (mSequenceFile.is_open()) mSequenceFile.close();
+        if (mBlocksFile.is_open()) mBlocksFile.close();
+        if (mThetaFile.is_open()) mThetaFile.close();
+        if (mCompressionsFile.is_open()) mCompressionsFile.close();
+        if (mSegmentFile.is_open()) mSegmentFile.close();
+    }
+};
+
+}  // namespace hammlet
+#endif

@@ -1,0 +1,441 @@
+// hammlet.hpp - the reference's in-process C++ surface (Emissions / Blocks / Statistics / Trellis /
+// StateSequence / Theta / Transitions / Initial / Records / sampleHMM) as thin host classes over the
+// C ABI of libhammlet_hip.so (include/hml.h).  All data and all arithmetic of the Gibbs sweep live on
+// the GPU; these classes only hold the handle, forward the calls and fetch results.
+//
+// A driver written in the shape of the reference's src/main.cpp compiles against these names:
+//     rng_t RNG(seed);                               // src/main.cpp:107-108
+//     MaxletTransform(fin, inputValues, stats, nrDataDim);   HaarBreakpointWeights(inputValues);
+//     Statistics<IntegralArray, Normal> ia(stats, nrDataDim);  Blocks<BreakpointArray> blocks(inputValues);
+//     Emissions<S, B> y(ia, blocks);   autoPrior(var, p, y, stdEstimate);   Theta<NormalInverseGamma> theta(...);
+//     StateSequence<ForwardBackward> q(RNG);  sampleHMM(y, q, theta, tau_theta, A, tau_A, pi, tau_pi, mapping, ...);
+// Differences that follow from the device residency are noted at each class.
+#ifndef HAMMLET_HPP
+#define HAMMLET_HPP
+
+#include <cmath>
+#include <cstdint>
+#include <fstream>
+#include <iostream>
+#include <istream>
+#include <limits>
+#include <sstream>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../hml.h"
+
+namespace hammlet {
+
+typedef float real_t;          // reference src/includes.hpp:10
+typedef int16_t marginal_t;    // reference src/includes.hpp:13
+
+// tag classes (reference src/Tags.hpp)
+class Normal {};
+class NormalParam {};
+typedef NormalParam NormalInverseGamma;
+class NormalInverseGammaParam {};
+class CategoricalParam {};
+typedef CategoricalParam Dirichlet;
+class DirichletParam {};
+class CategoricalParamVector {};
+typedef CategoricalParamVector DirichletVector;
+class DirichletParamVector {};
+class ForwardBackward {};
+class Mixture {};
+class IntegralArray {};
+class BreakpointArray {};
+enum MappingType { combinations, independent };
+
+inline void hml_check(int rc) {
+    if (rc != 0) throw std::runtime_error(hml_last_error());
+}
+
+// The reference hands one `rng_t& RNG` to every sampling object.  Here that object is the chain's device
+// context: it owns the Philox key (seed, chain) and every device buffer.
+class rng_t {
+    hml_ctx* mCtx = nullptr;
+    static rng_t*& currentSlot() { static rng_t* cur = nullptr; return cur; }
+
+public:
+    explicit rng_t(uint64_t seed, int device = 0, uint32_t chain = 0) {
+        hml_check(hml_create(&mCtx, device, seed, chain, nullptr));
+        currentSlot() = this;
+    }
+    ~rng_t() {
+        if (currentSlot() == this) currentSlot() = nullptr;
+        hml_destroy(mCtx);
+    }
+    rng_t(const rng_t&) = delete;
+    hml_ctx* ctx() const { return mCtx; }
+    // objects that the reference constructs without an RNG argument (Statistics, Blocks) attach to this
+    static rng_t& current() {
+        if (!currentSlot()) throw std::runtime_error("No device context: construct rng_t RNG(seed) first!");
+        return *currentSlot();
+    }
+};
+
+template <typename T>
+class SufficientStatistics;
+template <>
+class SufficientStatistics<Normal> {   // reference src/SufficientStatistics.hpp:49-142
+    real_t mSum = 0, mSumSq = 0;
+
+public:
+    SufficientStatistics() {}
+    SufficientStatistics(real_t v) : mSum(v), mSumSq(v * v) {}
+    SufficientStatistics(real_t s, real_t q) : mSum(s), mSumSq(q) {}
+    real_t sum() const { return mSum; }
+    real_t sumSq() const { return mSumSq; }
+    size_t nrDim() const { return 1; }
+};
+
+// MaxletTransform (reference src/wavelet.hpp:97-188): reads the text stream.  The transform itself runs
+// on the GPU when the statistics object is built, so `coeffs` receives the raw observations here.
+template <typename T>
+void MaxletTransform(std::istream& input, std::vector<real_t>& coeffs, std::vector<SufficientStatistics<T>>& suffstats,
+                     const size_t nrDim = 1, const size_t reserveT = 0) {
+    (void)suffstats;
+    if (nrDim != 1) throw std::runtime_error("Only univariate data is supported by the MI355X path!");
+    if (!input) throw std::runtime_error("Cannot read input file or stream!");
+    if (reserveT) coeffs.reserve(coeffs.size() + reserveT);
+    real_t v = 0;
+    while (input >> v) coeffs.push_back(v);
+}
+// HaarBreakpointWeights (reference src/wavelet.hpp:68-93): computed on the device together with the
+// transform; kept so that drivers read like the reference.
+inline void HaarBreakpointWeights(std::vector<real_t>& weights) {
+    if (weights.empty()) throw std::runtime_error("Cannot compute Haar breakpoint weights, vector is empty!");
+}
+
+template <typename A, typename B>
+class Statistics;
+template <typename B>
+class Blocks;
+template <typename S, typename B>
+class Emissions;
+template <typename P>
+class Theta;
+
+// Statistics<IntegralArray, Normal> (reference src/Statistics/IntegralArray.hpp:28-233).  The constructor
+// uploads the observations: K1-K3 build maxlet coefficients, breakpoint weights and the integral array.
+template <>
+class Statistics<IntegralArray, Normal> {
+    rng_t& mDev;
+    size_t mSize = 0;
+    SufficientStatistics<Normal> mCurrent;
+    friend class Emissions<Statistics<IntegralArray, Normal>, Blocks<BreakpointArray>>;
+
+public:
+    Statistics(const Statistics&) = delete;
+    // `values`: the vector MaxletTransform filled (swap-stolen like the reference's constructors)
+    Statistics(std::vector<real_t>& values, const size_t nrDim) : mDev(rng_t::current()) {
+        if (nrDim != 1) throw std::runtime_error("Only univariate data is supported by the MI355X path!");
+        if (values.empty()) throw std::runtime_error("Input vector for breakpoint weights is empty!");
+        mSize = values.size();
+        hml_check(hml_load_observations(mDev.ctx(), values.data(), values.size()));
+        std::vector<real_t>().swap(values);
+    }
+    size_t nrDim() const { return 1; }
+    size_t size() const { return mSize; }
+    const SufficientStatistics<Normal>& suffStat(size_t) const { return mCurrent; }
+    double noiseEstimate() const { double s; hml_check(hml_noise_sigma(mDev.ctx(), &s)); return s; }   // main.cpp:303-311
+    rng_t& device() const { return mDev; }
+};
+
+// Blocks<BreakpointArray> (reference src/Blocks/BreakpointArray.hpp:24-307): the device holds the weights;
+// an enumeration fetches the block starts of the current threshold once and iterates over them.
+template <>
+class Blocks<BreakpointArray> {
+    rng_t& mDev;
+    size_t mSize;
+    std::vector<uint32_t> mStarts;
+    std::vector<float> mSum, mSumSq;
+    size_t mPos = 0;
+    bool mIterating = false, mFinished = false;
+    friend class Emissions<Statistics<IntegralArray, Normal>, Blocks<BreakpointArray>>;
+
+public:
+    explicit Blocks(const Statistics<IntegralArray, Normal>& stats) : mDev(stats.device()), mSize(stats.size()) {}
+    void scaleWeights(real_t m) { hml_check(hml_scale_weights(mDev.ctx(), m)); }   // main.cpp:332-334
+    void createBlocks(real_t threshold) {
+        hml_check(hml_create_blocks(mDev.ctx(), threshold));
+        fetch();
+    }
+    void fetch() {
+        uint64_t B = 0;
+        hml_check(hml_get_num_blocks(mDev.ctx(), &B));
+        mStarts.resize(B + 1); mSum.resize(B); mSumSq.resize(B);
+        hml_check(hml_get_blocks(mDev.ctx(), mStarts.data()));
+        hml_check(hml_get_block_stats(mDev.ctx(), mSum.data(), mSumSq.data()));
+        mFinished = false;
+    }
+    void initForward() { mPos = 0; mIterating = true; mFinished = false; }
+    bool next() {
+        if (mPos + 1 >= mStarts.size()) { mIterating = false; mFinished = true; return false; }
+        ++mPos;
+        return true;
+    }
+    size_t start() const { return mStarts[mPos - 1]; }
+    size_t end() const { return mStarts[mPos]; }
+    size_t blockSize() const { return end() - start(); }
+    size_t size() const { return mSize; }
+    size_t nrBlocks() const {
+        if (mIterating) throw std::runtime_error("Cannot determine size of block structure before all blocks have been seen!");
+        return mStarts.empty() ? 0 : mStarts.size() - 1;
+    }
+};
+
+// Emissions<Statistics<S,T>, Blocks<B>> (reference src/Emissions.hpp:12-112)
+template <>
+class Emissions<Statistics<IntegralArray, Normal>, Blocks<BreakpointArray>> {
+    typedef Statistics<IntegralArray, Normal> S;
+    typedef Blocks<BreakpointArray> B;
+    S& mStats;
+    B& mBlocks;
+
+public:
+    Emissions(S& stats, B& blocks) : mStats(stats), mBlocks(blocks) {
+        if (mStats.size() != mBlocks.size())
+            throw std::runtime_error("Block structure and statistics have different number of data points!");
+    }
+    S& stats() { return mStats; }
+    B& blocks() { return mBlocks; }
+    const S& stats() const { return mStats; }
+    const B& blocks() const { return mBlocks; }
+    void createBlocks(real_t thresh) { mBlocks.createBlocks(thresh); }
+    template <typename P>
+    void createBlocks(const Theta<P>& theta);   // "S" token: fix the structure at the current theta
+    size_t nrBlocks() const { return mBlocks.nrBlocks(); }
+    size_t nrDim() const { return 1; }
+    size_t start() const { return mBlocks.start(); }
+    size_t end() const { return mBlocks.end(); }
+    size_t blockSize() const { return mBlocks.blockSize(); }
+    size_t size() const { return mBlocks.size(); }
+    void initForward() { mBlocks.initForward(); }
+    bool next() {
+        if (!mBlocks.next()) return false;
+        mStats.mCurrent = SufficientStatistics<Normal>(mBlocks.mSum[mBlocks.mPos - 1], mBlocks.mSumSq[mBlocks.mPos - 1]);
+        return true;
+    }
+    const SufficientStatistics<Normal>& suffStat(size_t dim) const { return mStats.suffStat(dim); }
+    hml_ctx* ctx() const { return mStats.device().ctx(); }
+};
+
+// autoPrior (reference src/AutoPriors.hpp:86-110): {alpha, beta, mu0, nu}
+template <typename E>
+std::vector<real_t> autoPrior(real_t s2, real_t p, E& y, const double /*noiseStdev: held by the device*/) {
+    std::vector<real_t> out(4);
+    hml_check(hml_autoprior(y.ctx(), s2, p, out.data()));
+    return out;
+}
+
+class Mapping {   // reference src/Mapping.hpp:53-137, univariate "combinations"
+    size_t mParams;
+
+public:
+    Mapping(size_t nrDataDim, size_t nrParams, MappingType) : mParams(nrParams) {
+        if (nrDataDim != 1) throw std::runtime_error("Only univariate data is supported by the MI355X path!");
+        if (nrParams <= 1) throw std::runtime_error("Requested parameters would yield an HMM with less than 2 states!");
+    }
+    size_t nrStates() const { return mParams; }
+    size_t nrParams() const { return mParams; }
+    size_t nrDataDims() const { return 1; }
+};
+
+// Hyper-parameter holders (reference src/ThetaHyperParam.hpp, TransitionHyperParam.hpp, InitialHyperParam.hpp):
+// plain values; the posteriors themselves live on the device.
+template <typename T>
+class ThetaHyperParam {
+    std::vector<std::vector<real_t>> mP;
+
+public:
+    explicit ThetaHyperParam(const std::vector<std::vector<real_t>>& hp) : mP(hp) {
+        if (mP.empty()) throw std::runtime_error("Number of hyperparameters must be positive");
+    }
+    size_t nrParams() const { return mP.size(); }
+    const std::vector<real_t>& prior(size_t d) const { return mP[d]; }
+};
+template <typename T>
+class TransitionHyperParam {
+public:
+    size_t nrStates; real_t off, diag;
+    TransitionHyperParam(size_t n, real_t o, real_t d) : nrStates(n), off(o), diag(d) {}
+};
+template <typename T>
+class InitialHyperParam {
+public:
+    size_t nrStates; real_t alpha;
+    InitialHyperParam(size_t n, real_t a) : nrStates(n), alpha(a) {}
+};
+
+template <typename T>
+class Transitions {   // reference src/Transitions.hpp:23-90 (values are fetched from the device on demand)
+    rng_t& mDev; size_t mK;
+public:
+    Transitions(size_t nrStates, rng_t& RNG) : mDev(RNG), mK(nrStates) {}
+    size_t nrStates() const { return mK; }
+    real_t operator()(size_t from, size_t to) const {
+        std::vector<real_t> A(mK * mK), pi(mK);
+        hml_check(hml_get_transitions(mDev.ctx(), A.data(), pi.data()));
+        return A[from * mK + to];
+    }
+};
+template <typename T>
+class Initial {       // reference src/Initial.hpp:13-58
+    rng_t& mDev; size_t mK;
+public:
+    Initial(size_t nrStates, rng_t& RNG) : mDev(RNG), mK(nrStates) {}
+    size_t nrStates() const { return mK; }
+    std::vector<real_t> valueVector() const {
+        std::vector<real_t> A(mK * mK), pi(mK);
+        hml_check(hml_get_transitions(mDev.ctx(), A.data(), pi.data()));
+        return pi;
+    }
+};
+
+// Theta<NormalInverseGamma> (reference src/Theta.hpp): constructing it fixes the model on the device and,
+// like the reference's constructor (Theta.hpp:126-127), draws once from the prior.
+template <>
+class Theta<NormalParam> {
+    rng_t& mDev; size_t mK;
+public:
+    Theta(const Theta&) = delete;
+    template <typename H, typename TA, typename TP>
+    Theta(ThetaHyperParam<H>& tau_theta, const TransitionHyperParam<TA>& tau_A, const InitialHyperParam<TP>& tau_pi,
+          bool useSelfTransitions, rng_t& RNG)
+        : mDev(RNG), mK(tau_theta.nrParams()) {
+        hml_check(hml_set_model(mDev.ctx(), (int)mK, tau_theta.prior(0).data(), tau_A.off, tau_A.diag, tau_pi.alpha,
+                                useSelfTransitions ? 1 : 0));
+    }
+    size_t nrParams() const { return mK; }
+    size_t nrStates() const { return mK; }
+    std::vector<real_t> meanVar() const {
+        std::vector<real_t> v(2 * mK);
+        hml_check(hml_get_theta(mDev.ctx(), v.data()));
+        return v;
+    }
+    // Theta::str(): to_string(mean) \t to_string(var) per state, tab-joined (Theta.hpp:215-219, Observation.hpp:205-210)
+    std::string str(const std::string& sep = "\t") const {
+        const std::vector<real_t> v = meanVar();
+        std::string s;
+        for (size_t k = 0; k < mK; ++k) {
+            if (k) s += sep;
+            s += std::to_string(v[2 * k]) + "\t" + std::to_string(v[2 * k + 1]);
+        }
+        return s;
+    }
+    real_t thresholdValue() const {   // Theta.hpp:227-234: smallest variance
+        const std::vector<real_t> v = meanVar();
+        real_t r = std::numeric_limits<real_t>::infinity();
+        for (size_t k = 0; k < mK; ++k) r = std::min(r, v[2 * k + 1]);
+        return r;
+    }
+    hml_ctx* ctx() const { return mDev.ctx(); }
+};
+
+template <typename P>
+void Emissions<Statistics<IntegralArray, Normal>, Blocks<BreakpointArray>>::createBlocks(const Theta<P>& theta) {
+    hml_check(hml_set_static_blocks(theta.ctx()));
+}
+
+// Trellis (reference src/Trellis.hpp:8-76): a read-only host view of the last sweep's normalised forward
+// rows (row 0 = pi); filling and sampling happen on the device.
+class Trellis {
+    rng_t& mDev;
+    std::vector<real_t> mVec;
+    size_t mNrStates = 2;
+
+public:
+    Trellis(const Trellis&) = delete;
+    explicit Trellis(rng_t& RNG) : mDev(RNG) {}
+    void setNrStates(size_t K) { mNrStates = K; }
+    void fetch() {
+        uint64_t B = 0;
+        hml_check(hml_get_num_blocks(mDev.ctx(), &B));
+        mVec.resize((B + 1) * mNrStates);
+        hml_check(hml_get_forward_rows(mDev.ctx(), mVec.data()));
+    }
+    real_t operator()(size_t t, size_t d) const {
+        if (d >= mNrStates) throw std::runtime_error("Trellis dimension index out of bounds!");
+        return mVec[t * mNrStates + d];
+    }
+    real_t back(size_t d) const { return mVec[mVec.size() - mNrStates + d]; }
+    size_t size() const { return mVec.size() / mNrStates; }
+    void clear() { mVec.clear(); }
+};
+
+class Records;
+
+// StateSequence<Tag> (reference src/StateSequence.hpp:18-106): sample() runs ONE Gibbs sweep of the given
+// kind on the device (state sequence + the conjugate parameter draws that follow it in sampleHMM).
+template <typename Tag>
+class StateSequence {
+    rng_t& mDev;
+    std::vector<marginal_t> mStates;
+    static char method();
+
+public:
+    StateSequence(const StateSequence&) = delete;
+    explicit StateSequence(rng_t& RNG) : mDev(RNG) {}
+    hml_ctx* ctx() const { return mDev.ctx(); }
+    void fetch() {
+        uint64_t B = 0;
+        hml_check(hml_get_num_blocks(mDev.ctx(), &B));
+        mStates.resize(B);
+        hml_check(hml_get_states(mDev.ctx(), mStates.data()));
+    }
+    size_t size() const { return mStates.size(); }
+    const std::vector<marginal_t>& states() const { return mStates; }
+    marginal_t operator[](size_t s) const {
+        if (s >= mStates.size()) throw std::runtime_error("State sequence index " + std::to_string(s) + " out of bounds!");
+        return mStates[s];
+    }
+    std::string str() const {
+        std::string s;
+        for (size_t i = 0; i < mStates.size(); ++i) { if (i) s += " "; s += std::to_string(mStates[i]); }
+        return s;
+    }
+    void clear() { std::vector<marginal_t>().swap(mStates); }
+    static char methodChar() { return method(); }
+};
+template <> inline char StateSequence<ForwardBackward>::method() { return HML_METHOD_FB; }
+template <> inline char StateSequence<Mixture>::method() { return HML_METHOD_MIXTURE; }
+
+}  // namespace hammlet
+
+#include "Records.hpp"
+
+namespace hammlet {
+
+// sampleHMM (reference src/HMM.hpp:60-125).  The whole loop is device-resident; when per-sweep side files
+// are requested the device calls back after every recorded sweep and `records` appends its lines.
+template <typename Q, typename E, typename TH, typename TTH, typename TA, typename TTA, typename TP, typename TTP>
+void sampleHMM(E& y, Q& q, TH& theta, TTH&, TA&, TTA&, TP&, TTP&, const Mapping&, const size_t iterations, const size_t thinning,
+               Records& records, const bool dynamic = true, const bool /*useSelfTransitions: fixed at model construction*/ = true) {
+    if (thinning > iterations)
+        std::cout << "[WARNING] Thinning parameter is larger than number of iterations. No data will be recorded!" << std::endl;
+    hml_ctx* ctx = y.ctx();
+    (void)dynamic;   // set by the "S"/"D" tokens through Emissions::createBlocks(theta) / hml_set_dynamic
+    struct Hook { Records* rec; Q* q; TH* theta; };
+    Hook hook{&records, &q, &theta};
+    const bool sideFiles = records.needsPerSweepData();
+    hml_check(hml_set_recording(ctx, records.recordsMarginals() ? 1 : 0,
+                                sideFiles ? +[](hml_ctx* c, uint64_t, void* user) {
+                                    Hook* h = static_cast<Hook*>(user);
+                                    h->rec->recordSweep(c, *h->theta);
+                                } : (hml_record_cb) nullptr,
+                                &hook));
+    hml_stats before{}, after{};
+    hml_check(hml_get_stats(ctx, &before));
+    hml_check(hml_iterate(ctx, Q::methodChar(), iterations, thinning));
+    hml_check(hml_sync(ctx));
+    hml_check(hml_get_stats(ctx, &after));
+    for (uint64_t i = before.uniform_fallbacks; i < after.uniform_fallbacks; ++i)
+        std::cout << "[WARNING] Uniform sampling of forward variables!" << std::endl;
+    hml_check(hml_set_recording(ctx, records.recordsMarginals() ? 1 : 0, nullptr, nullptr));
+}
+
+}  // namespace hammlet
+#endif

@@ -1,0 +1,74 @@
+"""End-to-end file-level parity of the `hammlet` driver (GPU) with the CPU checker's driver in device mode:
+same flags, same input, byte-identical marginals / sequences / blocks / parameters / compression files."""
+import os
+import subprocess
+import tempfile
+
+import numpy as np
+import pytest
+
+from tests import oracle_lib as ol
+
+pytestmark = pytest.mark.gpu
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CLI = os.path.join(REPO, "hammlet_amd", "hammlet")
+ORACLE_CLI = os.path.join(ol.ORACLE_DIR, "hammlet_oracle")
+OUTS = ["marginals", "sequences", "parameters", "blocks", "compression"]
+
+
+def run_pair(x, flags, text_input=False):
+    ol.load()
+    with tempfile.TemporaryDirectory() as tmp:
+        raw = os.path.join(tmp, "in.f32")
+        x.tofile(raw)
+        if text_input:
+            txt = os.path.join(tmp, "in.txt")
+            np.savetxt(txt, x, fmt="%.9g")
+            g_in = ["-f", txt]
+        else:
+            g_in = ["-raw", raw]
+        g = subprocess.run([CLI] + g_in + ["-o", os.path.join(tmp, "g-"), ".csv", "-a"] + flags + ["-O"] + OUTS,
+                           capture_output=True, text=True)
+        o = subprocess.run([ORACLE_CLI, "--raw", raw, "-o", os.path.join(tmp, "o-"), ".csv", "-a"] + flags + ["-O"] + OUTS +
+                           ["--rng", "2", "--math", "1", "--reduce", "1"], capture_output=True, text=True)
+        assert g.returncode == 0, g.stderr
+        assert o.returncode == 0, o.stderr
+        res = {}
+        for name in OUTS:
+            res[name] = (open(os.path.join(tmp, "g-%s.csv" % name)).read(), open(os.path.join(tmp, "o-%s.csv" % name)).read())
+        return res, g.stdout, o.stdout
+
+
+@pytest.mark.parametrize("T,K,flags,text", [
+    (100000, 3, "-s 3 -R 1 -i F 100 1", True),                                  # BASELINE config 1
+    (100000, 3, "-s 3 -R 11", False),                                            # default scheme M 500 0 S P F 200 0 F 300 3
+    (20000, 4, "-s 4 -R 3 -i M 50 5 D F 60 2 P M 10 1 S F 30 1", False),
+    (100000, 3, "-s 3 -R 5 -S -i F 50 1", False),
+    (100000, 3, "-s 3 -R 7 -m 1.5 -t 1 10 -I 2 -e normal 0.1 0.8 -i M 20 1 F 50 1", False),
+    (100000, 3, "-s 6 -R 8 -t 0.1 -i S F 50 1 P D F 20 1", False),
+    (300000, 5, "-s 5 -R 2 -i F 30 3", False),
+])
+def test_cli_files_equal_checker_files(T, K, flags, text):
+    x = ol.trace(T, K, 1)
+    res, g_out, o_out = run_pair(x, flags.split(), text_input=text)
+    for name, (g, o) in res.items():
+        assert g == o, name
+    assert sorted(g_out.splitlines()) == sorted(o_out.splitlines())
+
+
+def test_cli_errors_like_the_reference():
+    x = ol.trace(1000, 3, 1)
+    with tempfile.TemporaryDirectory() as tmp:
+        raw = os.path.join(tmp, "in.f32")
+        x.tofile(raw)
+        r = subprocess.run([CLI, "-raw", raw, "-o", os.path.join(tmp, "g-"), ".csv"], capture_output=True, text=True)
+        assert r.returncode == 1
+        assert r.stderr == "\n[ERROR] Manual theta priors not implemented, use -a!\nTerminating HaMMLET. The rest is silence.\n"
+        r = subprocess.run([CLI, "-raw", raw, "-o", os.path.join(tmp, "h-"), ".csv", "-a", "-i", "F", "10"], capture_output=True, text=True)
+        assert r.returncode == 1 and "must be multiples of 3" in r.stderr
+        ok = subprocess.run([CLI, "-raw", raw, "-o", os.path.join(tmp, "g-"), ".csv", "-a", "-i", "F", "5", "1"], capture_output=True, text=True)
+        assert ok.returncode == 0
+        again = subprocess.run([CLI, "-raw", raw, "-o", os.path.join(tmp, "g-"), ".csv", "-a", "-i", "F", "5", "1"], capture_output=True, text=True)
+        assert again.returncode == 1 and "already exists! Use -w to allow overwrite!" in again.stderr
+        r = subprocess.run([CLI, "-raw", raw, "-a", "-a"], capture_output=True, text=True)
+        assert r.returncode == 1 and "Duplicate flag -a!" in r.stderr
