@@ -168,6 +168,20 @@ def main():
             fam[nm] = round(1e3 * (ms - before[nm][0]) / max(1, n - before[nm][1]), 2)
         out["kernel_us_per_sweep"] = fam
 
+    # chain-parallel pooling (not timed): a few recorded sweeps, relabel by ascending mean, one RCCL all-reduce
+    if world > 1:
+        from hammlet_amd import chains
+        chain.set_recording(marginals=True)
+        chain.iterate("F", 10, 5)
+        chain.sync()
+        barrier()
+        tp0 = time.perf_counter()
+        seg, cnt, _ = chains.pooled_marginals(chain)
+        barrier()
+        if rank == 0:
+            out["pooling"] = {"all_reduce_bytes": int((K + 1) * T * 4), "seconds_incl_dense_export": time.perf_counter() - tp0,
+                              "pooled_segments": int(seg.numel()), "counts_per_position": int(cnt[0].sum().item())}
+
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(x, K, args.seed)
     elif rank == 0:

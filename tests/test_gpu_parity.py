@@ -193,3 +193,32 @@ def test_gamma_lanes_independent(hml):
     host = ol.debug_eval(5, a, b, seed=9)
     assert np.array_equal(bits(together), bits(alone))
     assert np.array_equal(bits(together), bits(host))
+
+
+def test_dense_marginals_export_and_pooling_path(hml):
+    """hml_marginals_dense_device (the buffer the chains all-reduce) against the checker's dense counts,
+    with the relabelling permutation applied; world size 1, so pooling is the identity."""
+    import torch
+    from hammlet_amd import chains
+    T, K = 60000, 4
+    x, o, g = make_pair(hml, T, K, 3, 21)
+    setup_model(o, g, K)
+    o.token("F")
+    g.sample_prior()
+    o.iterate("F", 24, 3)
+    g.iterate("F", 24, 3)
+    g.sync()
+    dense_o = o.marginals_dense()
+    perm = chains.relabel_permutation(g.theta()[0::2])
+    seg, cnt, perm2 = chains.pooled_marginals(g)
+    assert np.array_equal(perm, perm2)
+    buf = torch.empty((K + 1, T), dtype=torch.int32, device="cuda")
+    g.marginals_dense_device(buf.data_ptr(), perm)
+    got = buf.cpu().numpy()
+    assert np.array_equal(got[:K], dense_o[perm])
+    lens = [int(l.split("\t")[0]) for l in o.text("marginals").strip().split("\n")]
+    starts = np.cumsum([0] + lens[:-1])
+    assert np.array_equal(np.flatnonzero(got[K]), starts)
+    assert np.array_equal(seg.cpu().numpy(), np.asarray(lens))
+    assert np.array_equal(cnt.cpu().numpy(), dense_o[perm][:, starts].T)
+    assert np.all(got[:K].sum(0) == 8)

@@ -1,0 +1,78 @@
+"""Chain-parallel pooling on CPU: world_size 2 over gloo.  Each rank runs its own chain (the CPU checker,
+chain id = rank), relabels by ascending mean, all-reduces the dense [K+1][T] counts and checks the pooled
+result against the sum computed directly from both chains."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from tests import oracle_lib as ol
+
+T, K = 20000, 3
+
+
+def chain_dense(rank):
+    x = ol.trace(T, K, 4)
+    o = ol.OracleChain(K=K, seed=9, chain=rank, rng=ol.RNG_CTR, math=ol.MATH_DEV, reduce=ol.REDUCE_DEV)
+    o.load(x)
+    o.autoprior()
+    o.init_model()
+    o.iterate("F", 30, 2)
+    dense = o.marginals_dense()                    # [K][T]
+    means = o.theta()[0::2]
+    # boundary row from the checker's run-length text
+    lens = [int(l.split("\t")[0]) for l in o.text("marginals").strip().split("\n")]
+    bnd = np.zeros(T, np.int32)
+    bnd[np.cumsum([0] + lens[:-1])] = 1
+    return dense, means, bnd
+
+
+def worker(rank, world, port, out):
+    from hammlet_amd import chains
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dense, means, bnd = chain_dense(rank)
+    perm = chains.relabel_permutation(means)
+    t = torch.from_numpy(np.concatenate([dense[perm], bnd[None, :]], 0).astype(np.int32))
+    chains.pool_dense(t)
+    seg, cnt = chains.dense_to_rle(t)
+    if rank == 0:
+        np.savez(out, dense=t.numpy(), seg=seg.numpy(), cnt=cnt.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_pooled_marginals_world2(tmp_path):
+    from hammlet_amd import chains
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    out = str(tmp_path / "pooled.npz")
+    mp.spawn(worker, args=(2, port, out), nprocs=2, join=True)
+    got = np.load(out)
+    expect = np.zeros((K + 1, T), np.int64)
+    for r in range(2):
+        dense, means, bnd = chain_dense(r)
+        perm = chains.relabel_permutation(means)
+        assert np.all(np.diff(means[perm]) >= 0)
+        expect[:K] += dense[perm]
+        expect[K] += bnd
+    assert np.array_equal(got["dense"], expect)
+    # pooled row sums = chains x recorded sweeps; segments tile [0, T)
+    assert np.all(got["dense"][:K].sum(0) == 2 * 15)
+    assert got["seg"].sum() == T
+    starts = np.concatenate([[0], np.cumsum(got["seg"])[:-1]])
+    assert np.array_equal(got["cnt"], expect[:K, starts].T)
+    assert set(np.flatnonzero(expect[K])) == set(starts)
+
+
+def test_relabel_permutation():
+    from hammlet_amd import chains
+    assert list(chains.relabel_permutation([0.5, -1.0, 2.0])) == [1, 0, 2]
+    assert list(chains.relabel_permutation([1.0, 1.0, 0.0])) == [2, 0, 1]
