@@ -40,7 +40,10 @@ def build_library(force=False, verbose=False):
         cmd = [_hipcc()] + HIPCC_FLAGS + ["-shared", "-o", LIB_PATH, os.path.join(CSRC, "hml_capi.hip")]
         if verbose:
             print(" ".join(cmd))
-        subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE if not verbose else None)
+        r = subprocess.run(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE if not verbose else None, text=True)
+        if r.returncode != 0:
+            errs = [l for l in (r.stderr or "").splitlines() if "error" in l or "note:" in l]
+            raise RuntimeError("hipcc failed:\n" + "\n".join(errs[:40]))
     return LIB_PATH
 
 

@@ -21,7 +21,7 @@ class HmlError(RuntimeError):
 
 class HmlStats(C.Structure):
     _fields_ = [("sweeps", C.c_uint64), ("block_updates", C.c_uint64), ("uniform_fallbacks", C.c_uint64),
-                ("forward_refits", C.c_uint64), ("forward_serial", C.c_uint64)]
+                ("forward_refits", C.c_uint64), ("forward_serial", C.c_uint64), ("candidate_rebuilds", C.c_uint64)]
 
 
 RECORD_CB = C.CFUNCTYPE(None, C.c_void_p, C.c_uint64, C.c_void_p)
@@ -46,6 +46,7 @@ SIGNATURES = {
     "hml_create_blocks": (C.c_int, [_P, C.c_float]),
     "hml_iterate": (C.c_int, [_P, C.c_char, C.c_uint64, C.c_uint64]),
     "hml_set_recording": (C.c_int, [_P, C.c_int, RECORD_CB, _P]),
+    "hml_set_option": (C.c_int, [_P, C.c_char_p, C.c_int]),
     "hml_sync": (C.c_int, [_P]),
     "hml_get_num_blocks": (C.c_int, [_P, C.POINTER(C.c_uint64)]),
     "hml_get_blocks": (C.c_int, [_P, _P]),
@@ -191,6 +192,9 @@ class Chain:
         else:
             self._cb = C.cast(None, RECORD_CB)
         _check(self.lib.hml_set_recording(self.h, 1 if marginals else 0, self._cb, None))
+
+    def set_option(self, name, value):
+        _check(self.lib.hml_set_option(self.h, name.encode(), int(value)))
 
     def sync(self):
         _check(self.lib.hml_sync(self.h))

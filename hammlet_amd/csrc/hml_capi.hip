@@ -77,6 +77,11 @@ struct hml_ctx {
     float2* d_bstat = nullptr;
     uint32_t n_spans = 0;
     uint32_t* d_coarse1 = nullptr;   // block count per group of 64 spans
+    // candidate cache: positions/weights with w >= 0.9 x threshold, and the look-back descriptors
+    uint32_t* d_cand_pos = nullptr;
+    float* d_cand_w = nullptr;
+    unsigned long long* d_desc = nullptr;
+    bool cand_enabled = true;
     // sweep buffers (allocated by set_model)
     float *d_em = nullptr, *d_gsc = nullptr, *d_rows = nullptr, *d_eprobe = nullptr, *d_aprobe = nullptr;
     float *d_entry = nullptr, *d_exitA = nullptr, *d_exitB = nullptr;
@@ -264,13 +269,14 @@ int hml_create(hml_ctx** out, int device, uint64_t seed, uint32_t chain_id, void
     if (const char* e = getenv("HML_FWD_CHUNK")) { int l = std::max(1, atoi(e)); int sh = 0; while ((1 << (sh + 1)) <= l && sh < 10) ++sh; c->fwdL = 1 << sh; }
     if (const char* e = getenv("HML_FWD_WARMUP")) c->fwdW = std::max(0, atoi(e));
     if (const char* e = getenv("HML_FWD_ROUNDS")) c->fwdRounds = std::max(0, atoi(e));
+    if (const char* e = getenv("HML_CANDIDATE_CACHE")) c->cand_enabled = atoi(e) != 0;
     *out = c;
     return 0;
 }
 
 static void free_all(hml_ctx* c) {
     void* ptrs[] = {c->d_w, c->d_coeff, c->d_ia, c->d_stage, c->d_span_count, c->d_starts, c->d_bstat,
-                    c->d_em, c->d_gsc, c->d_rows, c->d_eprobe, c->d_aprobe, c->d_entry, c->d_exitA, c->d_exitB, c->d_fb, c->d_coarse1,
+                    c->d_em, c->d_gsc, c->d_rows, c->d_eprobe, c->d_aprobe, c->d_entry, c->d_exitA, c->d_exitB, c->d_fb, c->d_coarse1, c->d_cand_pos, c->d_cand_w, c->d_desc,
                     c->d_smap, c->d_cmap, c->d_bentry, c->d_q, c->d_partial, c->d_diff, c->d_boundary, c->d_mdl};
     for (void* p : ptrs) if (p) hipFree(p);
     if (c->h_B) hipHostFree(c->h_B);
@@ -399,30 +405,36 @@ int hml_scale_weights(hml_ctx* c, float mult) {
     hipLaunchKernelGGL(hml_k_scale, dim3(grid_for(c->T, 256, 1, 65536)), dim3(256), 0, c->stream, c->d_w, c->T, mult);
     KLAUNCH_CHECK();
     c->blocks_valid = false;
+    if (c->model_set) {   // cached candidates were selected on the old weights
+        hipLaunchKernelGGL(hml_k_invalidate_cache, dim3(1), dim3(64), 0, c->stream, c->d_mdl);
+        KLAUNCH_CHECK();
+    }
     return 0;
 }
 
 // ---------------------------------------------------------------------------------------- blocks
 // K4: scan (the HBM-bound kernel) + scatter with in-kernel offsets
-static void launch_compact_pair(hml_ctx* c, bool use_override, float thr) {
+static void launch_compact_pair(hml_ctx* c, int mode, float thr) {
+    // mode 0: model threshold; 1: explicit threshold; 2: candidate-cache rebuild (kernels exit at once unless needed)
     const uint32_t nwg = (c->n_spans + 3) / 4;
     {
-        ProfScope ps(c, "blocks_compact", 1);
-        hipLaunchKernelGGL(hml_k_compact_scan, dim3(nwg), dim3(256), 0, c->stream, c->d_w, (uint32_t)c->T, c->d_mdl, thr,
-                           use_override ? 1 : 0, c->d_stage, c->d_span_count);
+        ProfScope ps(c, mode == 2 ? "cand_rebuild" : "blocks_compact", mode == 2 ? 2 : 1);
+        hipLaunchKernelGGL(hml_k_compact_scan, dim3(nwg), dim3(256), 0, c->stream, c->d_w, (uint32_t)c->T, c->d_mdl, thr, mode,
+                           c->d_stage, c->d_span_count);
     }
     {
-        ProfScope ps(c, "blocks_scatter");
+        ProfScope ps(c, mode == 2 ? "cand_rebuild" : "blocks_scatter");
         const uint32_t n1 = (c->n_spans + 63u) >> 6;
         hipLaunchKernelGGL(hml_k_group_totals, dim3((n1 + 3) / 4), dim3(256), 0, c->stream, c->d_span_count, c->n_spans,
-                           c->d_coarse1);
+                           c->d_coarse1, c->d_mdl, mode == 2 ? 1 : 0);
         hipLaunchKernelGGL(hml_k_compact_scatter, dim3(nwg), dim3(256), 0, c->stream, c->d_stage, c->d_span_count,
-                           c->d_coarse1, c->n_spans, (uint32_t)c->T, c->d_mdl, c->d_starts, c->d_hB);
+                           c->d_coarse1, c->n_spans, (uint32_t)c->T, c->d_mdl, c->d_starts, c->d_hB, mode == 2 ? 1 : 0, c->d_w,
+                           c->d_cand_pos, c->d_cand_w);
     }
 }
 
 static int launch_compact(hml_ctx* c, bool use_override, float thr) {
-    launch_compact_pair(c, use_override, thr);
+    launch_compact_pair(c, use_override ? 1 : 0, thr);
     KLAUNCH_CHECK();
     {
         ProfScope ps(c, "block_stats");
@@ -523,6 +535,13 @@ int hml_set_model(hml_ctx* c, int K, const float nig4[4], float a_off, float a_d
     HIPCHK(hipMalloc(&c->d_cmap, bchunks * sizeof(unsigned long long)));
     HIPCHK(hipMalloc(&c->d_bentry, bchunks));
     HIPCHK(hipMalloc(&c->d_q, T * sizeof(int16_t)));
+    if (c->cand_enabled && !c->d_cand_pos) {
+        HIPCHK(hipMalloc(&c->d_cand_pos, (T + 1) * sizeof(uint32_t)));
+        HIPCHK(hipMalloc(&c->d_cand_w, (T + 1) * sizeof(float)));
+        const uint64_t nt = (T + HML_CAND_TILE - 1) / HML_CAND_TILE + 1;
+        HIPCHK(hipMalloc(&c->d_desc, nt * sizeof(unsigned long long)));
+        HIPCHK(hipMemsetAsync(c->d_desc, 0, nt * sizeof(unsigned long long), c->stream));
+    }
     HIPCHK(hipMalloc(&c->d_partial, (uint64_t)HML_REDUCE_GROUPS * K * 2 * sizeof(double)));
     HIPCHK(hipMemsetAsync(c->d_partial, 0, (uint64_t)HML_REDUCE_GROUPS * K * 2 * sizeof(double), c->stream));
 
@@ -539,6 +558,8 @@ int hml_set_model(hml_ctx* c, int K, const float nig4[4], float a_off, float a_d
         for (int j = 0; j < K; ++j) { m.dirA[k * K + j] = (k == j) ? a_diag : a_off; m.A[k * K + j] = 1.0f / K; }
     }
     m.max_state_recorded = -1;
+    m.cand_enabled = c->cand_enabled ? 1u : 0u;
+    m.need_rebuild = 1u;
     m.fwd_W = m.fwd_W0 = (uint32_t)c->fwdW;
     m.n_spans = c->n_spans;
     // keep the block count of an earlier enumeration (autoprior) out of the model: B = 0
@@ -622,7 +643,17 @@ static int sweep_k(hml_ctx* c, char method, bool record) {
     bool emitted = false;
     if (c->dynamic || !c->blocks_valid) {
         // K4 single-pass scan + compaction, then statistics and emission terms in one dense launch
-        launch_compact_pair(c, false, 0.0f);
+        if (c->dynamic && c->cand_enabled) {
+            // candidate cache: (rarely) rebuild the candidate list, then filter it at the current threshold
+            launch_compact_pair(c, 2, 0.0f);
+            refresh_hint(c);
+            const uint32_t h1 = c->B_hint ? c->B_hint : (uint32_t)std::min<uint64_t>(c->T, 1u << 20);
+            ProfScope ps(c, "cand_filter");
+            hipLaunchKernelGGL(hml_k_cand_filter, dim3(grid_for((uint64_t)h1 * 2 / HML_CAND_TILE + 1, 4, 16, 4096)), dim3(256), 0, s,
+                               c->d_cand_pos, c->d_cand_w, c->d_mdl, T, c->d_starts, c->d_desc, c->d_hB);
+        } else {
+            launch_compact_pair(c, 0, 0.0f);
+        }
         {
             refresh_hint(c);
             const uint32_t h0 = c->B_hint ? c->B_hint : (uint32_t)std::min<uint64_t>(c->T, 1u << 20);
@@ -723,6 +754,16 @@ int hml_iterate(hml_ctx* c, char method, uint64_t iterations, uint64_t thinning)
         }
     }
     return 0;
+}
+
+int hml_set_option(hml_ctx* c, const char* name, int value) {
+    if (!c || !name) return set_err(HML_ERR_ARG, "null argument");
+    if (std::string(name) == "candidate_cache") {
+        if (c->model_set) return set_err(HML_ERR_ARG, "candidate_cache must be set before hml_set_model");
+        c->cand_enabled = value != 0;
+        return 0;
+    }
+    return set_err(HML_ERR_ARG, std::string("unknown option ") + name);
 }
 
 int hml_sync(hml_ctx* c) {
@@ -940,6 +981,7 @@ int hml_get_stats(hml_ctx* c, hml_stats* out) {
     hml_model m; if (int r = fetch_model(c, &m)) return r;
     out->sweeps = m.sweeps; out->block_updates = m.block_updates; out->uniform_fallbacks = m.uniform_fallbacks;
     out->forward_refits = m.forward_refits; out->forward_serial = m.forward_serial;
+    out->candidate_rebuilds = m.cand_rebuilds;
     return 0;
 }
 

@@ -29,11 +29,14 @@ __global__ __launch_bounds__(256) void hml_k_compact_scan(const float* __restric
                                                           const hml_model* __restrict__ mdl, float thr_override,
                                                           int use_override, uint16_t* __restrict__ stage,
                                                           uint32_t* __restrict__ span_count) {
+    // use_override: 0 = the model's threshold, 1 = thr_override, 2 = candidate-cache rebuild (runs only when
+    // the parameter kernel asked for it, at the cache's lower threshold bound)
+    if (use_override == 2 && mdl->need_rebuild == 0u) return;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const uint32_t span = blockIdx.x * 4u + (uint32_t)wave;
     const uint64_t base = (uint64_t)span * HML_SPAN;
     if (base >= T) return;
-    const float thr = use_override ? thr_override : mdl->thr;
+    const float thr = use_override == 2 ? mdl->cand_thr_lo : (use_override ? thr_override : mdl->thr);
     uint32_t running = 0;
     uint16_t* __restrict__ out = stage + base;
     if (base + HML_SPAN <= T) {
@@ -91,7 +94,9 @@ __device__ __forceinline__ uint32_t hml_wave_sum_u32(uint32_t v) {
 // block count of every group of 64 spans (one wavefront per group; plain stores, no atomics: atomics from
 // the scan kernel itself were measured to cost it 10-16 us)
 __global__ __launch_bounds__(256) void hml_k_group_totals(const uint32_t* __restrict__ span_count, uint32_t n_spans,
-                                                          uint32_t* __restrict__ coarse1) {
+                                                          uint32_t* __restrict__ coarse1, const hml_model* __restrict__ mdl,
+                                                          int rebuild) {
+    if (rebuild && mdl->need_rebuild == 0u) return;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const uint32_t g = blockIdx.x * 4u + (uint32_t)wave;
     const uint32_t i = (g << 6) + (uint32_t)lane;
@@ -116,7 +121,10 @@ __global__ __launch_bounds__(256) void hml_k_compact_scatter(const uint16_t* __r
                                                              const uint32_t* __restrict__ span_count,
                                                              const uint32_t* __restrict__ coarse1, uint32_t n_spans,
                                                              uint32_t T, hml_model* __restrict__ mdl,
-                                                             uint32_t* __restrict__ starts, uint32_t* __restrict__ host_B) {
+                                                             uint32_t* __restrict__ starts, uint32_t* __restrict__ host_B,
+                                                             int rebuild, const float* __restrict__ w,
+                                                             uint32_t* __restrict__ cand_pos, float* __restrict__ cand_w) {
+    if (rebuild && mdl->need_rebuild == 0u) return;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const uint32_t span = blockIdx.x * 4u + (uint32_t)wave;
     if (span >= n_spans) return;
@@ -126,6 +134,20 @@ __global__ __launch_bounds__(256) void hml_k_compact_scatter(const uint16_t* __r
     const uint32_t off = hml_span_offset(span_count, coarse1, span, lane);
     const uint32_t base = span * (uint32_t)HML_SPAN;
     const uint16_t* __restrict__ in = stage + (uint64_t)base;
+    if (rebuild) {
+        // candidate-cache rebuild: the compacted positions and their weights become the candidate list
+        for (uint32_t k = lane; k < cnt; k += 64) {
+            const uint32_t t = base + (uint32_t)in[k];
+            cand_pos[off + k] = t;
+            cand_w[off + k] = w[t];
+        }
+        if (is_last && lane == 0) {
+            mdl->cand_M = off + cnt;
+            mdl->cand_valid = 1u;
+            mdl->cand_rebuilds += 1ull;
+        }
+        return;
+    }
     for (uint32_t k = lane; k < cnt; k += 64) starts[off + k] = base + (uint32_t)in[k];
     if (is_last && lane == 0) {
         const uint32_t B = off + cnt;
@@ -134,6 +156,100 @@ __global__ __launch_bounds__(256) void hml_k_compact_scatter(const uint16_t* __r
         // host-mapped word: lets the host size later grids without a copy in the stream
         if (host_B) __hip_atomic_store(host_B, B, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
+}
+
+// ------------------------------------------------------------------------------------------
+// K4' candidate filter - the per-sweep block enumeration when the candidate cache is valid: the block
+// starts of threshold thr >= cand_thr_lo are exactly the candidates with !(w < thr) (plus position 0), so
+// one small single-pass compaction over cand_M (~B) entries replaces the scan of w[0..T).  Tiles of 1024
+// candidates per wavefront; the global offset comes from a decoupled look-back over 8-byte
+// {generation, status, value} descriptors (with a few hundred tiles the look-back is one or two windows;
+// for the 24 k-tile full scan it was measured and rejected).  Tiles are handed out by a ticket counter so a
+// wavefront only waits for tiles that some wavefront has already started.
+// ------------------------------------------------------------------------------------------
+#define HML_LB_AGG 1ull
+#define HML_LB_PREFIX 2ull
+#define HML_CAND_TILE 1024
+
+__device__ __forceinline__ unsigned long long hml_lb_pack(uint32_t gen, unsigned long long status, uint32_t value) {
+    return ((unsigned long long)(gen & 0x3fffffffu) << 34) | (status << 32) | (unsigned long long)value;
+}
+
+__global__ __launch_bounds__(256) void hml_k_cand_filter(const uint32_t* __restrict__ cand_pos, const float* __restrict__ cand_w,
+                                                         hml_model* __restrict__ mdl, uint32_t T,
+                                                         uint32_t* __restrict__ starts, unsigned long long* __restrict__ desc,
+                                                         uint32_t* __restrict__ host_B) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t M = mdl->cand_M;
+    const uint32_t n_tiles = (M + HML_CAND_TILE - 1u) / HML_CAND_TILE;
+    const uint32_t gen = (uint32_t)mdl->epoch + 1u;   // one filter launch per parameter epoch
+    const float thr = mdl->thr;
+  // a wavefront keeps drawing tickets until the tiles are used up (the parameter kernel zeroes the counter)
+  while (true) {
+    uint32_t tile = 0;
+    if (lane == 0) tile = atomicAdd(&mdl->cand_ticket, 1u);
+    tile = (uint32_t)__builtin_amdgcn_readfirstlane((int)tile);
+    if (tile >= n_tiles) return;
+    const uint32_t base = tile * (uint32_t)HML_CAND_TILE;
+    // 16 candidates per lane, lane-major so that the order of positions is (lane, j)
+    float v[16];
+    bool f[16];
+    uint32_t cnt_lane = 0;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const uint32_t i = base + (uint32_t)lane * 16u + (uint32_t)j;
+        v[j] = (i < M) ? cand_w[i] : 0.0f;
+        f[j] = (i < M) && (i == 0u || !(v[j] < thr));
+        cnt_lane += f[j] ? 1u : 0u;
+    }
+    // exclusive prefix of cnt_lane across the wavefront + tile total
+    uint32_t incl = cnt_lane;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t o = __shfl_up(incl, d);
+        if (lane >= d) incl += o;
+    }
+    const uint32_t cnt = __shfl(incl, 63);
+    uint32_t excl = 0;
+    if (tile == 0) {
+        if (lane == 0) __hip_atomic_store(&desc[0], hml_lb_pack(gen, HML_LB_PREFIX, cnt), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+        if (lane == 0) __hip_atomic_store(&desc[tile], hml_lb_pack(gen, HML_LB_AGG, cnt), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int look = (int)tile - 1;
+        while (true) {
+            const int idx = look - lane;
+            unsigned long long d = hml_lb_pack(gen, HML_LB_PREFIX, 0u);   // virtual prefix 0 in front of tile 0
+            if (idx >= 0) {
+                d = __hip_atomic_load(&desc[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                while ((uint32_t)(d >> 34) != (gen & 0x3fffffffu) || ((d >> 32) & 3ull) == 0ull) {
+                    __builtin_amdgcn_s_sleep(1);
+                    d = __hip_atomic_load(&desc[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+            const unsigned long long pm = __ballot(((d >> 32) & 3ull) == HML_LB_PREFIX);
+            const int firstp = pm ? (__ffsll((long long)pm) - 1) : 64;
+            uint32_t contrib = (lane <= firstp) ? (uint32_t)d : 0u;
+#pragma unroll
+            for (int m = 1; m < 64; m <<= 1) contrib += __shfl_xor(contrib, m);
+            excl += contrib;
+            if (pm) break;
+            look -= 64;
+        }
+        if (lane == 0)
+            __hip_atomic_store(&desc[tile], hml_lb_pack(gen, HML_LB_PREFIX, excl + cnt), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    uint32_t pos = excl + incl - cnt_lane;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        if (f[j]) starts[pos++] = cand_pos[base + (uint32_t)lane * 16u + (uint32_t)j];
+    }
+    if (tile == n_tiles - 1u && lane == 0) {
+        const uint32_t B = excl + cnt;
+        mdl->B = B;
+        starts[B] = T;
+        if (host_B) __hip_atomic_store(host_B, B, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
 }
 
 // ------------------------------------------------------------------------------------------
