@@ -81,6 +81,7 @@ struct hml_ctx {
     uint32_t* d_cand_pos = nullptr;
     float* d_cand_w = nullptr;
     unsigned long long* d_desc = nullptr;
+    unsigned long long* d_descB = nullptr;
     bool cand_enabled = true;
     // sweep buffers (allocated by set_model)
     float *d_em = nullptr, *d_gsc = nullptr, *d_rows = nullptr, *d_eprobe = nullptr, *d_aprobe = nullptr;
@@ -276,7 +277,7 @@ int hml_create(hml_ctx** out, int device, uint64_t seed, uint32_t chain_id, void
 
 static void free_all(hml_ctx* c) {
     void* ptrs[] = {c->d_w, c->d_coeff, c->d_ia, c->d_stage, c->d_span_count, c->d_starts, c->d_bstat,
-                    c->d_em, c->d_gsc, c->d_rows, c->d_eprobe, c->d_aprobe, c->d_entry, c->d_exitA, c->d_exitB, c->d_fb, c->d_coarse1, c->d_cand_pos, c->d_cand_w, c->d_desc,
+                    c->d_em, c->d_gsc, c->d_rows, c->d_eprobe, c->d_aprobe, c->d_entry, c->d_exitA, c->d_exitB, c->d_fb, c->d_coarse1, c->d_cand_pos, c->d_cand_w, c->d_desc, c->d_descB,
                     c->d_smap, c->d_cmap, c->d_bentry, c->d_q, c->d_partial, c->d_diff, c->d_boundary, c->d_mdl};
     for (void* p : ptrs) if (p) hipFree(p);
     if (c->h_B) hipHostFree(c->h_B);
@@ -541,6 +542,8 @@ int hml_set_model(hml_ctx* c, int K, const float nig4[4], float a_off, float a_d
         const uint64_t nt = (T + HML_CAND_TILE - 1) / HML_CAND_TILE + 1;
         HIPCHK(hipMalloc(&c->d_desc, nt * sizeof(unsigned long long)));
         HIPCHK(hipMemsetAsync(c->d_desc, 0, nt * sizeof(unsigned long long), c->stream));
+        HIPCHK(hipMalloc(&c->d_descB, ((uint64_t)c->n_spans + 1) * sizeof(unsigned long long)));
+        HIPCHK(hipMemsetAsync(c->d_descB, 0, ((uint64_t)c->n_spans + 1) * sizeof(unsigned long long), c->stream));
     }
     HIPCHK(hipMalloc(&c->d_partial, (uint64_t)HML_REDUCE_GROUPS * K * 2 * sizeof(double)));
     HIPCHK(hipMemsetAsync(c->d_partial, 0, (uint64_t)HML_REDUCE_GROUPS * K * 2 * sizeof(double), c->stream));
@@ -644,13 +647,11 @@ static int sweep_k(hml_ctx* c, char method, bool record) {
     if (c->dynamic || !c->blocks_valid) {
         // K4 single-pass scan + compaction, then statistics and emission terms in one dense launch
         if (c->dynamic && c->cand_enabled) {
-            // candidate cache: (rarely) rebuild the candidate list, then filter it at the current threshold
-            launch_compact_pair(c, 2, 0.0f);
-            refresh_hint(c);
-            const uint32_t h1 = c->B_hint ? c->B_hint : (uint32_t)std::min<uint64_t>(c->T, 1u << 20);
-            ProfScope ps(c, "cand_filter");
-            hipLaunchKernelGGL(hml_k_cand_filter, dim3(grid_for((uint64_t)h1 * 2 / HML_CAND_TILE + 1, 4, 16, 4096)), dim3(256), 0, s,
-                               c->d_cand_pos, c->d_cand_w, c->d_mdl, T, c->d_starts, c->d_desc, c->d_hB);
+            // candidate cache: one launch filters the cached candidates (or, rarely, rebuilds the cache and
+            // compacts the block starts in the same pass)
+            ProfScope ps(c, "blocks_cached");
+            hipLaunchKernelGGL(hml_k_blocks_cached, dim3(64), dim3(256), 0, s, c->d_w, T, c->n_spans, c->d_cand_pos, c->d_cand_w,
+                               c->d_mdl, c->d_starts, c->d_desc, c->d_descB, c->d_hB);
         } else {
             launch_compact_pair(c, 0, 0.0f);
         }

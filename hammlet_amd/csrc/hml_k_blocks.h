@@ -175,81 +175,191 @@ __device__ __forceinline__ unsigned long long hml_lb_pack(uint32_t gen, unsigned
     return ((unsigned long long)(gen & 0x3fffffffu) << 34) | (status << 32) | (unsigned long long)value;
 }
 
-__global__ __launch_bounds__(256) void hml_k_cand_filter(const uint32_t* __restrict__ cand_pos, const float* __restrict__ cand_w,
-                                                         hml_model* __restrict__ mdl, uint32_t T,
-                                                         uint32_t* __restrict__ starts, unsigned long long* __restrict__ desc,
-                                                         uint32_t* __restrict__ host_B) {
-    const int lane = threadIdx.x & 63;
-    const uint32_t M = mdl->cand_M;
-    const uint32_t n_tiles = (M + HML_CAND_TILE - 1u) / HML_CAND_TILE;
-    const uint32_t gen = (uint32_t)mdl->epoch + 1u;   // one filter launch per parameter epoch
-    const float thr = mdl->thr;
-  // a wavefront keeps drawing tickets until the tiles are used up (the parameter kernel zeroes the counter)
-  while (true) {
-    uint32_t tile = 0;
-    if (lane == 0) tile = atomicAdd(&mdl->cand_ticket, 1u);
-    tile = (uint32_t)__builtin_amdgcn_readfirstlane((int)tile);
-    if (tile >= n_tiles) return;
-    const uint32_t base = tile * (uint32_t)HML_CAND_TILE;
-    // 16 candidates per lane, lane-major so that the order of positions is (lane, j)
-    float v[16];
-    bool f[16];
-    uint32_t cnt_lane = 0;
-#pragma unroll
-    for (int j = 0; j < 16; ++j) {
-        const uint32_t i = base + (uint32_t)lane * 16u + (uint32_t)j;
-        v[j] = (i < M) ? cand_w[i] : 0.0f;
-        f[j] = (i < M) && (i == 0u || !(v[j] < thr));
-        cnt_lane += f[j] ? 1u : 0u;
-    }
-    // exclusive prefix of cnt_lane across the wavefront + tile total
-    uint32_t incl = cnt_lane;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t o = __shfl_up(incl, d);
-        if (lane >= d) incl += o;
-    }
-    const uint32_t cnt = __shfl(incl, 63);
-    uint32_t excl = 0;
+// exclusive prefix over the tiles before `tile` by decoupled look-back; publishes this tile's count first and
+// its inclusive prefix afterwards.  All lanes of the wavefront call it together.
+__device__ __forceinline__ uint32_t hml_lb_exclusive(unsigned long long* __restrict__ desc, uint32_t tile, uint32_t cnt,
+                                                     uint32_t gen, int lane) {
     if (tile == 0) {
         if (lane == 0) __hip_atomic_store(&desc[0], hml_lb_pack(gen, HML_LB_PREFIX, cnt), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    } else {
-        if (lane == 0) __hip_atomic_store(&desc[tile], hml_lb_pack(gen, HML_LB_AGG, cnt), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        int look = (int)tile - 1;
-        while (true) {
-            const int idx = look - lane;
-            unsigned long long d = hml_lb_pack(gen, HML_LB_PREFIX, 0u);   // virtual prefix 0 in front of tile 0
-            if (idx >= 0) {
+        return 0u;
+    }
+    if (lane == 0) __hip_atomic_store(&desc[tile], hml_lb_pack(gen, HML_LB_AGG, cnt), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    uint32_t excl = 0;
+    int look = (int)tile - 1;
+    while (true) {
+        const int idx = look - lane;
+        unsigned long long d = hml_lb_pack(gen, HML_LB_PREFIX, 0u);   // virtual prefix 0 in front of tile 0
+        if (idx >= 0) {
+            d = __hip_atomic_load(&desc[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            while ((uint32_t)(d >> 34) != (gen & 0x3fffffffu) || ((d >> 32) & 3ull) == 0ull) {
+                __builtin_amdgcn_s_sleep(1);
                 d = __hip_atomic_load(&desc[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                while ((uint32_t)(d >> 34) != (gen & 0x3fffffffu) || ((d >> 32) & 3ull) == 0ull) {
-                    __builtin_amdgcn_s_sleep(1);
-                    d = __hip_atomic_load(&desc[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
             }
-            const unsigned long long pm = __ballot(((d >> 32) & 3ull) == HML_LB_PREFIX);
-            const int firstp = pm ? (__ffsll((long long)pm) - 1) : 64;
-            uint32_t contrib = (lane <= firstp) ? (uint32_t)d : 0u;
-#pragma unroll
-            for (int m = 1; m < 64; m <<= 1) contrib += __shfl_xor(contrib, m);
-            excl += contrib;
-            if (pm) break;
-            look -= 64;
         }
-        if (lane == 0)
-            __hip_atomic_store(&desc[tile], hml_lb_pack(gen, HML_LB_PREFIX, excl + cnt), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    uint32_t pos = excl + incl - cnt_lane;
+        const unsigned long long pm = __ballot(((d >> 32) & 3ull) == HML_LB_PREFIX);
+        const int firstp = pm ? (__ffsll((long long)pm) - 1) : 64;
+        uint32_t contrib = (lane <= firstp) ? (uint32_t)d : 0u;
 #pragma unroll
-    for (int j = 0; j < 16; ++j) {
-        if (f[j]) starts[pos++] = cand_pos[base + (uint32_t)lane * 16u + (uint32_t)j];
+        for (int m = 1; m < 64; m <<= 1) contrib += __shfl_xor(contrib, m);
+        excl += contrib;
+        if (pm) break;
+        look -= 64;
     }
-    if (tile == n_tiles - 1u && lane == 0) {
-        const uint32_t B = excl + cnt;
-        mdl->B = B;
-        starts[B] = T;
-        if (host_B) __hip_atomic_store(host_B, B, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (lane == 0)
+        __hip_atomic_store(&desc[tile], hml_lb_pack(gen, HML_LB_PREFIX, excl + cnt), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return excl;
+}
+
+// exclusive prefix by summing the published counts of ALL earlier tiles directly (no chaining: one
+// round trip); for small tile counts only (every lane reads ceil(tile/64) descriptors)
+__device__ __forceinline__ uint32_t hml_direct_exclusive(unsigned long long* __restrict__ desc, uint32_t tile, uint32_t cnt,
+                                                         uint32_t gen, int lane) {
+    if (lane == 0) __hip_atomic_store(&desc[tile], hml_lb_pack(gen, HML_LB_AGG, cnt), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    uint32_t acc = 0;
+    for (uint32_t idx = (uint32_t)lane; idx < tile; idx += 64u) {
+        unsigned long long d = __hip_atomic_load(&desc[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        while ((uint32_t)(d >> 34) != (gen & 0x3fffffffu)) {
+            __builtin_amdgcn_s_sleep(1);
+            d = __hip_atomic_load(&desc[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        acc += (uint32_t)d;
     }
-  }
+    return hml_wave_sum_u32(acc);
+}
+
+// One launch per dynamic sweep.  Normal case (cache valid): filter the candidates.  Rare case (the parameter
+// kernel asked for a rebuild): scan w[0..T) once with this small persistent grid and compact TWICE in the
+// same pass - positions with !(w < cand_thr_lo) become the new candidate list, positions with !(w < thr)
+// the block starts.  ~0.3 ms instead of 64 us for the dedicated scan kernel, but it happens only when the
+// threshold leaves the cached range (a handful of times during burn-in).
+__global__ __launch_bounds__(256) void hml_k_blocks_cached(const float* __restrict__ w, uint32_t T, uint32_t n_spans,
+                                                           uint32_t* __restrict__ cand_pos, float* __restrict__ cand_w,
+                                                           hml_model* __restrict__ mdl, uint32_t* __restrict__ starts,
+                                                           unsigned long long* __restrict__ descA,
+                                                           unsigned long long* __restrict__ descB,
+                                                           uint32_t* __restrict__ host_B) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t gen = (uint32_t)mdl->epoch + 1u;   // one launch per parameter epoch
+    const float thr = mdl->thr;
+    const bool rebuild = mdl->need_rebuild != 0u;
+    if (!rebuild) {
+        const uint32_t M = mdl->cand_M;
+        const uint32_t n_tiles = (M + HML_CAND_TILE - 1u) / HML_CAND_TILE;
+        const bool direct = n_tiles <= 2048u;
+        // a wavefront keeps drawing tickets until the tiles are used up (the parameter kernel zeroes the counter)
+        while (true) {
+            uint32_t tile = 0;
+            if (lane == 0) tile = atomicAdd(&mdl->cand_ticket, 1u);
+            tile = (uint32_t)__builtin_amdgcn_readfirstlane((int)tile);
+            if (tile >= n_tiles) return;
+            const uint32_t base = tile * (uint32_t)HML_CAND_TILE;
+            // 16 candidates per lane, lane-major so that the order of positions is (lane, j)
+            bool f[16];
+            uint32_t cnt_lane = 0;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const uint32_t i = base + (uint32_t)lane * 16u + (uint32_t)j;
+                const float v = (i < M) ? cand_w[i] : 0.0f;
+                f[j] = (i < M) && (i == 0u || !(v < thr));
+                cnt_lane += f[j] ? 1u : 0u;
+            }
+            uint32_t incl = cnt_lane;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint32_t o = __shfl_up(incl, d);
+                if (lane >= d) incl += o;
+            }
+            const uint32_t cnt = __shfl(incl, 63);
+            const uint32_t excl = direct ? hml_direct_exclusive(descA, tile, cnt, gen, lane)
+                                         : hml_lb_exclusive(descA, tile, cnt, gen, lane);
+            uint32_t pos = excl + incl - cnt_lane;
+#pragma unroll
+            for (int j = 0; j < 16; ++j)
+                if (f[j]) starts[pos++] = cand_pos[base + (uint32_t)lane * 16u + (uint32_t)j];
+            if (tile == n_tiles - 1u && lane == 0) {
+                const uint32_t B = excl + cnt;
+                mdl->B = B;
+                starts[B] = T;
+                if (host_B) __hip_atomic_store(host_B, B, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
+    }
+    // ---- rebuild: dual compaction over the weights, spans handed out by ticket
+    const float thr_lo = mdl->cand_thr_lo;
+    while (true) {
+        uint32_t span = 0;
+        if (lane == 0) span = atomicAdd(&mdl->cand_ticket, 1u);
+        span = (uint32_t)__builtin_amdgcn_readfirstlane((int)span);
+        if (span >= n_spans) return;
+        const uint64_t base = (uint64_t)span * HML_SPAN;
+        const uint32_t rem = (base + HML_SPAN <= T) ? (uint32_t)HML_SPAN : (uint32_t)(T - base);
+        float v[16][4];
+#pragma unroll
+        for (int it = 0; it < 16; ++it)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t e = (uint32_t)it * 256u + (uint32_t)lane * 4u + (uint32_t)j;
+                v[it][j] = (e < rem) ? w[base + e] : 0.0f;
+            }
+        uint32_t c_lo = 0, c_hi = 0;
+#pragma unroll
+        for (int it = 0; it < 16; ++it)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t e = (uint32_t)it * 256u + (uint32_t)lane * 4u + (uint32_t)j;
+                const bool first = (span == 0u && e == 0u);
+                const bool lo = (e < rem) && (first || !(v[it][j] < thr_lo));
+                const bool hi = (e < rem) && (first || !(v[it][j] < thr));
+                c_lo += (uint32_t)__popcll(__ballot(lo));
+                c_hi += (uint32_t)__popcll(__ballot(hi));
+            }
+        // (c_lo, c_hi are wave totals, identical in every lane)
+        const uint32_t ex_lo = hml_lb_exclusive(descA, span, c_lo, gen, lane);
+        const uint32_t ex_hi = hml_lb_exclusive(descB, span, c_hi, gen, lane);
+        uint32_t run_lo = ex_lo, run_hi = ex_hi;
+        const unsigned long long lt = (1ull << lane) - 1ull;
+#pragma unroll
+        for (int it = 0; it < 16; ++it) {
+            // position order inside an iteration is (lane, j): prefix over lanes of the per-lane counts
+            bool lo[4], hi[4];
+            uint32_t nlo = 0, nhi = 0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t e = (uint32_t)it * 256u + (uint32_t)lane * 4u + (uint32_t)j;
+                const bool first = (span == 0u && e == 0u);
+                lo[j] = (e < rem) && (first || !(v[it][j] < thr_lo));
+                hi[j] = (e < rem) && (first || !(v[it][j] < thr));
+                nlo += lo[j] ? 1u : 0u;
+                nhi += hi[j] ? 1u : 0u;
+            }
+            unsigned long long any = __ballot(nlo != 0u);
+            if (any == 0ull) continue;
+            uint32_t plo = 0, phi = 0, tlo = 0, thi = 0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const unsigned long long ml = __ballot(lo[j]), mh = __ballot(hi[j]);
+                plo += (uint32_t)__popcll(ml & lt); tlo += (uint32_t)__popcll(ml);
+                phi += (uint32_t)__popcll(mh & lt); thi += (uint32_t)__popcll(mh);
+            }
+            uint32_t pl = run_lo + plo, ph = run_hi + phi;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t t = (uint32_t)base + (uint32_t)it * 256u + (uint32_t)lane * 4u + (uint32_t)j;
+                if (lo[j]) { cand_pos[pl] = t; cand_w[pl] = v[it][j]; ++pl; }
+                if (hi[j]) starts[ph++] = t;
+            }
+            run_lo += tlo; run_hi += thi;
+        }
+        if (span == n_spans - 1u && lane == 0) {
+            mdl->cand_M = ex_lo + c_lo;
+            mdl->cand_valid = 1u;
+            mdl->cand_rebuilds += 1ull;
+            const uint32_t B = ex_hi + c_hi;
+            mdl->B = B;
+            starts[B] = T;
+            if (host_B) __hip_atomic_store(host_B, B, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------
