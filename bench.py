@@ -32,6 +32,22 @@ WORKLOADS = {
 }
 
 
+PMC_FILE = "profiles/round1_pmc_hbm_traffic.json"
+
+
+def pmc_traffic(workload):
+    """HBM bytes per launch of the scan kernel from the committed rocprofv3 --pmc passes of this same command
+    (FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE); PMC counters cannot be collected from inside
+    the timed run, so the JSON line quotes the profile."""
+    try:
+        if workload != "c3_1e8_k5_dynamic":
+            return None
+        with open(os.path.join(REPO, PMC_FILE)) as f:
+            return json.load(f)["kernels"]["hml_k_compact_scan"]["hbm_bytes_per_launch_corrected"]
+    except Exception:
+        return None
+
+
 def cpu_baseline(x, K, seed, budget_s=20.0):
     """The CPU restatement in reference mode (sequential mt19937, glibc math, pointer-jumping block
     enumeration), timed on this box's host cores; one thread like the reference."""
@@ -153,7 +169,7 @@ def main():
                        "parallelism": "chain-parallel x%d" % world},
             "roofline": {"bound": "hbm", "kernel": "hml_k_compact_scan (forward-trellis block scan)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None, "kernel_avg_us": 1e6 * scan_avg_s, "launches": scan_n,
+                         "traffic": pmc_traffic(args.workload), "traffic_source": PMC_FILE, "kernel_avg_us": 1e6 * scan_avg_s, "launches": scan_n,
                          "bytes_per_launch": scan_bytes,
                          "sweep_frac": sweep_bytes / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS},
             "forward_refits": st1["forward_refits"] - st0["forward_refits"],
