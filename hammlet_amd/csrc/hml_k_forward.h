@@ -267,16 +267,18 @@ __global__ __launch_bounds__(256) void hml_k_forward(const float* __restrict__ e
     }
 }
 
-// Final serial pass, only when the repair round left an inconsistency (mdl->fwd_mismatch): find the first
-// chunk whose start vector is not its predecessor's end vector and walk the chain from there, recomputing
-// every inconsistent chunk in order.  One workgroup; the walk is done by one lane.
+// Final serial pass, only when the repair round left an inconsistency (mdl->fwd_mismatch).  All threads mark
+// the chunks whose start vector is not their predecessor's end vector in an LDS bitmap (windows of 2^20
+// chunks); one lane then visits the marked chunks in increasing order, recomputes each from the true
+// vector and follows the chain while the recomputed end vector makes the next chunk inconsistent.
+#define HML_SERIAL_WINDOW_WORDS 8192   // 2^18 chunks per window
 template <int K>
 __global__ __launch_bounds__(256) void hml_k_forward_serial(const float* __restrict__ em, const float* __restrict__ gsc,
                                                             hml_model* __restrict__ mdl, float* __restrict__ rows,
                                                             float* __restrict__ aprobe, float* __restrict__ entry,
                                                             float* __restrict__ exitv, uint32_t* __restrict__ fb_count,
                                                             int L, int W_unused, const hml_layout lay) {
-    __shared__ uint32_t first_bad;
+    __shared__ uint32_t bad[HML_SERIAL_WINDOW_WORDS];
     if (mdl->fwd_mismatch == 0u) return;   // every chunk is consistent
     hml_fwd_ctx<K> cx;
     hml_fwd_ctx_load<K>(cx, mdl);
@@ -285,45 +287,55 @@ __global__ __launch_bounds__(256) void hml_k_forward_serial(const float* __restr
     (void)W_unused;
     const uint32_t C = (B + (uint32_t)L - 1u) / (uint32_t)L;
     const int tid = threadIdx.x;
-    if (tid == 0) first_bad = 0xffffffffu;
-    __syncthreads();
-    for (uint32_t c = 1u + (uint32_t)tid; c < C; c += 256u) {
-        const uint32_t first = c * (uint32_t)L;
-        if (first <= (uint32_t)W) continue;   // started from pi: exact by construction
-        bool same = true;
-#pragma unroll
-        for (int s = 0; s < K; ++s)
-            same = same && (hml_f2u(entry[(uint64_t)c * K + s]) == hml_f2u(exitv[(uint64_t)(c - 1) * K + s]));
-        if (!same) atomicMin(&first_bad, c);
-    }
-    __syncthreads();
-    const uint32_t fbad = first_bad;
-    if (fbad != 0xffffffffu && tid == 0) {
-        mdl->fwd_serial_ran = 1u;   // the parameter kernel lengthens the warm-up for the next sweeps
-        for (uint32_t c = fbad; c < C; ++c) {
-            const uint32_t first = c * (uint32_t)L;
-            const uint32_t last = (first + (uint32_t)L < B) ? first + (uint32_t)L : B;
-            float alpha[K];
+    if (tid == 0) mdl->fwd_serial_ran = 1u;   // the parameter kernel lengthens the warm-up for the next sweeps
+    const uint32_t win = HML_SERIAL_WINDOW_WORDS * 32u;
+    for (uint32_t w0 = 0; w0 < C; w0 += win) {
+        const uint32_t w1 = (w0 + win < C) ? w0 + win : C;
+        for (int i = tid; i < HML_SERIAL_WINDOW_WORDS; i += 256) bad[i] = 0u;
+        __syncthreads();
+        for (uint32_t c = w0 + (uint32_t)tid; c < w1; c += 256u) {
+            if (c == 0u || c * (uint32_t)L <= (uint32_t)W) continue;   // started from pi: exact by construction
             bool same = true;
 #pragma unroll
-            for (int s = 0; s < K; ++s) {
-                alpha[s] = exitv[(uint64_t)(c - 1) * K + s];
-                same = same && (hml_f2u(alpha[s]) == hml_f2u(entry[(uint64_t)c * K + s]));
-            }
-            if (same) continue;
-#pragma unroll
-            for (int s = 0; s < K; ++s) entry[(uint64_t)c * K + s] = alpha[s];
-            uint32_t nfb = 0;
-            hml_fwd_run<K, true>(cx, alpha, em, gsc, rows, aprobe, first, last, nfb, lay);
-#pragma unroll
-            for (int s = 0; s < K; ++s) exitv[(uint64_t)c * K + s] = alpha[s];
-            const uint32_t old = fb_count[c];
-            fb_count[c] = nfb;
-            if (nfb != old) atomicAdd(&mdl->uniform_fallbacks, (unsigned long long)(long long)((int)nfb - (int)old));
-            atomicAdd(&mdl->forward_serial, 1ull);
+            for (int s = 0; s < K; ++s)
+                same = same && (hml_f2u(entry[(uint64_t)c * K + s]) == hml_f2u(exitv[(uint64_t)(c - 1) * K + s]));
+            if (!same) atomicOr(&bad[(c - w0) >> 5], 1u << ((c - w0) & 31u));
         }
+        __syncthreads();
+        if (tid == 0) {
+            for (uint32_t wi = 0; wi < (w1 - w0 + 31u) / 32u; ++wi) {
+                uint32_t bits = bad[wi];
+                while (bits) {
+                    const int bit = __ffs(bits) - 1;
+                    bits &= bits - 1u;
+                    // repair chunk c and every following chunk that the repair makes inconsistent
+                    for (uint32_t c = w0 + wi * 32u + (uint32_t)bit; c < C; ++c) {
+                        float alpha[K];
+                        bool same = true;
+#pragma unroll
+                        for (int s = 0; s < K; ++s) {
+                            alpha[s] = exitv[(uint64_t)(c - 1) * K + s];
+                            same = same && (hml_f2u(alpha[s]) == hml_f2u(entry[(uint64_t)c * K + s]));
+                        }
+                        if (same) break;   // consistent (possibly repaired already by an earlier chain)
+                        const uint32_t first = c * (uint32_t)L;
+                        const uint32_t last = (first + (uint32_t)L < B) ? first + (uint32_t)L : B;
+#pragma unroll
+                        for (int s = 0; s < K; ++s) entry[(uint64_t)c * K + s] = alpha[s];
+                        uint32_t nfb = 0;
+                        hml_fwd_run<K, true>(cx, alpha, em, gsc, rows, aprobe, first, last, nfb, lay);
+#pragma unroll
+                        for (int s = 0; s < K; ++s) exitv[(uint64_t)c * K + s] = alpha[s];
+                        const uint32_t old = fb_count[c];
+                        fb_count[c] = nfb;
+                        if (nfb != old) atomicAdd(&mdl->uniform_fallbacks, (unsigned long long)(long long)((int)nfb - (int)old));
+                        atomicAdd(&mdl->forward_serial, 1ull);
+                    }
+                }
+            }
+        }
+        __syncthreads();
     }
-    __syncthreads();
     if (tid == 0) mdl->fwd_mismatch = 0u;
 }
 

@@ -85,17 +85,23 @@ __global__ __launch_bounds__(1024) void hml_k_params(hml_model* __restrict__ mdl
     // gather the split integer accumulators
     if (tid >= 128 && tid < 128 + K * K) {
         const int e = tid - 128;
+        unsigned long long v[HML_CNT_SPLIT];
+#pragma unroll
+        for (int sp = 0; sp < HML_CNT_SPLIT; ++sp) v[sp] = mdl->trans[sp][e];   // all loads in flight together
         unsigned long long t = 0ull;
 #pragma unroll
-        for (int sp = 0; sp < HML_CNT_SPLIT; ++sp) { t += mdl->trans[sp][e]; mdl->trans[sp][e] = 0ull; }
+        for (int sp = 0; sp < HML_CNT_SPLIT; ++sp) { t += v[sp]; mdl->trans[sp][e] = 0ull; }
         s_trans[e] = t;
         mdl->last_trans[e] = t;
     }
     if (tid >= 512 && tid < 512 + K) {
         const int k = tid - 512;
+        unsigned long long v[HML_CNT_SPLIT];
+#pragma unroll
+        for (int sp = 0; sp < HML_CNT_SPLIT; ++sp) v[sp] = mdl->occ[sp][k];
         unsigned long long t = 0ull;
 #pragma unroll
-        for (int sp = 0; sp < HML_CNT_SPLIT; ++sp) { t += mdl->occ[sp][k]; mdl->occ[sp][k] = 0ull; }
+        for (int sp = 0; sp < HML_CNT_SPLIT; ++sp) { t += v[sp]; mdl->occ[sp][k] = 0ull; }
         s_occ[k] = t;
         mdl->last_occ[k] = t;
     }
