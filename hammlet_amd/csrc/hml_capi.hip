@@ -69,6 +69,10 @@ struct hml_ctx {
     double sigma = 0;
     // construction
     float* d_w = nullptr;
+    uint8_t* d_keys = nullptr;     // monotone 8-bit codes of the weights (1 byte per position for the scan)
+    int32_t key_base = 0;
+    double key_scale = 1.0;         // product of the weight multipliers applied so far
+    bool use_keys = true;
     float* d_coeff = nullptr;
     float2* d_ia = nullptr;
     // block structure
@@ -83,6 +87,12 @@ struct hml_ctx {
     unsigned long long* d_desc = nullptr;
     unsigned long long* d_descB = nullptr;
     bool cand_enabled = true;
+    // hipGraph replay of a non-recording sweep (launch-bound inner loop); re-captured when the grid hint moves
+    bool use_graph = false;
+    hipGraphExec_t graph_exec = nullptr;
+    char graph_method = 0;
+    uint32_t graph_hint = 0;
+    bool graph_dynamic = false, graph_valid_blocks = false;
     // sweep buffers (allocated by set_model)
     float *d_em = nullptr, *d_gsc = nullptr, *d_rows = nullptr, *d_eprobe = nullptr, *d_aprobe = nullptr;
     float *d_entry = nullptr, *d_exitA = nullptr, *d_exitB = nullptr;
@@ -271,12 +281,14 @@ int hml_create(hml_ctx** out, int device, uint64_t seed, uint32_t chain_id, void
     if (const char* e = getenv("HML_FWD_WARMUP")) c->fwdW = std::max(0, atoi(e));
     if (const char* e = getenv("HML_FWD_ROUNDS")) c->fwdRounds = std::max(0, atoi(e));
     if (const char* e = getenv("HML_CANDIDATE_CACHE")) c->cand_enabled = atoi(e) != 0;
+    if (const char* e = getenv("HML_USE_GRAPH")) c->use_graph = atoi(e) != 0;
+    if (const char* e = getenv("HML_WEIGHT_KEYS")) c->use_keys = atoi(e) != 0;
     *out = c;
     return 0;
 }
 
 static void free_all(hml_ctx* c) {
-    void* ptrs[] = {c->d_w, c->d_coeff, c->d_ia, c->d_stage, c->d_span_count, c->d_starts, c->d_bstat,
+    void* ptrs[] = {c->d_keys, c->d_w, c->d_coeff, c->d_ia, c->d_stage, c->d_span_count, c->d_starts, c->d_bstat,
                     c->d_em, c->d_gsc, c->d_rows, c->d_eprobe, c->d_aprobe, c->d_entry, c->d_exitA, c->d_exitB, c->d_fb, c->d_coarse1, c->d_cand_pos, c->d_cand_w, c->d_desc, c->d_descB,
                     c->d_smap, c->d_cmap, c->d_bentry, c->d_q, c->d_partial, c->d_diff, c->d_boundary, c->d_mdl};
     for (void* p : ptrs) if (p) hipFree(p);
@@ -289,12 +301,27 @@ void hml_destroy(hml_ctx* c) {
     hipStreamSynchronize(c->stream);
     for (auto& kv : c->prof) for (auto& p : kv.second.pending) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
     for (auto e : c->ev_pool) hipEventDestroy(e);
+    if (c->graph_exec) hipGraphExecDestroy(c->graph_exec);
     free_all(c);
     if (c->own_stream) hipStreamDestroy(c->stream);
     delete c;
 }
 
 // ---------------------------------------------------------------------------------------- load
+// 8-bit keys of the current weights, bucket window centred on the universal threshold of the noise estimate
+static int build_keys(hml_ctx* c) {
+    if (!c->use_keys) return 0;
+    const uint64_t T = c->T;
+    if (!c->d_keys) HIPCHK(hipMalloc(&c->d_keys, (T + 15) / 16 * 16 + 16));
+    const float thr0 = (float)(std::sqrt(2 * std::log((double)std::max<uint64_t>(T, 2))) * c->sigma * c->key_scale);
+    uint32_t u; memcpy(&u, &thr0, 4);
+    c->key_base = (std::isfinite(thr0) && thr0 > 0 ? (int32_t)(u >> 20) : (int32_t)(0x3f800000u >> 20)) - 128;
+    hipLaunchKernelGGL(hml_k_build_keys, dim3(grid_for((T + 15) / 16, 256, 1, 65536)), dim3(256), 0, c->stream, c->d_w, T, c->key_base,
+                       c->d_keys);
+    KLAUNCH_CHECK();
+    return 0;
+}
+
 static int build_from_device_x(hml_ctx* c, const float* d_x, const float* h_x) {
     const uint64_t T = c->T;
     // noise estimate (src/main.cpp:303-311): f64 accumulation, in index order, of the finest-level
@@ -350,6 +377,7 @@ static int build_from_device_x(hml_ctx* c, const float* d_x, const float* h_x) {
     }
     hipLaunchKernelGGL(hml_k_weights, dim3(grid_for(T, 256, 1, 65536)), dim3(256), 0, c->stream, c->d_coeff, c->d_w, T, 1.0f);
     KLAUNCH_CHECK();
+    if (int r = build_keys(c)) return r;
     {
         const uint64_t cells = (T + 1 + HML_CELLSIZE - 1) / HML_CELLSIZE;
         hipLaunchKernelGGL(hml_k_integral, dim3((unsigned)((cells + 3) / 4)), dim3(256), 0, c->stream, d_x, c->d_ia, T);
@@ -405,6 +433,8 @@ int hml_scale_weights(hml_ctx* c, float mult) {
     if (int r = ctx_bind(c)) return r;
     hipLaunchKernelGGL(hml_k_scale, dim3(grid_for(c->T, 256, 1, 65536)), dim3(256), 0, c->stream, c->d_w, c->T, mult);
     KLAUNCH_CHECK();
+    c->key_scale *= std::fabs((double)mult) > 0 ? std::fabs((double)mult) : 1.0;
+    if (int r = build_keys(c)) return r;
     c->blocks_valid = false;
     if (c->model_set) {   // cached candidates were selected on the old weights
         hipLaunchKernelGGL(hml_k_invalidate_cache, dim3(1), dim3(64), 0, c->stream, c->d_mdl);
@@ -420,8 +450,12 @@ static void launch_compact_pair(hml_ctx* c, int mode, float thr) {
     const uint32_t nwg = (c->n_spans + 3) / 4;
     {
         ProfScope ps(c, mode == 2 ? "cand_rebuild" : "blocks_compact", mode == 2 ? 2 : 1);
-        hipLaunchKernelGGL(hml_k_compact_scan, dim3(nwg), dim3(256), 0, c->stream, c->d_w, (uint32_t)c->T, c->d_mdl, thr, mode,
-                           c->d_stage, c->d_span_count);
+        if (c->use_keys)
+            hipLaunchKernelGGL(hml_k_compact_scan_keys, dim3((nwg + HML_KEY_SPANS_PER_WAVE - 1) / HML_KEY_SPANS_PER_WAVE), dim3(256), 0, c->stream, c->d_keys, c->d_w, (uint32_t)c->T,
+                               c->d_mdl, thr, mode, c->key_base, c->d_stage, c->d_span_count);
+        else
+            hipLaunchKernelGGL(hml_k_compact_scan, dim3(nwg), dim3(256), 0, c->stream, c->d_w, (uint32_t)c->T, c->d_mdl, thr, mode,
+                               c->d_stage, c->d_span_count);
     }
     {
         ProfScope ps(c, mode == 2 ? "cand_rebuild" : "blocks_scatter");
@@ -747,6 +781,29 @@ int hml_iterate(hml_ctx* c, char method, uint64_t iterations, uint64_t thinning)
     if (int r = ctx_bind(c)) return r;
     for (uint64_t i = 0; i < iterations; ++i) {
         const bool record = thinning > 0 && ((i + 1) % thinning == 0);
+        if (c->use_graph && !record && !c->profiling && !c->probes && (c->dynamic || c->blocks_valid)) {
+            // replay a captured sweep; capture again when the launch geometry (grid hint / mode) changed
+            refresh_hint(c);
+            const uint32_t hint = c->B_hint;
+            const bool stale = !c->graph_exec || c->graph_method != method || c->graph_dynamic != c->dynamic ||
+                               hint > c->graph_hint || hint * 2u < c->graph_hint;
+            if (stale && hint) {
+                if (c->graph_exec) { hipGraphExecDestroy(c->graph_exec); c->graph_exec = nullptr; }
+                hipGraph_t g = nullptr;
+                HIPCHK(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+                int rr = 0;
+                HML_DISPATCH_K(c->K, rr = sweep_k<KK>(c, method, false));
+                HIPCHK(hipStreamEndCapture(c->stream, &g));
+                if (rr) return rr;
+                HIPCHK(hipGraphInstantiate(&c->graph_exec, g, nullptr, nullptr, 0));
+                hipGraphDestroy(g);
+                c->graph_method = method; c->graph_dynamic = c->dynamic; c->graph_hint = c->B_hint;
+            }
+            if (c->graph_exec) {
+                HIPCHK(hipGraphLaunch(c->graph_exec, c->stream));
+                continue;
+            }
+        }
         HML_DISPATCH_K(c->K, if (int r = sweep_k<KK>(c, method, record)) return r);
         if (record && c->cb) {
             HIPCHK(hipStreamSynchronize(c->stream));
@@ -759,6 +816,11 @@ int hml_iterate(hml_ctx* c, char method, uint64_t iterations, uint64_t thinning)
 
 int hml_set_option(hml_ctx* c, const char* name, int value) {
     if (!c || !name) return set_err(HML_ERR_ARG, "null argument");
+    if (std::string(name) == "weight_keys") {
+        if (c->loaded) return set_err(HML_ERR_ARG, "weight_keys must be set before the observations are loaded");
+        c->use_keys = value != 0;
+        return 0;
+    }
     if (std::string(name) == "candidate_cache") {
         if (c->model_set) return set_err(HML_ERR_ARG, "candidate_cache must be set before hml_set_model");
         c->cand_enabled = value != 0;

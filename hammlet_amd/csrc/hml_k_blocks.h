@@ -24,6 +24,7 @@
 // ------------------------------------------------------------------------------------------
 
 typedef float hml_f4 __attribute__((ext_vector_type(4)));
+typedef uint32_t hml_u4 __attribute__((ext_vector_type(4)));
 
 __global__ __launch_bounds__(256) void hml_k_compact_scan(const float* __restrict__ w, uint32_t T,
                                                           const hml_model* __restrict__ mdl, float thr_override,
@@ -83,6 +84,143 @@ __global__ __launch_bounds__(256) void hml_k_compact_scan(const float* __restric
         }
     }
     if (lane == 0) span_count[span] = running;
+}
+
+// ------------------------------------------------------------------------------------------
+// K4 over 8-bit keys.  The scan only has to decide !(w[t] < thr), and almost every weight is far below the
+// threshold, so the 4-byte weights are over-precise for it.  key(w) is a MONOTONE 8-bit code
+//   key(w) = 0 for negative w, else clamp((bits(w) >> 20) - base, 0, 255)      (1/8-binade buckets)
+// built once per weight array.  Monotonicity gives: key(w) > key(thr) => !(w < thr); key(w) < key(thr) =>
+// w < thr; only positions whose key EQUALS key(thr) are undecided and fetch the exact weight (a few percent
+// of the block starts).  Same block structure as the float scan, bit for bit, at 1 byte per position.
+// ------------------------------------------------------------------------------------------
+HML_HD uint32_t hml_weight_key(float w, int32_t base) {
+    const uint32_t u = hml_f2u(w);
+    if (u & 0x80000000u) return 0u;
+    const int32_t k = (int32_t)(u >> 20) - base;
+    return k < 0 ? 0u : (k > 255 ? 255u : (uint32_t)k);
+}
+
+__global__ __launch_bounds__(256) void hml_k_build_keys(const float* __restrict__ w, uint64_t T, int32_t base,
+                                                        uint8_t* __restrict__ keys) {
+    // 16 positions per thread: four float4 loads, one 16-byte store
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    const uint64_t n16 = (T + 15) / 16;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += stride) {
+        uint32_t packed[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const uint64_t t = i * 16 + (uint64_t)j;
+            const uint32_t k = (t < T) ? hml_weight_key(w[t], base) : 0u;
+            packed[j >> 2] |= k << (8 * (j & 3));
+        }
+        reinterpret_cast<uint4*>(keys)[i] = make_uint4(packed[0], packed[1], packed[2], packed[3]);
+    }
+}
+
+__device__ __forceinline__ uint32_t hml_wave_sum_u32(uint32_t v);
+
+// SWAR: 0x80 in every byte of x that is >= m (m in 0..256), no cross-byte carries
+struct hml_swar_ge {
+    uint32_t add;    // per-byte addend
+    int mode;        // 0: all bytes, 1: m <= 128, 2: m > 128, 3: none
+};
+__device__ __forceinline__ hml_swar_ge hml_swar_ge_make(uint32_t m) {
+    hml_swar_ge g;
+    if (m == 0u) { g.mode = 0; g.add = 0u; }
+    else if (m > 255u) { g.mode = 3; g.add = 0u; }
+    else if (m <= 128u) { g.mode = 1; g.add = (128u - m) * 0x01010101u; }
+    else { g.mode = 2; g.add = (256u - m) * 0x01010101u; }
+    return g;
+}
+__device__ __forceinline__ uint32_t hml_swar_ge_apply(const hml_swar_ge g, uint32_t x) {
+    const uint32_t t = (x & 0x7f7f7f7fu) + g.add;
+    const uint32_t r = g.mode == 1 ? (t | x) : (t & x);
+    return g.mode == 0 ? 0x80808080u : (g.mode == 3 ? 0u : (r & 0x80808080u));
+}
+// gather the four 0x80 flags of a word into bits 0..3
+__device__ __forceinline__ uint32_t hml_swar_compress(uint32_t flags) {
+    return (((flags >> 7) * 0x00204081u) >> 21) & 15u;
+}
+
+#define HML_KEY_SPANS_PER_WAVE 1
+__global__ __launch_bounds__(256) void hml_k_compact_scan_keys(const uint8_t* __restrict__ keys, const float* __restrict__ w,
+                                                               uint32_t T, const hml_model* __restrict__ mdl,
+                                                               float thr_override, int use_override, int32_t base,
+                                                               uint16_t* __restrict__ stage,
+                                                               uint32_t* __restrict__ span_count) {
+    if (use_override == 2 && mdl->need_rebuild == 0u) return;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    // one wavefront owns HML_KEY_SPANS_PER_WAVE consecutive spans (16 KB of keys), all of its loads in flight at once
+    const uint32_t span0 = (blockIdx.x * 4u + (uint32_t)wave) * HML_KEY_SPANS_PER_WAVE;
+    if ((uint64_t)span0 * HML_SPAN >= T) return;
+    const float thr = use_override == 2 ? mdl->cand_thr_lo : (use_override ? thr_override : mdl->thr);
+    const bool thr_nan = (thr != thr);
+    const uint32_t kthr = hml_weight_key(thr, base);
+    const hml_swar_ge sw_ge = hml_swar_ge_make(kthr), sw_gt = hml_swar_ge_make(kthr + 1u);
+    hml_u4 kv[HML_KEY_SPANS_PER_WAVE][4];
+#pragma unroll
+    for (int sp = 0; sp < HML_KEY_SPANS_PER_WAVE; ++sp) {
+        const uint64_t sbase = (uint64_t)(span0 + (uint32_t)sp) * HML_SPAN;
+        const hml_u4* __restrict__ p = reinterpret_cast<const hml_u4*>(keys + sbase) + lane;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const uint64_t t0 = sbase + (uint64_t)i * 1024u + (uint64_t)lane * 16u;
+            // the key array is padded to a multiple of 16 bytes; groups beyond T are masked below
+            kv[sp][i] = (t0 < T) ? __builtin_nontemporal_load(p + i * 64) : hml_u4{0u, 0u, 0u, 0u};
+        }
+    }
+#pragma unroll
+    for (int sp = 0; sp < HML_KEY_SPANS_PER_WAVE; ++sp) {
+        const uint32_t span = span0 + (uint32_t)sp;
+        const uint64_t sbase = (uint64_t)span * HML_SPAN;
+        if (sbase >= T) break;
+        const uint32_t rem = (sbase + HML_SPAN <= T) ? (uint32_t)HML_SPAN : (uint32_t)(T - sbase);
+        uint16_t* __restrict__ out = stage + sbase;
+        uint32_t running = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const uint32_t e0 = (uint32_t)i * 1024u + (uint32_t)lane * 16u;
+            const uint32_t words[4] = {kv[sp][i].x, kv[sp][i].y, kv[sp][i].z, kv[sp][i].w};
+            uint32_t ge_m = 0, gt_m = 0;
+#pragma unroll
+            for (int jw = 0; jw < 4; ++jw) {
+                ge_m |= hml_swar_compress(hml_swar_ge_apply(sw_ge, words[jw])) << (4 * jw);
+                gt_m |= hml_swar_compress(hml_swar_ge_apply(sw_gt, words[jw])) << (4 * jw);
+            }
+            const uint32_t left = (e0 < rem) ? rem - e0 : 0u;
+            const uint32_t inmask = left >= 16u ? 0xffffu : ((1u << left) - 1u);
+            uint32_t fm = (thr_nan ? 0xffffu : gt_m) & inmask;             // bit j: position e0 + j starts a block
+            uint32_t eq = thr_nan ? 0u : (ge_m & ~gt_m & inmask);           // bit j: undecided, needs the float
+            if (span == 0u && i == 0 && lane == 0) { fm |= 1u; eq &= ~1u; }   // position 0 always starts a block
+            if (__ballot(eq != 0u) != 0ull) {
+                // undecided positions: exact comparison on the float weight
+                uint32_t m = eq;
+                while (m) {
+                    const int j = __ffs(m) - 1;
+                    m &= m - 1u;
+                    if (!(w[sbase + e0 + (uint32_t)j] < thr)) fm |= 1u << j;
+                }
+            }
+            if (__ballot(fm != 0u) == 0ull) continue;   // wave-uniform
+            const uint32_t c = (uint32_t)__popc(fm);
+            uint32_t incl = c;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint32_t o = __shfl_up(incl, d);
+                if (lane >= d) incl += o;
+            }
+            uint32_t pos = running + incl - c;
+            uint32_t m = fm;
+            while (m) {
+                const int j = __ffs(m) - 1;
+                m &= m - 1u;
+                out[pos++] = (uint16_t)(e0 + (uint32_t)j);
+            }
+            running += __shfl(incl, 63);
+        }
+        if (lane == 0) span_count[span] = running;
+    }
 }
 
 __device__ __forceinline__ uint32_t hml_wave_sum_u32(uint32_t v) {

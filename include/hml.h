@@ -98,7 +98,9 @@ int hml_set_recording(hml_ctx* ctx, int marginals, hml_record_cb cb, void* user)
 
 /* Options (before hml_set_model): "candidate_cache" 1 (default) = dynamic sweeps filter a cached list of the
  * positions with weight >= 0.9 x threshold and rescan the weights only when the threshold leaves the cached
- * range; 0 = scan all T weights every sweep.  Same block structures either way (exact). */
+ * range; 0 = scan all T weights every sweep.  "weight_keys" (before loading) 1 (default) = the scan reads monotone
+ * 8-bit codes of the weights (1 byte per position, exact through a float re-check of undecided positions); 0 = it reads
+ * the float weights.  Same block structures in every combination (exact). */
 int hml_set_option(hml_ctx* ctx, const char* name, int value);
 
 /* wait for all enqueued work; surfaces model errors raised on the device */

@@ -222,3 +222,46 @@ def test_dense_marginals_export_and_pooling_path(hml):
     assert np.array_equal(seg.cpu().numpy(), np.asarray(lens))
     assert np.array_equal(cnt.cpu().numpy(), dense_o[perm][:, starts].T)
     assert np.all(got[:K].sum(0) == 8)
+
+
+@pytest.mark.parametrize("keys", [1, 0])
+def test_block_scan_edge_thresholds(hml, keys):
+    """The 8-bit key scan and the float scan against the checker on thresholds that hit weights exactly,
+    fall outside the key window, or are degenerate (0, inf, NaN), and on a ragged tail (T not a multiple of 16)."""
+    T = 150001
+    x = ol.trace(T, 3, 12)
+    o = ol.OracleChain(K=3)
+    o.load(x)
+    g = hml.Chain()
+    g.set_option("weight_keys", keys)
+    g.load(x)
+    w = o.weights()
+    finite = np.sort(w[np.isfinite(w)])
+    picks = [float(finite[len(finite) // 2]), float(finite[-1]), float(finite[-5]), float(np.nextafter(finite[-5], np.float32(np.inf))),
+             float(finite[len(finite) * 9 // 10])]
+    for thr in picks + [0.0, 1e-30, 1e-3, 0.7, 1e9, 3e38, float("inf"), float("nan"), -1.0]:
+        o.enumerate_blocks(thr)
+        g.create_blocks(thr)
+        assert np.array_equal(o.blocks(), g.blocks()), (keys, thr)
+        a, b = o.block_stats()
+        c, d = g.block_stats()
+        assert np.array_equal(bits(a), bits(c)) and np.array_equal(bits(b), bits(d)), (keys, thr)
+
+
+@pytest.mark.parametrize("mult", [-1.0, 1e-20, 1e20, 0.37])
+def test_block_scan_with_odd_weight_multipliers(hml, mult):
+    """`-m` multipliers that push the weights out of the key window or make them negative.  (A multiplier of 0
+    turns the infinite weights into NaN; the reference's pointer array is then ill-defined, so that input is
+    outside the equivalence - see DESIGN.md.)"""
+    T = 50000
+    x = ol.trace(T, 3, 13)
+    o = ol.OracleChain(K=3, weight_mult=mult)
+    o.load(x)
+    g = hml.Chain()
+    g.load(x)
+    g.scale_weights(mult)
+    assert np.array_equal(bits(o.weights()), bits(g.weights()))
+    for thr in [0.0, 1e-25, 0.5, 1e15, float("inf")]:
+        o.enumerate_blocks(thr)
+        g.create_blocks(thr)
+        assert np.array_equal(o.blocks(), g.blocks()), (mult, thr)
