@@ -43,7 +43,7 @@ def pmc_traffic(workload):
         if workload != "c3_1e8_k5_dynamic":
             return None
         with open(os.path.join(REPO, PMC_FILE)) as f:
-            return json.load(f)["kernels"]["hml_k_compact_scan"]["hbm_bytes_per_launch_corrected"]
+            return json.load(f)["scan_kernel"]["hbm_bytes_per_launch_corrected"]
     except Exception:
         return None
 
@@ -128,6 +128,7 @@ def main():
         s1 = ch.stats()
         return ch, t1 - t0, s1["block_updates"] - s0["block_updates"], s0, s1
 
+    chain_uses_keys = os.environ.get("HML_WEIGHT_KEYS", "1") != "0"
     # headline leg: the block structure is recompressed from all T breakpoint weights in every sweep
     chain, elapsed, blocks, st0, st1 = run_leg(candidate_cache=False, profile_level=1)
     scan_ms, scan_n = chain.profile_get("blocks_compact")
@@ -146,10 +147,14 @@ def main():
     if rank == 0:
         B_avg = blocks / max(1, args.steps)
         scan_avg_s = (scan_ms / max(1, scan_n)) * 1e-3
-        # algorithmic bytes of one blocks_compact launch: the weight stream (4 B/position) + one 32-bit
-        # start per block (DESIGN.md "K4"); per sweep: 4*T + B*(36 + 8*K)  
+        # algorithmic bytes of one blocks_compact launch per SURVEY.md section 8d: the weight stream at
+        # 4 B/position + one 32-bit start per block; per sweep: 4*T + B*(36 + 8*K).  The kernel itself reads the
+        # weights as monotone 8-bit keys (DESIGN.md "K4"), so it physically moves ~T + 6*B bytes: `traffic` (PMC)
+        # shows that, and `physical_*` prices the kernel against the bytes it really streams.
         scan_bytes = 4.0 * T + 4.0 * B_avg
         achieved = scan_bytes / scan_avg_s / 1e9 if scan_avg_s > 0 else 0.0
+        phys_bytes = (1.0 if chain_uses_keys else 4.0) * T + 6.0 * B_avg
+        phys_achieved = phys_bytes / scan_avg_s / 1e9 if scan_avg_s > 0 else 0.0
         sweep_bytes = 4.0 * T + B_avg * (36 + 8 * K)
         out = {
             "metric": "block-updates/sec (Gibbs sweep) + HBM GB/s, 10^8 pos / 5 states",
@@ -167,10 +172,11 @@ def main():
             "config": {"workload": args.workload, "positions": T, "states": K, "blocks_per_sweep": B_avg,
                        "compression": T / max(B_avg, 1.0), "block_structure": "dynamic", "chains": world,
                        "parallelism": "chain-parallel x%d" % world},
-            "roofline": {"bound": "hbm", "kernel": "hml_k_compact_scan (forward-trellis block scan)",
+            "roofline": {"bound": "hbm", "kernel": ("hml_k_compact_scan_keys" if chain_uses_keys else "hml_k_compact_scan") + " (forward-trellis block scan)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": pmc_traffic(args.workload), "traffic_source": PMC_FILE, "kernel_avg_us": 1e6 * scan_avg_s, "launches": scan_n,
-                         "bytes_per_launch": scan_bytes,
+                         "bytes_per_launch": scan_bytes, "physical_bytes_per_launch": phys_bytes,
+                         "physical_achieved": phys_achieved, "physical_frac": phys_achieved / HBM_PEAK_GBS,
                          "sweep_frac": sweep_bytes / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS},
             "forward_refits": st1["forward_refits"] - st0["forward_refits"],
             "forward_serial": st1["forward_serial"] - st0["forward_serial"],
