@@ -29,6 +29,8 @@ WORKLOADS = {
     "c2_1e7_k5": (10_000_000, 5, [-2, -1, 0, 1, 2], 0.3, 5000.0, 2),
     "c1_1e5_k3": (100_000, 3, [-1, 0, 1], 0.2, 2000.0, 1),
     "c4_1e8_k10": (100_000_000, 10, [x - 4.5 for x in range(10)], 0.3, 5000.0, 4),
+    # simulated WGS read depth (Poisson-lognormal, chr1 scale), 5-state CNV model: levels/sigma unused
+    "c5_2.5e8_depth_k5": (250_000_000, 5, None, 0.15, 15.0, 5),
 }
 
 
@@ -98,7 +100,11 @@ def main():
 
     import hammlet_amd
     T, K, levels, sigma, dwell, data_seed = WORKLOADS[args.workload]
-    x = hammlet_amd.synth_gauss(T, K, levels, sigma, dwell, data_seed, nthreads=max(1, (os.cpu_count() or 8) // max(1, world)))
+    nthr = max(1, min(64, (os.cpu_count() or 8) // max(1, world)))
+    if levels is None:
+        x = hammlet_amd.synth_depth(T, depth=dwell, ln_sigma=sigma, seed=data_seed, nthreads=nthr)
+    else:
+        x = hammlet_amd.synth_gauss(T, K, levels, sigma, dwell, data_seed, nthreads=nthr)
 
     def barrier():
         if dist is not None:

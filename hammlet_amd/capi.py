@@ -21,7 +21,7 @@ class HmlError(RuntimeError):
 
 class HmlStats(C.Structure):
     _fields_ = [("sweeps", C.c_uint64), ("block_updates", C.c_uint64), ("uniform_fallbacks", C.c_uint64),
-                ("forward_refits", C.c_uint64), ("forward_serial", C.c_uint64), ("candidate_rebuilds", C.c_uint64)]
+                ("forward_refits", C.c_uint64), ("forward_serial", C.c_uint64), ("candidate_rebuilds", C.c_uint64), ("forward_warmup", C.c_uint64)]
 
 
 RECORD_CB = C.CFUNCTYPE(None, C.c_void_p, C.c_uint64, C.c_void_p)
@@ -70,6 +70,7 @@ SIGNATURES = {
     "hml_profile_enable": (C.c_int, [_P, C.c_int]),
     "hml_profile_get": (C.c_int, [_P, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
     "hml_debug_eval": (C.c_int, [C.c_int, C.c_int, _P, _P, _P, C.c_uint64, C.c_uint64]),
+    "hml_synth_depth": (C.c_int, [_P, _P, C.c_uint64, C.c_double, C.c_double, C.c_uint64, C.c_int]),
     "hml_synth_gauss": (C.c_int, [_P, _P, C.c_uint64, C.c_int, _P, C.c_float, C.c_double, C.c_uint64, C.c_int]),
 }
 
@@ -104,6 +105,14 @@ def synth_gauss(T, K, mu, sigma, dwell, seed, nthreads=8, with_states=False):
     st = np.empty(T, np.int16) if with_states else None
     _check(lib.hml_synth_gauss(x.ctypes.data, st.ctypes.data if with_states else None, T, K, mu.ctypes.data, sigma,
                                dwell, seed, nthreads))
+    return (x, st) if with_states else x
+
+
+def synth_depth(T, depth=15.0, ln_sigma=0.15, seed=5, nthreads=8, with_states=False):
+    lib = load_library()
+    x = np.empty(T, np.float32)
+    st = np.empty(T, np.int16) if with_states else None
+    _check(lib.hml_synth_depth(x.ctypes.data, st.ctypes.data if with_states else None, T, depth, ln_sigma, seed, nthreads))
     return (x, st) if with_states else x
 
 

@@ -87,6 +87,7 @@ struct hml_ctx {
     unsigned long long* d_desc = nullptr;
     unsigned long long* d_descB = nullptr;
     bool cand_enabled = true;
+    int cached_grid = 256;
     // hipGraph replay of a non-recording sweep (launch-bound inner loop); re-captured when the grid hint moves
     bool use_graph = false;
     hipGraphExec_t graph_exec = nullptr;
@@ -282,6 +283,7 @@ int hml_create(hml_ctx** out, int device, uint64_t seed, uint32_t chain_id, void
     if (const char* e = getenv("HML_FWD_ROUNDS")) c->fwdRounds = std::max(0, atoi(e));
     if (const char* e = getenv("HML_CANDIDATE_CACHE")) c->cand_enabled = atoi(e) != 0;
     if (const char* e = getenv("HML_USE_GRAPH")) c->use_graph = atoi(e) != 0;
+    if (const char* e = getenv("HML_CACHED_GRID")) c->cached_grid = std::max(1, atoi(e));
     if (const char* e = getenv("HML_WEIGHT_KEYS")) c->use_keys = atoi(e) != 0;
     *out = c;
     return 0;
@@ -684,7 +686,7 @@ static int sweep_k(hml_ctx* c, char method, bool record) {
             // candidate cache: one launch filters the cached candidates (or, rarely, rebuilds the cache and
             // compacts the block starts in the same pass)
             ProfScope ps(c, "blocks_cached");
-            hipLaunchKernelGGL(hml_k_blocks_cached, dim3(64), dim3(256), 0, s, c->d_w, T, c->n_spans, c->d_cand_pos, c->d_cand_w,
+            hipLaunchKernelGGL(hml_k_blocks_cached, dim3(c->cached_grid), dim3(256), 0, s, c->d_w, T, c->n_spans, c->d_cand_pos, c->d_cand_w,
                                c->d_mdl, c->d_starts, c->d_desc, c->d_descB, c->d_hB);
         } else {
             launch_compact_pair(c, 0, 0.0f);
@@ -1045,6 +1047,7 @@ int hml_get_stats(hml_ctx* c, hml_stats* out) {
     out->sweeps = m.sweeps; out->block_updates = m.block_updates; out->uniform_fallbacks = m.uniform_fallbacks;
     out->forward_refits = m.forward_refits; out->forward_serial = m.forward_serial;
     out->candidate_rebuilds = m.cand_rebuilds;
+    out->forward_warmup = m.fwd_W;
     return 0;
 }
 
@@ -1088,6 +1091,13 @@ int hml_synth_gauss(float* x, int16_t* states, uint64_t T, int K, const float* m
                     uint64_t seed, int nthreads) {
     if (!x || !mu || K < 1) return set_err(HML_ERR_ARG, "invalid argument");
     hml_synth_gauss_trace(x, states, T, K, mu, sigma, mean_dwell, seed, nthreads);
+    return 0;
+}
+
+
+int hml_synth_depth(float* x, int16_t* states, uint64_t T, double depth, double ln_sigma, uint64_t seed, int nthreads) {
+    if (!x) return set_err(HML_ERR_ARG, "invalid argument");
+    hml_synth_depth_trace(x, states, T, depth, ln_sigma, seed, nthreads);
     return 0;
 }
 

@@ -376,6 +376,7 @@ __global__ __launch_bounds__(256) void hml_k_blocks_cached(const float* __restri
                                                            unsigned long long* __restrict__ descA,
                                                            unsigned long long* __restrict__ descB,
                                                            uint32_t* __restrict__ host_B) {
+    __shared__ uint32_t wg_ticket;
     const int lane = threadIdx.x & 63;
     const uint32_t gen = (uint32_t)mdl->epoch + 1u;   // one launch per parameter epoch
     const float thr = mdl->thr;
@@ -386,10 +387,13 @@ __global__ __launch_bounds__(256) void hml_k_blocks_cached(const float* __restri
         const bool direct = n_tiles <= 2048u;
         // a wavefront keeps drawing tickets until the tiles are used up (the parameter kernel zeroes the counter)
         while (true) {
-            uint32_t tile = 0;
-            if (lane == 0) tile = atomicAdd(&mdl->cand_ticket, 1u);
-            tile = (uint32_t)__builtin_amdgcn_readfirstlane((int)tile);
-            if (tile >= n_tiles) return;
+            // one ticket per workgroup hands out four consecutive tiles (one per wavefront)
+            __syncthreads();
+            if (threadIdx.x == 0) wg_ticket = atomicAdd(&mdl->cand_ticket, 4u);
+            __syncthreads();
+            const uint32_t tile = wg_ticket + (uint32_t)(threadIdx.x >> 6);
+            if (wg_ticket >= n_tiles) return;
+            if (tile >= n_tiles) continue;   // the other wavefronts of this workgroup still need the barrier above
             const uint32_t base = tile * (uint32_t)HML_CAND_TILE;
             // 16 candidates per lane, lane-major so that the order of positions is (lane, j)
             bool f[16];
@@ -425,10 +429,12 @@ __global__ __launch_bounds__(256) void hml_k_blocks_cached(const float* __restri
     // ---- rebuild: dual compaction over the weights, spans handed out by ticket
     const float thr_lo = mdl->cand_thr_lo;
     while (true) {
-        uint32_t span = 0;
-        if (lane == 0) span = atomicAdd(&mdl->cand_ticket, 1u);
-        span = (uint32_t)__builtin_amdgcn_readfirstlane((int)span);
-        if (span >= n_spans) return;
+        __syncthreads();
+        if (threadIdx.x == 0) wg_ticket = atomicAdd(&mdl->cand_ticket, 4u);
+        __syncthreads();
+        const uint32_t span = wg_ticket + (uint32_t)(threadIdx.x >> 6);
+        if (wg_ticket >= n_spans) return;
+        if (span >= n_spans) continue;
         const uint64_t base = (uint64_t)span * HML_SPAN;
         const uint32_t rem = (base + HML_SPAN <= T) ? (uint32_t)HML_SPAN : (uint32_t)(T - base);
         float v[16][4];

@@ -194,7 +194,7 @@ __device__ __forceinline__ void hml_fwd_run(const hml_fwd_ctx<K>& cx, float (&al
     }
 }
 
-// MODE 0: speculative main pass.  MODE 1: verify against exit_in and recompute stale chunks.
+// MODE 0: speculative main pass.  MODE 1: verify against exit_in; recompute stale chunks after a 16x longer warm-up.
 // MODE 2: verify only - raise mdl->fwd_mismatch if any chunk is still inconsistent (the serial pass then runs).
 template <int K, int MODE>
 __global__ __launch_bounds__(256) void hml_k_forward(const float* __restrict__ em, const float* __restrict__ gsc,
@@ -243,20 +243,23 @@ __global__ __launch_bounds__(256) void hml_k_forward(const float* __restrict__ e
                 for (int s = 0; s < K; ++s) exit_out[(uint64_t)c * K + s] = exit_in[(uint64_t)c * K + s];
                 continue;
             }
+            // stale: the warm-up was too short here.  Do not trust the neighbour (it may be stale too): warm up
+            // again over a 16x longer stretch, which ends in the true vector unless the filter hardly forgets
+            // at all; the serial pass then verifies every chunk and repairs what is still inconsistent.
+            {
+                const uint32_t Wl = (uint32_t)W * 16u;
+                const uint32_t ws2 = (first >= Wl) ? first - Wl : 0u;
+#pragma unroll
+                for (int s = 0; s < K; ++s) alpha[s] = (ws2 == 0u) ? mdl->pi[s] : cx.invK;
+                hml_fwd_run<K, false>(cx, alpha, em, gsc, rows, aprobe, ws2, first, nfb, lay);
+            }
 #pragma unroll
             for (int s = 0; s < K; ++s) entry[(uint64_t)c * K + s] = alpha[s];
             atomicAdd(&mdl->forward_refits, 1ull);
+            mdl->fwd_mismatch = 1u;
         }
         // the chunk proper over [first, last)
         hml_fwd_run<K, true>(cx, alpha, em, gsc, rows, aprobe, first, last, nfb, lay);
-        if (MODE == 1) {
-            // a recomputed chunk that ends in different bits leaves its successor inconsistent: only then
-            // does the serial pass have work
-            bool unchanged = true;
-#pragma unroll
-            for (int s = 0; s < K; ++s) unchanged = unchanged && (hml_f2u(alpha[s]) == hml_f2u(exit_in[(uint64_t)c * K + s]));
-            if (!unchanged) mdl->fwd_mismatch = 1u;
-        }
 #pragma unroll
         for (int s = 0; s < K; ++s) exit_out[(uint64_t)c * K + s] = alpha[s];
         // "[WARNING] Uniform sampling of forward variables!" events: keep the global tally consistent when a
@@ -308,13 +311,15 @@ __global__ __launch_bounds__(256) void hml_k_forward_serial(const float* __restr
                 while (bits) {
                     const int bit = __ffs(bits) - 1;
                     bits &= bits - 1u;
-                    // repair chunk c and every following chunk that the repair makes inconsistent
+                    // repair chunk c and every following chunk that the repair makes inconsistent; the end vector
+                    // of a repaired chunk stays in registers as the next chunk's true start vector
+                    float alpha[K];
+                    bool have_alpha = false;
                     for (uint32_t c = w0 + wi * 32u + (uint32_t)bit; c < C; ++c) {
-                        float alpha[K];
                         bool same = true;
 #pragma unroll
                         for (int s = 0; s < K; ++s) {
-                            alpha[s] = exitv[(uint64_t)(c - 1) * K + s];
+                            if (!have_alpha) alpha[s] = exitv[(uint64_t)(c - 1) * K + s];
                             same = same && (hml_f2u(alpha[s]) == hml_f2u(entry[(uint64_t)c * K + s]));
                         }
                         if (same) break;   // consistent (possibly repaired already by an earlier chain)
@@ -326,6 +331,7 @@ __global__ __launch_bounds__(256) void hml_k_forward_serial(const float* __restr
                         hml_fwd_run<K, true>(cx, alpha, em, gsc, rows, aprobe, first, last, nfb, lay);
 #pragma unroll
                         for (int s = 0; s < K; ++s) exitv[(uint64_t)c * K + s] = alpha[s];
+                        have_alpha = true;
                         const uint32_t old = fb_count[c];
                         fb_count[c] = nfb;
                         if (nfb != old) atomicAdd(&mdl->uniform_fallbacks, (unsigned long long)(long long)((int)nfb - (int)old));

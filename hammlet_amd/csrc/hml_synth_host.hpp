@@ -57,4 +57,46 @@ inline void hml_synth_gauss_trace(float* x, int16_t* states, uint64_t T, int K, 
     }
 }
 
+
+// Copy-number segments: diploid (cn = 2) runs with log-uniform length in [1e4, 1e6] alternate with CNV runs
+// (cn in {0, 1, 3, 4}) of log-uniform length in [1e3, 1e5]; counts are Poisson-lognormal around depth * cn.
+inline void hml_synth_depth_trace(float* x, int16_t* states, uint64_t T, double depth, double ln_sigma, uint64_t seed,
+                                  int nthreads) {
+    if (T == 0) return;
+    if (nthreads < 1) nthreads = 1;
+    std::vector<uint64_t> jt;
+    std::vector<int16_t> js;
+    uint64_t t = 0, seg = 0;
+    bool diploid = true;
+    while (t < T) {
+        const hml_u32x4 w = hml_philox4x32_10((uint32_t)seg, (uint32_t)(seg >> 32), 2u, (uint32_t)HML_KIND_DATA << 24,
+                                              (uint32_t)seed, (uint32_t)(seed >> 32) ^ 0x5EEDu);
+        const double u = ((double)w.v[0] + 0.5) / 4294967296.0;
+        const double lo = diploid ? 1e4 : 1e3, hi = diploid ? 1e6 : 1e5;
+        // log-uniform length: lo * (hi/lo)^u = lo * exp(-u' * ln(lo/hi)) with a non-positive exponent
+        const double len = hi * hml_exp_nonpos(-(1.0 - u) * hml_log(hi / lo));
+        const int cn = diploid ? 2 : (int)((const int[]){0, 1, 3, 4}[w.v[1] & 3u]);
+        jt.push_back(t);
+        js.push_back((int16_t)cn);
+        t += (uint64_t)(len < 1.0 ? 1.0 : len);
+        diploid = !diploid;
+        ++seg;
+    }
+    jt.push_back(T);
+    const uint64_t per = (T + nthreads - 1) / nthreads;
+    auto fill = [&](int th) {
+        const uint64_t a = (uint64_t)th * per, b = std::min(T, a + per);
+        if (a >= b) return;
+        size_t s = (size_t)(std::upper_bound(jt.begin(), jt.end(), a) - jt.begin()) - 1;
+        for (uint64_t p = a; p < b; ++p) {
+            while (jt[s + 1] <= p) ++s;
+            x[p] = hml_synth_depth_value(seed, p, js[s], depth, ln_sigma);
+            if (states) states[p] = js[s];
+        }
+    };
+    std::vector<std::thread> ths;
+    for (int th = 0; th < nthreads; ++th) ths.emplace_back(fill, th);
+    for (auto& th : ths) th.join();
+}
+
 #endif

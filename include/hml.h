@@ -148,6 +148,7 @@ typedef struct {
     uint64_t forward_refits;    /* chunks whose speculative forward pass had to be redone  */
     uint64_t forward_serial;    /* chunks finished by the sequential fallback              */
     uint64_t candidate_rebuilds; /* full scans of the weights done to (re)build the candidate cache */
+    uint64_t forward_warmup;     /* current (adaptive) warm-up length of the speculative forward pass */
 } hml_stats;
 int hml_get_stats(hml_ctx* ctx, hml_stats* out);
 
@@ -166,6 +167,9 @@ int hml_debug_eval(int device, int fn, const float* a, const float* b_or_null, f
 /* synthetic piecewise-constant Gaussian trace, host buffer */
 int hml_synth_gauss(float* x, int16_t* states_or_null, uint64_t T, int K, const float* mu, float sigma,
                     double mean_dwell, uint64_t seed, int nthreads);
+
+/* simulated read-depth trace: copy-number segments, Poisson-lognormal counts as floats */
+int hml_synth_depth(float* x, int16_t* states_or_null, uint64_t T, double depth, double ln_sigma, uint64_t seed, int nthreads);
 
 #ifdef __cplusplus
 }

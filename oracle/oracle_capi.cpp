@@ -244,6 +244,10 @@ void orc_synth_gauss(float* x, int16_t* states, uint64_t T, int K, const float* 
     hml_synth_gauss_trace(x, states, T, K, mu, sigma, dwell, seed, nthreads);
 }
 
+void orc_synth_depth(float* x, int16_t* states, uint64_t T, double depth, double ln_sigma, uint64_t seed, int nthreads) {
+    hml_synth_depth_trace(x, states, T, depth, ln_sigma, seed, nthreads);
+}
+
 // timed run for bench.py's cpu_baseline: returns seconds spent in `iters` sweeps
 double orc_time_sweeps(void* h, char method, uint64_t iters) {
     Oracle* o = (Oracle*)h;

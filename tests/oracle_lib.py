@@ -71,6 +71,7 @@ def load():
     lib.orc_check_categorical.argtypes = [C.c_uint32, C.c_uint64, C.c_int, C.c_int]
     lib.orc_synth_gauss.argtypes = [_P, _P, C.c_uint64, C.c_int, _P, C.c_float, C.c_double, C.c_uint64, C.c_int]
     lib.orc_debug_eval.argtypes = [C.c_int, _P, _P, _P, C.c_uint64, C.c_uint64]
+    lib.orc_synth_depth.argtypes = [_P, _P, C.c_uint64, C.c_double, C.c_double, C.c_uint64, C.c_int]
     lib.orc_time_sweeps.restype = C.c_double
     lib.orc_time_sweeps.argtypes = [_P, C.c_char, C.c_uint64]
     _lib = lib
@@ -83,6 +84,14 @@ def synth_gauss(T, K, mu, sigma, dwell, seed, nthreads=8):
     mu = np.ascontiguousarray(mu, np.float32)
     lib.orc_synth_gauss(x.ctypes.data, None, T, K, mu.ctypes.data, sigma, dwell, seed, nthreads)
     return x
+
+
+def synth_depth(T, depth=15.0, ln_sigma=0.15, seed=5, nthreads=8, with_states=False):
+    lib = load()
+    x = np.empty(T, np.float32)
+    st = np.empty(T, np.int16) if with_states else None
+    lib.orc_synth_depth(x.ctypes.data, st.ctypes.data if with_states else None, T, depth, ln_sigma, seed, nthreads)
+    return (x, st) if with_states else x
 
 
 def debug_eval(fn, a, b=None, seed=0):

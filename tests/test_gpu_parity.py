@@ -265,3 +265,17 @@ def test_block_scan_with_odd_weight_multipliers(hml, mult):
         o.enumerate_blocks(thr)
         g.create_blocks(thr)
         assert np.array_equal(o.blocks(), g.blocks()), (mult, thr)
+
+
+def test_sweeps_match_checker_on_depth_data(hml):
+    """Config-5-style input (integer Poisson-lognormal read depth, 5-state CNV model): same bit-exact agreement."""
+    T, K = 300000, 5
+    x = ol.synth_depth(T, seed=5)
+    x2, o, g = make_pair(hml, T, K, 0, 17, x=x)
+    setup_model(o, g, K)
+    g._pending_prior = True
+    o.set_record(marginals=True)
+    run_both(o, g, [("M", 10, 0), ("F", 30, 3)])
+    compare_state(o, g)
+    seg, cnt = g.marginals_rle()
+    assert hml.marginals_text(seg, cnt) == o.text("marginals")

@@ -80,3 +80,14 @@ def test_synthetic_trace_is_deterministic_and_plausible():
     jumps = np.count_nonzero(np.diff(st))
     assert 15 < jumps < 80          # mean dwell 5000 -> about 40 level changes
     assert np.all(st[1:][np.diff(st) != 0] != st[:-1][np.diff(st) != 0])
+
+
+def test_depth_trace_is_deterministic_and_plausible():
+    x1, st = ol.synth_depth(400000, seed=5, nthreads=1, with_states=True)
+    x2 = ol.synth_depth(400000, seed=5, nthreads=6)
+    assert np.array_equal(x1.view(np.uint32), x2.view(np.uint32))
+    assert np.all(x1 >= 0) and np.all(x1 == np.round(x1))
+    dip = x1[st == 2]
+    assert 29.0 < dip.mean() < 31.0            # depth 15 x copy number 2
+    assert 1.0 < dip.var() / dip.mean() < 2.5  # over-dispersed relative to Poisson
+    assert set(np.unique(st)).issubset({0, 1, 2, 3, 4})
