@@ -279,3 +279,93 @@ def test_sweeps_match_checker_on_depth_data(hml):
     compare_state(o, g)
     seg, cnt = g.marginals_rle()
     assert hml.marginals_text(seg, cnt) == o.text("marginals")
+
+
+def test_forward_repair_paths_on_twin_states(hml):
+    """Adversarial input for the speculative forward pass: two states with identical emission parameters and
+    sticky transitions forget their start very slowly, so the warm-up is too short, the long-warm-up repair and
+    the serial pass both run - and the stored rows must still equal the sequential recursion bit for bit."""
+    T, K = 1_000_000, 3
+    x = ol.trace(T, 3, 1)
+    xx, o, g = make_pair(hml, T, K, 0, 1, x=x)
+    setup_model(o, g, K)
+    o.token("F")
+    g.sample_prior()
+    mv = np.array([-1.0, 0.04, 0.5, 0.04, 0.5, 0.04], np.float32)    # states 1 and 2 are twins
+    A = np.array([[0.999, 0.0005, 0.0005], [0.0005, 0.9994, 0.0001], [0.0005, 0.0001, 0.9994]], np.float32)
+    pi = np.array([0.2, 0.5, 0.3], np.float32)
+    o.set_params(mv, A, pi)
+    g.set_parameters(mv, A, pi)
+    o.set_probes(True)
+    g.enable_probes(True)
+    s0 = g.stats()
+    o.iterate("F", 1, 0)
+    g.iterate("F", 1, 0)
+    g.sync()
+    s1 = g.stats()
+    assert np.array_equal(o.blocks(), g.blocks())
+    assert np.array_equal(bits(o.forward_rows()), bits(g.forward_rows()))
+    assert np.array_equal(o.states(), g.states())
+    assert s1["forward_refits"] > s0["forward_refits"]            # the repair round had work ...
+    assert s1["forward_serial"] > s0["forward_serial"]            # ... and so had the serial pass
+    assert s1["forward_warmup"] > s0["forward_warmup"]            # the warm-up adapts for the next sweeps
+    o.iterate("F", 5, 0)
+    g.iterate("F", 5, 0)
+    g.sync()
+    compare_state(o, g)
+
+
+def test_config2_static_block_structure(hml):
+    """BASELINE.json configs[1] shape (10^7 positions, 5 states, fixed wavelet block structure), shortened:
+    mixture burn-in, S, P, then FB sweeps with thinning - against the checker."""
+    T, K = 10_000_000, 5
+    x, o, g = make_pair(hml, T, K, 2, 1)
+    setup_model(o, g, K)
+    g._pending_prior = True
+    o.set_record(marginals=True)
+    run_both(o, g, [("M", 30, 0), "S", "P", ("F", 60, 10)])
+    compare_state(o, g)
+    seg, cnt = g.marginals_rle()
+    assert hml.marginals_text(seg, cnt) == o.text("marginals")
+    assert g.recorded_sweeps() == 6
+
+
+def test_config3_dynamic_scaled_down(hml):
+    """BASELINE.json configs[2] shape (dynamic per-sweep recompression, 5 states) at 10^7 positions."""
+    T, K = 10_000_000, 5
+    x, o, g = make_pair(hml, T, K, 3, 9)
+    setup_model(o, g, K)
+    g._pending_prior = True
+    o.set_record(marginals=True)
+    run_both(o, g, [("F", 60, 10)])
+    compare_state(o, g)
+    seg, cnt = g.marginals_rle()
+    assert hml.marginals_text(seg, cnt) == o.text("marginals")
+
+
+def test_independent_chains_and_device_input(hml):
+    """Chain ids select independent Philox sub-keys (config 4: one chain per GPU); loading from a device
+    pointer gives the same chain as loading from the host."""
+    import torch
+    T, K = 200000, 10
+    x = ol.trace(T, K, 4)
+    res = {}
+    for chain in (0, 1, 7):
+        o = ol.OracleChain(K=K, seed=3, chain=chain, rng=ol.RNG_CTR, math=ol.MATH_DEV, reduce=ol.REDUCE_DEV)
+        o.load(x)
+        g = hml.Chain(device=0, seed=3, chain_id=chain)
+        if chain == 7:
+            xd = torch.from_numpy(x).cuda()
+            g.load_device(xd.data_ptr(), T)
+        else:
+            g.load(x)
+        setup_model(o, g, K)
+        o.token("F")
+        g.sample_prior()
+        o.iterate("F", 12, 4)
+        g.iterate("F", 12, 4)
+        g.sync()
+        compare_state(o, g, what="chain %d" % chain)
+        res[chain] = g.states().copy(), g.theta().copy()
+    assert not np.array_equal(res[0][1], res[1][1])
+    assert not np.array_equal(res[1][1], res[7][1])
