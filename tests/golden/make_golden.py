@@ -36,6 +36,15 @@ CASES = {
     "k6_static_then_dynamic": (100000, 3, 1, "-s 6 -R 8 -t 0.1 -i S F 50 1 P D F 20 1", ["marginals", "parameters"]),
     "k2_thinning": (100000, 3, 1, "-s 2 -R 9 -i F 30 7 M 5 0 F 10 3", ["marginals", "sequences"]),
     "k5_200k": (200000, 5, 7, "-s 5 -R 42 -i F 25 5", ["marginals", "parameters", "compression"]),
+    # sizes around the structural edges: powers of two (the `R < size` rule of HaarBreakpointWeights forces
+    # breakpoints at T/2, 3T/4, ...), the 65535-position integral-array cell, tiny inputs
+    "t16": (16, 2, 21, "-s 2 -R 1 -i F 20 1", ["marginals", "sequences", "blocks", "parameters"]),
+    "t1000": (1000, 3, 22, "-s 3 -R 2 -i M 5 1 F 20 1", ["marginals", "sequences", "blocks", "parameters"]),
+    "t4096": (4096, 3, 23, "-s 3 -R 3 -i F 20 1", ["marginals", "blocks", "parameters"]),
+    "t65535": (65535, 3, 24, "-s 3 -R 4 -i F 20 2", ["marginals", "blocks", "parameters"]),
+    "t65536": (65536, 3, 25, "-s 3 -R 5 -i F 20 2", ["marginals", "blocks", "parameters"]),
+    "t65537": (65537, 3, 26, "-s 3 -R 6 -i F 20 2", ["marginals", "blocks", "parameters"]),
+    "t131071": (131071, 4, 27, "-s 4 -R 7 -i F 20 4", ["marginals", "parameters", "compression"]),
 }
 
 

@@ -109,6 +109,10 @@ def compare_state(o, g, what=""):
     (50000, 2, [("F", 10, 1)]),
     (50000, 10, [("F", 10, 2)]),
     (30000, 16, [("F", 6, 2)]),
+    (16, 2, [("F", 20, 1)]),
+    (1000, 3, [("M", 5, 1), ("F", 20, 1)]),
+    (4096, 3, [("F", 20, 1)]),
+    (65537, 3, [("F", 20, 2)]),
 ])
 def test_sweeps_match_checker(hml, T, K, scheme):
     """Whole sweeps (a7-a17): blocks, states, parameters and marginals equal the checker's, bit for bit."""
