@@ -47,9 +47,6 @@ int main(int argc, const char* argv[]) {
         args.registerFlags({"-g", "-arguments"});
         args.registerFlags({"-h", "-help", "--help"});
         args.registerFlags({"-f", "-input-file"});
-        args.registerFlags({"-raw"});
-        args.registerFlags({"-device"}, "0");
-        args.registerFlags({"-chain"}, "0");
         args.registerFlags({"-o", "-output-pattern"}, "hammlet- .csv");
         args.registerFlags({"-O", "-output-data"}, "marginals");
         args.registerFlags({"-w", "-overwrite"});
@@ -62,6 +59,10 @@ int main(int argc, const char* argv[]) {
         args.registerFlags({"-R", "-random-seed"}, std::to_string(time(0)));
         args.registerFlags({"-i", "-iterations"}, "M 500 0 S P F 200 0 F 300 3");
         args.registerFlags({"-m", "-weight-multiplier"}, "1");
+        // extensions (registered last so that `-g` prints the reference's lines first)
+        args.registerFlags({"-raw"});
+        args.registerFlags({"-device"}, "0");
+        args.registerFlags({"-chain"}, "0");
         args.parseArgs();
 
         if (args.isSet("-g")) args.print();
@@ -85,7 +86,8 @@ int main(int argc, const char* argv[]) {
         }
 
         const size_t rng_seed = args.parse<size_t>("-R", 0);
-        rng_t RNG(rng_seed, args.parse<int>("-device"), args.parse<uint32_t>("-chain"));
+        const int device = args.parse<int>("-device");
+        const uint32_t chain = args.parse<uint32_t>("-chain");
 
         // states: "-s K" (univariate); the multivariate "-s C P D" form is not on the MI355X path
         size_t nrParams;
@@ -106,11 +108,9 @@ int main(int argc, const char* argv[]) {
         const real_t trans = args.parse<real_t>("-t", 0);
         real_t selfTrans = trans;
         if (args.nrTokens("-t") > 1) selfTrans = args.parse<real_t>("-t", 1);
-        Transitions<DirichletVector> A(nrStates, RNG);
         TransitionHyperParam<DirichletParamVector> tau_A(nrStates, trans, selfTrans);
         const bool useSelfTrans = !args.isSet("-S");
         const real_t initialAlpha = args.parse<real_t>("-I", 0);
-        Initial<Dirichlet> pi(nrStates, RNG);
         InitialHyperParam<DirichletParam> tau_pi(nrStates, initialAlpha);
         const real_t weightMultiplier = args.parse<real_t>("-m");
 
@@ -168,6 +168,12 @@ int main(int argc, const char* argv[]) {
 
         if (verbose) cout << "Calculating Haar breakpoint weights" << endl << flush;
         HaarBreakpointWeights(inputValues);
+
+        // the device context: created once every argument has been parsed and the input has been read (and before
+        // `records`, whose destructor fetches the marginals from it)
+        rng_t RNG(rng_seed, device, chain);
+        Transitions<DirichletVector> A(nrStates, RNG);
+        Initial<Dirichlet> pi(nrStates, RNG);
 
         Records records(T, opref, osuff, nrStates);
         records.setRecordStateSequence(outputArgs.isSet("sequences"), overwrite);

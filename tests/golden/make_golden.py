@@ -70,6 +70,16 @@ def main():
                 g.write(r.stdout)
         manifest[name] = {"T": T, "trace_levels": K, "data_seed": dseed, "flags": flags, "outputs": outs}
         print(name, "ok")
+    # `-g` prints the parser state (Parser::print, reference src/Parser.hpp:242-269): golden for the host-side parser
+    with tempfile.TemporaryDirectory() as tmp:
+        inp = os.path.join(tmp, "tiny.txt")
+        with open(inp, "w") as f:
+            f.write(" ".join(str(v) for v in list(range(1, 17)) + [1, 2, 3, 4]) + "\n")
+        cmd = [REF, "-g", "-a", "-s", "4", "-R", "1", "-i", "F", "1", "0", "-f", "tiny.txt", "-o", "out-", ".csv", "-w",
+               "-O", "marginals", "blocks", "-t", "0.3", "0.7"]
+        r = subprocess.run(cmd, capture_output=True, text=True, cwd=tmp)
+        with open(os.path.join(HERE, "cli_g_output.txt"), "w") as g:
+            g.write("\n".join(r.stdout.splitlines()[:16]) + "\n")
     with open(os.path.join(HERE, "manifest.json"), "w") as f:
         json.dump(manifest, f, indent=1, sort_keys=True)
 
