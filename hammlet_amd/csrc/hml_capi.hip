@@ -88,6 +88,7 @@ struct hml_ctx {
     unsigned long long* d_descB = nullptr;
     bool cand_enabled = true;
     int cached_grid = 256;
+    int scan_grid = 0;              // cap on the key scan's workgroups (0: one wavefront per span)
     // hipGraph replay of a non-recording sweep (launch-bound inner loop); re-captured when the grid hint moves
     bool use_graph = false;
     hipGraphExec_t graph_exec = nullptr;
@@ -284,6 +285,7 @@ int hml_create(hml_ctx** out, int device, uint64_t seed, uint32_t chain_id, void
     if (const char* e = getenv("HML_CANDIDATE_CACHE")) c->cand_enabled = atoi(e) != 0;
     if (const char* e = getenv("HML_USE_GRAPH")) c->use_graph = atoi(e) != 0;
     if (const char* e = getenv("HML_CACHED_GRID")) c->cached_grid = std::max(1, atoi(e));
+    if (const char* e = getenv("HML_SCAN_GRID")) c->scan_grid = std::max(1, atoi(e));
     if (const char* e = getenv("HML_WEIGHT_KEYS")) c->use_keys = atoi(e) != 0;
     *out = c;
     return 0;
@@ -453,7 +455,7 @@ static void launch_compact_pair(hml_ctx* c, int mode, float thr) {
     {
         ProfScope ps(c, mode == 2 ? "cand_rebuild" : "blocks_compact", mode == 2 ? 2 : 1);
         if (c->use_keys)
-            hipLaunchKernelGGL(hml_k_compact_scan_keys, dim3((nwg + HML_KEY_SPANS_PER_WAVE - 1) / HML_KEY_SPANS_PER_WAVE), dim3(256), 0, c->stream, c->d_keys, c->d_w, (uint32_t)c->T,
+            hipLaunchKernelGGL(hml_k_compact_scan_keys, dim3(c->scan_grid > 0 ? std::min<uint32_t>(nwg, (uint32_t)c->scan_grid) : nwg), dim3(256), 0, c->stream, c->d_keys, c->d_w, (uint32_t)c->T,
                                c->d_mdl, thr, mode, c->key_base, c->d_stage, c->d_span_count);
         else
             hipLaunchKernelGGL(hml_k_compact_scan, dim3(nwg), dim3(256), 0, c->stream, c->d_w, (uint32_t)c->T, c->d_mdl, thr, mode,

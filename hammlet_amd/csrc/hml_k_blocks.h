@@ -107,12 +107,14 @@ __global__ __launch_bounds__(256) void hml_k_build_keys(const float* __restrict_
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     const uint64_t n16 = (T + 15) / 16;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += stride) {
+        // byte j of word k holds position 4*j + k of the group (a 4x4 transpose): the scan packs the per-byte
+        // flags of the four words into one mask whose bit order (8*j + k) is then the position order
         uint32_t packed[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            const uint64_t t = i * 16 + (uint64_t)j;
+        for (int p = 0; p < 16; ++p) {
+            const uint64_t t = i * 16 + (uint64_t)p;
             const uint32_t k = (t < T) ? hml_weight_key(w[t], base) : 0u;
-            packed[j >> 2] |= k << (8 * (j & 3));
+            packed[p & 3] |= k << (8 * (p >> 2));
         }
         reinterpret_cast<uint4*>(keys)[i] = make_uint4(packed[0], packed[1], packed[2], packed[3]);
     }
@@ -143,63 +145,68 @@ __device__ __forceinline__ uint32_t hml_swar_compress(uint32_t flags) {
     return (((flags >> 7) * 0x00204081u) >> 21) & 15u;
 }
 
-#define HML_KEY_SPANS_PER_WAVE 1
+// Persistent wavefronts: each one walks spans wave_global, wave_global + n_waves, ... and loads the keys of
+// its next span before it processes the current one, so the load latency hides behind the SWAR work.
 __global__ __launch_bounds__(256) void hml_k_compact_scan_keys(const uint8_t* __restrict__ keys, const float* __restrict__ w,
                                                                uint32_t T, const hml_model* __restrict__ mdl,
                                                                float thr_override, int use_override, int32_t base,
                                                                uint16_t* __restrict__ stage,
                                                                uint32_t* __restrict__ span_count) {
     if (use_override == 2 && mdl->need_rebuild == 0u) return;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    // one wavefront owns HML_KEY_SPANS_PER_WAVE consecutive spans (16 KB of keys), all of its loads in flight at once
-    const uint32_t span0 = (blockIdx.x * 4u + (uint32_t)wave) * HML_KEY_SPANS_PER_WAVE;
-    if ((uint64_t)span0 * HML_SPAN >= T) return;
+    const int lane = threadIdx.x & 63;
+    const uint32_t wave_global = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
+    const uint32_t n_spans = (uint32_t)(((uint64_t)T + HML_SPAN - 1) / HML_SPAN);
+    if (wave_global >= n_spans) return;
     const float thr = use_override == 2 ? mdl->cand_thr_lo : (use_override ? thr_override : mdl->thr);
     const bool thr_nan = (thr != thr);
     const uint32_t kthr = hml_weight_key(thr, base);
     const hml_swar_ge sw_ge = hml_swar_ge_make(kthr), sw_gt = hml_swar_ge_make(kthr + 1u);
-    hml_u4 kv[HML_KEY_SPANS_PER_WAVE][4];
-#pragma unroll
-    for (int sp = 0; sp < HML_KEY_SPANS_PER_WAVE; ++sp) {
-        const uint64_t sbase = (uint64_t)(span0 + (uint32_t)sp) * HML_SPAN;
+
+    hml_u4 cur[4], nxt[4];
+    auto load_span = [&](uint32_t span, hml_u4 (&dst)[4]) {
+        const uint64_t sbase = (uint64_t)span * HML_SPAN;
         const hml_u4* __restrict__ p = reinterpret_cast<const hml_u4*>(keys + sbase) + lane;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const uint64_t t0 = sbase + (uint64_t)i * 1024u + (uint64_t)lane * 16u;
             // the key array is padded to a multiple of 16 bytes; groups beyond T are masked below
-            kv[sp][i] = (t0 < T) ? __builtin_nontemporal_load(p + i * 64) : hml_u4{0u, 0u, 0u, 0u};
+            dst[i] = (t0 < T) ? __builtin_nontemporal_load(p + i * 64) : hml_u4{0u, 0u, 0u, 0u};
         }
-    }
-#pragma unroll
-    for (int sp = 0; sp < HML_KEY_SPANS_PER_WAVE; ++sp) {
-        const uint32_t span = span0 + (uint32_t)sp;
+    };
+    load_span(wave_global, cur);
+    for (uint32_t span = wave_global; span < n_spans; span += n_waves) {
+        const bool more = span + n_waves < n_spans;
+        if (more) load_span(span + n_waves, nxt);
         const uint64_t sbase = (uint64_t)span * HML_SPAN;
-        if (sbase >= T) break;
         const uint32_t rem = (sbase + HML_SPAN <= T) ? (uint32_t)HML_SPAN : (uint32_t)(T - sbase);
         uint16_t* __restrict__ out = stage + sbase;
         uint32_t running = 0;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const uint32_t e0 = (uint32_t)i * 1024u + (uint32_t)lane * 16u;
-            const uint32_t words[4] = {kv[sp][i].x, kv[sp][i].y, kv[sp][i].z, kv[sp][i].w};
-            uint32_t ge_m = 0, gt_m = 0;
-#pragma unroll
-            for (int jw = 0; jw < 4; ++jw) {
-                ge_m |= hml_swar_compress(hml_swar_ge_apply(sw_ge, words[jw])) << (4 * jw);
-                gt_m |= hml_swar_compress(hml_swar_ge_apply(sw_gt, words[jw])) << (4 * jw);
+            // flags of the four words (0x80 per byte) packed into one mask: bit 8*j + k <-> position e0 + 4*j + k
+            const uint32_t gem = (hml_swar_ge_apply(sw_ge, cur[i].x) >> 7) | (hml_swar_ge_apply(sw_ge, cur[i].y) >> 6) |
+                                 (hml_swar_ge_apply(sw_ge, cur[i].z) >> 5) | (hml_swar_ge_apply(sw_ge, cur[i].w) >> 4);
+            const uint32_t gtm = (hml_swar_ge_apply(sw_gt, cur[i].x) >> 7) | (hml_swar_ge_apply(sw_gt, cur[i].y) >> 6) |
+                                 (hml_swar_ge_apply(sw_gt, cur[i].z) >> 5) | (hml_swar_ge_apply(sw_gt, cur[i].w) >> 4);
+            uint32_t inmask = 0x0f0f0f0fu;
+            if (rem != (uint32_t)HML_SPAN) {   // ragged last span (wave-uniform branch)
+                const uint32_t left = (e0 < rem) ? rem - e0 : 0u;
+                inmask = 0u;
+                for (uint32_t p = 0; p < 16u && p < left; ++p) inmask |= 1u << (8u * (p >> 2) + (p & 3u));
             }
-            const uint32_t left = (e0 < rem) ? rem - e0 : 0u;
-            const uint32_t inmask = left >= 16u ? 0xffffu : ((1u << left) - 1u);
-            uint32_t fm = (thr_nan ? 0xffffu : gt_m) & inmask;             // bit j: position e0 + j starts a block
-            uint32_t eq = thr_nan ? 0u : (ge_m & ~gt_m & inmask);           // bit j: undecided, needs the float
+            uint32_t fm = (thr_nan ? 0x0f0f0f0fu : gtm) & inmask;          // set bits: positions that start a block
+            uint32_t eq = thr_nan ? 0u : (gem & ~gtm & inmask);             // set bits: undecided, need the float
             if (span == 0u && i == 0 && lane == 0) { fm |= 1u; eq &= ~1u; }   // position 0 always starts a block
             if (__ballot(eq != 0u) != 0ull) {
                 // undecided positions: exact comparison on the float weight
                 uint32_t m = eq;
                 while (m) {
-                    const int j = __ffs(m) - 1;
+                    const int q = __ffs(m) - 1;
                     m &= m - 1u;
-                    if (!(w[sbase + e0 + (uint32_t)j] < thr)) fm |= 1u << j;
+                    const uint32_t p = 4u * ((uint32_t)q >> 3) + ((uint32_t)q & 7u);
+                    if (!(w[sbase + e0 + p] < thr)) fm |= 1u << q;
                 }
             }
             if (__ballot(fm != 0u) == 0ull) continue;   // wave-uniform
@@ -213,13 +220,17 @@ __global__ __launch_bounds__(256) void hml_k_compact_scan_keys(const uint8_t* __
             uint32_t pos = running + incl - c;
             uint32_t m = fm;
             while (m) {
-                const int j = __ffs(m) - 1;
+                const int q = __ffs(m) - 1;
                 m &= m - 1u;
-                out[pos++] = (uint16_t)(e0 + (uint32_t)j);
+                out[pos++] = (uint16_t)(e0 + 4u * ((uint32_t)q >> 3) + ((uint32_t)q & 7u));
             }
             running += __shfl(incl, 63);
         }
         if (lane == 0) span_count[span] = running;
+        if (more) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) cur[i] = nxt[i];
+        }
     }
 }
 
