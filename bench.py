@@ -154,12 +154,13 @@ def main():
         B_avg = blocks / max(1, args.steps)
         scan_avg_s = (scan_ms / max(1, scan_n)) * 1e-3
         # algorithmic bytes of one blocks_compact launch per SURVEY.md section 8d: the weight stream at
-        # 4 B/position + one 32-bit start per block; per sweep: 4*T + B*(36 + 8*K).  The kernel itself reads the
-        # weights as monotone 8-bit keys (DESIGN.md "K4"), so it physically moves ~T + 6*B bytes: `traffic` (PMC)
-        # shows that, and `physical_*` prices the kernel against the bytes it really streams.
+        # 4 B/position + one 32-bit start per block; per sweep: 4*T + B*(36 + 8*K).  The kernel itself streams a
+        # one-byte-per-16-positions summary of the weights and opens only the groups that can hold a block start
+        # (DESIGN.md "K4"), so it physically moves ~T/16 + 70*B bytes (one 64-byte line per opened group + the
+        # staged offsets): `traffic` (PMC) shows that, and `physical_*` prices the kernel against those bytes.
         scan_bytes = 4.0 * T + 4.0 * B_avg
         achieved = scan_bytes / scan_avg_s / 1e9 if scan_avg_s > 0 else 0.0
-        phys_bytes = (1.0 if chain_uses_keys else 4.0) * T + 6.0 * B_avg
+        phys_bytes = (T / 16.0 + 70.0 * B_avg) if chain_uses_keys else (4.0 * T + 6.0 * B_avg)
         phys_achieved = phys_bytes / scan_avg_s / 1e9 if scan_avg_s > 0 else 0.0
         sweep_bytes = 4.0 * T + B_avg * (36 + 8 * K)
         out = {
@@ -178,7 +179,7 @@ def main():
             "config": {"workload": args.workload, "positions": T, "states": K, "blocks_per_sweep": B_avg,
                        "compression": T / max(B_avg, 1.0), "block_structure": "dynamic", "chains": world,
                        "parallelism": "chain-parallel x%d" % world},
-            "roofline": {"bound": "hbm", "kernel": ("hml_k_compact_scan_keys" if chain_uses_keys else "hml_k_compact_scan") + " (forward-trellis block scan)",
+            "roofline": {"bound": "hbm", "kernel": ("hml_k_compact_scan_summary" if chain_uses_keys else "hml_k_compact_scan") + " (forward-trellis block scan)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": pmc_traffic(args.workload), "traffic_source": PMC_FILE, "kernel_avg_us": 1e6 * scan_avg_s, "launches": scan_n,
                          "bytes_per_launch": scan_bytes, "physical_bytes_per_launch": phys_bytes,

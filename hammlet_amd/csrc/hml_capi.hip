@@ -69,7 +69,7 @@ struct hml_ctx {
     double sigma = 0;
     // construction
     float* d_w = nullptr;
-    uint8_t* d_keys = nullptr;     // monotone 8-bit codes of the weights (1 byte per position for the scan)
+    uint8_t* d_summary = nullptr;  // largest key of every 16-position group (what the scan streams)
     int32_t key_base = 0;
     double key_scale = 1.0;         // product of the weight multipliers applied so far
     bool use_keys = true;
@@ -80,7 +80,7 @@ struct hml_ctx {
     uint32_t *d_span_count = nullptr, *d_starts = nullptr;
     float2* d_bstat = nullptr;
     uint32_t n_spans = 0;
-    uint32_t* d_coarse1 = nullptr;   // block count per group of 64 spans
+    uint32_t* d_coarse1 = nullptr;   // block count per group of HML_GROUP_SPANS spans
     // candidate cache: positions/weights with w >= 0.9 x threshold, and the look-back descriptors
     uint32_t* d_cand_pos = nullptr;
     float* d_cand_w = nullptr;
@@ -88,7 +88,6 @@ struct hml_ctx {
     unsigned long long* d_descB = nullptr;
     bool cand_enabled = true;
     int cached_grid = 256;
-    int scan_grid = 0;              // cap on the key scan's workgroups (0: one wavefront per span)
     // hipGraph replay of a non-recording sweep (launch-bound inner loop); re-captured when the grid hint moves
     bool use_graph = false;
     hipGraphExec_t graph_exec = nullptr;
@@ -285,14 +284,13 @@ int hml_create(hml_ctx** out, int device, uint64_t seed, uint32_t chain_id, void
     if (const char* e = getenv("HML_CANDIDATE_CACHE")) c->cand_enabled = atoi(e) != 0;
     if (const char* e = getenv("HML_USE_GRAPH")) c->use_graph = atoi(e) != 0;
     if (const char* e = getenv("HML_CACHED_GRID")) c->cached_grid = std::max(1, atoi(e));
-    if (const char* e = getenv("HML_SCAN_GRID")) c->scan_grid = std::max(1, atoi(e));
     if (const char* e = getenv("HML_WEIGHT_KEYS")) c->use_keys = atoi(e) != 0;
     *out = c;
     return 0;
 }
 
 static void free_all(hml_ctx* c) {
-    void* ptrs[] = {c->d_keys, c->d_w, c->d_coeff, c->d_ia, c->d_stage, c->d_span_count, c->d_starts, c->d_bstat,
+    void* ptrs[] = {c->d_summary, c->d_w, c->d_coeff, c->d_ia, c->d_stage, c->d_span_count, c->d_starts, c->d_bstat,
                     c->d_em, c->d_gsc, c->d_rows, c->d_eprobe, c->d_aprobe, c->d_entry, c->d_exitA, c->d_exitB, c->d_fb, c->d_coarse1, c->d_cand_pos, c->d_cand_w, c->d_desc, c->d_descB,
                     c->d_smap, c->d_cmap, c->d_bentry, c->d_q, c->d_partial, c->d_diff, c->d_boundary, c->d_mdl};
     for (void* p : ptrs) if (p) hipFree(p);
@@ -316,12 +314,17 @@ void hml_destroy(hml_ctx* c) {
 static int build_keys(hml_ctx* c) {
     if (!c->use_keys) return 0;
     const uint64_t T = c->T;
-    if (!c->d_keys) HIPCHK(hipMalloc(&c->d_keys, (T + 15) / 16 * 16 + 16));
+    if (!c->d_summary) {
+        // one byte per 16-position group, padded with zeros to whole spans
+        const uint64_t n_spans = (T + HML_SPAN - 1) / HML_SPAN;
+        HIPCHK(hipMalloc(&c->d_summary, n_spans * (HML_SPAN / 16) + 16));
+        HIPCHK(hipMemsetAsync(c->d_summary, 0, n_spans * (HML_SPAN / 16) + 16, c->stream));
+    }
     const float thr0 = (float)(std::sqrt(2 * std::log((double)std::max<uint64_t>(T, 2))) * c->sigma * c->key_scale);
     uint32_t u; memcpy(&u, &thr0, 4);
     c->key_base = (std::isfinite(thr0) && thr0 > 0 ? (int32_t)(u >> 20) : (int32_t)(0x3f800000u >> 20)) - 128;
-    hipLaunchKernelGGL(hml_k_build_keys, dim3(grid_for((T + 15) / 16, 256, 1, 65536)), dim3(256), 0, c->stream, c->d_w, T, c->key_base,
-                       c->d_keys);
+    hipLaunchKernelGGL(hml_k_build_summary, dim3(grid_for((T + 15) / 16, 256, 1, 65536)), dim3(256), 0, c->stream, c->d_w, T,
+                       c->key_base, c->d_summary);
     KLAUNCH_CHECK();
     return 0;
 }
@@ -392,7 +395,7 @@ static int build_from_device_x(hml_ctx* c, const float* d_x, const float* h_x) {
     HIPCHK(hipMalloc(&c->d_stage, (uint64_t)c->n_spans * HML_SPAN * sizeof(uint16_t)));
     HIPCHK(hipMalloc(&c->d_span_count, c->n_spans * sizeof(uint32_t)));
     HIPCHK(hipMalloc(&c->d_starts, (T + 1) * sizeof(uint32_t)));
-    HIPCHK(hipMalloc(&c->d_coarse1, (((c->n_spans + 63u) >> 6) + 1u) * sizeof(uint32_t)));
+    HIPCHK(hipMalloc(&c->d_coarse1, ((c->n_spans + HML_GROUP_SPANS - 1) / HML_GROUP_SPANS + 1u) * sizeof(uint32_t)));
     HIPCHK(hipMalloc(&c->d_bstat, T * sizeof(float2)));
     HIPCHK(hipStreamSynchronize(c->stream));
     c->loaded = true;
@@ -451,22 +454,26 @@ int hml_scale_weights(hml_ctx* c, float mult) {
 // K4: scan (the HBM-bound kernel) + scatter with in-kernel offsets
 static void launch_compact_pair(hml_ctx* c, int mode, float thr) {
     // mode 0: model threshold; 1: explicit threshold; 2: candidate-cache rebuild (kernels exit at once unless needed)
-    const uint32_t nwg = (c->n_spans + 3) / 4;
+    const uint32_t n_groups = (c->n_spans + HML_GROUP_SPANS - 1) / HML_GROUP_SPANS;
+    // the summary scan skips unopened groups; when most groups would be opened (weak compression) the plain
+    // float stream is the better access pattern - both give the same blocks
+    const bool dense = c->B_hint && (uint64_t)c->B_hint * 24u > c->T;
     {
         ProfScope ps(c, mode == 2 ? "cand_rebuild" : "blocks_compact", mode == 2 ? 2 : 1);
-        if (c->use_keys)
-            hipLaunchKernelGGL(hml_k_compact_scan_keys, dim3(c->scan_grid > 0 ? std::min<uint32_t>(nwg, (uint32_t)c->scan_grid) : nwg), dim3(256), 0, c->stream, c->d_keys, c->d_w, (uint32_t)c->T,
-                               c->d_mdl, thr, mode, c->key_base, c->d_stage, c->d_span_count);
-        else
-            hipLaunchKernelGGL(hml_k_compact_scan, dim3(nwg), dim3(256), 0, c->stream, c->d_w, (uint32_t)c->T, c->d_mdl, thr, mode,
-                               c->d_stage, c->d_span_count);
+        if (c->use_keys && !dense) {
+            hipLaunchKernelGGL(hml_k_compact_scan_summary, dim3(n_groups), dim3(256), 0, c->stream, c->d_summary, c->d_w,
+                               (uint32_t)c->T, c->d_mdl, thr, mode, c->key_base, c->d_stage, c->d_span_count, c->d_coarse1);
+        } else {
+            hipLaunchKernelGGL(hml_k_compact_scan, dim3((c->n_spans + 3) / 4), dim3(256), 0, c->stream, c->d_w, (uint32_t)c->T,
+                               c->d_mdl, thr, mode, c->d_stage, c->d_span_count);
+        }
     }
     {
         ProfScope ps(c, mode == 2 ? "cand_rebuild" : "blocks_scatter");
-        const uint32_t n1 = (c->n_spans + 63u) >> 6;
-        hipLaunchKernelGGL(hml_k_group_totals, dim3((n1 + 3) / 4), dim3(256), 0, c->stream, c->d_span_count, c->n_spans,
-                           c->d_coarse1, c->d_mdl, mode == 2 ? 1 : 0);
-        hipLaunchKernelGGL(hml_k_compact_scatter, dim3(nwg), dim3(256), 0, c->stream, c->d_stage, c->d_span_count,
+        if (!(c->use_keys && !dense))
+            hipLaunchKernelGGL(hml_k_group_totals, dim3((n_groups + 255) / 256), dim3(256), 0, c->stream, c->d_span_count,
+                               c->n_spans, c->d_coarse1, c->d_mdl, mode == 2 ? 1 : 0);
+        hipLaunchKernelGGL(hml_k_compact_scatter, dim3(n_groups), dim3(256), 0, c->stream, c->d_stage, c->d_span_count,
                            c->d_coarse1, c->n_spans, (uint32_t)c->T, c->d_mdl, c->d_starts, c->d_hB, mode == 2 ? 1 : 0, c->d_w,
                            c->d_cand_pos, c->d_cand_w);
     }

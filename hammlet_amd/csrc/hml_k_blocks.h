@@ -87,40 +87,54 @@ __global__ __launch_bounds__(256) void hml_k_compact_scan(const float* __restric
 }
 
 // ------------------------------------------------------------------------------------------
-// K4 over 8-bit keys.  The scan only has to decide !(w[t] < thr), and almost every weight is far below the
-// threshold, so the 4-byte weights are over-precise for it.  key(w) is a MONOTONE 8-bit code
-//   key(w) = 0 for negative w, else clamp((bits(w) >> 20) - base, 0, 255)      (1/8-binade buckets)
-// built once per weight array.  Monotonicity gives: key(w) > key(thr) => !(w < thr); key(w) < key(thr) =>
-// w < thr; only positions whose key EQUALS key(thr) are undecided and fetch the exact weight (a few percent
-// of the block starts).  Same block structure as the float scan, bit for bit, at 1 byte per position.
+// K4 over a group summary.  The scan only has to decide !(w[t] < thr), and almost every weight is far below
+// the threshold.  key(w) is a MONOTONE 8-bit code
+//   key(w) = 255 for NaN, 0 for negative w, else clamp((bits(w) >> 20) - base, 0, 255)   (1/8-binade buckets)
+// and the summary holds, per group of 16 consecutive positions, the largest key of the group (built once per
+// weight array, T/16 bytes).  Monotonicity gives: summary < key(thr) => every weight of the group is < thr,
+// so the group holds no block start and its weights are never read.  A group whose summary reaches key(thr)
+// is opened: its 16 float weights (one 64-byte line) are compared exactly.  Same block structure as the
+// float scan, bit for bit, from T/16 + 64 * (opened groups) bytes instead of 4 * T.
 // ------------------------------------------------------------------------------------------
 HML_HD uint32_t hml_weight_key(float w, int32_t base) {
     const uint32_t u = hml_f2u(w);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return 255u;   // NaN of either sign: !(w < thr) holds for every thr
     if (u & 0x80000000u) return 0u;
     const int32_t k = (int32_t)(u >> 20) - base;
     return k < 0 ? 0u : (k > 255 ? 255u : (uint32_t)k);
 }
 
-__global__ __launch_bounds__(256) void hml_k_build_keys(const float* __restrict__ w, uint64_t T, int32_t base,
-                                                        uint8_t* __restrict__ keys) {
-    // 16 positions per thread: four float4 loads, one 16-byte store
+// one thread per group: four float4 loads, one byte out
+__global__ __launch_bounds__(256) void hml_k_build_summary(const float* __restrict__ w, uint64_t T, int32_t base,
+                                                           uint8_t* __restrict__ summary) {
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     const uint64_t n16 = (T + 15) / 16;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += stride) {
-        // byte j of word k holds position 4*j + k of the group (a 4x4 transpose): the scan packs the per-byte
-        // flags of the four words into one mask whose bit order (8*j + k) is then the position order
-        uint32_t packed[4] = {0u, 0u, 0u, 0u};
+        uint32_t top = 0u;
+        if (i * 16 + 16 <= T) {
+            const float4* __restrict__ p = reinterpret_cast<const float4*>(w + i * 16);
 #pragma unroll
-        for (int p = 0; p < 16; ++p) {
-            const uint64_t t = i * 16 + (uint64_t)p;
-            const uint32_t k = (t < T) ? hml_weight_key(w[t], base) : 0u;
-            packed[p & 3] |= k << (8 * (p >> 2));
+            for (int r = 0; r < 4; ++r) {
+                const float4 v = p[r];
+                const uint32_t k0 = hml_weight_key(v.x, base), k1 = hml_weight_key(v.y, base),
+                               k2 = hml_weight_key(v.z, base), k3 = hml_weight_key(v.w, base);
+                const uint32_t m01 = k0 > k1 ? k0 : k1, m23 = k2 > k3 ? k2 : k3;
+                const uint32_t m = m01 > m23 ? m01 : m23;
+                top = m > top ? m : top;
+            }
+        } else {
+            for (uint64_t t = i * 16; t < T; ++t) {
+                const uint32_t k = hml_weight_key(w[t], base);
+                top = k > top ? k : top;
+            }
         }
-        reinterpret_cast<uint4*>(keys)[i] = make_uint4(packed[0], packed[1], packed[2], packed[3]);
+        // within a span, byte j of word l holds group 64*j + l: the scan's lane l then sees groups l, 64+l,
+        // 128+l, 192+l, and a ballot over byte j is a bit mask of groups 64*j .. 64*j+63 in position order
+        const uint64_t sp = i >> 8;
+        const uint32_t g = (uint32_t)(i & 255u);
+        summary[sp * 256u + (uint64_t)(g & 63u) * 4u + (g >> 6)] = (uint8_t)top;
     }
 }
-
-__device__ __forceinline__ uint32_t hml_wave_sum_u32(uint32_t v);
 
 // SWAR: 0x80 in every byte of x that is >= m (m in 0..256), no cross-byte carries
 struct hml_swar_ge {
@@ -145,93 +159,127 @@ __device__ __forceinline__ uint32_t hml_swar_compress(uint32_t flags) {
     return (((flags >> 7) * 0x00204081u) >> 21) & 15u;
 }
 
-// Persistent wavefronts: each one walks spans wave_global, wave_global + n_waves, ... and loads the keys of
-// its next span before it processes the current one, so the load latency hides behind the SWAR work.
-__global__ __launch_bounds__(256) void hml_k_compact_scan_keys(const uint8_t* __restrict__ keys, const float* __restrict__ w,
-                                                               uint32_t T, const hml_model* __restrict__ mdl,
-                                                               float thr_override, int use_override, int32_t base,
-                                                               uint16_t* __restrict__ stage,
-                                                               uint32_t* __restrict__ span_count) {
+// Summary scan: a wavefront takes HML_SUM_SPANS consecutive 4096-position spans.  Lane l reads one summary
+// word per span (groups l, 64+l, 128+l, 192+l); ballots turn the per-group flags into bit masks in position
+// order, from which every opened group gets its rank (mbcnt) in ONE list over all the wavefront's spans, kept
+// in LDS.  Lane i then opens the i-th listed group: 16 float weights (one 64-byte line), compared exactly.
+// All lanes work on different groups at once, so a wavefront carries the two dependent memory round trips
+// (summary, weights) once for all its spans; the listed order is the position order, one wave scan places
+// the block starts, and the scan value at a span's first listed group separates the spans.
+#define HML_SUM_SPANS 4   // x 4 wavefronts per workgroup = one HML_GROUP_SPANS group
+__device__ __forceinline__ uint32_t hml_mbcnt(unsigned long long m) {
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+}
+__device__ __forceinline__ uint32_t hml_group_mask16(const float* __restrict__ w, uint64_t t0, uint32_t T, float thr) {
+    uint32_t m16 = 0u;
+    if (t0 + 16u <= T) {
+        const float4* __restrict__ p = reinterpret_cast<const float4*>(w + t0);
+        const float4 v0 = p[0], v1 = p[1], v2 = p[2], v3 = p[3];
+        m16 = (uint32_t)!(v0.x < thr) | ((uint32_t)!(v0.y < thr) << 1) | ((uint32_t)!(v0.z < thr) << 2) | ((uint32_t)!(v0.w < thr) << 3) |
+              ((uint32_t)!(v1.x < thr) << 4) | ((uint32_t)!(v1.y < thr) << 5) | ((uint32_t)!(v1.z < thr) << 6) | ((uint32_t)!(v1.w < thr) << 7) |
+              ((uint32_t)!(v2.x < thr) << 8) | ((uint32_t)!(v2.y < thr) << 9) | ((uint32_t)!(v2.z < thr) << 10) | ((uint32_t)!(v2.w < thr) << 11) |
+              ((uint32_t)!(v3.x < thr) << 12) | ((uint32_t)!(v3.y < thr) << 13) | ((uint32_t)!(v3.z < thr) << 14) | ((uint32_t)!(v3.w < thr) << 15);
+    } else {
+        // the group that straddles T (groups wholly beyond T hold nothing)
+        for (uint32_t r = 0; r < 16u && t0 + r < T; ++r) m16 |= (uint32_t)!(w[t0 + r] < thr) << r;
+    }
+    return m16;
+}
+__global__ __launch_bounds__(256) void hml_k_compact_scan_summary(const uint8_t* __restrict__ summary, const float* __restrict__ w,
+                                                                  uint32_t T, const hml_model* __restrict__ mdl,
+                                                                  float thr_override, int use_override, int32_t base,
+                                                                  uint16_t* __restrict__ stage,
+                                                                  uint32_t* __restrict__ span_count,
+                                                                  uint32_t* __restrict__ group_total) {
+    static_assert(4 * HML_SUM_SPANS == HML_GROUP_SPANS, "a scan workgroup covers one span group");
+    __shared__ uint16_t listed_all[4][HML_SUM_SPANS * 256];   // per wavefront: opened groups (span << 8 | group), position order
+    __shared__ uint32_t wave_total[4];
     if (use_override == 2 && mdl->need_rebuild == 0u) return;
     const int lane = threadIdx.x & 63;
-    const uint32_t wave_global = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
+    const uint32_t span0 = ((blockIdx.x * blockDim.x + threadIdx.x) >> 6) * HML_SUM_SPANS;
     const uint32_t n_spans = (uint32_t)(((uint64_t)T + HML_SPAN - 1) / HML_SPAN);
-    if (wave_global >= n_spans) return;
-    const float thr = use_override == 2 ? mdl->cand_thr_lo : (use_override ? thr_override : mdl->thr);
-    const bool thr_nan = (thr != thr);
-    const uint32_t kthr = hml_weight_key(thr, base);
-    const hml_swar_ge sw_ge = hml_swar_ge_make(kthr), sw_gt = hml_swar_ge_make(kthr + 1u);
+    uint32_t wave_sum = 0u;
+    if (span0 < n_spans) {   // wave-uniform
+        // the summary is padded with zeros to whole spans
+        uint32_t gw[HML_SUM_SPANS];
+#pragma unroll
+        for (int s = 0; s < HML_SUM_SPANS; ++s)
+            gw[s] = (span0 + s < n_spans)
+                        ? __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(summary) + (uint64_t)(span0 + s) * 64u + lane)
+                        : 0u;
+        uint16_t* listed = listed_all[threadIdx.x >> 6];
+        const float thr = use_override == 2 ? mdl->cand_thr_lo : (use_override ? thr_override : mdl->thr);
+        // NaN threshold: !(w < thr) holds everywhere, every position starts a block; key 0 opens every group
+        const uint32_t kthr = (thr != thr) ? 0u : hml_weight_key(thr, base);
+        const hml_swar_ge sw_ge = hml_swar_ge_make(kthr);
 
-    hml_u4 cur[4], nxt[4];
-    auto load_span = [&](uint32_t span, hml_u4 (&dst)[4]) {
-        const uint64_t sbase = (uint64_t)span * HML_SPAN;
-        const hml_u4* __restrict__ p = reinterpret_cast<const hml_u4*>(keys + sbase) + lane;
+        uint32_t first_of[HML_SUM_SPANS + 1];   // index of a span's first listed group
+        uint32_t n_listed = 0u;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const uint64_t t0 = sbase + (uint64_t)i * 1024u + (uint64_t)lane * 16u;
-            // the key array is padded to a multiple of 16 bytes; groups beyond T are masked below
-            dst[i] = (t0 < T) ? __builtin_nontemporal_load(p + i * 64) : hml_u4{0u, 0u, 0u, 0u};
+        for (int s = 0; s < HML_SUM_SPANS; ++s) {
+            first_of[s] = n_listed;
+            const uint32_t fl = (span0 + s < n_spans) ? hml_swar_ge_apply(sw_ge, gw[s]) : 0u;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                // group 0 of span 0 is always opened: position 0 starts a block whatever its weight
+                const bool open = ((fl >> (8 * j + 7)) & 1u) || (span0 + s == 0u && j == 0 && lane == 0);
+                const unsigned long long m = __ballot(open);
+                if (open) listed[n_listed + hml_mbcnt(m)] = (uint16_t)((s << 8) | (64 * j + lane));
+                n_listed += (uint32_t)__popcll(m);
+            }
         }
-    };
-    load_span(wave_global, cur);
-    for (uint32_t span = wave_global; span < n_spans; span += n_waves) {
-        const bool more = span + n_waves < n_spans;
-        if (more) load_span(span + n_waves, nxt);
-        const uint64_t sbase = (uint64_t)span * HML_SPAN;
-        const uint32_t rem = (sbase + HML_SPAN <= T) ? (uint32_t)HML_SPAN : (uint32_t)(T - sbase);
-        uint16_t* __restrict__ out = stage + sbase;
-        uint32_t running = 0;
+        first_of[HML_SUM_SPANS] = n_listed;
+        // (LDS operations of one wavefront complete in order: the reads below see the writes above)
+        uint32_t starts_before[HML_SUM_SPANS + 1];   // block starts of the wavefront before a span's first listed group
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const uint32_t e0 = (uint32_t)i * 1024u + (uint32_t)lane * 16u;
-            // flags of the four words (0x80 per byte) packed into one mask: bit 8*j + k <-> position e0 + 4*j + k
-            const uint32_t gem = (hml_swar_ge_apply(sw_ge, cur[i].x) >> 7) | (hml_swar_ge_apply(sw_ge, cur[i].y) >> 6) |
-                                 (hml_swar_ge_apply(sw_ge, cur[i].z) >> 5) | (hml_swar_ge_apply(sw_ge, cur[i].w) >> 4);
-            const uint32_t gtm = (hml_swar_ge_apply(sw_gt, cur[i].x) >> 7) | (hml_swar_ge_apply(sw_gt, cur[i].y) >> 6) |
-                                 (hml_swar_ge_apply(sw_gt, cur[i].z) >> 5) | (hml_swar_ge_apply(sw_gt, cur[i].w) >> 4);
-            uint32_t inmask = 0x0f0f0f0fu;
-            if (rem != (uint32_t)HML_SPAN) {   // ragged last span (wave-uniform branch)
-                const uint32_t left = (e0 < rem) ? rem - e0 : 0u;
-                inmask = 0u;
-                for (uint32_t p = 0; p < 16u && p < left; ++p) inmask |= 1u << (8u * (p >> 2) + (p & 3u));
+        for (int s = 0; s <= HML_SUM_SPANS; ++s) starts_before[s] = 0xffffffffu;
+        uint32_t running = 0u;
+        for (uint32_t i0 = 0; i0 < n_listed; i0 += 64u) {   // wave-uniform; one pass unless > 64 groups are open
+            const uint32_t i = i0 + (uint32_t)lane;
+            uint32_t m16 = 0u, sg = 0u;
+            if (i < n_listed) {
+                sg = listed[i];
+                m16 = hml_group_mask16(w, (uint64_t)(span0 + (sg >> 8)) * HML_SPAN + (uint64_t)(sg & 255u) * 16u, T, thr);
             }
-            uint32_t fm = (thr_nan ? 0x0f0f0f0fu : gtm) & inmask;          // set bits: positions that start a block
-            uint32_t eq = thr_nan ? 0u : (gem & ~gtm & inmask);             // set bits: undecided, need the float
-            if (span == 0u && i == 0 && lane == 0) { fm |= 1u; eq &= ~1u; }   // position 0 always starts a block
-            if (__ballot(eq != 0u) != 0ull) {
-                // undecided positions: exact comparison on the float weight
-                uint32_t m = eq;
-                while (m) {
-                    const int q = __ffs(m) - 1;
-                    m &= m - 1u;
-                    const uint32_t p = 4u * ((uint32_t)q >> 3) + ((uint32_t)q & 7u);
-                    if (!(w[sbase + e0 + p] < thr)) fm |= 1u << q;
-                }
-            }
-            if (__ballot(fm != 0u) == 0ull) continue;   // wave-uniform
-            const uint32_t c = (uint32_t)__popc(fm);
+            if (span0 == 0u && i == 0u) m16 |= 1u;   // position 0 (group 0 of span 0 is listed first)
+            const uint32_t c = (uint32_t)__popc(m16);
             uint32_t incl = c;
 #pragma unroll
             for (int d = 1; d < 64; d <<= 1) {
                 const uint32_t o = __shfl_up(incl, d);
                 if (lane >= d) incl += o;
             }
-            uint32_t pos = running + incl - c;
-            uint32_t m = fm;
-            while (m) {
-                const int q = __ffs(m) - 1;
-                m &= m - 1u;
-                out[pos++] = (uint16_t)(e0 + 4u * ((uint32_t)q >> 3) + ((uint32_t)q & 7u));
+            const uint32_t excl = running + incl - c;
+#pragma unroll
+            for (int s = 0; s <= HML_SUM_SPANS; ++s)
+                if (first_of[s] >= i0 && first_of[s] < i0 + 64u) starts_before[s] = __shfl(excl, (int)(first_of[s] - i0));
+            const uint32_t sp = sg >> 8;
+            uint32_t mine = starts_before[0];
+#pragma unroll
+            for (int s = 1; s < HML_SUM_SPANS; ++s) mine = (sp == (uint32_t)s) ? starts_before[s] : mine;
+            uint16_t* __restrict__ out = stage + (uint64_t)(span0 + sp) * HML_SPAN;
+            uint32_t pos = excl - mine;
+            const uint32_t g16 = (sg & 255u) * 16u;
+            while (m16) {
+                const int b = __ffs(m16) - 1;
+                m16 &= m16 - 1u;
+                out[pos++] = (uint16_t)(g16 + (uint32_t)b);
             }
             running += __shfl(incl, 63);
         }
-        if (lane == 0) span_count[span] = running;
-        if (more) {
+        // spans whose first index is the end of the list (nothing listed from there on)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) cur[i] = nxt[i];
-        }
+        for (int s = 0; s <= HML_SUM_SPANS; ++s)
+            if (starts_before[s] == 0xffffffffu) starts_before[s] = running;
+#pragma unroll
+        for (int s = 0; s < HML_SUM_SPANS; ++s)
+            if (span0 + s < n_spans && lane == s) span_count[span0 + s] = starts_before[s + 1] - starts_before[s];
+        wave_sum = running;
     }
+    // the workgroup's block count: what the scatter kernel sums over the groups before a span
+    if (lane == 0) wave_total[threadIdx.x >> 6] = wave_sum;
+    __syncthreads();
+    if (threadIdx.x == 0) group_total[blockIdx.x] = wave_total[0] + wave_total[1] + wave_total[2] + wave_total[3];
 }
 
 __device__ __forceinline__ uint32_t hml_wave_sum_u32(uint32_t v) {
@@ -240,70 +288,84 @@ __device__ __forceinline__ uint32_t hml_wave_sum_u32(uint32_t v) {
     return v;
 }
 
-// block count of every group of 64 spans (one wavefront per group; plain stores, no atomics: atomics from
-// the scan kernel itself were measured to cost it 10-16 us)
+// block count of every group of HML_GROUP_SPANS spans, for the float scan (the summary scan writes its own)
 __global__ __launch_bounds__(256) void hml_k_group_totals(const uint32_t* __restrict__ span_count, uint32_t n_spans,
-                                                          uint32_t* __restrict__ coarse1, const hml_model* __restrict__ mdl,
+                                                          uint32_t* __restrict__ group_total, const hml_model* __restrict__ mdl,
                                                           int rebuild) {
     if (rebuild && mdl->need_rebuild == 0u) return;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const uint32_t g = blockIdx.x * 4u + (uint32_t)wave;
-    const uint32_t i = (g << 6) + (uint32_t)lane;
-    if ((g << 6) >= n_spans) return;
-    const uint32_t v = hml_wave_sum_u32(i < n_spans ? span_count[i] : 0u);
-    if (lane == 0) coarse1[g] = v;
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t first = g * HML_GROUP_SPANS;
+    if (first >= n_spans) return;
+    uint32_t v = 0u;
+#pragma unroll
+    for (uint32_t i = 0; i < HML_GROUP_SPANS; ++i) v += (first + i < n_spans) ? span_count[first + i] : 0u;
+    group_total[g] = v;
 }
 
-// exclusive offset of `span`: totals of the 64-span groups before it + counts of the spans before it
-// inside its group (T = 10^8: 6 + 1 coalesced reads per lane)
-__device__ __forceinline__ uint32_t hml_span_offset(const uint32_t* __restrict__ span_count,
-                                                    const uint32_t* __restrict__ coarse1, uint32_t span, int lane) {
-    uint32_t acc = 0;
-    const uint32_t g1 = span >> 6;
-    for (uint32_t i = (uint32_t)lane; i < g1; i += 64u) acc += coarse1[i];
-    const uint32_t s_first = g1 << 6;
-    if (s_first + (uint32_t)lane < span) acc += span_count[s_first + (uint32_t)lane];
-    return hml_wave_sum_u32(acc);
-}
-
+// One workgroup per span group, HML_SUM_SPANS spans per wavefront.  The exclusive offset of a span is the sum
+// of the totals of the groups before its group (summed once per workgroup: T = 10^8 has 1526 groups, six
+// loads per thread) plus the counts of the spans before it inside the group.
 __global__ __launch_bounds__(256) void hml_k_compact_scatter(const uint16_t* __restrict__ stage,
                                                              const uint32_t* __restrict__ span_count,
-                                                             const uint32_t* __restrict__ coarse1, uint32_t n_spans,
+                                                             const uint32_t* __restrict__ group_total, uint32_t n_spans,
                                                              uint32_t T, hml_model* __restrict__ mdl,
                                                              uint32_t* __restrict__ starts, uint32_t* __restrict__ host_B,
                                                              int rebuild, const float* __restrict__ w,
                                                              uint32_t* __restrict__ cand_pos, float* __restrict__ cand_w) {
+    static_assert(4 * HML_SUM_SPANS == HML_GROUP_SPANS && HML_GROUP_SPANS <= 64, "one workgroup per span group");
+    __shared__ uint32_t part[4];
     if (rebuild && mdl->need_rebuild == 0u) return;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const uint32_t span = blockIdx.x * 4u + (uint32_t)wave;
-    if (span >= n_spans) return;
-    const uint32_t cnt = span_count[span];
-    const bool is_last = (span == n_spans - 1u);
-    if (cnt == 0u && !is_last) return;
-    const uint32_t off = hml_span_offset(span_count, coarse1, span, lane);
-    const uint32_t base = span * (uint32_t)HML_SPAN;
-    const uint16_t* __restrict__ in = stage + (uint64_t)base;
-    if (rebuild) {
-        // candidate-cache rebuild: the compacted positions and their weights become the candidate list
-        for (uint32_t k = lane; k < cnt; k += 64) {
-            const uint32_t t = base + (uint32_t)in[k];
-            cand_pos[off + k] = t;
-            cand_w[off + k] = w[t];
-        }
-        if (is_last && lane == 0) {
-            mdl->cand_M = off + cnt;
-            mdl->cand_valid = 1u;
-            mdl->cand_rebuilds += 1ull;
-        }
-        return;
+    const uint32_t g = blockIdx.x;
+    const uint32_t first = g * HML_GROUP_SPANS;
+    uint32_t acc = 0u;
+    for (uint32_t i = threadIdx.x; i < g; i += 256u) acc += group_total[i];
+    // lane l of every wavefront holds the count of span l of the group
+    const uint32_t cnt_l = ((uint32_t)lane < HML_GROUP_SPANS && first + (uint32_t)lane < n_spans) ? span_count[first + (uint32_t)lane] : 0u;
+    acc = hml_wave_sum_u32(acc);
+    if (lane == 0) part[wave] = acc;
+    __syncthreads();
+    const uint32_t before_group = part[0] + part[1] + part[2] + part[3];
+    // exclusive prefix of the group's span counts (16 lanes)
+    uint32_t incl = cnt_l;
+#pragma unroll
+    for (int d = 1; d < HML_GROUP_SPANS; d <<= 1) {
+        const uint32_t o = __shfl_up(incl, d);
+        if (lane >= d) incl += o;
     }
-    for (uint32_t k = lane; k < cnt; k += 64) starts[off + k] = base + (uint32_t)in[k];
-    if (is_last && lane == 0) {
-        const uint32_t B = off + cnt;
-        mdl->B = B;
-        starts[B] = T;
-        // host-mapped word: lets the host size later grids without a copy in the stream
-        if (host_B) __hip_atomic_store(host_B, B, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    const uint32_t excl_l = before_group + incl - cnt_l;
+#pragma unroll
+    for (int k = 0; k < HML_SUM_SPANS; ++k) {
+        const uint32_t in_group = (uint32_t)wave * HML_SUM_SPANS + (uint32_t)k;
+        const uint32_t span = first + in_group;
+        if (span >= n_spans) break;   // wave-uniform
+        const uint32_t cnt = __shfl(cnt_l, (int)in_group);
+        const uint32_t off = __shfl(excl_l, (int)in_group);
+        const bool is_last = (span == n_spans - 1u);
+        const uint32_t base = span * (uint32_t)HML_SPAN;
+        const uint16_t* __restrict__ in = stage + (uint64_t)base;
+        if (rebuild) {
+            // candidate-cache rebuild: the compacted positions and their weights become the candidate list
+            for (uint32_t i = lane; i < cnt; i += 64) {
+                const uint32_t t = base + (uint32_t)in[i];
+                cand_pos[off + i] = t;
+                cand_w[off + i] = w[t];
+            }
+            if (is_last && lane == 0) {
+                mdl->cand_M = off + cnt;
+                mdl->cand_valid = 1u;
+                mdl->cand_rebuilds += 1ull;
+            }
+            continue;
+        }
+        for (uint32_t i = lane; i < cnt; i += 64) starts[off + i] = base + (uint32_t)in[i];
+        if (is_last && lane == 0) {
+            const uint32_t B = off + cnt;
+            mdl->B = B;
+            starts[B] = T;
+            // host-mapped word: lets the host size later grids without a copy in the stream
+            if (host_B) __hip_atomic_store(host_B, B, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     }
 }
 

@@ -6,7 +6,8 @@
 #include "hml_philox.h"
 
 // ---- fixed geometry (the CPU checker mirrors these numbers) ----
-#define HML_SPAN 4096          // positions scanned by one wavefront in blocks_compact
+#define HML_SPAN 4096
+#define HML_GROUP_SPANS 16   // spans per group of the two-level block offset (one scatter workgroup)          // positions scanned by one wavefront in blocks_compact
 #define HML_REDUCE_CHUNK 256   // blocks per reduction chunk (one workgroup)
 #define HML_REDUCE_GROUPS 1024 // chunk c is accumulated by group c % HML_REDUCE_GROUPS
 #define HML_BWD_CHUNK 64       // trellis rows per backward map chunk (one wavefront)
