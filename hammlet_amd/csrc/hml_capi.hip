@@ -14,6 +14,7 @@
 #include "../../include/hml.h"
 #include "hml_k_backward.h"
 #include "hml_k_blocks.h"
+#include "hml_k_blocks_fused.h"
 #include "hml_k_build.h"
 #include "hml_k_forward.h"
 #include "hml_k_marginals.h"
@@ -81,6 +82,9 @@ struct hml_ctx {
     float2* d_bstat = nullptr;
     uint32_t n_spans = 0;
     uint32_t* d_coarse1 = nullptr;   // block count per group of HML_GROUP_SPANS spans
+    unsigned long long* d_group_word = nullptr;   // fused block kernel: {generation, starts, last start} per span group
+    uint32_t* d_launch_gen = nullptr;             // its launch generation
+    unsigned long long* d_dbg = nullptr;
     // candidate cache: positions/weights with w >= 0.9 x threshold, and the look-back descriptors
     uint32_t* d_cand_pos = nullptr;
     float* d_cand_w = nullptr;
@@ -290,7 +294,7 @@ int hml_create(hml_ctx** out, int device, uint64_t seed, uint32_t chain_id, void
 }
 
 static void free_all(hml_ctx* c) {
-    void* ptrs[] = {c->d_summary, c->d_w, c->d_coeff, c->d_ia, c->d_stage, c->d_span_count, c->d_starts, c->d_bstat,
+    void* ptrs[] = {c->d_group_word, c->d_launch_gen, c->d_summary, c->d_w, c->d_coeff, c->d_ia, c->d_stage, c->d_span_count, c->d_starts, c->d_bstat,
                     c->d_em, c->d_gsc, c->d_rows, c->d_eprobe, c->d_aprobe, c->d_entry, c->d_exitA, c->d_exitB, c->d_fb, c->d_coarse1, c->d_cand_pos, c->d_cand_w, c->d_desc, c->d_descB,
                     c->d_smap, c->d_cmap, c->d_bentry, c->d_q, c->d_partial, c->d_diff, c->d_boundary, c->d_mdl};
     for (void* p : ptrs) if (p) hipFree(p);
@@ -396,6 +400,14 @@ static int build_from_device_x(hml_ctx* c, const float* d_x, const float* h_x) {
     HIPCHK(hipMalloc(&c->d_span_count, c->n_spans * sizeof(uint32_t)));
     HIPCHK(hipMalloc(&c->d_starts, (T + 1) * sizeof(uint32_t)));
     HIPCHK(hipMalloc(&c->d_coarse1, ((c->n_spans + HML_GROUP_SPANS - 1) / HML_GROUP_SPANS + 1u) * sizeof(uint32_t)));
+    {
+        const uint64_t n_groups = (c->n_spans + HML_GROUP_SPANS - 1) / HML_GROUP_SPANS;
+        HIPCHK(hipMalloc(&c->d_group_word, (n_groups + 1) * sizeof(unsigned long long)));
+        HIPCHK(hipMalloc(&c->d_launch_gen, sizeof(uint32_t)));
+        HIPCHK(hipMemsetAsync(c->d_group_word, 0, (n_groups + 1) * sizeof(unsigned long long), c->stream));
+        HIPCHK(hipMemsetAsync(c->d_launch_gen, 0, sizeof(uint32_t), c->stream));
+        if (getenv("HML_FUSED_DEBUG")) { HIPCHK(hipMalloc(&c->d_dbg, 4096 * 4 * 8)); HIPCHK(hipMemset(c->d_dbg, 0, 4096 * 4 * 8)); }
+    }
     HIPCHK(hipMalloc(&c->d_bstat, T * sizeof(float2)));
     HIPCHK(hipStreamSynchronize(c->stream));
     c->loaded = true;
@@ -688,7 +700,7 @@ static int sweep_k(hml_ctx* c, char method, bool record) {
     hipStream_t s = c->stream;
     const bool mix = (method == HML_METHOD_MIXTURE);
     const uint32_t T = (uint32_t)c->T;
-    bool emitted = false;
+    bool emitted = false, fused = false;
     if (c->dynamic || !c->blocks_valid) {
         // K4 single-pass scan + compaction, then statistics and emission terms in one dense launch
         if (c->dynamic && c->cand_enabled) {
@@ -697,10 +709,18 @@ static int sweep_k(hml_ctx* c, char method, bool record) {
             ProfScope ps(c, "blocks_cached");
             hipLaunchKernelGGL(hml_k_blocks_cached, dim3(c->cached_grid), dim3(256), 0, s, c->d_w, T, c->n_spans, c->d_cand_pos, c->d_cand_w,
                                c->d_mdl, c->d_starts, c->d_desc, c->d_descB, c->d_hB);
+        } else if (c->use_keys && !(c->B_hint && (uint64_t)c->B_hint * 24u > c->T)) {
+            // K4 + K5 + K6a in one launch (hml_k_blocks_fused.h); weak compression takes the float stream below
+            ProfScope ps(c, "blocks_compact", 1);
+            const uint32_t n_wg = (uint32_t)(((uint64_t)T + HML_FUSED_POSITIONS - 1) / HML_FUSED_POSITIONS);
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_blocks_fused<KK>), dim3(n_wg), dim3(HML_FUSED_WAVES * 64), 0, s, c->d_summary, c->d_w, c->d_ia,
+                               T, c->d_mdl, c->key_base, c->d_group_word, c->d_launch_gen, c->d_starts, c->d_bstat, c->d_em,
+                               c->d_gsc, c->probes ? c->d_eprobe : nullptr, mix ? 1 : 0, c->lay, c->d_hB, c->d_dbg);
+            fused = true;
         } else {
             launch_compact_pair(c, 0, 0.0f);
         }
-        {
+        if (!fused) {
             refresh_hint(c);
             const uint32_t h0 = c->B_hint ? c->B_hint : (uint32_t)std::min<uint64_t>(c->T, 1u << 20);
             ProfScope ps(c, "stats_emission");
@@ -844,6 +864,18 @@ int hml_sync(hml_ctx* c) {
     if (!c) return set_err(HML_ERR_ARG, "null context");
     if (int r = ctx_bind(c)) return r;
     HIPCHK(hipStreamSynchronize(c->stream));
+    if (c->d_dbg) {
+        std::vector<unsigned long long> h(4096 * 4);
+        hipMemcpy(h.data(), c->d_dbg, h.size() * 8, hipMemcpyDeviceToHost);
+        const uint32_t n = (uint32_t)((c->T + HML_FUSED_POSITIONS - 1) / HML_FUSED_POSITIONS);
+        unsigned long long t0 = ~0ull; for (uint32_t i = 0; i < n; ++i) if (h[i * 4]) t0 = std::min(t0, h[i * 4]);
+        double mx[4] = {0, 0, 0, 0}, av[4] = {0, 0, 0, 0};
+        for (uint32_t i = 0; i < n; ++i) for (int k = 0; k < 4; ++k) { const double d = (double)(h[i * 4 + k] - t0) * 0.01; mx[k] = std::max(mx[k], d); av[k] += d / n; }
+        fprintf(stderr, "[fused dbg] n=%u start avg %.2f max %.2f | phaseA avg %.2f max %.2f | offsets avg %.2f max %.2f | end avg %.2f max %.2f (us)\n", n, av[0], mx[0], av[1], mx[1], av[2], mx[2], av[3], mx[3]);
+        { uint32_t late = 0, first_late = n; for (uint32_t i = 0; i < n; ++i) if ((h[i * 4] - t0) * 0.01 > 2.0) { ++late; first_late = std::min(first_late, i); }
+          fprintf(stderr, "   late starters: %u, first index %u\n", late, first_late); }
+        for (uint32_t i : {0u, n / 4, n / 2, n - 1}) fprintf(stderr, "   wg %u: %.2f %.2f %.2f %.2f\n", i, (h[i*4]-t0)*0.01, (h[i*4+1]-t0)*0.01, (h[i*4+2]-t0)*0.01, (h[i*4+3]-t0)*0.01);
+    }
     if (c->model_set) return check_device_error(c);
     return 0;
 }
