@@ -80,7 +80,7 @@ def main():
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--breakdown", action="store_true", help="extra profiled pass: per-kernel-family times")
-    ap.add_argument("--no-cached-leg", action="store_true", help="skip the second (candidate-cache) leg")
+    ap.add_argument("--no-stream-leg", action="store_true", help="skip the second leg (float weight stream instead of the summary)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -111,10 +111,10 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def run_leg(candidate_cache, profile_level):
+    def run_leg(weight_summary, profile_level):
         """warm-up + K timed sweeps of a fresh chain; returns (chain, elapsed, blocks, stats0, stats1)"""
         ch = hammlet_amd.Chain(device=local_rank, seed=args.seed, chain_id=rank)
-        ch.set_option("candidate_cache", 1 if candidate_cache else 0)
+        ch.set_option("weight_keys", 1 if weight_summary else 0)
         ch.load(x)
         prior = ch.autoprior(0.2, 0.9)
         ch.set_model(K, prior)
@@ -134,9 +134,8 @@ def main():
         s1 = ch.stats()
         return ch, t1 - t0, s1["block_updates"] - s0["block_updates"], s0, s1
 
-    chain_uses_keys = os.environ.get("HML_WEIGHT_KEYS", "1") != "0"
-    # headline leg: the block structure is recompressed from all T breakpoint weights in every sweep
-    chain, elapsed, blocks, st0, st1 = run_leg(candidate_cache=False, profile_level=1)
+    # headline leg: the library's default path - the block structure is recomputed in every sweep (dynamic blocks)
+    chain, elapsed, blocks, st0, st1 = run_leg(weight_summary=True, profile_level=1)
     scan_ms, scan_n = chain.profile_get("blocks_compact")
 
     if dist is not None:
@@ -153,16 +152,18 @@ def main():
     if rank == 0:
         B_avg = blocks / max(1, args.steps)
         scan_avg_s = (scan_ms / max(1, scan_n)) * 1e-3
-        # algorithmic bytes of one blocks_compact launch per SURVEY.md section 8d: the weight stream at
-        # 4 B/position + one 32-bit start per block; per sweep: 4*T + B*(36 + 8*K).  The kernel itself streams a
-        # one-byte-per-16-positions summary of the weights and opens only the groups that can hold a block start
-        # (DESIGN.md "K4"), so it physically moves ~T/16 + 70*B bytes (one 64-byte line per opened group + the
-        # staged offsets): `traffic` (PMC) shows that, and `physical_*` prices the kernel against those bytes.
-        scan_bytes = 4.0 * T + 4.0 * B_avg
+        # The timed kernel is hml_k_blocks_fused: block starts from the weights, their order, block statistics,
+        # emission terms.  Algorithmic bytes per SURVEY.md section 8d, the part of bytes_iter this launch covers:
+        # the weight stream at 4 B/position + per block one 32-bit start and two 8-byte integral-array gathers.
+        # The kernel itself streams a one-byte-per-16-positions summary of the weights and opens only the groups
+        # that can hold a block start (DESIGN.md "K4"), so it physically moves far fewer bytes: `traffic` (PMC)
+        # shows that, and `physical_*` prices the kernel against an estimate of the bytes it really touches
+        # (T/16 summary + per block: one 64-byte weight line, two 64-byte integral-array sectors, 12 + 8K written).
+        scan_bytes = 4.0 * T + 20.0 * B_avg
         achieved = scan_bytes / scan_avg_s / 1e9 if scan_avg_s > 0 else 0.0
-        phys_bytes = (T / 16.0 + 70.0 * B_avg) if chain_uses_keys else (4.0 * T + 6.0 * B_avg)
+        phys_bytes = T / 16.0 + B_avg * (64.0 + 128.0 + 12.0 + 8.0 * K)
         phys_achieved = phys_bytes / scan_avg_s / 1e9 if scan_avg_s > 0 else 0.0
-        sweep_bytes = 4.0 * T + B_avg * (36 + 8 * K)
+        sweep_bytes = 4.0 * T + B_avg * (36 + 8 * K)   # SURVEY.md 8d bytes_iter
         out = {
             "metric": "block-updates/sec (Gibbs sweep) + HBM GB/s, 10^8 pos / 5 states",
             "value": blocks_all / elapsed,
@@ -179,7 +180,7 @@ def main():
             "config": {"workload": args.workload, "positions": T, "states": K, "blocks_per_sweep": B_avg,
                        "compression": T / max(B_avg, 1.0), "block_structure": "dynamic", "chains": world,
                        "parallelism": "chain-parallel x%d" % world},
-            "roofline": {"bound": "hbm", "kernel": ("hml_k_compact_scan_summary" if chain_uses_keys else "hml_k_compact_scan") + " (forward-trellis block scan)",
+            "roofline": {"bound": "hbm", "kernel": "hml_k_blocks_fused (block scan + block statistics + emission terms)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": pmc_traffic(args.workload), "traffic_source": PMC_FILE, "kernel_avg_us": 1e6 * scan_avg_s, "launches": scan_n,
                          "bytes_per_launch": scan_bytes, "physical_bytes_per_launch": phys_bytes,
@@ -216,23 +217,21 @@ def main():
             out["pooling"] = {"all_reduce_bytes": int((K + 1) * T * 4), "seconds_incl_dense_export": time.perf_counter() - tp0,
                               "pooled_segments": int(seg.numel()), "counts_per_position": int(cnt[0].sum().item())}
 
-    # second leg: the library's default mode - the same sweeps with the candidate cache:
-    # identical block structures, but the T-sized weight stream is only re-read when the threshold leaves the
-    # cached range
-    if not args.no_cached_leg:
+    # second leg: the same chain with the float weight stream (option weight_keys = 0): every sweep reads all T
+    # float weights - the one genuinely bandwidth-bound kernel of the path, priced against the HBM roofline
+    if not args.no_stream_leg and world == 1:
         chain.close()
-        chain, el2, bl2, c0, c1 = run_leg(candidate_cache=True, profile_level=0)
-        if dist is not None:
-            tt = torch.tensor([el2], dtype=torch.float64, device="cuda")
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            el2 = float(tt.item())
-            bb = torch.tensor([bl2], dtype=torch.int64, device="cuda")
-            dist.all_reduce(bb, op=dist.ReduceOp.SUM)
-            bl2 = int(bb.item())
-        if rank == 0:
-            out["candidate_cache"] = {"value": bl2 / el2, "unit": "block-updates/s", "ms_per_step": 1e3 * el2 / args.steps,
-                                      "full_rescans_in_timed_region": c1["candidate_rebuilds"] - c0["candidate_rebuilds"],
-                                      "note": "same chain, same results; weights rescanned only when the threshold leaves the cached range"}
+        chain, el2, bl2, c0, c1 = run_leg(weight_summary=False, profile_level=1)
+        f_ms, f_n = chain.profile_get("blocks_compact")
+        if rank == 0 and f_n:
+            f_s = f_ms / f_n * 1e-3
+            f_bytes = 4.0 * T + 6.0 * (bl2 / max(1, args.steps))
+            out["float_stream"] = {"value": bl2 / el2, "unit": "block-updates/s", "ms_per_step": 1e3 * el2 / args.steps,
+                                   "roofline": {"bound": "hbm", "kernel": "hml_k_compact_scan (all T float weights)",
+                                                "achieved": f_bytes / f_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                                "frac": f_bytes / f_s / 1e9 / HBM_PEAK_GBS, "kernel_avg_us": 1e6 * f_s,
+                                                "bytes_per_launch": f_bytes, "launches": f_n},
+                                   "note": "same chain, same results; the default path above replaces this stream by the group summary"}
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(x, K, args.seed)

@@ -85,13 +85,6 @@ struct hml_ctx {
     unsigned long long* d_group_word = nullptr;   // fused block kernel: {generation, starts, last start} per span group
     uint32_t* d_launch_gen = nullptr;             // its launch generation
     unsigned long long* d_dbg = nullptr;
-    // candidate cache: positions/weights with w >= 0.9 x threshold, and the look-back descriptors
-    uint32_t* d_cand_pos = nullptr;
-    float* d_cand_w = nullptr;
-    unsigned long long* d_desc = nullptr;
-    unsigned long long* d_descB = nullptr;
-    bool cand_enabled = true;
-    int cached_grid = 256;
     // hipGraph replay of a non-recording sweep (launch-bound inner loop); re-captured when the grid hint moves
     bool use_graph = false;
     hipGraphExec_t graph_exec = nullptr;
@@ -285,9 +278,7 @@ int hml_create(hml_ctx** out, int device, uint64_t seed, uint32_t chain_id, void
     if (const char* e = getenv("HML_FWD_CHUNK")) { int l = std::max(1, atoi(e)); int sh = 0; while ((1 << (sh + 1)) <= l && sh < 10) ++sh; c->fwdL = 1 << sh; }
     if (const char* e = getenv("HML_FWD_WARMUP")) c->fwdW = std::max(0, atoi(e));
     if (const char* e = getenv("HML_FWD_ROUNDS")) c->fwdRounds = std::max(0, atoi(e));
-    if (const char* e = getenv("HML_CANDIDATE_CACHE")) c->cand_enabled = atoi(e) != 0;
     if (const char* e = getenv("HML_USE_GRAPH")) c->use_graph = atoi(e) != 0;
-    if (const char* e = getenv("HML_CACHED_GRID")) c->cached_grid = std::max(1, atoi(e));
     if (const char* e = getenv("HML_WEIGHT_KEYS")) c->use_keys = atoi(e) != 0;
     *out = c;
     return 0;
@@ -295,7 +286,7 @@ int hml_create(hml_ctx** out, int device, uint64_t seed, uint32_t chain_id, void
 
 static void free_all(hml_ctx* c) {
     void* ptrs[] = {c->d_group_word, c->d_launch_gen, c->d_summary, c->d_w, c->d_coeff, c->d_ia, c->d_stage, c->d_span_count, c->d_starts, c->d_bstat,
-                    c->d_em, c->d_gsc, c->d_rows, c->d_eprobe, c->d_aprobe, c->d_entry, c->d_exitA, c->d_exitB, c->d_fb, c->d_coarse1, c->d_cand_pos, c->d_cand_w, c->d_desc, c->d_descB,
+                    c->d_em, c->d_gsc, c->d_rows, c->d_eprobe, c->d_aprobe, c->d_entry, c->d_exitA, c->d_exitB, c->d_fb, c->d_coarse1,
                     c->d_smap, c->d_cmap, c->d_bentry, c->d_q, c->d_partial, c->d_diff, c->d_boundary, c->d_mdl};
     for (void* p : ptrs) if (p) hipFree(p);
     if (c->h_B) hipHostFree(c->h_B);
@@ -455,23 +446,19 @@ int hml_scale_weights(hml_ctx* c, float mult) {
     c->key_scale *= std::fabs((double)mult) > 0 ? std::fabs((double)mult) : 1.0;
     if (int r = build_keys(c)) return r;
     c->blocks_valid = false;
-    if (c->model_set) {   // cached candidates were selected on the old weights
-        hipLaunchKernelGGL(hml_k_invalidate_cache, dim3(1), dim3(64), 0, c->stream, c->d_mdl);
-        KLAUNCH_CHECK();
-    }
     return 0;
 }
 
 // ---------------------------------------------------------------------------------------- blocks
 // K4: scan (the HBM-bound kernel) + scatter with in-kernel offsets
 static void launch_compact_pair(hml_ctx* c, int mode, float thr) {
-    // mode 0: model threshold; 1: explicit threshold; 2: candidate-cache rebuild (kernels exit at once unless needed)
+    // mode 0: model threshold; 1: explicit threshold
     const uint32_t n_groups = (c->n_spans + HML_GROUP_SPANS - 1) / HML_GROUP_SPANS;
     // the summary scan skips unopened groups; when most groups would be opened (weak compression) the plain
     // float stream is the better access pattern - both give the same blocks
     const bool dense = c->B_hint && (uint64_t)c->B_hint * 24u > c->T;
     {
-        ProfScope ps(c, mode == 2 ? "cand_rebuild" : "blocks_compact", mode == 2 ? 2 : 1);
+        ProfScope ps(c, "blocks_compact", 1);
         if (c->use_keys && !dense) {
             hipLaunchKernelGGL(hml_k_compact_scan_summary, dim3(n_groups), dim3(256), 0, c->stream, c->d_summary, c->d_w,
                                (uint32_t)c->T, c->d_mdl, thr, mode, c->key_base, c->d_stage, c->d_span_count, c->d_coarse1);
@@ -481,13 +468,12 @@ static void launch_compact_pair(hml_ctx* c, int mode, float thr) {
         }
     }
     {
-        ProfScope ps(c, mode == 2 ? "cand_rebuild" : "blocks_scatter");
+        ProfScope ps(c, "blocks_scatter");
         if (!(c->use_keys && !dense))
             hipLaunchKernelGGL(hml_k_group_totals, dim3((n_groups + 255) / 256), dim3(256), 0, c->stream, c->d_span_count,
-                               c->n_spans, c->d_coarse1, c->d_mdl, mode == 2 ? 1 : 0);
+                               c->n_spans, c->d_coarse1);
         hipLaunchKernelGGL(hml_k_compact_scatter, dim3(n_groups), dim3(256), 0, c->stream, c->d_stage, c->d_span_count,
-                           c->d_coarse1, c->n_spans, (uint32_t)c->T, c->d_mdl, c->d_starts, c->d_hB, mode == 2 ? 1 : 0, c->d_w,
-                           c->d_cand_pos, c->d_cand_w);
+                           c->d_coarse1, c->n_spans, (uint32_t)c->T, c->d_mdl, c->d_starts, c->d_hB);
     }
 }
 
@@ -593,15 +579,6 @@ int hml_set_model(hml_ctx* c, int K, const float nig4[4], float a_off, float a_d
     HIPCHK(hipMalloc(&c->d_cmap, bchunks * sizeof(unsigned long long)));
     HIPCHK(hipMalloc(&c->d_bentry, bchunks));
     HIPCHK(hipMalloc(&c->d_q, T * sizeof(int16_t)));
-    if (c->cand_enabled && !c->d_cand_pos) {
-        HIPCHK(hipMalloc(&c->d_cand_pos, (T + 1) * sizeof(uint32_t)));
-        HIPCHK(hipMalloc(&c->d_cand_w, (T + 1) * sizeof(float)));
-        const uint64_t nt = (T + HML_CAND_TILE - 1) / HML_CAND_TILE + 1;
-        HIPCHK(hipMalloc(&c->d_desc, nt * sizeof(unsigned long long)));
-        HIPCHK(hipMemsetAsync(c->d_desc, 0, nt * sizeof(unsigned long long), c->stream));
-        HIPCHK(hipMalloc(&c->d_descB, ((uint64_t)c->n_spans + 1) * sizeof(unsigned long long)));
-        HIPCHK(hipMemsetAsync(c->d_descB, 0, ((uint64_t)c->n_spans + 1) * sizeof(unsigned long long), c->stream));
-    }
     HIPCHK(hipMalloc(&c->d_partial, (uint64_t)HML_REDUCE_GROUPS * K * 2 * sizeof(double)));
     HIPCHK(hipMemsetAsync(c->d_partial, 0, (uint64_t)HML_REDUCE_GROUPS * K * 2 * sizeof(double), c->stream));
 
@@ -618,8 +595,6 @@ int hml_set_model(hml_ctx* c, int K, const float nig4[4], float a_off, float a_d
         for (int j = 0; j < K; ++j) { m.dirA[k * K + j] = (k == j) ? a_diag : a_off; m.A[k * K + j] = 1.0f / K; }
     }
     m.max_state_recorded = -1;
-    m.cand_enabled = c->cand_enabled ? 1u : 0u;
-    m.need_rebuild = 1u;
     m.fwd_W = m.fwd_W0 = (uint32_t)c->fwdW;
     m.n_spans = c->n_spans;
     // keep the block count of an earlier enumeration (autoprior) out of the model: B = 0
@@ -702,14 +677,7 @@ static int sweep_k(hml_ctx* c, char method, bool record) {
     const uint32_t T = (uint32_t)c->T;
     bool emitted = false, fused = false;
     if (c->dynamic || !c->blocks_valid) {
-        // K4 single-pass scan + compaction, then statistics and emission terms in one dense launch
-        if (c->dynamic && c->cand_enabled) {
-            // candidate cache: one launch filters the cached candidates (or, rarely, rebuilds the cache and
-            // compacts the block starts in the same pass)
-            ProfScope ps(c, "blocks_cached");
-            hipLaunchKernelGGL(hml_k_blocks_cached, dim3(c->cached_grid), dim3(256), 0, s, c->d_w, T, c->n_spans, c->d_cand_pos, c->d_cand_w,
-                               c->d_mdl, c->d_starts, c->d_desc, c->d_descB, c->d_hB);
-        } else if (c->use_keys && !(c->B_hint && (uint64_t)c->B_hint * 24u > c->T)) {
+        if (c->use_keys && !(c->B_hint && (uint64_t)c->B_hint * 24u > c->T)) {
             // K4 + K5 + K6a in one launch (hml_k_blocks_fused.h); weak compression takes the float stream below
             ProfScope ps(c, "blocks_compact", 1);
             const uint32_t n_wg = (uint32_t)(((uint64_t)T + HML_FUSED_POSITIONS - 1) / HML_FUSED_POSITIONS);
@@ -850,11 +818,6 @@ int hml_set_option(hml_ctx* c, const char* name, int value) {
     if (std::string(name) == "weight_keys") {
         if (c->loaded) return set_err(HML_ERR_ARG, "weight_keys must be set before the observations are loaded");
         c->use_keys = value != 0;
-        return 0;
-    }
-    if (std::string(name) == "candidate_cache") {
-        if (c->model_set) return set_err(HML_ERR_ARG, "candidate_cache must be set before hml_set_model");
-        c->cand_enabled = value != 0;
         return 0;
     }
     return set_err(HML_ERR_ARG, std::string("unknown option ") + name);
@@ -1087,7 +1050,6 @@ int hml_get_stats(hml_ctx* c, hml_stats* out) {
     hml_model m; if (int r = fetch_model(c, &m)) return r;
     out->sweeps = m.sweeps; out->block_updates = m.block_updates; out->uniform_fallbacks = m.uniform_fallbacks;
     out->forward_refits = m.forward_refits; out->forward_serial = m.forward_serial;
-    out->candidate_rebuilds = m.cand_rebuilds;
     out->forward_warmup = m.fwd_W;
     return 0;
 }

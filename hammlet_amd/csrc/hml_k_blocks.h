@@ -30,14 +30,12 @@ __global__ __launch_bounds__(256) void hml_k_compact_scan(const float* __restric
                                                           const hml_model* __restrict__ mdl, float thr_override,
                                                           int use_override, uint16_t* __restrict__ stage,
                                                           uint32_t* __restrict__ span_count) {
-    // use_override: 0 = the model's threshold, 1 = thr_override, 2 = candidate-cache rebuild (runs only when
-    // the parameter kernel asked for it, at the cache's lower threshold bound)
-    if (use_override == 2 && mdl->need_rebuild == 0u) return;
+    // use_override: 0 = the model's threshold, 1 = thr_override
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const uint32_t span = blockIdx.x * 4u + (uint32_t)wave;
     const uint64_t base = (uint64_t)span * HML_SPAN;
     if (base >= T) return;
-    const float thr = use_override == 2 ? mdl->cand_thr_lo : (use_override ? thr_override : mdl->thr);
+    const float thr = use_override ? thr_override : mdl->thr;
     uint32_t running = 0;
     uint16_t* __restrict__ out = stage + base;
     if (base + HML_SPAN <= T) {
@@ -194,7 +192,6 @@ __global__ __launch_bounds__(256) void hml_k_compact_scan_summary(const uint8_t*
     static_assert(4 * HML_SUM_SPANS == HML_GROUP_SPANS, "a scan workgroup covers one span group");
     __shared__ uint16_t listed_all[4][HML_SUM_SPANS * 256];   // per wavefront: opened groups (span << 8 | group), position order
     __shared__ uint32_t wave_total[4];
-    if (use_override == 2 && mdl->need_rebuild == 0u) return;
     const int lane = threadIdx.x & 63;
     const uint32_t span0 = ((blockIdx.x * blockDim.x + threadIdx.x) >> 6) * HML_SUM_SPANS;
     const uint32_t n_spans = (uint32_t)(((uint64_t)T + HML_SPAN - 1) / HML_SPAN);
@@ -208,7 +205,7 @@ __global__ __launch_bounds__(256) void hml_k_compact_scan_summary(const uint8_t*
                         ? __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(summary) + (uint64_t)(span0 + s) * 64u + lane)
                         : 0u;
         uint16_t* listed = listed_all[threadIdx.x >> 6];
-        const float thr = use_override == 2 ? mdl->cand_thr_lo : (use_override ? thr_override : mdl->thr);
+        const float thr = use_override ? thr_override : mdl->thr;
         // NaN threshold: !(w < thr) holds everywhere, every position starts a block; key 0 opens every group
         const uint32_t kthr = (thr != thr) ? 0u : hml_weight_key(thr, base);
         const hml_swar_ge sw_ge = hml_swar_ge_make(kthr);
@@ -290,9 +287,7 @@ __device__ __forceinline__ uint32_t hml_wave_sum_u32(uint32_t v) {
 
 // block count of every group of HML_GROUP_SPANS spans, for the float scan (the summary scan writes its own)
 __global__ __launch_bounds__(256) void hml_k_group_totals(const uint32_t* __restrict__ span_count, uint32_t n_spans,
-                                                          uint32_t* __restrict__ group_total, const hml_model* __restrict__ mdl,
-                                                          int rebuild) {
-    if (rebuild && mdl->need_rebuild == 0u) return;
+                                                          uint32_t* __restrict__ group_total) {
     const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t first = g * HML_GROUP_SPANS;
     if (first >= n_spans) return;
@@ -309,12 +304,9 @@ __global__ __launch_bounds__(256) void hml_k_compact_scatter(const uint16_t* __r
                                                              const uint32_t* __restrict__ span_count,
                                                              const uint32_t* __restrict__ group_total, uint32_t n_spans,
                                                              uint32_t T, hml_model* __restrict__ mdl,
-                                                             uint32_t* __restrict__ starts, uint32_t* __restrict__ host_B,
-                                                             int rebuild, const float* __restrict__ w,
-                                                             uint32_t* __restrict__ cand_pos, float* __restrict__ cand_w) {
+                                                             uint32_t* __restrict__ starts, uint32_t* __restrict__ host_B) {
     static_assert(4 * HML_SUM_SPANS == HML_GROUP_SPANS && HML_GROUP_SPANS <= 64, "one workgroup per span group");
     __shared__ uint32_t part[4];
-    if (rebuild && mdl->need_rebuild == 0u) return;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const uint32_t g = blockIdx.x;
     const uint32_t first = g * HML_GROUP_SPANS;
@@ -344,236 +336,12 @@ __global__ __launch_bounds__(256) void hml_k_compact_scatter(const uint16_t* __r
         const bool is_last = (span == n_spans - 1u);
         const uint32_t base = span * (uint32_t)HML_SPAN;
         const uint16_t* __restrict__ in = stage + (uint64_t)base;
-        if (rebuild) {
-            // candidate-cache rebuild: the compacted positions and their weights become the candidate list
-            for (uint32_t i = lane; i < cnt; i += 64) {
-                const uint32_t t = base + (uint32_t)in[i];
-                cand_pos[off + i] = t;
-                cand_w[off + i] = w[t];
-            }
-            if (is_last && lane == 0) {
-                mdl->cand_M = off + cnt;
-                mdl->cand_valid = 1u;
-                mdl->cand_rebuilds += 1ull;
-            }
-            continue;
-        }
         for (uint32_t i = lane; i < cnt; i += 64) starts[off + i] = base + (uint32_t)in[i];
         if (is_last && lane == 0) {
             const uint32_t B = off + cnt;
             mdl->B = B;
             starts[B] = T;
             // host-mapped word: lets the host size later grids without a copy in the stream
-            if (host_B) __hip_atomic_store(host_B, B, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------
-// K4' candidate filter - the per-sweep block enumeration when the candidate cache is valid: the block
-// starts of threshold thr >= cand_thr_lo are exactly the candidates with !(w < thr) (plus position 0), so
-// one small single-pass compaction over cand_M (~B) entries replaces the scan of w[0..T).  Tiles of 1024
-// candidates per wavefront; the global offset comes from a decoupled look-back over 8-byte
-// {generation, status, value} descriptors (with a few hundred tiles the look-back is one or two windows;
-// for the 24 k-tile full scan it was measured and rejected).  Tiles are handed out by a ticket counter so a
-// wavefront only waits for tiles that some wavefront has already started.
-// ------------------------------------------------------------------------------------------
-#define HML_LB_AGG 1ull
-#define HML_LB_PREFIX 2ull
-#define HML_CAND_TILE 1024
-
-__device__ __forceinline__ unsigned long long hml_lb_pack(uint32_t gen, unsigned long long status, uint32_t value) {
-    return ((unsigned long long)(gen & 0x3fffffffu) << 34) | (status << 32) | (unsigned long long)value;
-}
-
-// exclusive prefix over the tiles before `tile` by decoupled look-back; publishes this tile's count first and
-// its inclusive prefix afterwards.  All lanes of the wavefront call it together.
-__device__ __forceinline__ uint32_t hml_lb_exclusive(unsigned long long* __restrict__ desc, uint32_t tile, uint32_t cnt,
-                                                     uint32_t gen, int lane) {
-    if (tile == 0) {
-        if (lane == 0) __hip_atomic_store(&desc[0], hml_lb_pack(gen, HML_LB_PREFIX, cnt), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        return 0u;
-    }
-    if (lane == 0) __hip_atomic_store(&desc[tile], hml_lb_pack(gen, HML_LB_AGG, cnt), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    uint32_t excl = 0;
-    int look = (int)tile - 1;
-    while (true) {
-        const int idx = look - lane;
-        unsigned long long d = hml_lb_pack(gen, HML_LB_PREFIX, 0u);   // virtual prefix 0 in front of tile 0
-        if (idx >= 0) {
-            d = __hip_atomic_load(&desc[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            while ((uint32_t)(d >> 34) != (gen & 0x3fffffffu) || ((d >> 32) & 3ull) == 0ull) {
-                __builtin_amdgcn_s_sleep(1);
-                d = __hip_atomic_load(&desc[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-        }
-        const unsigned long long pm = __ballot(((d >> 32) & 3ull) == HML_LB_PREFIX);
-        const int firstp = pm ? (__ffsll((long long)pm) - 1) : 64;
-        uint32_t contrib = (lane <= firstp) ? (uint32_t)d : 0u;
-#pragma unroll
-        for (int m = 1; m < 64; m <<= 1) contrib += __shfl_xor(contrib, m);
-        excl += contrib;
-        if (pm) break;
-        look -= 64;
-    }
-    if (lane == 0)
-        __hip_atomic_store(&desc[tile], hml_lb_pack(gen, HML_LB_PREFIX, excl + cnt), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    return excl;
-}
-
-// exclusive prefix by summing the published counts of ALL earlier tiles directly (no chaining: one
-// round trip); for small tile counts only (every lane reads ceil(tile/64) descriptors)
-__device__ __forceinline__ uint32_t hml_direct_exclusive(unsigned long long* __restrict__ desc, uint32_t tile, uint32_t cnt,
-                                                         uint32_t gen, int lane) {
-    if (lane == 0) __hip_atomic_store(&desc[tile], hml_lb_pack(gen, HML_LB_AGG, cnt), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    uint32_t acc = 0;
-    for (uint32_t idx = (uint32_t)lane; idx < tile; idx += 64u) {
-        unsigned long long d = __hip_atomic_load(&desc[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        while ((uint32_t)(d >> 34) != (gen & 0x3fffffffu)) {
-            __builtin_amdgcn_s_sleep(1);
-            d = __hip_atomic_load(&desc[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        acc += (uint32_t)d;
-    }
-    return hml_wave_sum_u32(acc);
-}
-
-// One launch per dynamic sweep.  Normal case (cache valid): filter the candidates.  Rare case (the parameter
-// kernel asked for a rebuild): scan w[0..T) once with this small persistent grid and compact TWICE in the
-// same pass - positions with !(w < cand_thr_lo) become the new candidate list, positions with !(w < thr)
-// the block starts.  ~0.3 ms instead of 64 us for the dedicated scan kernel, but it happens only when the
-// threshold leaves the cached range (a handful of times during burn-in).
-__global__ __launch_bounds__(256) void hml_k_blocks_cached(const float* __restrict__ w, uint32_t T, uint32_t n_spans,
-                                                           uint32_t* __restrict__ cand_pos, float* __restrict__ cand_w,
-                                                           hml_model* __restrict__ mdl, uint32_t* __restrict__ starts,
-                                                           unsigned long long* __restrict__ descA,
-                                                           unsigned long long* __restrict__ descB,
-                                                           uint32_t* __restrict__ host_B) {
-    __shared__ uint32_t wg_ticket;
-    const int lane = threadIdx.x & 63;
-    const uint32_t gen = (uint32_t)mdl->epoch + 1u;   // one launch per parameter epoch
-    const float thr = mdl->thr;
-    const bool rebuild = mdl->need_rebuild != 0u;
-    if (!rebuild) {
-        const uint32_t M = mdl->cand_M;
-        const uint32_t n_tiles = (M + HML_CAND_TILE - 1u) / HML_CAND_TILE;
-        const bool direct = n_tiles <= 2048u;
-        // a wavefront keeps drawing tickets until the tiles are used up (the parameter kernel zeroes the counter)
-        while (true) {
-            // one ticket per workgroup hands out four consecutive tiles (one per wavefront)
-            __syncthreads();
-            if (threadIdx.x == 0) wg_ticket = atomicAdd(&mdl->cand_ticket, 4u);
-            __syncthreads();
-            const uint32_t tile = wg_ticket + (uint32_t)(threadIdx.x >> 6);
-            if (wg_ticket >= n_tiles) return;
-            if (tile >= n_tiles) continue;   // the other wavefronts of this workgroup still need the barrier above
-            const uint32_t base = tile * (uint32_t)HML_CAND_TILE;
-            // 16 candidates per lane, lane-major so that the order of positions is (lane, j)
-            bool f[16];
-            uint32_t cnt_lane = 0;
-#pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                const uint32_t i = base + (uint32_t)lane * 16u + (uint32_t)j;
-                const float v = (i < M) ? cand_w[i] : 0.0f;
-                f[j] = (i < M) && (i == 0u || !(v < thr));
-                cnt_lane += f[j] ? 1u : 0u;
-            }
-            uint32_t incl = cnt_lane;
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) {
-                const uint32_t o = __shfl_up(incl, d);
-                if (lane >= d) incl += o;
-            }
-            const uint32_t cnt = __shfl(incl, 63);
-            const uint32_t excl = direct ? hml_direct_exclusive(descA, tile, cnt, gen, lane)
-                                         : hml_lb_exclusive(descA, tile, cnt, gen, lane);
-            uint32_t pos = excl + incl - cnt_lane;
-#pragma unroll
-            for (int j = 0; j < 16; ++j)
-                if (f[j]) starts[pos++] = cand_pos[base + (uint32_t)lane * 16u + (uint32_t)j];
-            if (tile == n_tiles - 1u && lane == 0) {
-                const uint32_t B = excl + cnt;
-                mdl->B = B;
-                starts[B] = T;
-                if (host_B) __hip_atomic_store(host_B, B, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            }
-        }
-    }
-    // ---- rebuild: dual compaction over the weights, spans handed out by ticket
-    const float thr_lo = mdl->cand_thr_lo;
-    while (true) {
-        __syncthreads();
-        if (threadIdx.x == 0) wg_ticket = atomicAdd(&mdl->cand_ticket, 4u);
-        __syncthreads();
-        const uint32_t span = wg_ticket + (uint32_t)(threadIdx.x >> 6);
-        if (wg_ticket >= n_spans) return;
-        if (span >= n_spans) continue;
-        const uint64_t base = (uint64_t)span * HML_SPAN;
-        const uint32_t rem = (base + HML_SPAN <= T) ? (uint32_t)HML_SPAN : (uint32_t)(T - base);
-        float v[16][4];
-#pragma unroll
-        for (int it = 0; it < 16; ++it)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const uint32_t e = (uint32_t)it * 256u + (uint32_t)lane * 4u + (uint32_t)j;
-                v[it][j] = (e < rem) ? w[base + e] : 0.0f;
-            }
-        uint32_t c_lo = 0, c_hi = 0;
-#pragma unroll
-        for (int it = 0; it < 16; ++it)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const uint32_t e = (uint32_t)it * 256u + (uint32_t)lane * 4u + (uint32_t)j;
-                const bool first = (span == 0u && e == 0u);
-                const bool lo = (e < rem) && (first || !(v[it][j] < thr_lo));
-                const bool hi = (e < rem) && (first || !(v[it][j] < thr));
-                c_lo += (uint32_t)__popcll(__ballot(lo));
-                c_hi += (uint32_t)__popcll(__ballot(hi));
-            }
-        // (c_lo, c_hi are wave totals, identical in every lane)
-        const uint32_t ex_lo = hml_lb_exclusive(descA, span, c_lo, gen, lane);
-        const uint32_t ex_hi = hml_lb_exclusive(descB, span, c_hi, gen, lane);
-        uint32_t run_lo = ex_lo, run_hi = ex_hi;
-        const unsigned long long lt = (1ull << lane) - 1ull;
-#pragma unroll
-        for (int it = 0; it < 16; ++it) {
-            // position order inside an iteration is (lane, j): prefix over lanes of the per-lane counts
-            bool lo[4], hi[4];
-            uint32_t nlo = 0, nhi = 0;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const uint32_t e = (uint32_t)it * 256u + (uint32_t)lane * 4u + (uint32_t)j;
-                const bool first = (span == 0u && e == 0u);
-                lo[j] = (e < rem) && (first || !(v[it][j] < thr_lo));
-                hi[j] = (e < rem) && (first || !(v[it][j] < thr));
-                nlo += lo[j] ? 1u : 0u;
-                nhi += hi[j] ? 1u : 0u;
-            }
-            unsigned long long any = __ballot(nlo != 0u);
-            if (any == 0ull) continue;
-            uint32_t plo = 0, phi = 0, tlo = 0, thi = 0;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const unsigned long long ml = __ballot(lo[j]), mh = __ballot(hi[j]);
-                plo += (uint32_t)__popcll(ml & lt); tlo += (uint32_t)__popcll(ml);
-                phi += (uint32_t)__popcll(mh & lt); thi += (uint32_t)__popcll(mh);
-            }
-            uint32_t pl = run_lo + plo, ph = run_hi + phi;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const uint32_t t = (uint32_t)base + (uint32_t)it * 256u + (uint32_t)lane * 4u + (uint32_t)j;
-                if (lo[j]) { cand_pos[pl] = t; cand_w[pl] = v[it][j]; ++pl; }
-                if (hi[j]) starts[ph++] = t;
-            }
-            run_lo += tlo; run_hi += thi;
-        }
-        if (span == n_spans - 1u && lane == 0) {
-            mdl->cand_M = ex_lo + c_lo;
-            mdl->cand_valid = 1u;
-            mdl->cand_rebuilds += 1ull;
-            const uint32_t B = ex_hi + c_hi;
-            mdl->B = B;
-            starts[B] = T;
             if (host_B) __hip_atomic_store(host_B, B, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }

@@ -13,18 +13,6 @@ struct hml_dev_src {
 
 // logNormalizer / logA / threshold from the current parameters (EFD.hpp:35-38,
 // ForwardBackward.hpp:47-52, BreakpointArray.hpp:196-199 + Theta.hpp:227-234)
-// candidate cache: the next dynamic sweep may filter the cached candidates iff its threshold is not below
-// the bound the cache was built for (and not so far above it that the list is needlessly long); otherwise
-// the cache is rebuilt at 0.9 x the new threshold
-__device__ __forceinline__ void hml_cand_update(hml_model* mdl) {
-    mdl->cand_ticket = 0u;
-    if (!mdl->cand_enabled) return;
-    const float cur = mdl->thr;
-    const bool ok = mdl->cand_valid && !(cur < mdl->cand_thr_lo) && (cur <= 1.5f * mdl->cand_thr_lo) && hml_isfinite(cur);
-    mdl->need_rebuild = ok ? 0u : 1u;
-    if (!ok) { mdl->cand_thr_lo = 0.9f * cur; mdl->cand_valid = 0u; }
-}
-
 template <int K>
 __device__ __forceinline__ void hml_derive(hml_model* mdl, int tid) {
     if (tid < K) {
@@ -41,7 +29,6 @@ __device__ __forceinline__ void hml_derive(hml_model* mdl, int tid) {
         const float t = HML_SQRTF(arg);
         mdl->thr_theta = t;
         if (mdl->dynamic) mdl->thr = t;
-        hml_cand_update(mdl);
     }
 }
 
@@ -52,12 +39,7 @@ __global__ __launch_bounds__(64) void hml_k_set_dynamic(hml_model* mdl, int on, 
     if (threadIdx.x == 0) {
         mdl->dynamic = on;
         if (take_threshold) mdl->thr = mdl->thr_theta;
-        hml_cand_update(mdl);
     }
-}
-
-__global__ __launch_bounds__(64) void hml_k_invalidate_cache(hml_model* mdl) {
-    if (threadIdx.x == 0) { mdl->cand_valid = 0u; hml_cand_update(mdl); }
 }
 
 // ------------------------------------------------------------------------------------------

@@ -66,11 +66,6 @@ struct hml_model {
     float dirPi[HML_MAX_K];
     // ---- block structure ----
     uint32_t B;                  // number of blocks
-    // candidate cache: positions with w >= cand_thr_lo (a superset of every block structure whose threshold
-    // is >= cand_thr_lo); while it is valid a sweep filters these cand_M entries instead of scanning w[0..T)
-    uint32_t cand_enabled, cand_valid, cand_M, need_rebuild, cand_ticket;
-    float cand_thr_lo;
-    unsigned long long cand_rebuilds;
     uint32_t n_spans;
     // ---- per-sweep accumulators (zeroed by the parameter kernel) ----
     unsigned long long trans[HML_CNT_SPLIT][HML_MAX_K * HML_MAX_K];

@@ -96,11 +96,10 @@ int hml_iterate(hml_ctx* ctx, char method, uint64_t iterations, uint64_t thinnin
 typedef void (*hml_record_cb)(hml_ctx* ctx, uint64_t sweep_in_call, void* user);
 int hml_set_recording(hml_ctx* ctx, int marginals, hml_record_cb cb, void* user);
 
-/* Options (before hml_set_model): "candidate_cache" 1 (default) = dynamic sweeps filter a cached list of the
- * positions with weight >= 0.9 x threshold and rescan the weights only when the threshold leaves the cached
- * range; 0 = scan all T weights every sweep.  "weight_keys" (before loading) 1 (default) = the scan reads monotone
- * 8-bit codes of the weights (1 byte per position, exact through a float re-check of undecided positions); 0 = it reads
- * the float weights.  Same block structures in every combination (exact). */
+/* Options.  "weight_keys" (before the observations are loaded), 1 (default): the per-sweep block scan reads a
+ * one-byte-per-16-positions summary of the breakpoint weights (largest monotone 8-bit key of the group) and opens only
+ * the groups that can hold a block start, comparing their float weights exactly; 0: it streams all T float weights.
+ * Same block structures either way (exact). */
 int hml_set_option(hml_ctx* ctx, const char* name, int value);
 
 /* wait for all enqueued work; surfaces model errors raised on the device */
@@ -147,7 +146,6 @@ typedef struct {
     uint64_t uniform_fallbacks; /* "[WARNING] Uniform sampling of forward variables!" count */
     uint64_t forward_refits;    /* chunks whose speculative forward pass had to be redone  */
     uint64_t forward_serial;    /* chunks finished by the sequential fallback              */
-    uint64_t candidate_rebuilds; /* full scans of the weights done to (re)build the candidate cache */
     uint64_t forward_warmup;     /* current (adaptive) warm-up length of the speculative forward pass */
 } hml_stats;
 int hml_get_stats(hml_ctx* ctx, hml_stats* out);

@@ -1,7 +1,7 @@
 """Size-independent properties at BASELINE.json's full size (10^8 positions, 5 states, dynamic blocks), where the
 CPU checker is too slow to run inside the test suite: the block structure against an independent evaluation of
 its definition, conservation laws of the count pass and the marginals, run-to-run determinism, and equality of
-the two block-enumeration modes."""
+the two block-enumeration paths (group summary / float stream)."""
 import numpy as np
 import pytest
 
@@ -17,9 +17,9 @@ def big_trace():
     return ol.trace(T, K, 3)
 
 
-def make_chain(hml, x, cache, seed=1):
+def make_chain(hml, x, summary, seed=1):
     c = hml.Chain(device=0, seed=seed)
-    c.set_option("candidate_cache", 1 if cache else 0)
+    c.set_option("weight_keys", 1 if summary else 0)
     c.load(x)
     c.set_model(K, c.autoprior(0.2, 0.9))
     c.sample_prior()
@@ -28,7 +28,7 @@ def make_chain(hml, x, cache, seed=1):
 
 def test_full_size_properties(hml, big_trace):
     x = big_trace
-    c = make_chain(hml, x, cache=True)
+    c = make_chain(hml, x, summary=True)
     c.iterate("F", 30, 0)
     c.iterate("F", 20, 4)      # 5 recorded sweeps
     c.sync()
@@ -68,14 +68,15 @@ def test_full_size_properties(hml, big_trace):
     c.close()
 
 
-def test_cached_and_streaming_enumeration_give_identical_chains(hml, big_trace):
+def test_summary_and_float_stream_give_identical_chains(hml, big_trace):
+    """the fused summary kernel (default) against scan + scatter + statistics over the float weights"""
     x = big_trace
     res = []
-    for cache in (True, False):
-        c = make_chain(hml, x, cache=cache, seed=5)
+    for summary in (True, False):
+        c = make_chain(hml, x, summary=summary, seed=5)
         c.iterate("F", 25, 5)
         c.sync()
-        res.append((c.blocks(), c.states(), c.theta(), c.transitions()[0], c.marginals_rle(), c.stats()))
+        res.append((c.blocks(), c.states(), c.theta(), c.transitions()[0], c.marginals_rle(), c.stats(), c.block_stats()))
         c.close()
     a, b = res
     assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
@@ -83,4 +84,5 @@ def test_cached_and_streaming_enumeration_give_identical_chains(hml, big_trace):
     assert np.array_equal(a[3].view(np.uint32), b[3].view(np.uint32))
     assert np.array_equal(a[4][0], b[4][0]) and np.array_equal(a[4][1], b[4][1])
     assert a[5]["block_updates"] == b[5]["block_updates"]
-    assert a[5]["candidate_rebuilds"] >= 1 and b[5]["candidate_rebuilds"] == 0
+    assert np.array_equal(a[6][0].view(np.uint32), b[6][0].view(np.uint32))
+    assert np.array_equal(a[6][1].view(np.uint32), b[6][1].view(np.uint32))
