@@ -74,6 +74,7 @@ struct hml_ctx {
     int32_t key_base = 0;
     double key_scale = 1.0;         // product of the weight multipliers applied so far
     bool use_keys = true;
+    bool summary_always = false;    // option weight_keys = 2: never fall back to the float stream (tests)
     float* d_coeff = nullptr;
     float2* d_ia = nullptr;
     // block structure
@@ -456,7 +457,7 @@ static void launch_compact_pair(hml_ctx* c, int mode, float thr) {
     const uint32_t n_groups = (c->n_spans + HML_GROUP_SPANS - 1) / HML_GROUP_SPANS;
     // the summary scan skips unopened groups; when most groups would be opened (weak compression) the plain
     // float stream is the better access pattern - both give the same blocks
-    const bool dense = c->B_hint && (uint64_t)c->B_hint * 24u > c->T;
+    const bool dense = !c->summary_always && c->B_hint && (uint64_t)c->B_hint * 24u > c->T;
     {
         ProfScope ps(c, "blocks_compact", 1);
         if (c->use_keys && !dense) {
@@ -677,7 +678,7 @@ static int sweep_k(hml_ctx* c, char method, bool record) {
     const uint32_t T = (uint32_t)c->T;
     bool emitted = false, fused = false;
     if (c->dynamic || !c->blocks_valid) {
-        if (c->use_keys && !(c->B_hint && (uint64_t)c->B_hint * 24u > c->T)) {
+        if (c->use_keys && !(!c->summary_always && c->B_hint && (uint64_t)c->B_hint * 24u > c->T)) {
             // K4 + K5 + K6a in one launch (hml_k_blocks_fused.h); weak compression takes the float stream below
             ProfScope ps(c, "blocks_compact", 1);
             const uint32_t n_wg = (uint32_t)(((uint64_t)T + HML_FUSED_POSITIONS - 1) / HML_FUSED_POSITIONS);
@@ -818,6 +819,7 @@ int hml_set_option(hml_ctx* c, const char* name, int value) {
     if (std::string(name) == "weight_keys") {
         if (c->loaded) return set_err(HML_ERR_ARG, "weight_keys must be set before the observations are loaded");
         c->use_keys = value != 0;
+        c->summary_always = value == 2;
         return 0;
     }
     return set_err(HML_ERR_ARG, std::string("unknown option ") + name);

@@ -98,8 +98,9 @@ int hml_set_recording(hml_ctx* ctx, int marginals, hml_record_cb cb, void* user)
 
 /* Options.  "weight_keys" (before the observations are loaded), 1 (default): the per-sweep block scan reads a
  * one-byte-per-16-positions summary of the breakpoint weights (largest monotone 8-bit key of the group) and opens only
- * the groups that can hold a block start, comparing their float weights exactly; 0: it streams all T float weights.
- * Same block structures either way (exact). */
+ * the groups that can hold a block start, comparing their float weights exactly (sweeps whose compression is
+ * below 24 positions per block stream the floats instead); 2: the summary at any compression; 0: always stream all T
+ * float weights.  Same block structures every way (exact). */
 int hml_set_option(hml_ctx* ctx, const char* name, int value);
 
 /* wait for all enqueued work; surfaces model errors raised on the device */

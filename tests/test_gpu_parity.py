@@ -11,11 +11,13 @@ def bits(a):
     return np.ascontiguousarray(a, np.float32).view(np.uint32)
 
 
-def make_pair(hml, T, K, data_seed, seed, chain=0, x=None, **kw):
+def make_pair(hml, T, K, data_seed, seed, chain=0, x=None, weight_keys=None, **kw):
     x = ol.trace(T, K, data_seed) if x is None else x
     o = ol.OracleChain(K=K, seed=seed, chain=chain, rng=ol.RNG_CTR, math=ol.MATH_DEV, reduce=ol.REDUCE_DEV, **kw)
     o.load(x)
     g = hml.Chain(device=0, seed=seed, chain_id=chain)
+    if weight_keys is not None:
+        g.set_option("weight_keys", weight_keys)
     g.load(x)
     if kw.get("weight_mult", 1.0) != 1.0:
         g.scale_weights(kw["weight_mult"])
@@ -228,9 +230,9 @@ def test_dense_marginals_export_and_pooling_path(hml):
     assert np.all(got[:K].sum(0) == 8)
 
 
-@pytest.mark.parametrize("keys", [1, 0])
+@pytest.mark.parametrize("keys", [1, 2, 0])
 def test_block_scan_edge_thresholds(hml, keys):
-    """The 8-bit key scan and the float scan against the checker on thresholds that hit weights exactly,
+    """The group-summary scan and the float scan against the checker on thresholds that hit weights exactly,
     fall outside the key window, or are degenerate (0, inf, NaN), and on a ragged tail (T not a multiple of 16)."""
     T = 150001
     x = ol.trace(T, 3, 12)
@@ -271,11 +273,15 @@ def test_block_scan_with_odd_weight_multipliers(hml, mult):
         assert np.array_equal(o.blocks(), g.blocks()), (mult, thr)
 
 
-def test_sweeps_match_checker_on_depth_data(hml):
-    """Config-5-style input (integer Poisson-lognormal read depth, 5-state CNV model): same bit-exact agreement."""
+@pytest.mark.parametrize("keys", [1, 2, 0])
+def test_sweeps_match_checker_on_depth_data(hml, keys):
+    """Config-5-style input (integer Poisson-lognormal read depth, 5-state CNV model): same bit-exact agreement.
+    Compression is ~1.4 positions per block here: with keys = 2 the fused summary kernel is forced to take its
+    multi-round path (more block starts per workgroup than its LDS list holds); keys = 1 falls back to the float
+    stream after the first sweep; keys = 0 never uses the summary."""
     T, K = 300000, 5
     x = ol.synth_depth(T, seed=5)
-    x2, o, g = make_pair(hml, T, K, 0, 17, x=x)
+    x2, o, g = make_pair(hml, T, K, 0, 17, x=x, weight_keys=keys)
     setup_model(o, g, K)
     g._pending_prior = True
     o.set_record(marginals=True)
