@@ -94,7 +94,8 @@ struct hml_ctx {
     bool graph_dynamic = false, graph_valid_blocks = false;
     // sweep buffers (allocated by set_model)
     float *d_em = nullptr, *d_gsc = nullptr, *d_rows = nullptr, *d_eprobe = nullptr, *d_aprobe = nullptr;
-    float *d_entry = nullptr, *d_exitA = nullptr, *d_exitB = nullptr;
+    float *d_entry = nullptr, *d_exitA = nullptr;
+    uint32_t* d_redo = nullptr;    // backward chunks whose maps the repair step must (re)compute, tagged with the sweep
     uint32_t* d_fb = nullptr;
     unsigned long long *d_smap = nullptr, *d_cmap = nullptr;
     uint8_t* d_bentry = nullptr;
@@ -107,7 +108,7 @@ struct hml_ctx {
     uint32_t* d_hB = nullptr;       // device view of h_B
     uint32_t B_hint = 0;
     // forward geometry
-    int fwdL = 4, fwdW = 24, fwdRounds = 1;
+    int fwdL = 4, fwdW = 24;
     hml_layout lay = {2, 0};
     bool probes = false;
     bool rec_marginals = true;
@@ -278,7 +279,6 @@ int hml_create(hml_ctx** out, int device, uint64_t seed, uint32_t chain_id, void
     HIPCHK(hipHostGetDevicePointer((void**)&c->d_hB, c->h_B, 0));
     if (const char* e = getenv("HML_FWD_CHUNK")) { int l = std::max(1, atoi(e)); int sh = 0; while ((1 << (sh + 1)) <= l && sh < 10) ++sh; c->fwdL = 1 << sh; }
     if (const char* e = getenv("HML_FWD_WARMUP")) c->fwdW = std::max(0, atoi(e));
-    if (const char* e = getenv("HML_FWD_ROUNDS")) c->fwdRounds = std::max(0, atoi(e));
     if (const char* e = getenv("HML_USE_GRAPH")) c->use_graph = atoi(e) != 0;
     if (const char* e = getenv("HML_WEIGHT_KEYS")) c->use_keys = atoi(e) != 0;
     *out = c;
@@ -287,7 +287,7 @@ int hml_create(hml_ctx** out, int device, uint64_t seed, uint32_t chain_id, void
 
 static void free_all(hml_ctx* c) {
     void* ptrs[] = {c->d_group_word, c->d_launch_gen, c->d_summary, c->d_w, c->d_coeff, c->d_ia, c->d_stage, c->d_span_count, c->d_starts, c->d_bstat,
-                    c->d_em, c->d_gsc, c->d_rows, c->d_eprobe, c->d_aprobe, c->d_entry, c->d_exitA, c->d_exitB, c->d_fb, c->d_coarse1,
+                    c->d_em, c->d_gsc, c->d_rows, c->d_eprobe, c->d_aprobe, c->d_entry, c->d_exitA, c->d_redo, c->d_fb, c->d_coarse1,
                     c->d_smap, c->d_cmap, c->d_bentry, c->d_q, c->d_partial, c->d_diff, c->d_boundary, c->d_mdl};
     for (void* p : ptrs) if (p) hipFree(p);
     if (c->h_B) hipHostFree(c->h_B);
@@ -573,12 +573,13 @@ int hml_set_model(hml_ctx* c, int K, const float nig4[4], float a_off, float a_d
     HIPCHK(hipMalloc(&c->d_rows, plane * sizeof(float)));
     HIPCHK(hipMalloc(&c->d_entry, maxChunks * K * sizeof(float)));
     HIPCHK(hipMalloc(&c->d_exitA, maxChunks * K * sizeof(float)));
-    HIPCHK(hipMalloc(&c->d_exitB, maxChunks * K * sizeof(float)));
     HIPCHK(hipMalloc(&c->d_fb, maxChunks * sizeof(uint32_t)));
     HIPCHK(hipMalloc(&c->d_smap, (T + 2) * sizeof(unsigned long long)));
     const uint64_t bchunks = (T + HML_BWD_CHUNK - 1) / HML_BWD_CHUNK + 1;
     HIPCHK(hipMalloc(&c->d_cmap, bchunks * sizeof(unsigned long long)));
     HIPCHK(hipMalloc(&c->d_bentry, bchunks));
+    HIPCHK(hipMalloc(&c->d_redo, bchunks * sizeof(uint32_t)));
+    HIPCHK(hipMemsetAsync(c->d_redo, 0, bchunks * sizeof(uint32_t), c->stream));
     HIPCHK(hipMalloc(&c->d_q, T * sizeof(int16_t)));
     HIPCHK(hipMalloc(&c->d_partial, (uint64_t)HML_REDUCE_GROUPS * K * 2 * sizeof(double)));
     HIPCHK(hipMemsetAsync(c->d_partial, 0, (uint64_t)HML_REDUCE_GROUPS * K * 2 * sizeof(double), c->stream));
@@ -710,37 +711,24 @@ static int sweep_k(hml_ctx* c, char method, bool record) {
                            c->d_em, c->d_gsc, c->probes ? c->d_eprobe : nullptr, mix ? 1 : 0, c->lay);
     }
     if (!mix) {
-        const int L = c->fwdL, W = c->fwdW;
+        const int L = c->fwdL;
         const uint64_t chunks = ((uint64_t)hint + L - 1) / L;
         const int gF = grid_for(chunks, 256, 16, 1 << 20);
-        float* ein = c->d_exitA; float* eout = c->d_exitB;
         {
             ProfScope ps(c, "forward");
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_forward<KK, 0>), dim3(gF), dim3(256), 0, s, c->d_em, c->d_gsc, c->d_mdl,
-                               c->d_rows, c->probes ? c->d_aprobe : nullptr, c->d_entry, (const float*)nullptr, c->d_exitA,
-                               c->d_fb, L, W, c->lay);
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_forward<KK>), dim3(gF), dim3(256), 0, s, c->d_em, c->d_gsc, c->d_mdl, c->d_rows,
+                               c->probes ? c->d_aprobe : nullptr, c->d_entry, c->d_exitA, c->d_fb, L, c->lay);
         }
         {
-            ProfScope ps(c, "forward_fix");
-            for (int r = 0; r < c->fwdRounds; ++r) {
-                hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_forward<KK, 1>), dim3(gF), dim3(256), 0, s, c->d_em, c->d_gsc, c->d_mdl,
-                                   c->d_rows, c->probes ? c->d_aprobe : nullptr, c->d_entry, (const float*)ein, eout, c->d_fb,
-                                   L, W, c->lay);
-                std::swap(ein, eout);
-            }
-            if (c->fwdRounds == 0)   // no repair round: a verify-only pass decides whether the serial pass must run
-                hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_forward<KK, 2>), dim3(gF), dim3(256), 0, s, c->d_em, c->d_gsc, c->d_mdl,
-                                   c->d_rows, (float*)nullptr, c->d_entry, (const float*)ein, eout, c->d_fb, L, W, c->lay);
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_forward_serial<KK>), dim3(1), dim3(256), 0, s, c->d_em, c->d_gsc, c->d_mdl,
-                               c->d_rows, c->probes ? c->d_aprobe : nullptr, c->d_entry, ein, c->d_fb, L, W, c->lay);
-        }
-        {
+            // backward maps (verifies the forward chunks on the way), then one workgroup: repair if a check failed,
+            // and the chain over the chunk maps
             ProfScope ps(c, "backward");
             const uint64_t bch = ((uint64_t)hint + HML_BWD_CHUNK - 1) / HML_BWD_CHUNK;
             hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_backward_maps<KK>), dim3(grid_for(bch * 64, 256, 16, 1 << 18)), dim3(256), 0,
-                               s, c->d_rows, c->d_mdl, c->d_smap, c->d_cmap, c->lay);
+                               s, c->d_rows, c->d_mdl, c->d_smap, c->d_cmap, c->lay, c->d_entry, c->d_exitA, c->d_redo, L);
             hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_backward_chain<KK>), dim3(1), dim3(1024), 0, s, c->d_cmap, c->d_mdl,
-                               c->d_bentry);
+                               c->d_bentry, c->d_em, c->d_gsc, c->d_rows, c->probes ? c->d_aprobe : nullptr, c->d_entry,
+                               c->d_exitA, c->d_fb, c->d_redo, c->d_smap, L, c->lay);
         }
         {
             ProfScope ps(c, "counts");

@@ -56,66 +56,124 @@ __device__ __forceinline__ int hml_categorical_k(const float (&w)[K], double u) 
 // suffix scan over the wavefront yields S_t = cand_t o ... o cand_{64c+64} for each row and the
 // chunk's map S_{64c+1}.
 // ------------------------------------------------------------------------------------------
+// the maps of backward chunk c (rows 64c+1 .. 64c+64), by one wavefront
+template <int K>
+__device__ __forceinline__ void hml_bwd_chunk_maps(const float* __restrict__ rows, hml_model* __restrict__ mdl,
+                                                   unsigned long long* __restrict__ smap, unsigned long long* __restrict__ cmap,
+                                                   const hml_layout lay, uint32_t c, int lane, uint32_t B,
+                                                   unsigned long long epoch, const hml_key key) {
+    const uint32_t t = c * HML_BWD_CHUNK + (uint32_t)lane + 1u;
+    unsigned long long map = HML_MAP_IDENTITY;
+    if (t <= B) {
+        const hml_u32x4 o = hml_stream4(key, HML_KIND_CAT, epoch, t, 0);
+        const double u = hml_canonical_f64(o.v[0], o.v[1]);
+        float r[K];
+#pragma unroll
+        for (int i = 0; i < K; ++i) r[i] = rows[hml_bk(lay, t - 1u, K, i)];   // rows are stored by block b = t-1
+        map = 0ull;
+        if (t == B) {
+            const unsigned long long st = (unsigned long long)hml_categorical_k<K>(r, u);
+#pragma unroll
+            for (int x = 0; x < K; ++x) map |= st << (4 * x);
+        } else {
+#pragma unroll
+            for (int x = 0; x < K; ++x) {
+                float w[K];
+#pragma unroll
+                for (int i = 0; i < K; ++i) {
+                    w[i] = r[i] * mdl->A[i * K + x];
+                    if (w[i] < 0.0f) hml_raise(mdl, HML_DEVERR_NEG_BACKWARD, w[i]);
+                }
+                map |= (unsigned long long)hml_categorical_k<K>(w, u) << (4 * x);
+            }
+        }
+    }
+    // suffix scan of map composition across the wavefront
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        unsigned long long o = hml_shfl_down_u64(map, d);
+        if (lane + d >= 64) o = HML_MAP_IDENTITY;
+        map = hml_map_compose<K>(map, o);
+    }
+    if (t <= B) smap[t] = map;
+    if (lane == 0) cmap[c] = map;
+}
+
+// One wavefront per backward chunk.  It first verifies the forward chunks whose rows it is about to read
+// (start vector == predecessor's end vector, bit for bit; see hml_k_forward): a failed check raises
+// mdl->fwd_mismatch and leaves the chunk's maps to the repair step (redo[c] = gen).
 template <int K>
 __global__ __launch_bounds__(256) void hml_k_backward_maps(const float* __restrict__ rows, hml_model* __restrict__ mdl,
                                                            unsigned long long* __restrict__ smap,
-                                                           unsigned long long* __restrict__ cmap, const hml_layout lay) {
+                                                           unsigned long long* __restrict__ cmap, const hml_layout lay,
+                                                           const float* __restrict__ entry, const float* __restrict__ exitv,
+                                                           uint32_t* __restrict__ redo, int L) {
     const uint32_t B = mdl->B;
     const uint32_t nchunks = (B + HML_BWD_CHUNK - 1u) / HML_BWD_CHUNK;
     const int lane = threadIdx.x & 63;
     const uint32_t wave_global = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
     const unsigned long long epoch = mdl->epoch;
+    const uint32_t gen = (uint32_t)epoch + 1u;
     const hml_key key = mdl->key;
+    const int W = (int)mdl->fwd_W;
+    const uint32_t C = (B + (uint32_t)L - 1u) / (uint32_t)L;
     for (uint32_t c = wave_global; c < nchunks; c += nwaves) {
-        const uint32_t t = c * HML_BWD_CHUNK + (uint32_t)lane + 1u;
-        unsigned long long map = HML_MAP_IDENTITY;
-        if (t <= B) {
-            const hml_u32x4 o = hml_stream4(key, HML_KIND_CAT, epoch, t, 0);
-            const double u = hml_canonical_f64(o.v[0], o.v[1]);
-            float r[K];
+        // forward chunks that overlap blocks [64c, 64c+64): at most 64 of them, one per lane
+        bool ok = true;
+        {
+            const uint32_t f0 = (c * HML_BWD_CHUNK) / (uint32_t)L;
+            const uint32_t f1 = (c * HML_BWD_CHUNK + HML_BWD_CHUNK - 1u) / (uint32_t)L;
+            const uint32_t f = f0 + (uint32_t)lane;
+            if (f <= f1 && f < C && !hml_fwd_chunk_exact(f, L, W)) {
 #pragma unroll
-            for (int i = 0; i < K; ++i) r[i] = rows[hml_bk(lay, t - 1u, K, i)];   // rows are stored by block b = t-1
-            map = 0ull;
-            if (t == B) {
-                const unsigned long long st = (unsigned long long)hml_categorical_k<K>(r, u);
-#pragma unroll
-                for (int x = 0; x < K; ++x) map |= st << (4 * x);
-            } else {
-#pragma unroll
-                for (int x = 0; x < K; ++x) {
-                    float w[K];
-#pragma unroll
-                    for (int i = 0; i < K; ++i) {
-                        w[i] = r[i] * mdl->A[i * K + x];
-                        if (w[i] < 0.0f) hml_raise(mdl, HML_DEVERR_NEG_BACKWARD, w[i]);
-                    }
-                    map |= (unsigned long long)hml_categorical_k<K>(w, u) << (4 * x);
-                }
+                for (int s = 0; s < K; ++s) ok = ok && (hml_f2u(entry[(uint64_t)f * K + s]) == hml_f2u(exitv[(uint64_t)(f - 1) * K + s]));
             }
         }
-        // suffix scan of map composition across the wavefront
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            unsigned long long o = hml_shfl_down_u64(map, d);
-            if (lane + d >= 64) o = HML_MAP_IDENTITY;
-            map = hml_map_compose<K>(map, o);
+        if (__ballot(!ok) != 0ull) {   // wave-uniform
+            if (lane == 0) { mdl->fwd_mismatch = 1u; redo[c] = gen; }
+            continue;
         }
-        if (t <= B) smap[t] = map;
-        if (lane == 0) cmap[c] = map;
+        hml_bwd_chunk_maps<K>(rows, mdl, smap, cmap, lay, c, lane, B, epoch, key);
     }
 }
 
-// K7b backward_chain - compose the chunk maps from the last chunk down: entry[c] = state of the first
-// row of chunk c+1 (entry of the last chunk is a dummy 0: its map is constant).  One workgroup.
+// K7b repair + chain, one workgroup.  Normally only the chain: compose the chunk maps from the last chunk down,
+// entry[c] = state of the first row of chunk c+1 (entry of the last chunk is a dummy 0: its map is constant).
+// When a verification failed, the forward repair (hml_fwd_repair) and the maps of the affected chunks come first.
 template <int K>
-__global__ __launch_bounds__(1024) void hml_k_backward_chain(const unsigned long long* __restrict__ cmap,
-                                                             const hml_model* __restrict__ mdl,
-                                                             uint8_t* __restrict__ entry) {
+__global__ __launch_bounds__(1024) void hml_k_backward_chain(unsigned long long* __restrict__ cmap, hml_model* __restrict__ mdl,
+                                                             uint8_t* __restrict__ entry_state, const float* __restrict__ em,
+                                                             const float* __restrict__ gsc, float* __restrict__ rows,
+                                                             float* __restrict__ aprobe, float* __restrict__ entry,
+                                                             float* __restrict__ exitv, uint32_t* __restrict__ fb_count,
+                                                             uint32_t* __restrict__ redo, unsigned long long* __restrict__ smap,
+                                                             int L, const hml_layout lay) {
     __shared__ unsigned long long P[1024];
+    __shared__ uint32_t bad[HML_SERIAL_WINDOW_WORDS];
     const uint32_t B = mdl->B;
     const uint32_t NC = (B + HML_BWD_CHUNK - 1u) / HML_BWD_CHUNK;
     const int tid = threadIdx.x;
+    if (mdl->fwd_mismatch != 0u) {   // workgroup-uniform: written by the previous launch
+        const unsigned long long epoch = mdl->epoch;
+        const uint32_t gen = (uint32_t)epoch + 1u;
+        const hml_key key = mdl->key;
+        hml_fwd_repair<K>(em, gsc, mdl, rows, aprobe, entry, exitv, fb_count, redo, gen, L, lay, bad);
+        __syncthreads();
+        // maps of the chunks that failed verification or whose rows were recomputed
+        const int lane = tid & 63, wave = tid >> 6;
+        for (uint32_t c0 = (uint32_t)wave * 64u; c0 < NC; c0 += 16u * 64u) {
+            const uint32_t c = c0 + (uint32_t)lane;
+            unsigned long long todo = __ballot(c < NC && hml_ld_u32_coherent(redo + c) == gen);
+            while (todo) {
+                const int j = __ffsll((long long)todo) - 1;
+                todo &= todo - 1ull;
+                hml_bwd_chunk_maps<K>(rows, mdl, smap, cmap, lay, c0 + (uint32_t)j, lane, B, epoch, key);
+            }
+        }
+        __threadfence_block();
+        __syncthreads();
+    }
     const uint32_t per = (NC + 1023u) / 1024u;
     const uint32_t a = (uint32_t)tid * per < NC ? (uint32_t)tid * per : NC;
     const uint32_t b = (a + per < NC) ? a + per : NC;
@@ -136,7 +194,7 @@ __global__ __launch_bounds__(1024) void hml_k_backward_chain(const unsigned long
     const unsigned long long later = (tid + 1 < 1024) ? P[tid + 1] : HML_MAP_IDENTITY;
     unsigned x = (unsigned)(later & 15ull);
     for (uint32_t c = b; c > a; --c) {
-        entry[c - 1] = (uint8_t)x;
+        entry_state[c - 1] = (uint8_t)x;
         x = (unsigned)(cmap[c - 1] >> (4 * x)) & 15u;
     }
 }

@@ -194,14 +194,15 @@ __device__ __forceinline__ void hml_fwd_run(const hml_fwd_ctx<K>& cx, float (&al
     }
 }
 
-// MODE 0: speculative main pass.  MODE 1: verify against exit_in; recompute stale chunks after a 16x longer warm-up.
-// MODE 2: verify only - raise mdl->fwd_mismatch if any chunk is still inconsistent (the serial pass then runs).
-template <int K, int MODE>
+// The speculative pass: every chunk warms up over the W blocks before it, stores the vector it then starts from
+// (entry) and the one it ends in (exit).  Verification (entry[c] == exit[c-1], bit for bit) happens in the
+// backward-map kernel, which reads the rows anyway; repairs in hml_fwd_repair.
+template <int K>
 __global__ __launch_bounds__(256) void hml_k_forward(const float* __restrict__ em, const float* __restrict__ gsc,
                                                      hml_model* __restrict__ mdl, float* __restrict__ rows,
                                                      float* __restrict__ aprobe, float* __restrict__ entry,
-                                                     const float* __restrict__ exit_in, float* __restrict__ exit_out,
-                                                     uint32_t* __restrict__ fb_count, int L, int W_unused, const hml_layout lay) {
+                                                     float* __restrict__ exitv, uint32_t* __restrict__ fb_count, int L,
+                                                     const hml_layout lay) {
     hml_fwd_ctx<K> cx;
     hml_fwd_ctx_load<K>(cx, mdl);
     const uint32_t B = cx.B;
@@ -209,7 +210,7 @@ __global__ __launch_bounds__(256) void hml_k_forward(const float* __restrict__ e
     const uint32_t C = (B + (uint32_t)L - 1u) / (uint32_t)L;
     const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t nthreads = gridDim.x * blockDim.x;
-    if (MODE == 0 && gid < (uint32_t)K && aprobe) aprobe[gid] = mdl->pi[gid];
+    if (gid < (uint32_t)K && aprobe) aprobe[gid] = mdl->pi[gid];
     // grid-stride over chunks: correctness never depends on the launch size (B is only known on the device)
     for (uint32_t c = gid; c < C; c += nthreads) {
         const uint32_t first = c * (uint32_t)L;
@@ -218,93 +219,115 @@ __global__ __launch_bounds__(256) void hml_k_forward(const float* __restrict__ e
         const bool exact = (ws == 0u);
         float alpha[K];
         uint32_t nfb = 0;
-        if (MODE == 0) {
 #pragma unroll
-            for (int s = 0; s < K; ++s) alpha[s] = exact ? mdl->pi[s] : cx.invK;
-            hml_fwd_run<K, false>(cx, alpha, em, gsc, rows, aprobe, ws, first, nfb, lay);   // warm-up, nothing stored
+        for (int s = 0; s < K; ++s) alpha[s] = exact ? mdl->pi[s] : cx.invK;
+        hml_fwd_run<K, false>(cx, alpha, em, gsc, rows, aprobe, ws, first, nfb, lay);   // warm-up, nothing stored
 #pragma unroll
-            for (int s = 0; s < K; ++s) entry[(uint64_t)c * K + s] = alpha[s];
-        } else {
-            // verification: was the vector this chunk started from the one its predecessor really ended in?
-            bool same = true;
-            if (!exact) {
-#pragma unroll
-                for (int s = 0; s < K; ++s) {
-                    alpha[s] = exit_in[(uint64_t)(c - 1) * K + s];
-                    same = same && (hml_f2u(alpha[s]) == hml_f2u(entry[(uint64_t)c * K + s]));
-                }
-            }
-            if (MODE == 2) {
-                if (!same) mdl->fwd_mismatch = 1u;
-                continue;
-            }
-            if (exact || same) {
-#pragma unroll
-                for (int s = 0; s < K; ++s) exit_out[(uint64_t)c * K + s] = exit_in[(uint64_t)c * K + s];
-                continue;
-            }
-            // stale: the warm-up was too short here.  Do not trust the neighbour (it may be stale too): warm up
-            // again over a 16x longer stretch, which ends in the true vector unless the filter hardly forgets
-            // at all; the serial pass then verifies every chunk and repairs what is still inconsistent.
-            {
-                const uint32_t Wl = (uint32_t)W * 16u;
-                const uint32_t ws2 = (first >= Wl) ? first - Wl : 0u;
-#pragma unroll
-                for (int s = 0; s < K; ++s) alpha[s] = (ws2 == 0u) ? mdl->pi[s] : cx.invK;
-                hml_fwd_run<K, false>(cx, alpha, em, gsc, rows, aprobe, ws2, first, nfb, lay);
-            }
-#pragma unroll
-            for (int s = 0; s < K; ++s) entry[(uint64_t)c * K + s] = alpha[s];
-            atomicAdd(&mdl->forward_refits, 1ull);
-            mdl->fwd_mismatch = 1u;
-        }
+        for (int s = 0; s < K; ++s) entry[(uint64_t)c * K + s] = alpha[s];
         // the chunk proper over [first, last)
         hml_fwd_run<K, true>(cx, alpha, em, gsc, rows, aprobe, first, last, nfb, lay);
 #pragma unroll
-        for (int s = 0; s < K; ++s) exit_out[(uint64_t)c * K + s] = alpha[s];
-        // "[WARNING] Uniform sampling of forward variables!" events: keep the global tally consistent when a
-        // chunk is recomputed (two's-complement delta on the unsigned counter)
-        const uint32_t old = (MODE == 0) ? 0u : fb_count[c];
+        for (int s = 0; s < K; ++s) exitv[(uint64_t)c * K + s] = alpha[s];
+        // "[WARNING] Uniform sampling of forward variables!" events of this chunk
         fb_count[c] = nfb;
-        if (nfb != old) atomicAdd(&mdl->uniform_fallbacks, (unsigned long long)(long long)((int)nfb - (int)old));
+        if (nfb) atomicAdd(&mdl->uniform_fallbacks, (unsigned long long)nfb);
     }
 }
 
-// Final serial pass, only when the repair round left an inconsistency (mdl->fwd_mismatch).  All threads mark
-// the chunks whose start vector is not their predecessor's end vector in an LDS bitmap (windows of 2^20
-// chunks); one lane then visits the marked chunks in increasing order, recomputes each from the true
-// vector and follows the chain while the recomputed end vector makes the next chunk inconsistent.
+// a chunk started from pi itself (its warm-up window reaches block 0): exact by construction
+__device__ __forceinline__ bool hml_fwd_chunk_exact(uint32_t c, int L, int W) { return c == 0u || c * (uint32_t)L <= (uint32_t)W; }
+
+// a word another wavefront of this workgroup may have rewritten in this launch (the load bypasses the L1)
+__device__ __forceinline__ uint32_t hml_ld_u32_coherent(const uint32_t* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ uint32_t hml_ld_bits_coherent(const float* p) {
+    return hml_ld_u32_coherent(reinterpret_cast<const uint32_t*>(p));
+}
+
+template <int K>
+__device__ __forceinline__ bool hml_fwd_chunk_consistent(const float* __restrict__ entry, const float* __restrict__ exitv, uint32_t c) {
+    bool same = true;
+#pragma unroll
+    for (int s = 0; s < K; ++s)
+        same = same && (hml_ld_bits_coherent(entry + (uint64_t)c * K + s) == hml_ld_bits_coherent(exitv + (uint64_t)(c - 1) * K + s));
+    return same;
+}
+
+// ------------------------------------------------------------------------------------------
+// Repair, by ONE workgroup, only when the verification found a chunk whose start vector is not its
+// predecessor's end vector (mdl->fwd_mismatch).  Windows of 2^18 chunks, an LDS bitmap per window:
+//   1. mark the inconsistent chunks (all threads), then recompute each of them after a 16x longer warm-up
+//      (one thread per marked chunk) - the neighbour is not trusted, it may be stale too; this ends in the
+//      true vector unless the filter hardly forgets at all;
+//   2. mark again; one lane visits the still-inconsistent chunks in increasing order, recomputes each from its
+//      predecessor's true end vector and follows the chain while the recomputed end vector makes the next
+//      chunk inconsistent.  After this pass induction from chunk 0 holds: the rows are the sequential ones.
+// Every recomputed chunk marks its backward chunk in redo[] (= gen) so that the caller recomputes its maps.
+// ------------------------------------------------------------------------------------------
 #define HML_SERIAL_WINDOW_WORDS 8192   // 2^18 chunks per window
 template <int K>
-__global__ __launch_bounds__(256) void hml_k_forward_serial(const float* __restrict__ em, const float* __restrict__ gsc,
-                                                            hml_model* __restrict__ mdl, float* __restrict__ rows,
-                                                            float* __restrict__ aprobe, float* __restrict__ entry,
-                                                            float* __restrict__ exitv, uint32_t* __restrict__ fb_count,
-                                                            int L, int W_unused, const hml_layout lay) {
-    __shared__ uint32_t bad[HML_SERIAL_WINDOW_WORDS];
-    if (mdl->fwd_mismatch == 0u) return;   // every chunk is consistent
+__device__ void hml_fwd_repair(const float* __restrict__ em, const float* __restrict__ gsc, hml_model* __restrict__ mdl,
+                               float* __restrict__ rows, float* __restrict__ aprobe, float* __restrict__ entry,
+                               float* __restrict__ exitv, uint32_t* __restrict__ fb_count, uint32_t* __restrict__ redo,
+                               uint32_t gen, int L, const hml_layout lay, uint32_t* bad /* LDS, HML_SERIAL_WINDOW_WORDS */) {
     hml_fwd_ctx<K> cx;
     hml_fwd_ctx_load<K>(cx, mdl);
     const uint32_t B = cx.B;
     const int W = (int)mdl->fwd_W;
-    (void)W_unused;
     const uint32_t C = (B + (uint32_t)L - 1u) / (uint32_t)L;
-    const int tid = threadIdx.x;
-    if (tid == 0) mdl->fwd_serial_ran = 1u;   // the parameter kernel lengthens the warm-up for the next sweeps
+    const int tid = threadIdx.x, nthr = blockDim.x;
     const uint32_t win = HML_SERIAL_WINDOW_WORDS * 32u;
-    for (uint32_t w0 = 0; w0 < C; w0 += win) {
-        const uint32_t w1 = (w0 + win < C) ? w0 + win : C;
-        for (int i = tid; i < HML_SERIAL_WINDOW_WORDS; i += 256) bad[i] = 0u;
+    auto mark_window = [&](uint32_t w0, uint32_t w1) {
+        for (int i = tid; i < HML_SERIAL_WINDOW_WORDS; i += nthr) bad[i] = 0u;
         __syncthreads();
-        for (uint32_t c = w0 + (uint32_t)tid; c < w1; c += 256u) {
-            if (c == 0u || c * (uint32_t)L <= (uint32_t)W) continue;   // started from pi: exact by construction
-            bool same = true;
-#pragma unroll
-            for (int s = 0; s < K; ++s)
-                same = same && (hml_f2u(entry[(uint64_t)c * K + s]) == hml_f2u(exitv[(uint64_t)(c - 1) * K + s]));
-            if (!same) atomicOr(&bad[(c - w0) >> 5], 1u << ((c - w0) & 31u));
+        for (uint32_t c = w0 + (uint32_t)tid; c < w1; c += (uint32_t)nthr) {
+            if (hml_fwd_chunk_exact(c, L, W)) continue;
+            if (!hml_fwd_chunk_consistent<K>(entry, exitv, c)) atomicOr(&bad[(c - w0) >> 5], 1u << ((c - w0) & 31u));
         }
         __syncthreads();
+    };
+    auto account = [&](uint32_t c, uint32_t nfb) {
+        const uint32_t old = fb_count[c];
+        fb_count[c] = nfb;
+        // keep the global tally of uniform fallbacks consistent (two's-complement delta on the unsigned counter)
+        if (nfb != old) atomicAdd(&mdl->uniform_fallbacks, (unsigned long long)(long long)((int)nfb - (int)old));
+        redo[((uint64_t)c * (uint32_t)L) / HML_BWD_CHUNK] = gen;
+        if (L > (int)HML_BWD_CHUNK) {   // (a forward chunk longer than a backward chunk covers several)
+            for (uint32_t b = c * (uint32_t)L; b < (c + 1u) * (uint32_t)L && b < B; b += HML_BWD_CHUNK) redo[b / HML_BWD_CHUNK] = gen;
+        }
+    };
+    if (tid == 0) mdl->fwd_serial_ran = 1u;   // the parameter kernel lengthens the warm-up for the next sweeps
+    // ---- 1. long warm-up, in parallel
+    for (uint32_t w0 = 0; w0 < C; w0 += win) {
+        const uint32_t w1 = (w0 + win < C) ? w0 + win : C;
+        mark_window(w0, w1);
+        for (uint32_t c = w0 + (uint32_t)tid; c < w1; c += (uint32_t)nthr) {   // one thread per marked chunk
+            if (((bad[(c - w0) >> 5] >> ((c - w0) & 31u)) & 1u) == 0u) continue;
+            const uint32_t first = c * (uint32_t)L;
+            const uint32_t last = (first + (uint32_t)L < B) ? first + (uint32_t)L : B;
+            const uint32_t Wl = (uint32_t)W * 16u;
+            const uint32_t ws = (first >= Wl) ? first - Wl : 0u;
+            float alpha[K];
+            uint32_t nfb = 0;
+#pragma unroll
+            for (int s = 0; s < K; ++s) alpha[s] = (ws == 0u) ? mdl->pi[s] : cx.invK;
+            hml_fwd_run<K, false>(cx, alpha, em, gsc, rows, aprobe, ws, first, nfb, lay);
+#pragma unroll
+            for (int s = 0; s < K; ++s) entry[(uint64_t)c * K + s] = alpha[s];
+            hml_fwd_run<K, true>(cx, alpha, em, gsc, rows, aprobe, first, last, nfb, lay);
+#pragma unroll
+            for (int s = 0; s < K; ++s) exitv[(uint64_t)c * K + s] = alpha[s];
+            account(c, nfb);
+            atomicAdd(&mdl->forward_refits, 1ull);
+        }
+        __syncthreads();
+    }
+    __threadfence_block();
+    // ---- 2. what is still inconsistent, serially
+    for (uint32_t w0 = 0; w0 < C; w0 += win) {
+        const uint32_t w1 = (w0 + win < C) ? w0 + win : C;
+        mark_window(w0, w1);
         if (tid == 0) {
             for (uint32_t wi = 0; wi < (w1 - w0 + 31u) / 32u; ++wi) {
                 uint32_t bits = bad[wi];
@@ -319,8 +342,8 @@ __global__ __launch_bounds__(256) void hml_k_forward_serial(const float* __restr
                         bool same = true;
 #pragma unroll
                         for (int s = 0; s < K; ++s) {
-                            if (!have_alpha) alpha[s] = exitv[(uint64_t)(c - 1) * K + s];
-                            same = same && (hml_f2u(alpha[s]) == hml_f2u(entry[(uint64_t)c * K + s]));
+                            if (!have_alpha) alpha[s] = hml_u2f(hml_ld_bits_coherent(exitv + (uint64_t)(c - 1) * K + s));
+                            same = same && (hml_f2u(alpha[s]) == hml_ld_bits_coherent(entry + (uint64_t)c * K + s));
                         }
                         if (same) break;   // consistent (possibly repaired already by an earlier chain)
                         const uint32_t first = c * (uint32_t)L;
@@ -332,9 +355,7 @@ __global__ __launch_bounds__(256) void hml_k_forward_serial(const float* __restr
 #pragma unroll
                         for (int s = 0; s < K; ++s) exitv[(uint64_t)c * K + s] = alpha[s];
                         have_alpha = true;
-                        const uint32_t old = fb_count[c];
-                        fb_count[c] = nfb;
-                        if (nfb != old) atomicAdd(&mdl->uniform_fallbacks, (unsigned long long)(long long)((int)nfb - (int)old));
+                        account(c, nfb);
                         atomicAdd(&mdl->forward_serial, 1ull);
                     }
                 }
@@ -342,6 +363,7 @@ __global__ __launch_bounds__(256) void hml_k_forward_serial(const float* __restr
         }
         __syncthreads();
     }
+    __threadfence_block();
     if (tid == 0) mdl->fwd_mismatch = 0u;
 }
 
