@@ -56,20 +56,25 @@ __device__ __forceinline__ int hml_categorical_k(const float (&w)[K], double u) 
 // suffix scan over the wavefront yields S_t = cand_t o ... o cand_{64c+64} for each row and the
 // chunk's map S_{64c+1}.
 // ------------------------------------------------------------------------------------------
+// row t = 64c + lane + 1 of backward chunk c (rows are stored by block b = t-1)
+template <int K>
+__device__ __forceinline__ void hml_bwd_row_load(const float* __restrict__ rows, const hml_layout lay, uint32_t c, int lane,
+                                                 uint32_t B, float (&r)[K]) {
+    const uint32_t t = c * HML_BWD_CHUNK + (uint32_t)lane + 1u;
+#pragma unroll
+    for (int i = 0; i < K; ++i) r[i] = (t <= B) ? rows[hml_bk(lay, t - 1u, K, i)] : 0.0f;
+}
+
 // the maps of backward chunk c (rows 64c+1 .. 64c+64), by one wavefront
 template <int K>
-__device__ __forceinline__ void hml_bwd_chunk_maps(const float* __restrict__ rows, hml_model* __restrict__ mdl,
+__device__ __forceinline__ void hml_bwd_chunk_maps(const float (&r)[K], hml_model* __restrict__ mdl,
                                                    unsigned long long* __restrict__ smap, unsigned long long* __restrict__ cmap,
-                                                   const hml_layout lay, uint32_t c, int lane, uint32_t B,
-                                                   unsigned long long epoch, const hml_key key) {
+                                                   uint32_t c, int lane, uint32_t B, unsigned long long epoch, const hml_key key) {
     const uint32_t t = c * HML_BWD_CHUNK + (uint32_t)lane + 1u;
     unsigned long long map = HML_MAP_IDENTITY;
     if (t <= B) {
         const hml_u32x4 o = hml_stream4(key, HML_KIND_CAT, epoch, t, 0);
         const double u = hml_canonical_f64(o.v[0], o.v[1]);
-        float r[K];
-#pragma unroll
-        for (int i = 0; i < K; ++i) r[i] = rows[hml_bk(lay, t - 1u, K, i)];   // rows are stored by block b = t-1
         map = 0ull;
         if (t == B) {
             const unsigned long long st = (unsigned long long)hml_categorical_k<K>(r, u);
@@ -119,6 +124,8 @@ __global__ __launch_bounds__(256) void hml_k_backward_maps(const float* __restri
     const int W = (int)mdl->fwd_W;
     const uint32_t C = (B + (uint32_t)L - 1u) / (uint32_t)L;
     for (uint32_t c = wave_global; c < nchunks; c += nwaves) {
+        float r[K];
+        hml_bwd_row_load<K>(rows, lay, c, lane, B, r);   // in flight together with the verification's loads
         // forward chunks that overlap blocks [64c, 64c+64): at most 64 of them, one per lane
         bool ok = true;
         {
@@ -134,7 +141,7 @@ __global__ __launch_bounds__(256) void hml_k_backward_maps(const float* __restri
             if (lane == 0) { mdl->fwd_mismatch = 1u; redo[c] = gen; }
             continue;
         }
-        hml_bwd_chunk_maps<K>(rows, mdl, smap, cmap, lay, c, lane, B, epoch, key);
+        hml_bwd_chunk_maps<K>(r, mdl, smap, cmap, c, lane, B, epoch, key);
     }
 }
 
@@ -168,7 +175,9 @@ __global__ __launch_bounds__(1024) void hml_k_backward_chain(unsigned long long*
             while (todo) {
                 const int j = __ffsll((long long)todo) - 1;
                 todo &= todo - 1ull;
-                hml_bwd_chunk_maps<K>(rows, mdl, smap, cmap, lay, c0 + (uint32_t)j, lane, B, epoch, key);
+                float r[K];
+                hml_bwd_row_load<K>(rows, lay, c0 + (uint32_t)j, lane, B, r);
+                hml_bwd_chunk_maps<K>(r, mdl, smap, cmap, c0 + (uint32_t)j, lane, B, epoch, key);
             }
         }
         __threadfence_block();

@@ -61,8 +61,14 @@ __global__ __launch_bounds__(1024) void hml_k_params(hml_model* __restrict__ mdl
     __shared__ unsigned long long s_trans[K * K];
     __shared__ unsigned long long s_occ[K];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    __shared__ float s_var[K];
     const unsigned long long epoch = mdl->epoch;
     const hml_key key = mdl->key;
+    // hyperparameters of this thread's variate, requested before the reductions below need the memory pipeline
+    float hyp0 = 0.0f, hyp1 = 0.0f, hyp2 = 0.0f, hyp3 = 0.0f;
+    if (wave == 0 && lane < K) { hyp0 = mdl->nig_post[lane][0]; hyp1 = mdl->nig_post[lane][1]; hyp2 = mdl->nig_post[lane][2]; hyp3 = mdl->nig_post[lane][3]; }
+    if (wave == 1 && lane < K) hyp0 = mdl->dirPi[lane];
+    if (tid >= 128 && tid < 128 + K * K) hyp0 = mdl->dirA[tid - 128];
 
     // gather the split integer accumulators
     if (tid >= 128 && tid < 128 + K * K) {
@@ -118,7 +124,7 @@ __global__ __launch_bounds__(1024) void hml_k_params(hml_model* __restrict__ mdl
 
     if (wave == 0 && lane < K) {
         const int k = lane;
-        float alpha = mdl->nig_post[k][0], beta = mdl->nig_post[k][1], mu0 = mdl->nig_post[k][2], nu = mdl->nig_post[k][3];
+        float alpha = hyp0, beta = hyp1, mu0 = hyp2, nu = hyp3;
         const unsigned long long cnt = (mode == 0) ? s_occ[k] : 0ull;   // n_s == occupancy (exact integers)
         if (mode == 0) { mdl->last_sum[k] = fin[k][0]; mdl->last_sumsq[k] = fin[k][1]; }
         if (cnt > 0ull) {
@@ -151,21 +157,26 @@ __global__ __launch_bounds__(1024) void hml_k_params(hml_model* __restrict__ mdl
         if (!hml_isfinite(m)) hml_raise(mdl, HML_DEVERR_MEAN_NOT_FINITE, m);
         if (!hml_isfinite(v)) hml_raise(mdl, HML_DEVERR_VAR_NOT_FINITE, v);
         else if (v <= 0.0f) hml_raise(mdl, HML_DEVERR_VAR_NOT_POSITIVE, v);
-        mdl->mu[k] = m; mdl->var[k] = v; mdl->sd[k] = HML_SQRTF(v);
+        const float sd = HML_SQRTF(v);
+        mdl->mu[k] = m; mdl->var[k] = v; mdl->sd[k] = sd;
+        if (mode == 0) {   // hml_derive's logNormalizer, from the registers instead of a round trip through memory
+            mdl->logN[k] = hml_logf(sd) + m * m / (2 * v);
+            s_var[k] = v;
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i) mdl->nig_post[k][i] = mdl->nig_prior[i];
     }
     if (mode != 2) {
         if (wave == 1 && lane < K) {
             const int k = lane;
-            const float al = mdl->dirPi[k] + (float)s_occ[k];
+            const float al = hyp0 + (float)s_occ[k];
             hml_dev_src src;
             src.s = hml_stream_open(key, HML_KIND_PI, epoch, (uint32_t)k);
             praw[k] = hml_gamma_f32<hml_devmath>(src, al, 1.0f);
         }
         if (tid >= 128 && tid < 128 + K * K) {
             const int e = tid - 128;
-            const float al = mdl->dirA[e] + (float)s_trans[e];
+            const float al = hyp0 + (float)s_trans[e];
             hml_dev_src src;
             src.s = hml_stream_open(key, HML_KIND_TRANS, epoch, (uint32_t)e);
             graw[e] = hml_gamma_f32<hml_devmath>(src, al, 1.0f);
@@ -180,6 +191,18 @@ __global__ __launch_bounds__(1024) void hml_k_params(hml_model* __restrict__ mdl
             for (int d = 0; d < K; ++d) sum += graw[tid * K + d];
 #pragma unroll
             for (int d = 0; d < K; ++d) mdl->A[tid * K + d] = graw[tid * K + d] / sum;
+            if (mode == 0) mdl->logA[tid] = hml_logf(graw[tid * K + tid] / sum);   // hml_derive's logA
+        }
+        if (mode == 0 && tid == 65) {
+            // hml_derive's threshold
+            float mv = HML_INF_F;
+#pragma unroll
+            for (int k = 0; k < K; ++k) { const float v = s_var[k]; mv = (v < mv) ? v : mv; }   // std::min(result, var)
+            const float l = hml_logf((float)mdl->T);
+            const float arg = 2 * l * mv;
+            const float t = HML_SQRTF(arg);
+            mdl->thr_theta = t;
+            if (mdl->dynamic) mdl->thr = t;
         }
         if (tid == 64) {
             float sum = 0.0f;
@@ -198,9 +221,11 @@ __global__ __launch_bounds__(1024) void hml_k_params(hml_model* __restrict__ mdl
             mdl->dirPi[k] = mdl->pi_alpha;
         }
     }
-    __threadfence_block();
-    __syncthreads();
-    hml_derive<K>(mdl, tid);
+    if (mode != 0) {
+        __threadfence_block();
+        __syncthreads();
+        hml_derive<K>(mdl, tid);
+    }
     if (tid == 1023) {
         // adapt the forward warm-up: double it whenever the serial repair had to run, shrink it slowly
         // after 32 sweeps without a single refit (speed only - the rows are bit-exact for every W)
