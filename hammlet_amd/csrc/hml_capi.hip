@@ -95,7 +95,8 @@ struct hml_ctx {
     // sweep buffers (allocated by set_model)
     float *d_em = nullptr, *d_gsc = nullptr, *d_rows = nullptr, *d_eprobe = nullptr, *d_aprobe = nullptr;
     float *d_entry = nullptr, *d_exitA = nullptr;
-    uint32_t* d_redo = nullptr;    // backward chunks whose maps the repair step must (re)compute, tagged with the sweep
+    uint32_t* d_redo = nullptr;    // backward chunks that failed the forward verification (list for the repair step)
+    uint32_t* d_touched = nullptr; // backward chunks whose rows the repair recomputed, tagged with the sweep
     uint32_t* d_fb = nullptr;
     unsigned long long *d_smap = nullptr, *d_cmap = nullptr;
     uint8_t* d_bentry = nullptr;
@@ -300,7 +301,7 @@ int hml_create(hml_ctx** out, int device, uint64_t seed, uint32_t chain_id, void
 
 static void free_all(hml_ctx* c) {
     void* ptrs[] = {c->d_group_word, c->d_launch_gen, c->d_summary, c->d_w, c->d_coeff, c->d_ia, c->d_stage, c->d_span_count, c->d_starts, c->d_bstat,
-                    c->d_em, c->d_gsc, c->d_rows, c->d_eprobe, c->d_aprobe, c->d_entry, c->d_exitA, c->d_redo, c->d_fb, c->d_coarse1,
+                    c->d_em, c->d_gsc, c->d_rows, c->d_eprobe, c->d_aprobe, c->d_entry, c->d_exitA, c->d_redo, c->d_touched, c->d_fb, c->d_coarse1,
                     c->d_smap, c->d_cmap, c->d_bentry, c->d_q, c->d_partial, c->d_diff, c->d_boundary, c->d_mdl};
     for (void* p : ptrs) if (p) hipFree(p);
     if (c->h_B) hipHostFree(c->h_B);
@@ -593,6 +594,8 @@ int hml_set_model(hml_ctx* c, int K, const float nig4[4], float a_off, float a_d
     HIPCHK(hipMalloc(&c->d_bentry, bchunks));
     HIPCHK(hipMalloc(&c->d_redo, bchunks * sizeof(uint32_t)));
     HIPCHK(hipMemsetAsync(c->d_redo, 0, bchunks * sizeof(uint32_t), c->stream));
+    HIPCHK(hipMalloc(&c->d_touched, bchunks * sizeof(uint32_t)));
+    HIPCHK(hipMemsetAsync(c->d_touched, 0, bchunks * sizeof(uint32_t), c->stream));
     HIPCHK(hipMalloc(&c->d_q, T * sizeof(int16_t)));
     HIPCHK(hipMalloc(&c->d_partial, (uint64_t)HML_REDUCE_GROUPS * K * 2 * sizeof(double)));
     HIPCHK(hipMemsetAsync(c->d_partial, 0, (uint64_t)HML_REDUCE_GROUPS * K * 2 * sizeof(double), c->stream));
@@ -741,7 +744,7 @@ static int sweep_k(hml_ctx* c, char method, bool record) {
                                s, c->d_rows, c->d_mdl, c->d_smap, c->d_cmap, c->lay, c->d_entry, c->d_exitA, c->d_redo, L);
             hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_backward_chain<KK>), dim3(1), dim3(1024), 0, s, c->d_cmap, c->d_mdl,
                                c->d_bentry, c->d_em, c->d_gsc, c->d_rows, c->probes ? c->d_aprobe : nullptr, c->d_entry,
-                               c->d_exitA, c->d_fb, c->d_redo, c->d_smap, L, c->lay);
+                               c->d_exitA, c->d_fb, c->d_redo, c->d_touched, c->d_smap, L, c->lay);
         }
         {
             ProfScope ps(c, "counts");

@@ -105,21 +105,20 @@ __device__ __forceinline__ void hml_bwd_chunk_maps(const float (&r)[K], hml_mode
 }
 
 // One wavefront per backward chunk.  It first verifies the forward chunks whose rows it is about to read
-// (start vector == predecessor's end vector, bit for bit; see hml_k_forward): a failed check raises
-// mdl->fwd_mismatch and leaves the chunk's maps to the repair step (redo[c] = gen).
+// (start vector == predecessor's end vector, bit for bit; see hml_k_forward): after a failed check the chunk
+// goes on the list of the repair step (fail_list, counted by mdl->fwd_mismatch), which also computes its maps.
 template <int K>
 __global__ __launch_bounds__(256) void hml_k_backward_maps(const float* __restrict__ rows, hml_model* __restrict__ mdl,
                                                            unsigned long long* __restrict__ smap,
                                                            unsigned long long* __restrict__ cmap, const hml_layout lay,
                                                            const float* __restrict__ entry, const float* __restrict__ exitv,
-                                                           uint32_t* __restrict__ redo, int L) {
+                                                           uint32_t* __restrict__ fail_list, int L) {
     const uint32_t B = mdl->B;
     const uint32_t nchunks = (B + HML_BWD_CHUNK - 1u) / HML_BWD_CHUNK;
     const int lane = threadIdx.x & 63;
     const uint32_t wave_global = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
     const unsigned long long epoch = mdl->epoch;
-    const uint32_t gen = (uint32_t)epoch + 1u;
     const hml_key key = mdl->key;
     const int W = (int)mdl->fwd_W;
     const uint32_t C = (B + (uint32_t)L - 1u) / (uint32_t)L;
@@ -138,7 +137,7 @@ __global__ __launch_bounds__(256) void hml_k_backward_maps(const float* __restri
             }
         }
         if (__ballot(!ok) != 0ull) {   // wave-uniform
-            if (lane == 0) { mdl->fwd_mismatch = 1u; redo[c] = gen; }
+            if (lane == 0) fail_list[atomicAdd(&mdl->fwd_mismatch, 1u)] = c;   // at most one entry per backward chunk
             continue;
         }
         hml_bwd_chunk_maps<K>(r, mdl, smap, cmap, c, lane, B, epoch, key);
@@ -154,34 +153,45 @@ __global__ __launch_bounds__(1024) void hml_k_backward_chain(unsigned long long*
                                                              const float* __restrict__ gsc, float* __restrict__ rows,
                                                              float* __restrict__ aprobe, float* __restrict__ entry,
                                                              float* __restrict__ exitv, uint32_t* __restrict__ fb_count,
-                                                             uint32_t* __restrict__ redo, unsigned long long* __restrict__ smap,
-                                                             int L, const hml_layout lay) {
+                                                             const uint32_t* __restrict__ fail_list, uint32_t* __restrict__ touched,
+                                                             unsigned long long* __restrict__ smap, int L, const hml_layout lay) {
     __shared__ unsigned long long P[1024];
-    __shared__ uint32_t bad[HML_SERIAL_WINDOW_WORDS];
+    __shared__ hml_repair_lds sh;
     const uint32_t B = mdl->B;
     const uint32_t NC = (B + HML_BWD_CHUNK - 1u) / HML_BWD_CHUNK;
     const int tid = threadIdx.x;
-    if (mdl->fwd_mismatch != 0u) {   // workgroup-uniform: written by the previous launch
+    const uint32_t n_fail = mdl->fwd_mismatch;   // workgroup-uniform: written by the previous launch
+    if (n_fail != 0u) {
         const unsigned long long epoch = mdl->epoch;
         const uint32_t gen = (uint32_t)epoch + 1u;
         const hml_key key = mdl->key;
-        hml_fwd_repair<K>(em, gsc, mdl, rows, aprobe, entry, exitv, fb_count, redo, gen, L, lay, bad);
-        __syncthreads();
-        // maps of the chunks that failed verification or whose rows were recomputed
+        hml_fwd_repair<K>(em, gsc, mdl, rows, aprobe, entry, exitv, fb_count, fail_list, n_fail, touched, gen, L, lay, sh);
+        // maps of the chunks that failed verification and of those whose rows were recomputed
         const int lane = tid & 63, wave = tid >> 6;
-        for (uint32_t c0 = (uint32_t)wave * 64u; c0 < NC; c0 += 16u * 64u) {
-            const uint32_t c = c0 + (uint32_t)lane;
-            unsigned long long todo = __ballot(c < NC && hml_ld_u32_coherent(redo + c) == gen);
-            while (todo) {
-                const int j = __ffsll((long long)todo) - 1;
-                todo &= todo - 1ull;
-                float r[K];
-                hml_bwd_row_load<K>(rows, lay, c0 + (uint32_t)j, lane, B, r);
-                hml_bwd_chunk_maps<K>(r, mdl, smap, cmap, c0 + (uint32_t)j, lane, B, epoch, key);
+        auto redo = [&](uint32_t c) {
+            float r[K];
+            hml_bwd_row_load<K>(rows, lay, c, lane, B, r);
+            hml_bwd_chunk_maps<K>(r, mdl, smap, cmap, c, lane, B, epoch, key);
+        };
+        for (uint32_t i = (uint32_t)wave; i < n_fail; i += 16u) redo(fail_list[i]);
+        const uint32_t n_touched = sh.tcount;
+        if (n_touched <= (uint32_t)HML_REPAIR_TOUCHED_CAP) {
+            for (uint32_t i = (uint32_t)wave; i < n_touched; i += 16u) redo(sh.tlist[i]);
+        } else {
+            // the list overflowed: scan the marks in memory
+            for (uint32_t c0 = (uint32_t)wave * 64u; c0 < NC; c0 += 16u * 64u) {
+                const uint32_t c = c0 + (uint32_t)lane;
+                unsigned long long todo = __ballot(c < NC && hml_ld_u32_coherent(touched + c) == gen);
+                while (todo) {
+                    const int j = __ffsll((long long)todo) - 1;
+                    todo &= todo - 1ull;
+                    redo(c0 + (uint32_t)j);
+                }
             }
         }
         __threadfence_block();
         __syncthreads();
+        if (tid == 0) mdl->fwd_mismatch = 0u;
     }
     const uint32_t per = (NC + 1023u) / 1024u;
     const uint32_t a = (uint32_t)tid * per < NC ? (uint32_t)tid * per : NC;

@@ -255,82 +255,124 @@ __device__ __forceinline__ bool hml_fwd_chunk_consistent(const float* __restrict
 }
 
 // ------------------------------------------------------------------------------------------
-// Repair, by ONE workgroup, only when the verification found a chunk whose start vector is not its
-// predecessor's end vector (mdl->fwd_mismatch).  Windows of 2^18 chunks, an LDS bitmap per window:
-//   1. mark the inconsistent chunks (all threads), then recompute each of them after a 16x longer warm-up
-//      (one thread per marked chunk) - the neighbour is not trusted, it may be stale too; this ends in the
-//      true vector unless the filter hardly forgets at all;
-//   2. mark again; one lane visits the still-inconsistent chunks in increasing order, recomputes each from its
-//      predecessor's true end vector and follows the chain while the recomputed end vector makes the next
-//      chunk inconsistent.  After this pass induction from chunk 0 holds: the rows are the sequential ones.
-// Every recomputed chunk marks its backward chunk in redo[] (= gen) so that the caller recomputes its maps.
+// Repair, by ONE workgroup, only when the verification found chunks whose start vector is not their
+// predecessor's end vector.  The backward-map kernel lists the backward chunks it could not verify
+// (fail_list, n_fail entries); all work here is proportional to that list, not to B.  Forward chunks are
+// handled in windows of 2^17 (two LDS bitmaps):
+//   1. the stale forward chunks of the listed backward chunks are marked and each is recomputed after a 2x
+//      longer warm-up (one thread per chunk) - the neighbour is not trusted, it may be stale too; every
+//      recomputed chunk and its successor are checked again, and what is still inconsistent repeats the step
+//      with 4x, 8x, 16x: this ends in the true vectors unless the filter hardly forgets at all;
+//   2. one lane visits the chunks that are inconsistent even then in increasing order, recomputes each from its predecessor's true end vector and follows the chain
+//      while the recomputed end vector makes the next chunk inconsistent.  After this pass induction from
+//      chunk 0 holds: the rows are the sequential ones.
+// Every recomputed chunk puts its backward chunk on the touched list (LDS, and touched[] = gen in memory in
+// case the list overflows) so that the caller recomputes its maps.
 // ------------------------------------------------------------------------------------------
-#define HML_SERIAL_WINDOW_WORDS 8192   // 2^18 chunks per window
+#define HML_REPAIR_WINDOW_WORDS 4096   // 2^17 forward chunks per window
+#define HML_REPAIR_TOUCHED_CAP 2048
+struct hml_repair_lds {
+    uint32_t bad[HML_REPAIR_WINDOW_WORDS];    // stale after the speculative pass
+    uint32_t bad2[HML_REPAIR_WINDOW_WORDS];   // still inconsistent after the long warm-up
+    uint32_t tlist[HML_REPAIR_TOUCHED_CAP];
+    uint32_t tcount;
+    uint32_t next_first_bad;                  // the first chunk of the next window became inconsistent
+    uint32_t any_bad;
+};
+
 template <int K>
 __device__ void hml_fwd_repair(const float* __restrict__ em, const float* __restrict__ gsc, hml_model* __restrict__ mdl,
                                float* __restrict__ rows, float* __restrict__ aprobe, float* __restrict__ entry,
-                               float* __restrict__ exitv, uint32_t* __restrict__ fb_count, uint32_t* __restrict__ redo,
-                               uint32_t gen, int L, const hml_layout lay, uint32_t* bad /* LDS, HML_SERIAL_WINDOW_WORDS */) {
+                               float* __restrict__ exitv, uint32_t* __restrict__ fb_count,
+                               const uint32_t* __restrict__ fail_list, uint32_t n_fail, uint32_t* __restrict__ touched,
+                               uint32_t gen, int L, const hml_layout lay, hml_repair_lds& sh) {
     hml_fwd_ctx<K> cx;
     hml_fwd_ctx_load<K>(cx, mdl);
     const uint32_t B = cx.B;
     const int W = (int)mdl->fwd_W;
     const uint32_t C = (B + (uint32_t)L - 1u) / (uint32_t)L;
     const int tid = threadIdx.x, nthr = blockDim.x;
-    const uint32_t win = HML_SERIAL_WINDOW_WORDS * 32u;
-    auto mark_window = [&](uint32_t w0, uint32_t w1) {
-        for (int i = tid; i < HML_SERIAL_WINDOW_WORDS; i += nthr) bad[i] = 0u;
-        __syncthreads();
-        for (uint32_t c = w0 + (uint32_t)tid; c < w1; c += (uint32_t)nthr) {
-            if (hml_fwd_chunk_exact(c, L, W)) continue;
-            if (!hml_fwd_chunk_consistent<K>(entry, exitv, c)) atomicOr(&bad[(c - w0) >> 5], 1u << ((c - w0) & 31u));
-        }
-        __syncthreads();
-    };
+    const uint32_t win = HML_REPAIR_WINDOW_WORDS * 32u;
+    const uint32_t nfper = HML_BWD_CHUNK / (uint32_t)L + 1u;   // forward chunks that can overlap one backward chunk
     auto account = [&](uint32_t c, uint32_t nfb) {
         const uint32_t old = fb_count[c];
         fb_count[c] = nfb;
         // keep the global tally of uniform fallbacks consistent (two's-complement delta on the unsigned counter)
         if (nfb != old) atomicAdd(&mdl->uniform_fallbacks, (unsigned long long)(long long)((int)nfb - (int)old));
-        redo[((uint64_t)c * (uint32_t)L) / HML_BWD_CHUNK] = gen;
-        if (L > (int)HML_BWD_CHUNK) {   // (a forward chunk longer than a backward chunk covers several)
-            for (uint32_t b = c * (uint32_t)L; b < (c + 1u) * (uint32_t)L && b < B; b += HML_BWD_CHUNK) redo[b / HML_BWD_CHUNK] = gen;
+        for (uint32_t b = c * (uint32_t)L; b < (c + 1u) * (uint32_t)L && b < B; b += HML_BWD_CHUNK) {
+            const uint32_t bc = b / HML_BWD_CHUNK;
+            touched[bc] = gen;
+            const uint32_t k = atomicAdd(&sh.tcount, 1u);
+            if (k < (uint32_t)HML_REPAIR_TOUCHED_CAP) sh.tlist[k] = bc;
         }
     };
-    if (tid == 0) mdl->fwd_serial_ran = 1u;   // the parameter kernel lengthens the warm-up for the next sweeps
-    // ---- 1. long warm-up, in parallel
+    if (tid == 0) { mdl->fwd_serial_ran = 1u; sh.tcount = 0u; sh.next_first_bad = 0u; }   // (the parameter kernel lengthens the warm-up)
+    __syncthreads();
     for (uint32_t w0 = 0; w0 < C; w0 += win) {
         const uint32_t w1 = (w0 + win < C) ? w0 + win : C;
-        mark_window(w0, w1);
-        for (uint32_t c = w0 + (uint32_t)tid; c < w1; c += (uint32_t)nthr) {   // one thread per marked chunk
-            if (((bad[(c - w0) >> 5] >> ((c - w0) & 31u)) & 1u) == 0u) continue;
-            const uint32_t first = c * (uint32_t)L;
-            const uint32_t last = (first + (uint32_t)L < B) ? first + (uint32_t)L : B;
-            const uint32_t Wl = (uint32_t)W * 16u;
-            const uint32_t ws = (first >= Wl) ? first - Wl : 0u;
-            float alpha[K];
-            uint32_t nfb = 0;
+        for (int i = tid; i < HML_REPAIR_WINDOW_WORDS; i += nthr) { sh.bad[i] = 0u; sh.bad2[i] = 0u; }
+        __syncthreads();
+        if (tid == 0 && sh.next_first_bad) { sh.bad2[0] = 1u; sh.next_first_bad = 0u; }
+        // ---- 1a. stale forward chunks of the listed backward chunks
+        for (uint64_t i = (uint64_t)tid; i < (uint64_t)n_fail * nfper; i += (uint64_t)nthr) {
+            const uint32_t cb = fail_list[i / nfper];
+            const uint32_t f = (cb * HML_BWD_CHUNK) / (uint32_t)L + (uint32_t)(i % nfper);
+            if (f > (cb * HML_BWD_CHUNK + HML_BWD_CHUNK - 1u) / (uint32_t)L || f >= C || f < w0 || f >= w1) continue;
+            // a forward chunk longer than a backward chunk is listed by each of them: the one that holds its first
+            // block takes it
+            if ((uint32_t)(((uint64_t)f * (uint32_t)L) / HML_BWD_CHUNK) != cb) continue;
+            if (hml_fwd_chunk_exact(f, L, W)) continue;
+            bool same = true;
 #pragma unroll
-            for (int s = 0; s < K; ++s) alpha[s] = (ws == 0u) ? mdl->pi[s] : cx.invK;
-            hml_fwd_run<K, false>(cx, alpha, em, gsc, rows, aprobe, ws, first, nfb, lay);
-#pragma unroll
-            for (int s = 0; s < K; ++s) entry[(uint64_t)c * K + s] = alpha[s];
-            hml_fwd_run<K, true>(cx, alpha, em, gsc, rows, aprobe, first, last, nfb, lay);
-#pragma unroll
-            for (int s = 0; s < K; ++s) exitv[(uint64_t)c * K + s] = alpha[s];
-            account(c, nfb);
-            atomicAdd(&mdl->forward_refits, 1ull);
+            for (int s = 0; s < K; ++s) same = same && (hml_f2u(entry[(uint64_t)f * K + s]) == hml_f2u(exitv[(uint64_t)(f - 1) * K + s]));
+            if (!same) atomicOr(&sh.bad[(f - w0) >> 5], 1u << ((f - w0) & 31u));
         }
         __syncthreads();
-    }
-    __threadfence_block();
-    // ---- 2. what is still inconsistent, serially
-    for (uint32_t w0 = 0; w0 < C; w0 += win) {
-        const uint32_t w1 = (w0 + win < C) ? w0 + win : C;
-        mark_window(w0, w1);
+        // ---- 1b / 2a. recompute the marked chunks after a longer warm-up (one thread per chunk), check them and
+        // their successors again (loads that bypass the L1), and escalate what is still inconsistent: 2W, 4W, 8W, 16W
+        for (uint32_t factor = 2u; factor <= 16u; factor *= 2u) {
+            for (uint32_t c = w0 + (uint32_t)tid; c < w1; c += (uint32_t)nthr) {
+                if (((sh.bad[(c - w0) >> 5] >> ((c - w0) & 31u)) & 1u) == 0u) continue;
+                if (hml_fwd_chunk_exact(c, L, W)) continue;   // (a successor that was only to be re-checked)
+                const uint32_t first = c * (uint32_t)L;
+                const uint32_t last = (first + (uint32_t)L < B) ? first + (uint32_t)L : B;
+                const uint32_t Wl = (uint32_t)W * factor;
+                const uint32_t ws = (first >= Wl) ? first - Wl : 0u;
+                float alpha[K];
+                uint32_t nfb = 0;
+#pragma unroll
+                for (int s = 0; s < K; ++s) alpha[s] = (ws == 0u) ? mdl->pi[s] : cx.invK;
+                hml_fwd_run<K, false>(cx, alpha, em, gsc, rows, aprobe, ws, first, nfb, lay);
+#pragma unroll
+                for (int s = 0; s < K; ++s) entry[(uint64_t)c * K + s] = alpha[s];
+                hml_fwd_run<K, true>(cx, alpha, em, gsc, rows, aprobe, first, last, nfb, lay);
+#pragma unroll
+                for (int s = 0; s < K; ++s) exitv[(uint64_t)c * K + s] = alpha[s];
+                account(c, nfb);
+                atomicAdd(&mdl->forward_refits, 1ull);
+            }
+            __threadfence_block();
+            __syncthreads();
+            if (tid == 0) sh.any_bad = 0u;
+            __syncthreads();
+            for (uint32_t c = w0 + (uint32_t)tid; c < w1; c += (uint32_t)nthr) {
+                if (((sh.bad[(c - w0) >> 5] >> ((c - w0) & 31u)) & 1u) == 0u) continue;
+                for (uint32_t cc = c; cc <= c + 1u && cc < C; ++cc) {
+                    if (hml_fwd_chunk_exact(cc, L, W) || hml_fwd_chunk_consistent<K>(entry, exitv, cc)) continue;
+                    if (cc < w1) { atomicOr(&sh.bad2[(cc - w0) >> 5], 1u << ((cc - w0) & 31u)); sh.any_bad = 1u; }
+                    else sh.next_first_bad = 1u;
+                }
+            }
+            __syncthreads();
+            if (sh.any_bad == 0u || factor == 16u) break;   // workgroup-uniform
+            // escalate: the still-inconsistent chunks become the marked ones
+            for (int i = tid; i < HML_REPAIR_WINDOW_WORDS; i += nthr) { sh.bad[i] = sh.bad2[i]; sh.bad2[i] = 0u; }
+            __syncthreads();
+        }
+        // ---- 2b. what is still inconsistent, serially
         if (tid == 0) {
             for (uint32_t wi = 0; wi < (w1 - w0 + 31u) / 32u; ++wi) {
-                uint32_t bits = bad[wi];
+                uint32_t bits = sh.bad2[wi];
                 while (bits) {
                     const int bit = __ffs(bits) - 1;
                     bits &= bits - 1u;
@@ -361,10 +403,9 @@ __device__ void hml_fwd_repair(const float* __restrict__ em, const float* __rest
                 }
             }
         }
+        __threadfence_block();
         __syncthreads();
     }
-    __threadfence_block();
-    if (tid == 0) mdl->fwd_mismatch = 0u;
 }
 
 #endif

@@ -15,5 +15,7 @@ ch.iterate("F", 40, 0); ch.sync()
 s0 = ch.stats()
 t0 = time.perf_counter(); ch.iterate("F", n, 0); ch.sync(); t1 = time.perf_counter()
 s1 = ch.stats()
-print("%s: %.4f ms/sweep, %.3e block-updates/s, refits %d serial %d" % (wl, 1e3 * (t1 - t0) / n, (s1["block_updates"] - s0["block_updates"]) / (t1 - t0),
-      s1["forward_refits"] - s0["forward_refits"], s1["forward_serial"] - s0["forward_serial"]))
+print("%s: %.4f ms/sweep, %.3e block-updates/s, refits %d serial %d, warm-up %d -> %d, B %d" % (
+      wl, 1e3 * (t1 - t0) / n, (s1["block_updates"] - s0["block_updates"]) / (t1 - t0),
+      s1["forward_refits"] - s0["forward_refits"], s1["forward_serial"] - s0["forward_serial"], s0["forward_warmup"], s1["forward_warmup"],
+      (s1["block_updates"] - s0["block_updates"]) // n))
