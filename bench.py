@@ -37,15 +37,15 @@ WORKLOADS = {
 PMC_FILE = "profiles/round1_pmc_hbm_traffic.json"
 
 
-def pmc_traffic(workload):
-    """HBM bytes per launch of the scan kernel from the committed rocprofv3 --pmc passes of this same command
-    (FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE); PMC counters cannot be collected from inside
-    the timed run, so the JSON line quotes the profile."""
+def pmc_traffic(workload, which="scan_kernel"):
+    """HBM bytes per launch of a kernel from the committed rocprofv3 --pmc passes of this same command
+    (FETCH_SIZE doubled per the gfx950 correction for wide coalesced reads + WRITE_SIZE; tools/pmc_summary.py);
+    PMC counters cannot be collected from inside the timed run, so the JSON line quotes the profile."""
     try:
         if workload != "c3_1e8_k5_dynamic":
             return None
         with open(os.path.join(REPO, PMC_FILE)) as f:
-            return json.load(f)["scan_kernel"]["hbm_bytes_per_launch_corrected"]
+            return json.load(f)[which]["hbm_bytes_per_launch_corrected"]
     except Exception:
         return None
 
@@ -236,7 +236,8 @@ def main():
             out["float_stream"] = {"value": bl2 / el2, "unit": "block-updates/s", "ms_per_step": 1e3 * el2 / args.steps,
                                    "roofline": {"bound": "hbm", "kernel": "hml_k_compact_scan (all T float weights)",
                                                 "achieved": f_bytes / f_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                                "frac": f_bytes / f_s / 1e9 / HBM_PEAK_GBS, "kernel_avg_us": 1e6 * f_s,
+                                                "frac": f_bytes / f_s / 1e9 / HBM_PEAK_GBS, "traffic": pmc_traffic(args.workload, "float_scan_kernel"),
+                                                "kernel_avg_us": 1e6 * f_s,
                                                 "bytes_per_launch": f_bytes, "launches": f_n},
                                    "note": "same chain, same results; the default path above replaces this stream by the group summary"}
 
