@@ -325,6 +325,38 @@ def test_forward_repair_paths_on_twin_states(hml):
     compare_state(o, g)
 
 
+def test_forward_repair_across_windows_without_compression(hml):
+    """The same adversarial parameters on an uncompressed trace (`-m 1e9`: every position is its own block, so the
+    emissions hardly inform and nearly every chunk is stale): 6*10^5 blocks = 1.5*10^5 forward chunks, more than one
+    2^17-chunk window of the repair step, failures in most backward chunks, long serial chains."""
+    T, K = 600_000, 3
+    x = ol.trace(T, 3, 1)
+    xx, o, g = make_pair(hml, T, K, 0, 1, x=x, weight_mult=1e9)
+    setup_model(o, g, K)
+    o.token("F")
+    g.sample_prior()
+    mv = np.array([-1.0, 0.04, 0.5, 0.04, 0.5, 0.04], np.float32)    # states 1 and 2 are twins
+    A = np.array([[0.999, 0.0005, 0.0005], [0.0005, 0.9994, 0.0001], [0.0005, 0.0001, 0.9994]], np.float32)
+    pi = np.array([0.2, 0.5, 0.3], np.float32)
+    o.set_params(mv, A, pi)
+    g.set_parameters(mv, A, pi)
+    o.set_probes(True)
+    g.enable_probes(True)
+    s0 = g.stats()
+    o.iterate("F", 1, 0)
+    g.iterate("F", 1, 0)
+    g.sync()
+    s1 = g.stats()
+    assert len(g.blocks()) - 1 == T
+    assert np.array_equal(bits(o.forward_rows()), bits(g.forward_rows()))
+    assert np.array_equal(o.states(), g.states())
+    assert s1["forward_refits"] > s0["forward_refits"]
+    o.iterate("F", 3, 0)
+    g.iterate("F", 3, 0)
+    g.sync()
+    compare_state(o, g)
+
+
 def test_config2_static_block_structure(hml):
     """BASELINE.json configs[1] shape (10^7 positions, 5 states, fixed wavelet block structure), shortened:
     mixture burn-in, S, P, then FB sweeps with thinning - against the checker."""
