@@ -218,18 +218,6 @@ __global__ __launch_bounds__(1024) void hml_k_backward_chain(unsigned long long*
     }
 }
 
-// K7c backward_apply - q_b = S_{b+1}(entry[chunk])
-__global__ __launch_bounds__(256) void hml_k_backward_apply(const unsigned long long* __restrict__ smap,
-                                                            const uint8_t* __restrict__ entry,
-                                                            const hml_model* __restrict__ mdl, int16_t* __restrict__ q) {
-    const uint32_t B = mdl->B;
-    const uint32_t stride = gridDim.x * blockDim.x;
-    for (uint32_t b = blockIdx.x * blockDim.x + threadIdx.x; b < B; b += stride) {
-        const unsigned x = entry[b / HML_BWD_CHUNK];
-        q[b] = (int16_t)((smap[b + 1] >> (4 * x)) & 15ull);
-    }
-}
-
 // ------------------------------------------------------------------------------------------
 // K6m mixture - StateSequence<Mixture>::sample (reference src/StateSequence/Mixture.hpp:90-129):
 // q_b ~ Cat(expf(E_s - max E)) independently per block, uniform from sub-stream (MIX, epoch, b).
@@ -266,7 +254,7 @@ __device__ __forceinline__ double hml_shfl_xor_f64(double v, int m) {
     return hml_u2d(((unsigned long long)hi << 32) | lo);
 }
 
-// FB = true: the states come straight from the backward maps (q_b = S_{b+1}(entry[chunk]), K7c) and are
+// FB = true: the states come straight from the backward maps (q_b = S_{b+1}(entry[chunk])) and are
 // written to q[] on the way; FB = false (mixture sweeps): q[] was written by the mixture kernel.
 template <int K, bool FB>
 __global__ __launch_bounds__(256) void hml_k_counts(int16_t* __restrict__ q, const uint32_t* __restrict__ starts,

@@ -1,4 +1,7 @@
-// Per-sweep block structure: threshold scan + compaction (the HBM-bound kernel) and block statistics.
+// Per-sweep block structure, the separate-launch form: threshold scan (float stream or group summary) +
+// compaction, and block statistics.  Dynamic sweeps normally use hml_k_blocks_fused.h, which shares the summary
+// scan's building blocks from this file; these kernels serve explicit thresholds (hml_create_blocks, the auto
+// prior), weakly compressed sweeps and weight_keys = 0.
 #ifndef HML_K_BLOCKS_H
 #define HML_K_BLOCKS_H
 
@@ -13,10 +16,10 @@
 //   (a) scan:    one wavefront per span of 4096 positions, 16 x (64 lanes x float4) coalesced loads
 //                issued up-front; flagged positions are written, in order, as 16-bit offsets into
 //                the span's slot of a staging array; the span's count goes to span_count[].
-//   (b) scatter: every span's wavefront derives its global offset from the totals of the 64-span groups
-//                before it (a tiny kernel sums them, one wavefront per group) plus the counts of the
-//                <= 63 spans before it in its own group - a handful of coalesced reads instead of a
-//                serial scan launch - and turns the staged offsets into starts[], starts[B] = T.
+//   (b) scatter: one workgroup per group of 16 spans derives the group's global offset from the totals of
+//                the groups before it (summed once per workgroup) plus the counts of the spans before each
+//                span inside the group - a handful of coalesced reads instead of a serial scan launch -
+//                and turns the staged offsets into starts[], starts[B] = T.
 //   A decoupled look-back single-pass version was measured and rejected: with ~8000 one-span tiles in
 //   flight its first generation serialises ~128 look-back windows (318 us vs 64 us for the scan alone).
 // Nothing but flagged positions is ever written, so at typical compression (1 start per ~500
@@ -24,7 +27,6 @@
 // ------------------------------------------------------------------------------------------
 
 typedef float hml_f4 __attribute__((ext_vector_type(4)));
-typedef uint32_t hml_u4 __attribute__((ext_vector_type(4)));
 
 __global__ __launch_bounds__(256) void hml_k_compact_scan(const float* __restrict__ w, uint32_t T,
                                                           const hml_model* __restrict__ mdl, float thr_override,
