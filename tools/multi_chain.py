@@ -1,0 +1,33 @@
+"""Several independent chains on ONE GPU, each on its own stream and host thread: aggregate block-updates/s.
+    python tools/multi_chain.py [chains] [sweeps] [workload]"""
+import os, sys, threading, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench, hammlet_amd
+R = int(sys.argv[1]) if len(sys.argv) > 1 else 4
+n = int(sys.argv[2]) if len(sys.argv) > 2 else 500
+wl = sys.argv[3] if len(sys.argv) > 3 else "c3_1e8_k5_dynamic"
+T, K, levels, sigma, dwell, data_seed = bench.WORKLOADS[wl]
+x = hammlet_amd.synth_gauss(T, K, levels, sigma, dwell, data_seed, nthreads=8)
+chains = []
+for r in range(R):
+    ch = hammlet_amd.Chain(device=0, seed=1, chain_id=r)
+    ch.load(x)
+    ch.set_model(K, ch.autoprior(0.2, 0.9))
+    ch.sample_prior()
+    ch.set_recording(marginals=False)
+    ch.iterate("F", 40, 0)
+    chains.append(ch)
+for ch in chains:
+    ch.sync()
+s0 = [ch.stats() for ch in chains]
+def run(ch):
+    ch.iterate("F", n, 0)
+    ch.sync()
+ths = [threading.Thread(target=run, args=(ch,)) for ch in chains]
+t0 = time.perf_counter()
+for t in ths: t.start()
+for t in ths: t.join()
+t1 = time.perf_counter()
+blocks = sum(ch.stats()["block_updates"] - s["block_updates"] for ch, s in zip(chains, s0))
+print("%d chains x %d sweeps on one GPU: %.4f ms per sweep-round, %.3e block-updates/s aggregate (%.3e per chain)" % (
+    R, n, 1e3 * (t1 - t0) / n, blocks / (t1 - t0), blocks / (t1 - t0) / R))
