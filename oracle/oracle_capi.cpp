@@ -96,6 +96,15 @@ void orc_set_params(void* h, const float* mean_var, const float* A, const float*
     memcpy(o->A.data(), A, (size_t)K * K * 4); memcpy(o->pi.data(), pi, K * 4);
     o->sample_prior_pending = false;
 }
+// emission terms of the CURRENT block list (orc_enumerate_blocks) under the current theta, without the
+// self-transition term: innerProduct - N * logNormalizer (EFD.hpp:23-38, ForwardBackward.hpp:74-76)
+void orc_eval_emission(void* h, float* E) {
+    Oracle* o = (Oracle*)h; const int K = o->cfg.K; const size_t B = o->starts.size() - 1;
+    for (size_t b = 0; b < B; ++b) {
+        const float N = (float)(o->starts[b + 1] - o->starts[b]);
+        for (int s = 0; s < K; ++s) E[b * K + s] = (0.0f + o->emission_ip(o->bs_s[b], o->bs_q[b], s)) - N * o->log_normalizer(s);
+    }
+}
 void orc_get_loglik(void* h, float* E) { Oracle* o = (Oracle*)h; memcpy(E, o->lastE.data(), o->lastE.size() * 4); }
 void orc_get_forward_rows(void* h, float* rows) { Oracle* o = (Oracle*)h; memcpy(rows, o->fwd_rows.data(), o->fwd_rows.size() * 4); }
 void orc_get_counts(void* h, uint64_t* trans, uint64_t* occ, float* sum_s, float* sum_q, uint64_t* nterms) {

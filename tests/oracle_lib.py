@@ -51,6 +51,7 @@ def load():
         getattr(lib, n).argtypes = [_P, _P]
     lib.orc_get_integral.argtypes = [_P, _P, _P]
     lib.orc_get_block_stats.argtypes = [_P, _P, _P]
+    lib.orc_eval_emission.argtypes = [_P, _P]
     lib.orc_set_params.argtypes = [_P, _P, _P, _P]
     lib.orc_get_counts.argtypes = [_P] * 6
     lib.orc_get_posterior.argtypes = [_P] * 4
@@ -225,6 +226,12 @@ class OracleChain:
 
     def loglik(self):
         return self._arr("orc_get_loglik", self.num_blocks() * self.K, np.float32).reshape(-1, self.K)
+
+    def emission_terms(self):
+        """innerProduct - N * logNormalizer of the current block list under the current theta (no self-transition term)"""
+        E = np.empty((self.num_blocks(), self.K), np.float32)
+        self.lib.orc_eval_emission(self.h, E.ctypes.data)
+        return E
 
     def forward_rows(self):
         return self._arr("orc_get_forward_rows", (self.num_blocks() + 1) * self.K, np.float32).reshape(-1, self.K)
