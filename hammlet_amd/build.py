@@ -30,20 +30,50 @@ def _sources():
     out = []
     for root in (CSRC, os.path.join(REPO_DIR, "include")):
         for dp, _, fns in os.walk(root):
+            if os.path.basename(dp) == "build":
+                continue
             out += [os.path.join(dp, f) for f in fns if f.endswith((".h", ".hpp", ".hip", ".cpp"))]
     return out
 
 
+OBJ_DIR = os.path.join(CSRC, "build")
+
+
+def _deps(depfile, fallback):
+    """prerequisites recorded by `hipcc -MMD` for one object (all sources if there is no record yet)"""
+    try:
+        with open(depfile) as f:
+            text = f.read().replace("\\\n", " ")
+        deps = [d for d in text.split(":", 1)[1].split() if os.path.exists(d)]
+        return deps or fallback
+    except (OSError, IndexError):
+        return fallback
+
+
+def _run(cmd, verbose):
+    if verbose:
+        print(" ".join(cmd))
+    r = subprocess.run(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE if not verbose else None, text=True)
+    if r.returncode != 0:
+        errs = [l for l in (r.stderr or "").splitlines() if "error" in l or "note:" in l]
+        raise RuntimeError("hipcc failed:\n" + "\n".join(errs[:40]))
+
+
 def build_library(force=False, verbose=False):
-    """hipcc --offload-arch=gfx950 ... -shared -o hammlet_amd/libhammlet_hip.so"""
-    if force or _newer(LIB_PATH, _sources()):
-        cmd = [_hipcc()] + HIPCC_FLAGS + ["-shared", "-o", LIB_PATH, os.path.join(CSRC, "hml_capi.hip")]
-        if verbose:
-            print(" ".join(cmd))
-        r = subprocess.run(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE if not verbose else None, text=True)
-        if r.returncode != 0:
-            errs = [l for l in (r.stderr or "").splitlines() if "error" in l or "note:" in l]
-            raise RuntimeError("hipcc failed:\n" + "\n".join(errs[:40]))
+    """every hammlet_amd/csrc/*.hip -> object (hipcc --offload-arch=gfx950 -c) -> hammlet_amd/libhammlet_hip.so"""
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    units = sorted(f for f in os.listdir(CSRC) if f.endswith(".hip"))
+    objs, relink = [], force or not os.path.exists(LIB_PATH)
+    for u in units:
+        src = os.path.join(CSRC, u)
+        obj = os.path.join(OBJ_DIR, u[:-4] + ".o")
+        dep = obj[:-2] + ".d"
+        if force or _newer(obj, _deps(dep, _sources())):
+            _run([_hipcc()] + HIPCC_FLAGS + ["-MMD", "-MF", dep, "-c", "-o", obj, src], verbose)
+            relink = True
+        objs.append(obj)
+    if relink or _newer(LIB_PATH, objs):
+        _run([_hipcc()] + HIPCC_FLAGS + ["-shared", "-o", LIB_PATH] + objs, verbose)
     return LIB_PATH
 
 

@@ -36,6 +36,14 @@ SIGNATURES = {
     "hml_destroy": (None, [_P]),
     "hml_load_observations": (C.c_int, [_P, _P, C.c_uint64]),
     "hml_load_observations_device": (C.c_int, [_P, _P, C.c_uint64]),
+    "hml_text_open": (C.c_int, [C.POINTER(_P), C.c_int, C.c_uint64]),
+    "hml_text_close": (None, [_P]),
+    "hml_text_buffer": (C.c_int, [_P, C.POINTER(_P), C.POINTER(C.c_uint64)]),
+    "hml_text_commit": (C.c_int, [_P, C.c_uint64]),
+    "hml_text_feed": (C.c_int, [_P, C.c_char_p, C.c_uint64]),
+    "hml_text_finish": (C.c_int, [_P, C.POINTER(C.c_uint64), C.POINTER(C.c_int)]),
+    "hml_text_values": (C.c_int, [_P, _P]),
+    "hml_text_counters": (C.c_int, [_P, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "hml_noise_sigma": (C.c_int, [_P, C.POINTER(C.c_double)]),
     "hml_scale_weights": (C.c_int, [_P, C.c_float]),
     "hml_autoprior": (C.c_int, [_P, C.c_float, C.c_float, _P]),
@@ -96,6 +104,43 @@ def load_library(path=None):
 def _check(rc):
     if rc != 0:
         raise HmlError(rc, load_library().hml_last_error().decode())
+
+
+def parse_text(source, device=0, chunk_bytes=0, feed_bytes=None, with_info=False):
+    """The float32 values that the reference's reader (`while ( input >> v )`, reference src/wavelet.hpp:131)
+    extracts from whitespace-separated decimal text, converted on the GPU.  `source`: bytes or a file path.
+    Returns the array (and, with_info, a dict: stopped, bytes, irregular_tokens, host_chunks)."""
+    lib = load_library()
+    h = _P()
+    _check(lib.hml_text_open(C.byref(h), device, chunk_bytes))
+    try:
+        if isinstance(source, (bytes, bytearray, memoryview)):
+            data = bytes(source)
+            step = feed_bytes or max(len(data), 1)
+            for i in range(0, len(data), step):
+                part = data[i:i + step]
+                _check(lib.hml_text_feed(h, part, len(part)))
+        else:
+            with open(source, "rb", buffering=0) as f:
+                while True:
+                    buf, cap = _P(), C.c_uint64()
+                    _check(lib.hml_text_buffer(h, C.byref(buf), C.byref(cap)))
+                    view = (C.c_char * cap.value).from_address(buf.value)
+                    n = f.readinto(view)
+                    if not n:
+                        break
+                    _check(lib.hml_text_commit(h, n))
+        n, stopped = C.c_uint64(), C.c_int()
+        _check(lib.hml_text_finish(h, C.byref(n), C.byref(stopped)))
+        out = np.empty(n.value, np.float32)
+        _check(lib.hml_text_values(h, out.ctypes.data))
+        if not with_info:
+            return out
+        a, b, c = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        _check(lib.hml_text_counters(h, C.byref(a), C.byref(b), C.byref(c)))
+        return out, {"stopped": bool(stopped.value), "bytes": a.value, "irregular_tokens": b.value, "host_chunks": c.value}
+    finally:
+        lib.hml_text_close(h)
 
 
 def synth_gauss(T, K, mu, sigma, dwell, seed, nthreads=8, with_states=False):

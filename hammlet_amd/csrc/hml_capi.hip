@@ -22,17 +22,11 @@
 #include "hml_state.h"
 #include "hml_synth_host.hpp"
 
+#include "hml_host_common.hpp"
+
 static thread_local std::string g_err;
-static int set_err(int code, const std::string& msg) { g_err = msg; return code; }
-
-#define HIPCHK(call)                                                                                  \
-    do {                                                                                              \
-        hipError_t e_ = (call);                                                                       \
-        if (e_ != hipSuccess)                                                                         \
-            return set_err(HML_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_));           \
-    } while (0)
-
-#define KLAUNCH_CHECK() HIPCHK(hipGetLastError())
+int hml_set_err(int code, const std::string& msg) { g_err = msg; return code; }
+static int set_err(int code, const std::string& msg) { return hml_set_err(code, msg); }
 
 #define HML_DISPATCH_K(KV, ...)                                                   \
     switch (KV) {                                                                 \

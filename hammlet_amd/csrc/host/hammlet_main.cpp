@@ -140,6 +140,7 @@ int main(int argc, const char* argv[]) {
         outputArgs.parseArgs();
 
         // ---- input
+        inputDevice() = device;
         vector<real_t> inputValues;
         vector<SufficientStatistics<Normal>> stats;
         if (args.isSet("-raw")) {

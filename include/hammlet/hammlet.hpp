@@ -91,17 +91,38 @@ public:
     size_t nrDim() const { return 1; }
 };
 
-// MaxletTransform (reference src/wavelet.hpp:97-188): reads the text stream.  The transform itself runs
-// on the GPU when the statistics object is built, so `coeffs` receives the raw observations here.
+// GPU index used by objects that exist before the chain's context does (the text reader); set by the driver.
+inline int& inputDevice() { static int dev = 0; return dev; }
+
+// MaxletTransform (reference src/wavelet.hpp:97-188): reads the text stream - every value that
+// `while ( input >> v )` extracts (wavelet.hpp:131), converted on the GPU chunk by chunk (hml_text_*; tokens the
+// device cannot decide with proof go through the stream extraction on the host, so the values are the
+// reference's bit for bit).  The transform itself runs on the GPU when the statistics object is built, so
+// `coeffs` receives the raw observations here.  Values of several streams are concatenated.
 template <typename T>
 void MaxletTransform(std::istream& input, std::vector<real_t>& coeffs, std::vector<SufficientStatistics<T>>& suffstats,
                      const size_t nrDim = 1, const size_t reserveT = 0) {
-    (void)suffstats;
+    (void)suffstats; (void)reserveT;
     if (nrDim != 1) throw std::runtime_error("Only univariate data is supported by the MI355X path!");
     if (!input) throw std::runtime_error("Cannot read input file or stream!");
-    if (reserveT) coeffs.reserve(coeffs.size() + reserveT);
-    real_t v = 0;
-    while (input >> v) coeffs.push_back(v);
+    hml_text* reader = nullptr;
+    hml_check(hml_text_open(&reader, inputDevice(), 0));
+    struct Closer { hml_text* r; ~Closer() { hml_text_close(r); } } closer{reader};
+    for (;;) {
+        char* buf = nullptr;
+        uint64_t cap = 0;
+        hml_check(hml_text_buffer(reader, &buf, &cap));
+        input.read(buf, (std::streamsize)cap);
+        const std::streamsize got = input.gcount();
+        if (got <= 0) break;
+        hml_check(hml_text_commit(reader, (uint64_t)got));
+    }
+    uint64_t n = 0;
+    int stopped = 0;
+    hml_check(hml_text_finish(reader, &n, &stopped));
+    const size_t at = coeffs.size();
+    coeffs.resize(at + n);
+    hml_check(hml_text_values(reader, coeffs.data() + at));
 }
 // HaarBreakpointWeights (reference src/wavelet.hpp:68-93): computed on the device together with the
 // transform; kept so that drivers read like the reference.

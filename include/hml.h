@@ -53,6 +53,26 @@ void hml_destroy(hml_ctx* ctx);
 int hml_load_observations(hml_ctx* ctx, const float* x, uint64_t T);
 int hml_load_observations_device(hml_ctx* ctx, const void* x_dev, uint64_t T);
 
+/* Text input: the values that `while ( input >> v )` extracts from a whitespace-separated decimal stream
+ * (src/wavelet.hpp:131, called from src/main.cpp:266-291), converted on the GPU chunk by chunk.  The result is
+ * bit-identical to the stream extraction, including where it stops: tokens the device cannot decide with proof
+ * (more than 19 significant digits, ties, sub-normal or overflowing values, anything that is not one plain decimal
+ * number from blank to blank) are re-read by the host with that same extraction.
+ *   hml_text_open(&r, device, chunk_bytes);          (chunk_bytes 0 = 64 MiB staging)
+ *   loop: hml_text_buffer(r, &buf, &cap); n = read(fd, buf, cap); hml_text_commit(r, n);   (or hml_text_feed)
+ *   hml_text_finish(r, &n_values, &stopped);  hml_text_values(r, out);  hml_text_close(r);
+ * `stopped` = 1 if an extraction failed before the end of the text (the reference silently stops reading there). */
+typedef struct hml_text hml_text;
+int hml_text_open(hml_text** out, int device, uint64_t chunk_bytes);
+void hml_text_close(hml_text* reader);
+int hml_text_buffer(hml_text* reader, char** buf, uint64_t* capacity);
+int hml_text_commit(hml_text* reader, uint64_t nbytes);
+int hml_text_feed(hml_text* reader, const char* bytes, uint64_t nbytes);
+int hml_text_finish(hml_text* reader, uint64_t* n_values, int* stopped);
+int hml_text_values(hml_text* reader, float* out /* n_values */);
+/* bytes consumed, tokens resolved by the host, chunks that went through the host extraction entirely */
+int hml_text_counters(hml_text* reader, uint64_t* bytes_in, uint64_t* irregular_tokens, uint64_t* host_chunks);
+
 /* stdEstimate of src/main.cpp:303-311 */
 int hml_noise_sigma(hml_ctx* ctx, double* sigma);
 

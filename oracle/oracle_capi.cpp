@@ -5,8 +5,11 @@
 #include <cmath>
 #include <cstring>
 #include <random>
+#include <sstream>
+#include <vector>
 
 #include "../hammlet_amd/csrc/hml_synth_host.hpp"
+#include "../hammlet_amd/csrc/hml_text.h"
 #include "hml_oracle.hpp"
 
 using namespace hml_oracle;
@@ -258,6 +261,44 @@ void orc_synth_depth(float* x, int16_t* states, uint64_t T, double depth, double
 }
 
 // timed run for bench.py's cpu_baseline: returns seconds spent in `iters` sweeps
+// The reference's reader, restated: `real_t v; while ( input >> v ) { ... push_back( v ) ... }`
+// (reference src/wavelet.hpp:127-134, univariate) over an in-memory text.  Returns the number of values;
+// *stopped = 1 if the loop ended on a failed extraction before the end of the text.
+uint64_t orc_parse_text(const char* text, uint64_t n, float* out, uint64_t cap, int* stopped) {
+    std::istringstream input(std::string(text, text + n));
+    std::vector<float> vals;
+    float v = 0;
+    bool early = false;
+    for (;;) {
+        // the extraction's sentry skips blanks itself; doing it first tells "text used up" from "extraction failed"
+        input >> std::ws;
+        if (input.eof()) break;
+        if (!(input >> v)) { early = true; break; }
+        vals.push_back(v);
+    }
+    if (stopped) *stopped = early ? 1 : 0;
+    const uint64_t k = vals.size() < cap ? vals.size() : cap;
+    if (k) memcpy(out, vals.data(), k * sizeof(float));
+    return vals.size();
+}
+
+// probe of the product's token converter (hml_text.h, compiled by gcc here) against strtof: status per token
+// (0 = converted, 1 = left to the stream extraction); tokens are NUL-terminated, `stride` bytes apart
+void orc_parse_tokens(const char* toks, uint64_t n, uint32_t stride, float* out, uint8_t* status, float* strtof_out) {
+    std::vector<char> buf(stride + HML_TOK_MAX + 2);
+    for (uint64_t i = 0; i < n; ++i) {
+        const char* t = toks + i * stride;
+        const size_t len = strlen(t);
+        std::fill(buf.begin(), buf.end(), ' ');
+        memcpy(buf.data(), t, len);
+        const char* p = buf.data();
+        float v = 0;
+        status[i] = (uint8_t)hml_parse_token([p](int j) { return (uint32_t)(unsigned char)p[j]; }, HML_TOK_MAX + 1, &v);
+        out[i] = v;
+        strtof_out[i] = strtof(t, nullptr);
+    }
+}
+
 double orc_time_sweeps(void* h, char method, uint64_t iters) {
     Oracle* o = (Oracle*)h;
     o->token_begin();

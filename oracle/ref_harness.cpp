@@ -11,6 +11,8 @@
 // -fno-access-control to read them.
 //
 //   ref_harness INPUT.f32 OUTPUT.bin MULT THR [THR ...]
+//   ref_harness --parse INPUT.txt OUTPUT.f32     the values the reference's reader extracts from a text file
+//                                                (MaxletTransform, wavelet.hpp:97-134: suffstats[i].sum() = v_i)
 // OUTPUT.bin: a sequence of records {char name[16]; uint64 count; uint32 elem_size; payload}.
 #include <cstdint>
 #include <cstdio>
@@ -45,6 +47,18 @@ static void put(const char* name, const void* data, uint64_t count, uint32_t ele
 }
 
 int main(int argc, char** argv) {
+    if (argc == 4 && std::string(argv[1]) == "--parse") {
+        std::ifstream fin(argv[2]);
+        vector<real_t> coeffs;
+        vector<SufficientStatistics<Normal>> stats;
+        MaxletTransform(fin, coeffs, stats, 1);
+        std::vector<float> vals(stats.size());
+        for (size_t i = 0; i < stats.size(); ++i) vals[i] = stats[i].sum();
+        FILE* f = fopen(argv[3], "wb");
+        if (!vals.empty()) fwrite(vals.data(), 4, vals.size(), f);
+        fclose(f);
+        return 0;
+    }
     if (argc < 5) { fprintf(stderr, "usage: ref_harness INPUT.f32 OUTPUT.bin MULT THR [THR ...]\n"); return 2; }
     std::vector<float> x;
     {

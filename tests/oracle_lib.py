@@ -263,3 +263,31 @@ class OracleChain:
 
     def total_blocks(self):
         return self.lib.orc_total_blocks(self.h)
+
+
+def parse_text(data):
+    """The reference's reader restated (`while ( input >> v )`, reference src/wavelet.hpp:131): (values, stopped)."""
+    lib = load()
+    lib.orc_parse_text.restype = C.c_uint64
+    lib.orc_parse_text.argtypes = [C.c_char_p, C.c_uint64, _P, C.c_uint64, C.POINTER(C.c_int)]
+    data = bytes(data)
+    cap = len(data) // 2 + 2
+    out = np.empty(cap, np.float32)
+    stopped = C.c_int()
+    n = lib.orc_parse_text(data, len(data), out.ctypes.data, cap, C.byref(stopped))
+    return out[:n].copy(), bool(stopped.value)
+
+
+def parse_tokens(tokens):
+    """hml_text.h's token converter compiled by gcc: (values, status, strtof values) for a list of ASCII tokens."""
+    lib = load()
+    lib.orc_parse_tokens.restype = None
+    lib.orc_parse_tokens.argtypes = [C.c_char_p, C.c_uint64, C.c_uint32, _P, _P, _P]
+    stride = max(len(t) for t in tokens) + 1
+    blob = b"".join(t.encode().ljust(stride, b"\0") for t in tokens)
+    n = len(tokens)
+    out = np.empty(n, np.float32)
+    st = np.empty(n, np.uint8)
+    ref = np.empty(n, np.float32)
+    lib.orc_parse_tokens(blob, n, stride, out.ctypes.data, st.ctypes.data, ref.ctypes.data)
+    return out, st, ref
