@@ -8,6 +8,7 @@ REPO_DIR = os.path.dirname(PKG_DIR)
 CSRC = os.path.join(PKG_DIR, "csrc")
 LIB_PATH = os.path.join(PKG_DIR, "libhammlet_hip.so")
 CLI_PATH = os.path.join(PKG_DIR, "hammlet")
+TOOL_PATH = os.path.join(PKG_DIR, "maxSegmentation")
 
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC"]
 
@@ -86,6 +87,13 @@ def build_cli(force=False, verbose=False):
         build_library(force=False, verbose=verbose)
         cmd = ["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-o", CLI_PATH, src, "-I", os.path.join(REPO_DIR, "include"),
                "-L", PKG_DIR, "-lhammlet_hip", "-Wl,-rpath,$ORIGIN"]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.run(cmd, check=True)
+    # post-processing tool (file in, text out; no GPU)
+    tsrc = os.path.join(CSRC, "host", "maxSegmentation_main.cpp")
+    if force or _newer(TOOL_PATH, [tsrc, os.path.join(REPO_DIR, "include", "hammlet", "Parser.hpp")]):
+        cmd = ["g++", "-O2", "-std=c++17", "-o", TOOL_PATH, tsrc, "-I", os.path.join(REPO_DIR, "include")]
         if verbose:
             print(" ".join(cmd))
         subprocess.run(cmd, check=True)

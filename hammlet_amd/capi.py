@@ -72,6 +72,7 @@ SIGNATURES = {
     "hml_get_coefficients": (C.c_int, [_P, _P]),
     "hml_get_integral_array": (C.c_int, [_P, _P, _P]),
     "hml_marginals_rle": (C.c_int, [_P, C.POINTER(C.c_uint64), C.POINTER(C.c_int), _P, _P]),
+    "hml_max_segmentation": (C.c_int, [_P, C.POINTER(C.c_uint64), _P, _P]),
     "hml_marginals_dense_device": (C.c_int, [_P, _P, _P]),
     "hml_recorded_sweeps": (C.c_int, [_P, C.POINTER(C.c_uint64)]),
     "hml_get_stats": (C.c_int, [_P, C.POINTER(HmlStats)]),
@@ -355,6 +356,15 @@ class Chain:
         cnt = np.empty((n.value, max(k.value, 0)), np.int32)
         _check(self.lib.hml_marginals_rle(self.h, C.byref(n), C.byref(k), seg.ctypes.data, cnt.ctypes.data if k.value else None))
         return seg, cnt
+
+    def max_segmentation(self):
+        """(run lengths, arg-max state per run) of the recorded marginals, merged (maxSegmentation.cpp:53-82)"""
+        n = C.c_uint64()
+        _check(self.lib.hml_max_segmentation(self.h, C.byref(n), None, None))
+        ln = np.empty(n.value, np.uint64)
+        st = np.empty(n.value, np.int32)
+        _check(self.lib.hml_max_segmentation(self.h, C.byref(n), ln.ctypes.data, st.ctypes.data))
+        return ln, st
 
     def marginals_dense_device(self, out_ptr, perm=None):
         p = None

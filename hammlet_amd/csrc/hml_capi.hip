@@ -18,6 +18,7 @@
 #include "hml_k_build.h"
 #include "hml_k_forward.h"
 #include "hml_k_marginals.h"
+#include "hml_k_segment.h"
 #include "hml_k_params.h"
 #include "hml_state.h"
 #include "hml_synth_host.hpp"
@@ -967,6 +968,33 @@ int hml_recorded_sweeps(hml_ctx* c, uint64_t* n) {
     *n = m.n_recorded; return 0;
 }
 
+// marginal segments on the device: starts d_seg[M] and count differences d_g[M*K] at the starts (caller frees)
+static int gather_marginal_segments(hml_ctx* c, uint64_t* M_out, uint32_t** d_seg_out, int32_t** d_g_out) {
+    const uint32_t T = (uint32_t)c->T;
+    const int K = c->K;
+    uint32_t *d_cnt = nullptr, *d_off = nullptr, *d_seg = nullptr;
+    int32_t* d_g = nullptr;
+    HIPCHK(hipMalloc(&d_cnt, c->n_spans * sizeof(uint32_t)));
+    HIPCHK(hipMalloc(&d_off, c->n_spans * sizeof(uint32_t)));
+    hipLaunchKernelGGL(hml_k_marg_count, dim3((c->n_spans + 3) / 4), dim3(256), 0, c->stream, c->d_boundary, T, d_cnt);
+    std::vector<uint32_t> h_cnt(c->n_spans), h_off(c->n_spans);
+    HIPCHK(hipMemcpyAsync(h_cnt.data(), d_cnt, c->n_spans * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    uint64_t M = 0;
+    for (uint32_t i = 0; i < c->n_spans; ++i) { h_off[i] = (uint32_t)M; M += h_cnt[i]; }
+    HIPCHK(hipMemcpyAsync(d_off, h_off.data(), c->n_spans * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMalloc(&d_seg, (M + 1) * sizeof(uint32_t)));
+    HIPCHK(hipMalloc(&d_g, M * K * sizeof(int32_t)));
+    hipLaunchKernelGGL(hml_k_marg_scatter, dim3((c->n_spans + 3) / 4), dim3(256), 0, c->stream, c->d_boundary, T, d_off, d_seg);
+    hipLaunchKernelGGL(hml_k_marg_gather, dim3(grid_for(M, 256, 1, 16384)), dim3(256), 0, c->stream, c->d_diff, T, K, d_seg,
+                       (uint32_t)M, d_g);
+    KLAUNCH_CHECK();
+    HIPCHK(hipStreamSynchronize(c->stream));
+    hipFree(d_cnt); hipFree(d_off);
+    *M_out = M; *d_seg_out = d_seg; *d_g_out = d_g;
+    return 0;
+}
+
 int hml_marginals_rle(hml_ctx* c, uint64_t* n_segments, int* n_columns, uint64_t* seg_len, int32_t* counts) {
     NEED_MODEL();
     hml_model m; if (int r = fetch_model(c, &m)) return r;
@@ -979,33 +1007,18 @@ int hml_marginals_rle(hml_ctx* c, uint64_t* n_segments, int* n_columns, uint64_t
         if (seg_len) seg_len[0] = T;
         return 0;
     }
-    uint32_t *d_cnt = nullptr, *d_off = nullptr, *d_seg = nullptr;
-    int32_t* d_g = nullptr;
-    HIPCHK(hipMalloc(&d_cnt, c->n_spans * sizeof(uint32_t)));
-    HIPCHK(hipMalloc(&d_off, c->n_spans * sizeof(uint32_t)));
-    hipLaunchKernelGGL(hml_k_marg_count, dim3((c->n_spans + 3) / 4), dim3(256), 0, c->stream, c->d_boundary, T, d_cnt);
-    // reuse the span-offset scan; it writes the total into mdl->B, so save and restore B
-    std::vector<uint32_t> h_cnt(c->n_spans);
-    HIPCHK(hipMemcpyAsync(h_cnt.data(), d_cnt, c->n_spans * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
-    std::vector<uint32_t> h_off(c->n_spans);
     uint64_t M = 0;
-    for (uint32_t i = 0; i < c->n_spans; ++i) { h_off[i] = (uint32_t)M; M += h_cnt[i]; }
+    uint32_t* d_seg = nullptr;
+    int32_t* d_g = nullptr;
+    if (int r = gather_marginal_segments(c, &M, &d_seg, &d_g)) return r;
     *n_segments = M; *n_columns = ncol;
-    if (!seg_len) { hipFree(d_cnt); hipFree(d_off); return 0; }
-    HIPCHK(hipMemcpyAsync(d_off, h_off.data(), c->n_spans * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipMalloc(&d_seg, (M + 1) * sizeof(uint32_t)));
-    HIPCHK(hipMalloc(&d_g, M * K * sizeof(int32_t)));
-    hipLaunchKernelGGL(hml_k_marg_scatter, dim3((c->n_spans + 3) / 4), dim3(256), 0, c->stream, c->d_boundary, T, d_off, d_seg);
-    hipLaunchKernelGGL(hml_k_marg_gather, dim3(grid_for(M, 256, 1, 16384)), dim3(256), 0, c->stream, c->d_diff, T, K, d_seg,
-                       (uint32_t)M, d_g);
-    KLAUNCH_CHECK();
+    if (!seg_len) { hipFree(d_seg); hipFree(d_g); return 0; }
     std::vector<uint32_t> h_seg(M);
     std::vector<int32_t> h_g(M * K);
     HIPCHK(hipMemcpyAsync(h_seg.data(), d_seg, M * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipMemcpyAsync(h_g.data(), d_g, M * K * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
-    hipFree(d_cnt); hipFree(d_off); hipFree(d_seg); hipFree(d_g);
+    hipFree(d_seg); hipFree(d_g);
     // running sums over segments: counts of a segment = sum of the differences at all boundaries up to it
     std::vector<int32_t> cur(K, 0);
     for (uint64_t i = 0; i < M; ++i) {
@@ -1014,6 +1027,63 @@ int hml_marginals_rle(hml_ctx* c, uint64_t* n_segments, int* n_columns, uint64_t
         if (counts) for (int s = 0; s < ncol; ++s) counts[i * ncol + s] = cur[s];
     }
     return 0;
+}
+
+int hml_max_segmentation(hml_ctx* c, uint64_t* n_runs, uint64_t* run_len, int32_t* run_state) {
+    NEED_MODEL();
+    if (!n_runs) return set_err(HML_ERR_ARG, "null argument");
+    hml_model m; if (int r = fetch_model(c, &m)) return r;
+    if (m.err_code) { char buf[256]; return set_err(HML_ERR_MODEL, deverr_text(m.err_code, m.err_value, buf, sizeof buf)); }
+    const uint32_t T = (uint32_t)c->T;
+    const int K = c->K;
+    if (!c->d_diff || m.n_recorded == 0) {   // nothing recorded: every count is zero, the arg-max is state 0
+        *n_runs = 1;
+        if (run_len) run_len[0] = T;
+        if (run_state) run_state[0] = 0;
+        return 0;
+    }
+    uint64_t M = 0;
+    uint32_t* d_seg = nullptr;
+    int32_t* d_g = nullptr;
+    if (int r = gather_marginal_segments(c, &M, &d_seg, &d_g)) return r;
+    const uint32_t n_chunks = (uint32_t)((M + 255) / 256);
+    int32_t *d_cs = nullptr, *d_rc = nullptr;
+    int16_t* d_st = nullptr;
+    HIPCHK(hipMalloc(&d_cs, (uint64_t)K * n_chunks * sizeof(int32_t)));
+    HIPCHK(hipMalloc(&d_rc, ((uint64_t)n_chunks + 1) * sizeof(int32_t)));
+    HIPCHK(hipMalloc(&d_st, M * sizeof(int16_t)));
+    HIPCHK(hipMemsetAsync(d_rc + n_chunks, 0, sizeof(int32_t), c->stream));
+    hipLaunchKernelGGL(hml_k_seg_partial, dim3(n_chunks), dim3(256), 0, c->stream, d_g, (uint32_t)M, K, d_cs, n_chunks);
+    hipLaunchKernelGGL(hml_k_dense_chunkscan, dim3(K), dim3(1024), 0, c->stream, d_cs, n_chunks);
+    hipLaunchKernelGGL(hml_k_seg_argmax, dim3(n_chunks), dim3(256), 0, c->stream, d_g, (uint32_t)M, K, d_cs, n_chunks, d_st);
+    hipLaunchKernelGGL(hml_k_seg_run_count, dim3(n_chunks), dim3(256), 0, c->stream, d_st, (uint32_t)M, d_rc);
+    hipLaunchKernelGGL(hml_k_dense_chunkscan, dim3(1), dim3(1024), 0, c->stream, d_rc, n_chunks + 1u);   // d_rc[n_chunks] = total
+    KLAUNCH_CHECK();
+    int32_t R = 0;
+    HIPCHK(hipMemcpyAsync(&R, d_rc + n_chunks, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    *n_runs = (uint64_t)R;
+    int rc = 0;
+    if (run_len) {
+        uint32_t* d_rs = nullptr;
+        int16_t* d_rq = nullptr;
+        HIPCHK(hipMalloc(&d_rs, (uint64_t)R * sizeof(uint32_t)));
+        HIPCHK(hipMalloc(&d_rq, (uint64_t)R * sizeof(int16_t)));
+        hipLaunchKernelGGL(hml_k_seg_run_scatter, dim3(n_chunks), dim3(256), 0, c->stream, d_st, d_seg, (uint32_t)M, d_rc, d_rs, d_rq);
+        KLAUNCH_CHECK();
+        std::vector<uint32_t> h_rs(R);
+        std::vector<int16_t> h_rq(R);
+        HIPCHK(hipMemcpyAsync(h_rs.data(), d_rs, (uint64_t)R * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipMemcpyAsync(h_rq.data(), d_rq, (uint64_t)R * sizeof(int16_t), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        for (int32_t r = 0; r < R; ++r) {
+            run_len[r] = (uint64_t)((r + 1 < R ? h_rs[r + 1] : T) - h_rs[r]);
+            if (run_state) run_state[r] = h_rq[r];
+        }
+        hipFree(d_rs); hipFree(d_rq);
+    }
+    hipFree(d_seg); hipFree(d_g); hipFree(d_cs); hipFree(d_rc); hipFree(d_st);
+    return rc;
 }
 
 int hml_marginals_dense_device(hml_ctx* c, void* out_dev, const int32_t* perm) {

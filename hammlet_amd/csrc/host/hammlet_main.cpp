@@ -3,7 +3,7 @@
 // flag semantics doc/hammlet-manpage.md:33-175); everything between reading the input and writing the
 // files runs on the GPU through libhammlet_hip.so.
 //
-// Extensions (not in the reference): -raw FILE reads float32 values instead of text; -device N selects
+// Extensions (not in the reference): `-O X` writes PREFIXmaxsegmentationSUFFIX; -raw FILE reads float32 values instead of text; -device N selects
 // the GPU; -chain N selects the Philox sub-key of an independent chain.
 #include <ctime>
 #include <fstream>
@@ -28,6 +28,7 @@ static const char* kHelp =
     "  -raw FILE                      float32 input file (extension)\n"
     "  -o, -output-pattern PRE SUF    output files are PRE{marginals,...}SUF (default: hammlet- .csv)\n"
     "  -O, -output-data M S P B C G   marginals sequences parameters blocks compression segments\n"
+    "                    X            maxsegmentation: the maxSegmentation tool's output for the marginals (extension)\n"
     "  -w, -overwrite                 allow overwriting output files\n"
     "  -s, -states K                  number of states (default 3)\n"
     "  -e, -emissions normal VAR P    automatic prior: P(variance < VAR) = P (default normal 0.2 0.9)\n"
@@ -137,6 +138,7 @@ int main(int argc, const char* argv[]) {
         outputArgs.registerFlags({"C", "compression"});
         outputArgs.registerFlags({"D", "mapping"});
         outputArgs.registerFlags({"G", "segments"});
+        outputArgs.registerFlags({"X", "maxsegmentation"});   // extension
         outputArgs.parseArgs();
 
         // ---- input
@@ -183,6 +185,7 @@ int main(int argc, const char* argv[]) {
         records.setRecordCompression(outputArgs.isSet("compression"), overwrite);
         records.setRecordMarginals(outputArgs.isSet("marginals"), overwrite);
         records.setRecordSegments(outputArgs.isSet("segments"), overwrite);
+        records.setRecordMaxSegmentation(outputArgs.isSet("maxsegmentation"), overwrite);
 
         typedef Statistics<IntegralArray, Normal> S;
         typedef Blocks<BreakpointArray> B;

@@ -5,6 +5,8 @@
 //   PREFIXparametersSUFFIX   one line per recorded sweep: mean \t var per state
 //   PREFIXcompressionSUFFIX  one line per recorded sweep: T / #blocks
 //   PREFIXsegmentsSUFFIX     one line per recorded sweep: #marginal segments \t internal size (see note)
+//   PREFIXmaxsegmentationSUFFIX  (extension, `-O X`) what the reference's maxSegmentation tool prints for the marginals
+//                            file (reference src/tools/maxSegmentation.cpp:53-82), computed on the device at close
 // The marginal counts are accumulated on the device (difference arrays + boundary bitmap) and fetched in
 // run-length form at close(); the per-sweep files are appended from the device's block list and state
 // sequence after every recorded sweep.
@@ -31,8 +33,8 @@ class Records {
     std::string mPrefix, mSuffix;
     hml_ctx* mCtx = nullptr;
     bool mRecordMarginals = true, mRecordBlocks = false, mRecordCompression = false, mRecordSequences = false,
-         mRecordTheta = false, mRecordSegments = false;
-    std::ofstream mMarginalsFile, mSequenceFile, mBlocksFile, mThetaFile, mCompressionsFile, mSegmentFile;
+         mRecordTheta = false, mRecordSegments = false, mRecordMaxSeg = false;
+    std::ofstream mMarginalsFile, mSequenceFile, mBlocksFile, mThetaFile, mCompressionsFile, mSegmentFile, mMaxSegFile;
     bool mClosed = false;
     std::set<uint32_t> mBoundaries;   // only maintained when the segments file is requested
 
@@ -63,7 +65,9 @@ public:
     void setRecordTheta(bool b, bool overwrite = false) { setRecordX(mThetaFile, "parameters", mRecordTheta, b, overwrite); }
     void setRecordSegments(bool b, bool overwrite = false) { setRecordX(mSegmentFile, "segments", mRecordSegments, b, overwrite); }
 
-    bool recordsMarginals() const { return mRecordMarginals; }
+    void setRecordMaxSegmentation(bool b, bool overwrite = false) { setRecordX(mMaxSegFile, "maxsegmentation", mRecordMaxSeg, b, overwrite); }
+
+    bool recordsMarginals() const { return mRecordMarginals || mRecordMaxSeg; }
     bool needsPerSweepData() const { return mRecordBlocks || mRecordCompression || mRecordSequences || mRecordTheta || mRecordSegments; }
 
     // one recorded sweep: Records::record(state, N) for every block in order + Records::record(theta)
@@ -117,6 +121,21 @@ public:
                 mMarginalsFile << mSize << "\n";
             }
             mMarginalsFile.close();
+        }
+        if (mRecordMaxSeg && mMaxSegFile.is_open()) {
+            // the tool's output format: the running state starts at 0, so a first run of another state is preceded by "0\t0"
+            if (mCtx) {
+                uint64_t n = 0;
+                hml_check(hml_max_segmentation(mCtx, &n, nullptr, nullptr));
+                std::vector<uint64_t> len(n);
+                std::vector<int32_t> st(n);
+                hml_check(hml_max_segmentation(mCtx, &n, len.data(), st.data()));
+                if (n && st[0] != 0) mMaxSegFile << 0 << "\t" << 0 << "\n";
+                for (uint64_t i = 0; i < n; ++i) mMaxSegFile << len[i] << "\t" << st[i] << "\n";
+            } else {
+                mMaxSegFile << mSize << "\t" << 0 << "\n";
+            }
+            mMaxSegFile.close();
         }
         if (mSequenceFile.is_open()) mSequenceFile.close();
         if (mBlocksFile.is_open()) mBlocksFile.close();

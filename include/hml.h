@@ -154,6 +154,11 @@ int hml_get_integral_array(hml_ctx* ctx, float* sum /*T+1*/, float* sum_sq /*T+1
  * seg_len == NULL to obtain the number of segments and of printed state columns. */
 int hml_marginals_rle(hml_ctx* ctx, uint64_t* n_segments, int* n_columns, uint64_t* seg_len /*n_segments*/,
                       int32_t* counts /*n_segments * n_columns*/);
+/* Maximum-posterior-margin segmentation of the recorded marginals, computed on the device - the post-processing
+ * step of src/tools/maxSegmentation.cpp:53-82 without the round trip through the marginals file: arg-max state of
+ * every marginal segment (first maximum; state 0 if all counts are zero), adjacent segments of equal state merged.
+ * Call with run_len == NULL to obtain the number of runs. */
+int hml_max_segmentation(hml_ctx* ctx, uint64_t* n_runs, uint64_t* run_len /*n_runs*/, int32_t* run_state /*n_runs*/);
 /* dense per-position counts, [K+1][T] int32 on the DEVICE (row K = 1 at segment boundaries), with
  * the state rows permuted by `perm` (perm[new] = old; NULL = identity): the buffer that the
  * chain-parallel pooling all-reduces over RCCL. */

@@ -291,3 +291,24 @@ def parse_tokens(tokens):
     ref = np.empty(n, np.float32)
     lib.orc_parse_tokens(blob, n, stride, out.ctypes.data, st.ctypes.data, ref.ctypes.data)
     return out, st, ref
+
+
+def max_segmentation_text(marginals_text):
+    """The reference's post-processing tool restated (reference src/tools/maxSegmentation.cpp:53-82): per line the
+    arg-max column (first maximum, strict `>` from 0), runs of equal arg-max merged, running state starting at 0."""
+    out = []
+    total, prev, best_i = 0, 0, 0
+    for line in marginals_text.splitlines():
+        f = line.split()
+        rle = int(f[0]) if f else 0
+        best, best_i = 0, 0
+        for i, c in enumerate(f[1:]):
+            if int(c) > best:
+                best, best_i = int(c), i
+        if best_i == prev:
+            total += rle
+        else:
+            out.append("%d\t%d\n" % (total, prev))
+            total, prev = rle, best_i
+    out.append("%d\t%d\n" % (total, best_i))
+    return "".join(out)
