@@ -106,6 +106,12 @@ struct hml_ctx {
     // forward geometry
     int fwdL = 4, fwdW = 24;
     hml_layout lay = {2, 0};
+    // weakly compressed sweeps (B_hint >= dense_min_blocks): longer forward chunks - the warm-up is a smaller share
+    // of the work - in their own chunk-transposed layout; which geometry a sweep uses never changes its results
+    int fwdL_dense = 16;
+    hml_layout lay_dense = {4, 0};
+    uint32_t dense_min_blocks = 1u << 22;
+    bool graph_dense = false;
     bool probes = false;
     bool rec_marginals = true;
     hml_record_cb cb = nullptr;
@@ -258,6 +264,18 @@ __global__ void hml_k_debug_eval(int fn, const float* __restrict__ a, const floa
                 if (fn == 22) r = nd.draw(src, 0.0f, 1.0f);   // third normal (fresh pair)
                 if (fn == 23) { hml_normal_f32<hml_devmath> nf; r = nf.draw(src, 0.0f, 1.0f); r = nf.draw(src, 0.0f, 1.0f); }  // saved of the fresh pair
             } break;
+            case 30: case 31: {   // categorical draw over K = 16 / 5 weights a[i..i+K), u = b[i]: out = {combined, literal, unsure}
+                r = 0.0f;
+                const int Kc = fn == 30 ? 16 : 5;
+                if (i % Kc == 0 && i + Kc <= n) {
+                    bool unsure = false;
+                    int fastr, lit;
+                    if (fn == 30) { float w[16]; for (int j = 0; j < 16; ++j) w[j] = a[i + j]; fastr = hml_categorical_k_fast<16>(w, (double)y, unsure); lit = hml_categorical_k_literal<16>(w, (double)y); if (unsure) fastr = lit; }
+                    else { float w[5]; for (int j = 0; j < 5; ++j) w[j] = a[i + j]; fastr = hml_categorical_k_fast<5>(w, (double)y, unsure); lit = hml_categorical_k_literal<5>(w, (double)y); if (unsure) fastr = lit; }
+                    out[i] = (float)fastr; out[i + 1] = (float)lit; out[i + 2] = unsure ? 1.0f : 0.0f;
+                }
+                continue;
+            }
             case 11: { const double d = HML_SQRT((double)x * 1.0000001); r = (float)((d - (double)(float)d) * 1e9); } break;
         }
         out[i] = r;
@@ -288,6 +306,8 @@ int hml_create(hml_ctx** out, int device, uint64_t seed, uint32_t chain_id, void
     HIPCHK(hipHostGetDevicePointer((void**)&c->d_hB, c->h_B, 0));
     if (const char* e = getenv("HML_FWD_CHUNK")) { int l = std::max(1, atoi(e)); int sh = 0; while ((1 << (sh + 1)) <= l && sh < 10) ++sh; c->fwdL = 1 << sh; }
     if (const char* e = getenv("HML_FWD_WARMUP")) c->fwdW = std::max(0, atoi(e));
+    if (const char* e = getenv("HML_FWD_CHUNK_DENSE")) { int l = std::max(1, atoi(e)); int sh = 0; while ((1 << (sh + 1)) <= l && sh < 10) ++sh; c->fwdL_dense = 1 << sh; }
+    if (const char* e = getenv("HML_DENSE_MIN_BLOCKS")) c->dense_min_blocks = (uint32_t)strtoul(e, nullptr, 10);
     if (const char* e = getenv("HML_USE_GRAPH")) c->use_graph = atoi(e) != 0;
     if (const char* e = getenv("HML_WEIGHT_KEYS")) c->use_keys = atoi(e) != 0;
     *out = c;
@@ -570,13 +590,21 @@ int hml_set_model(hml_ctx* c, int K, const float nig4[4], float a_off, float a_d
     if (int r = ctx_bind(c)) return r;
     c->K = K;
     const uint64_t T = c->T;
-    const uint64_t maxChunks = (T + c->fwdL - 1) / c->fwdL + 1;
+    const uint64_t layChunks = (T + c->fwdL - 1) / c->fwdL + 1;
+    const int minL = std::min(c->fwdL, c->fwdL_dense);
+    const uint64_t maxChunks = (T + minL - 1) / minL + 1;   // per-chunk arrays serve either geometry
     {
         int sh = 0; while ((1 << sh) < c->fwdL) ++sh;
         c->lay.lshift = (uint32_t)sh;
-        c->lay.cstride = (uint32_t)((maxChunks + 63) / 64 * 64);
+        c->lay.cstride = (uint32_t)((layChunks + 63) / 64 * 64);
     }
-    const uint64_t plane = (uint64_t)c->fwdL * K * c->lay.cstride;   // floats in one chunk-transposed [L][K][cstride] array
+    uint64_t plane = (uint64_t)c->fwdL * K * c->lay.cstride;   // floats in one chunk-transposed [L][K][cstride] array
+    {
+        int sh = 0; while ((1 << sh) < c->fwdL_dense) ++sh;
+        c->lay_dense.lshift = (uint32_t)sh;
+        c->lay_dense.cstride = (uint32_t)(((T + c->fwdL_dense - 1) / c->fwdL_dense + 1 + 63) / 64 * 64);
+        plane = std::max(plane, (uint64_t)c->fwdL_dense * K * c->lay_dense.cstride);
+    }
     HIPCHK(hipMalloc(&c->d_em, plane * sizeof(float)));
     HIPCHK(hipMalloc(&c->d_gsc, plane * sizeof(float)));
     HIPCHK(hipMalloc(&c->d_rows, plane * sizeof(float)));
@@ -689,6 +717,11 @@ static int sweep_k(hml_ctx* c, char method, bool record) {
     const bool mix = (method == HML_METHOD_MIXTURE);
     const uint32_t T = (uint32_t)c->T;
     bool emitted = false, fused = false;
+    // forward geometry of this sweep, fixed before its first launch
+    refresh_hint(c);
+    const bool dense_geo = c->B_hint >= c->dense_min_blocks;
+    const int L = dense_geo ? c->fwdL_dense : c->fwdL;
+    const hml_layout lay = dense_geo ? c->lay_dense : c->lay;
     if (c->dynamic || !c->blocks_valid) {
         if (c->use_keys && !(!c->summary_always && c->B_hint && (uint64_t)c->B_hint * 24u > c->T)) {
             // K4 + K5 + K6a in one launch (hml_k_blocks_fused.h); weak compression takes the float stream below
@@ -696,7 +729,7 @@ static int sweep_k(hml_ctx* c, char method, bool record) {
             const uint32_t n_wg = (uint32_t)(((uint64_t)T + HML_FUSED_POSITIONS - 1) / HML_FUSED_POSITIONS);
             hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_blocks_fused<KK>), dim3(n_wg), dim3(HML_FUSED_WAVES * 64), 0, s, c->d_summary, c->d_w, c->d_ia,
                                T, c->d_mdl, c->key_base, c->d_group_word, c->d_launch_gen, c->d_starts, c->d_bstat, c->d_em,
-                               c->d_gsc, c->probes ? c->d_eprobe : nullptr, mix ? 1 : 0, c->lay, c->d_hB, c->d_dbg);
+                               c->d_gsc, c->probes ? c->d_eprobe : nullptr, mix ? 1 : 0, lay, c->d_hB, c->d_dbg);
             fused = true;
         } else {
             launch_compact_pair(c, 0, 0.0f);
@@ -707,7 +740,7 @@ static int sweep_k(hml_ctx* c, char method, bool record) {
             ProfScope ps(c, "stats_emission");
             hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_stats_emission<KK>), dim3(grid_for(h0, 256, 64, 16384)), dim3(256), 0, s,
                                c->d_ia, c->d_starts, c->d_mdl, c->d_bstat, c->d_em, c->d_gsc, c->probes ? c->d_eprobe : nullptr,
-                               mix ? 1 : 0, c->lay);
+                               mix ? 1 : 0, lay);
         }
         KLAUNCH_CHECK();
         emitted = true;
@@ -719,16 +752,15 @@ static int sweep_k(hml_ctx* c, char method, bool record) {
     if (!emitted) {
         ProfScope ps(c, "emission");
         hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_emission<KK>), dim3(gB), dim3(256), 0, s, c->d_bstat, c->d_starts, c->d_mdl,
-                           c->d_em, c->d_gsc, c->probes ? c->d_eprobe : nullptr, mix ? 1 : 0, c->lay);
+                           c->d_em, c->d_gsc, c->probes ? c->d_eprobe : nullptr, mix ? 1 : 0, lay);
     }
     if (!mix) {
-        const int L = c->fwdL;
         const uint64_t chunks = ((uint64_t)hint + L - 1) / L;
         const int gF = grid_for(chunks, 256, 16, 1 << 20);
         {
             ProfScope ps(c, "forward");
             hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_forward<KK>), dim3(gF), dim3(256), 0, s, c->d_em, c->d_gsc, c->d_mdl, c->d_rows,
-                               c->probes ? c->d_aprobe : nullptr, c->d_entry, c->d_exitA, c->d_fb, L, c->lay);
+                               c->probes ? c->d_aprobe : nullptr, c->d_entry, c->d_exitA, c->d_fb, L, lay);
         }
         {
             // backward maps (verifies the forward chunks on the way), then one workgroup: repair if a check failed,
@@ -736,10 +768,10 @@ static int sweep_k(hml_ctx* c, char method, bool record) {
             ProfScope ps(c, "backward");
             const uint64_t bch = ((uint64_t)hint + HML_BWD_CHUNK - 1) / HML_BWD_CHUNK;
             hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_backward_maps<KK>), dim3(grid_for(bch * 64, 256, 16, 1 << 18)), dim3(256), 0,
-                               s, c->d_rows, c->d_mdl, c->d_smap, c->d_cmap, c->lay, c->d_entry, c->d_exitA, c->d_redo, L);
+                               s, c->d_rows, c->d_mdl, c->d_smap, c->d_cmap, lay, c->d_entry, c->d_exitA, c->d_redo, L);
             hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_backward_chain<KK>), dim3(1), dim3(1024), 0, s, c->d_cmap, c->d_mdl,
                                c->d_bentry, c->d_em, c->d_gsc, c->d_rows, c->probes ? c->d_aprobe : nullptr, c->d_entry,
-                               c->d_exitA, c->d_fb, c->d_redo, c->d_touched, c->d_smap, L, c->lay);
+                               c->d_exitA, c->d_fb, c->d_redo, c->d_touched, c->d_smap, L, lay);
         }
         {
             ProfScope ps(c, "counts");
@@ -749,7 +781,7 @@ static int sweep_k(hml_ctx* c, char method, bool record) {
     } else {
         {
             ProfScope ps(c, "backward");
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_mixture<KK>), dim3(gB), dim3(256), 0, s, c->d_em, c->d_mdl, c->d_q, c->lay);
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_mixture<KK>), dim3(gB), dim3(256), 0, s, c->d_em, c->d_mdl, c->d_q, lay);
         }
         {
             ProfScope ps(c, "counts");
@@ -785,7 +817,8 @@ int hml_iterate(hml_ctx* c, char method, uint64_t iterations, uint64_t thinning)
             refresh_hint(c);
             const uint32_t hint = c->B_hint;
             const bool stale = !c->graph_exec || c->graph_method != method || c->graph_dynamic != c->dynamic ||
-                               hint > c->graph_hint || hint * 2u < c->graph_hint;
+                               hint > c->graph_hint || hint * 2u < c->graph_hint ||
+                               c->graph_dense != (hint >= c->dense_min_blocks);
             if (stale && hint) {
                 if (c->graph_exec) { hipGraphExecDestroy(c->graph_exec); c->graph_exec = nullptr; }
                 hipGraph_t g = nullptr;
@@ -797,6 +830,7 @@ int hml_iterate(hml_ctx* c, char method, uint64_t iterations, uint64_t thinning)
                 HIPCHK(hipGraphInstantiate(&c->graph_exec, g, nullptr, nullptr, 0));
                 hipGraphDestroy(g);
                 c->graph_method = method; c->graph_dynamic = c->dynamic; c->graph_hint = c->B_hint;
+                c->graph_dense = c->B_hint >= c->dense_min_blocks;
             }
             if (c->graph_exec) {
                 HIPCHK(hipGraphLaunch(c->graph_exec, c->stream));

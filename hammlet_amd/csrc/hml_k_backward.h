@@ -28,9 +28,10 @@ __device__ __forceinline__ unsigned long long hml_shfl_down_u64(unsigned long lo
     return ((unsigned long long)hi2 << 32) | lo2;
 }
 
-// std::discrete_distribution draw (hml_dist.h) over K register-resident weights
+// std::discrete_distribution draw (hml_dist.h) over K register-resident weights: the literal form - p_i = w_i / sum in
+// double, running sum cp_i, first i with !(cp_i < u), cp_{K-1} = 1 - with its K double divisions
 template <int K>
-__device__ __forceinline__ int hml_categorical_k(const float (&w)[K], double u) {
+__device__ __forceinline__ int hml_categorical_k_literal(const float (&w)[K], double u) {
     double sum = 0.0;
 #pragma unroll
     for (int i = 0; i < K; ++i) sum += (double)w[i];
@@ -44,6 +45,42 @@ __device__ __forceinline__ int hml_categorical_k(const float (&w)[K], double u) 
         if (!done && !(c < u)) { res = i; done = true; }
     }
     return res;
+}
+
+// The same draw without the divisions: cp_i >= u is decided by s_i >= u * sum, where s_i are the running double
+// sums of the weights (sum = s_{K-1} is the very double the literal form divides by).  With R_i the real quotient
+// (w_0 + .. + w_i) / sum, the literal cp_i lies within (i+1) 2^-53 R_i of R_i (one rounding per quotient, one per
+// addition; all terms are non-negative) and (s_i - u sum) / sum within (i+1) 2^-53 max(R_i, u) of R_i - u.  So
+// whenever |s_i - u sum| > 2^-44 sum for every i both forms make the same comparison as the real numbers
+// (K <= 16: 34 * 2^-53 < 2^-47); otherwise - about K * 2^-43 of the draws, and every row whose sum is not a
+// positive finite number (all-zero rows, negative or NaN weights) - `unsure` is set and the caller lets the literal
+// form decide.
+template <int K>
+__device__ __forceinline__ int hml_categorical_k_fast(const float (&w)[K], double u, bool& unsure_out) {
+    double s[K];
+    double acc = 0.0;
+#pragma unroll
+    for (int i = 0; i < K; ++i) { acc += (double)w[i]; s[i] = acc; }
+    const double t = u * acc;
+    const double margin = acc * 5.684341886080802e-14;   // 2^-44
+    bool unsure = !(acc > 0.0) || !(acc < 1.7976931348623157e308);
+    int res = K - 1;
+    bool done = false;
+#pragma unroll
+    for (int i = 0; i < K - 1; ++i) {
+        const double d = s[i] - t;
+        unsure = unsure || !(__builtin_fabs(d) > margin);
+        if (!done && d >= 0.0) { res = i; done = true; }
+    }
+    unsure_out = unsure_out || unsure;
+    return res;
+}
+
+template <int K>
+__device__ __forceinline__ int hml_categorical_k(const float (&w)[K], double u) {
+    bool unsure = false;
+    const int res = hml_categorical_k_fast<K>(w, u, unsure);
+    return unsure ? hml_categorical_k_literal<K>(w, u) : res;
 }
 
 // ------------------------------------------------------------------------------------------

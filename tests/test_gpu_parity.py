@@ -411,3 +411,26 @@ def test_independent_chains_and_device_input(hml):
         res[chain] = g.states().copy(), g.theta().copy()
     assert not np.array_equal(res[0][1], res[1][1])
     assert not np.array_equal(res[1][1], res[7][1])
+
+
+@pytest.mark.parametrize("dense_L,min_blocks", [(16, 1000), (32, 1000), (64, 50000), (8, 1)])
+def test_dense_forward_geometry_is_invisible_in_the_results(hml, monkeypatch, dense_L, min_blocks):
+    """Sweeps with many blocks run the forward pass with longer chunks in their own layout (HML_FWD_CHUNK_DENSE,
+    threshold HML_DENSE_MIN_BLOCKS); the scheme below crosses the threshold in both directions (mixture sweeps at the
+    universal threshold, FB sweeps on an almost uncompressed structure, static and dynamic), adversarial twin states
+    keep the repair step busy - every bit must still equal the checker's."""
+    monkeypatch.setenv("HML_FWD_CHUNK_DENSE", str(dense_L))
+    monkeypatch.setenv("HML_DENSE_MIN_BLOCKS", str(min_blocks))
+    T, K = 200_000, 4
+    x = ol.synth_depth(T, seed=9)
+    xx, o, g = make_pair(hml, T, K, 0, 23, x=x)
+    setup_model(o, g, K)
+    g._pending_prior = True
+    o.set_record(marginals=True)
+    o.set_probes(True)
+    g.enable_probes(True)
+    run_both(o, g, [("M", 3, 1), ("F", 6, 2), "S", ("F", 4, 1), "D", ("F", 3, 1)])
+    compare_state(o, g)
+    assert np.array_equal(bits(o.forward_rows()), bits(g.forward_rows()))
+    seg, cnt = g.marginals_rle()
+    assert hml.marginals_text(seg, cnt) == o.text("marginals")
