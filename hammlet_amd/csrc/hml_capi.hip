@@ -94,7 +94,8 @@ struct hml_ctx {
     uint32_t* d_touched = nullptr; // backward chunks whose rows the repair recomputed, tagged with the sweep
     uint32_t* d_fb = nullptr;
     unsigned long long *d_smap = nullptr, *d_cmap = nullptr;
-    uint8_t* d_bentry = nullptr;
+    unsigned long long *d_scmap = nullptr, *d_super = nullptr;   // two-level chain (weakly compressed sweeps)
+    uint8_t *d_bentry = nullptr, *d_bentry2 = nullptr;
     int16_t* d_q = nullptr;
     double* d_partial = nullptr;
     int32_t* d_diff = nullptr;
@@ -317,7 +318,7 @@ int hml_create(hml_ctx** out, int device, uint64_t seed, uint32_t chain_id, void
 static void free_all(hml_ctx* c) {
     void* ptrs[] = {c->d_group_word, c->d_launch_gen, c->d_summary, c->d_w, c->d_coeff, c->d_ia, c->d_stage, c->d_span_count, c->d_starts, c->d_bstat,
                     c->d_em, c->d_gsc, c->d_rows, c->d_eprobe, c->d_aprobe, c->d_entry, c->d_exitA, c->d_redo, c->d_touched, c->d_fb, c->d_coarse1,
-                    c->d_smap, c->d_cmap, c->d_bentry, c->d_q, c->d_partial, c->d_diff, c->d_boundary, c->d_mdl};
+                    c->d_smap, c->d_cmap, c->d_scmap, c->d_super, c->d_bentry2, c->d_bentry, c->d_q, c->d_partial, c->d_diff, c->d_boundary, c->d_mdl};
     for (void* p : ptrs) if (p) hipFree(p);
     if (c->h_B) hipHostFree(c->h_B);
 }
@@ -615,6 +616,9 @@ int hml_set_model(hml_ctx* c, int K, const float nig4[4], float a_off, float a_d
     const uint64_t bchunks = (T + HML_BWD_CHUNK - 1) / HML_BWD_CHUNK + 1;
     HIPCHK(hipMalloc(&c->d_cmap, bchunks * sizeof(unsigned long long)));
     HIPCHK(hipMalloc(&c->d_bentry, bchunks));
+    HIPCHK(hipMalloc(&c->d_scmap, bchunks * sizeof(unsigned long long)));
+    HIPCHK(hipMalloc(&c->d_super, (bchunks / 64 + 2) * sizeof(unsigned long long)));
+    HIPCHK(hipMalloc(&c->d_bentry2, bchunks / 64 + 2));
     HIPCHK(hipMalloc(&c->d_redo, bchunks * sizeof(uint32_t)));
     HIPCHK(hipMemsetAsync(c->d_redo, 0, bchunks * sizeof(uint32_t), c->stream));
     HIPCHK(hipMalloc(&c->d_touched, bchunks * sizeof(uint32_t)));
@@ -769,9 +773,23 @@ static int sweep_k(hml_ctx* c, char method, bool record) {
             const uint64_t bch = ((uint64_t)hint + HML_BWD_CHUNK - 1) / HML_BWD_CHUNK;
             hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_backward_maps<KK>), dim3(grid_for(bch * 64, 256, 16, 1 << 18)), dim3(256), 0,
                                s, c->d_rows, c->d_mdl, c->d_smap, c->d_cmap, lay, c->d_entry, c->d_exitA, c->d_redo, L);
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_backward_chain<KK>), dim3(1), dim3(1024), 0, s, c->d_cmap, c->d_mdl,
-                               c->d_bentry, c->d_em, c->d_gsc, c->d_rows, c->probes ? c->d_aprobe : nullptr, c->d_entry,
-                               c->d_exitA, c->d_fb, c->d_redo, c->d_touched, c->d_smap, L, lay);
+            if (!dense_geo) {
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_backward_chain<KK>), dim3(1), dim3(1024), 0, s, c->d_cmap, c->d_mdl,
+                                   c->d_bentry, c->d_em, c->d_gsc, c->d_rows, c->probes ? c->d_aprobe : nullptr, c->d_entry,
+                                   c->d_exitA, c->d_fb, c->d_redo, c->d_touched, c->d_smap, L, lay, 3, 0);
+            } else {
+                // millions of backward chunks: repair step alone, then the two-level chain
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_backward_chain<KK>), dim3(1), dim3(1024), 0, s, c->d_cmap, c->d_mdl,
+                                   c->d_bentry, c->d_em, c->d_gsc, c->d_rows, c->probes ? c->d_aprobe : nullptr, c->d_entry,
+                                   c->d_exitA, c->d_fb, c->d_redo, c->d_touched, c->d_smap, L, lay, 1, 0);
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_backward_super<KK>), dim3(grid_for(bch, 256, 16, 1 << 16)), dim3(256), 0, s,
+                                   c->d_cmap, c->d_mdl, c->d_scmap, c->d_super);
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_backward_chain<KK>), dim3(1), dim3(1024), 0, s, c->d_super, c->d_mdl,
+                                   c->d_bentry2, c->d_em, c->d_gsc, c->d_rows, c->probes ? c->d_aprobe : nullptr, c->d_entry,
+                                   c->d_exitA, c->d_fb, c->d_redo, c->d_touched, c->d_smap, L, lay, 2, 1);
+                hipLaunchKernelGGL(hml_k_backward_entries, dim3(grid_for(bch, 256, 16, 1 << 16)), dim3(256), 0, s, c->d_scmap,
+                                   c->d_bentry2, c->d_mdl, c->d_bentry);
+            }
         }
         {
             ProfScope ps(c, "counts");

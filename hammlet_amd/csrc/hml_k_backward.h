@@ -191,13 +191,17 @@ __global__ __launch_bounds__(1024) void hml_k_backward_chain(unsigned long long*
                                                              float* __restrict__ aprobe, float* __restrict__ entry,
                                                              float* __restrict__ exitv, uint32_t* __restrict__ fb_count,
                                                              const uint32_t* __restrict__ fail_list, uint32_t* __restrict__ touched,
-                                                             unsigned long long* __restrict__ smap, int L, const hml_layout lay) {
+                                                             unsigned long long* __restrict__ smap, int L, const hml_layout lay,
+                                                             int mode, int super_level) {
+    // mode: bit 0 = repair step, bit 1 = chain.  super_level: the chain runs over the maps of super-chunks (64 backward
+    // chunks each, hml_k_backward_super) - `cmap` and `entry_state` are then the super-level arrays.
     __shared__ unsigned long long P[1024];
     __shared__ hml_repair_lds sh;
     const uint32_t B = mdl->B;
-    const uint32_t NC = (B + HML_BWD_CHUNK - 1u) / HML_BWD_CHUNK;
+    const uint32_t NCb = (B + HML_BWD_CHUNK - 1u) / HML_BWD_CHUNK;
+    const uint32_t NC = super_level ? (NCb + 63u) / 64u : NCb;
     const int tid = threadIdx.x;
-    const uint32_t n_fail = mdl->fwd_mismatch;   // workgroup-uniform: written by the previous launch
+    const uint32_t n_fail = (mode & 1) ? mdl->fwd_mismatch : 0u;   // workgroup-uniform: written by the previous launch
     if (n_fail != 0u) {
         const unsigned long long epoch = mdl->epoch;
         const uint32_t gen = (uint32_t)epoch + 1u;
@@ -216,9 +220,9 @@ __global__ __launch_bounds__(1024) void hml_k_backward_chain(unsigned long long*
             for (uint32_t i = (uint32_t)wave; i < n_touched; i += 16u) redo(sh.tlist[i]);
         } else {
             // the list overflowed: scan the marks in memory
-            for (uint32_t c0 = (uint32_t)wave * 64u; c0 < NC; c0 += 16u * 64u) {
+            for (uint32_t c0 = (uint32_t)wave * 64u; c0 < NCb; c0 += 16u * 64u) {
                 const uint32_t c = c0 + (uint32_t)lane;
-                unsigned long long todo = __ballot(c < NC && hml_ld_u32_coherent(touched + c) == gen);
+                unsigned long long todo = __ballot(c < NCb && hml_ld_u32_coherent(touched + c) == gen);
                 while (todo) {
                     const int j = __ffsll((long long)todo) - 1;
                     todo &= todo - 1ull;
@@ -230,6 +234,7 @@ __global__ __launch_bounds__(1024) void hml_k_backward_chain(unsigned long long*
         __syncthreads();
         if (tid == 0) mdl->fwd_mismatch = 0u;
     }
+    if (!(mode & 2)) return;
     const uint32_t per = (NC + 1023u) / 1024u;
     const uint32_t a = (uint32_t)tid * per < NC ? (uint32_t)tid * per : NC;
     const uint32_t b = (a + per < NC) ? a + per : NC;
@@ -252,6 +257,42 @@ __global__ __launch_bounds__(1024) void hml_k_backward_chain(unsigned long long*
     for (uint32_t c = b; c > a; --c) {
         entry_state[c - 1] = (uint8_t)x;
         x = (unsigned)(cmap[c - 1] >> (4 * x)) & 15u;
+    }
+}
+
+// Two-level chain for sweeps with millions of backward chunks (one workgroup walking all chunk maps would take
+// milliseconds): a wavefront composes the maps of 64 consecutive chunks - scmap[c] = cmap[c] o .. o cmap[last chunk of
+// its super-chunk], super[S] = scmap[64 S] -, the one-workgroup chain runs over the super maps only (super_level = 1),
+// and the state entering chunk c follows from its super-chunk's: entry[c] = scmap[c + 1](entry2[S]).
+template <int K>
+__global__ __launch_bounds__(256) void hml_k_backward_super(const unsigned long long* __restrict__ cmap, const hml_model* __restrict__ mdl,
+                                                            unsigned long long* __restrict__ scmap, unsigned long long* __restrict__ super) {
+    const uint32_t NC = (mdl->B + HML_BWD_CHUNK - 1u) / HML_BWD_CHUNK;
+    const uint32_t NS = (NC + 63u) / 64u;
+    const int lane = threadIdx.x & 63;
+    const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
+    for (uint32_t S = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; S < NS; S += nwaves) {
+        const uint32_t c = S * 64u + (uint32_t)lane;
+        unsigned long long map = c < NC ? cmap[c] : HML_MAP_IDENTITY;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            unsigned long long o = hml_shfl_down_u64(map, d);
+            if (lane + d >= 64) o = HML_MAP_IDENTITY;
+            map = hml_map_compose<K>(map, o);
+        }
+        if (c < NC) scmap[c] = map;
+        if (lane == 0) super[S] = map;
+    }
+}
+
+__global__ __launch_bounds__(256) void hml_k_backward_entries(const unsigned long long* __restrict__ scmap, const uint8_t* __restrict__ entry2,
+                                                              const hml_model* __restrict__ mdl, uint8_t* __restrict__ entry_state) {
+    const uint32_t NC = (mdl->B + HML_BWD_CHUNK - 1u) / HML_BWD_CHUNK;
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t c = blockIdx.x * blockDim.x + threadIdx.x; c < NC; c += stride) {
+        const unsigned e2 = entry2[c >> 6];
+        const bool last = (c & 63u) == 63u || c + 1u == NC;
+        entry_state[c] = last ? (uint8_t)e2 : (uint8_t)((scmap[c + 1u] >> (4u * e2)) & 15ull);
     }
 }
 
