@@ -742,6 +742,11 @@ static int sweep_k(hml_ctx* c, char method, bool record) {
             refresh_hint(c);
             const uint32_t h0 = c->B_hint ? c->B_hint : (uint32_t)std::min<uint64_t>(c->T, 1u << 20);
             ProfScope ps(c, "stats_emission");
+            if (dense_geo && L <= hml_emit_tile<KK>::MAXL)
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_emission_tiled<KK, true>), dim3(grid_for(h0, hml_emit_tile<KK>::BLOCKS, 64, 65536)),
+                                   dim3(256), 0, s, c->d_ia, c->d_starts, c->d_mdl, c->d_bstat, c->d_em, c->d_gsc,
+                                   c->probes ? c->d_eprobe : nullptr, mix ? 1 : 0, lay);
+            else
             hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_stats_emission<KK>), dim3(grid_for(h0, 256, 64, 16384)), dim3(256), 0, s,
                                c->d_ia, c->d_starts, c->d_mdl, c->d_bstat, c->d_em, c->d_gsc, c->probes ? c->d_eprobe : nullptr,
                                mix ? 1 : 0, lay);
@@ -755,6 +760,11 @@ static int sweep_k(hml_ctx* c, char method, bool record) {
     const int gB = grid_for(hint, 256, 64, 16384);
     if (!emitted) {
         ProfScope ps(c, "emission");
+        if (dense_geo && L <= hml_emit_tile<KK>::MAXL)
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_emission_tiled<KK, false>), dim3(grid_for(hint, hml_emit_tile<KK>::BLOCKS, 64, 65536)),
+                               dim3(256), 0, s, c->d_ia, c->d_starts, c->d_mdl, c->d_bstat, c->d_em, c->d_gsc,
+                               c->probes ? c->d_eprobe : nullptr, mix ? 1 : 0, lay);
+        else
         hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_emission<KK>), dim3(gB), dim3(256), 0, s, c->d_bstat, c->d_starts, c->d_mdl,
                            c->d_em, c->d_gsc, c->probes ? c->d_eprobe : nullptr, mix ? 1 : 0, lay);
     }

@@ -350,9 +350,17 @@ __global__ __launch_bounds__(256) void hml_k_counts(int16_t* __restrict__ q, con
     if (tid < K) h_occ[tid] = 0ull;
     __syncthreads();
     double acc_s[K], acc_q[K];   // only thread 0 uses them
+    // integer counts: every lane keeps, per state, the positions and blocks it saw in that state and the blocks that
+    // stayed in it (registers, no cross-lane traffic in the loop); only changes of state - rare - go to LDS.  From
+    // these: occ[s] = positions, trans[s][s] = positions - blocks + stayed, trans[p][s] (p != s) from the LDS counters.
+    unsigned long long n_pos[K];
+    uint32_t n_blk[K], n_stay[K];
 #pragma unroll
-    for (int s = 0; s < K; ++s) { acc_s[s] = 0.0; acc_q[s] = 0.0; }
+    for (int s = 0; s < K; ++s) { n_pos[s] = 0ull; n_blk[s] = 0u; n_stay[s] = 0u; }
     const uint32_t nchunks = (B + HML_REDUCE_CHUNK - 1u) / HML_REDUCE_CHUNK;
+    // with one or two chunks per workgroup (strongly compressed sweeps) the fold at the end would cost more than it
+    // saves: the counts then go straight to LDS
+    const bool direct = nchunks <= 2u * HML_REDUCE_GROUPS;
     for (uint32_t c = g; c < nchunks; c += HML_REDUCE_GROUPS) {
         const uint32_t b = c * HML_REDUCE_CHUNK + (uint32_t)tid;
         int st = -1;
@@ -370,9 +378,17 @@ __global__ __launch_bounds__(256) void hml_k_counts(int16_t* __restrict__ q, con
             const uint32_t n = starts[b + 1] - starts[b];
             const float2 v = bstat[b];
             vx = (double)v.x; vq = (double)v.y;
-            atomicAdd(&h_trans[st * K + st], (unsigned long long)(n - 1u));
-            atomicAdd(&h_trans[prev * K + st], 1ull);
-            atomicAdd(&h_occ[st], (unsigned long long)n);
+            if (direct) {
+                atomicAdd(&h_trans[st * K + st], (unsigned long long)(n - 1u));
+                atomicAdd(&h_trans[prev * K + st], 1ull);
+                atomicAdd(&h_occ[st], (unsigned long long)n);
+            } else {
+#pragma unroll
+                for (int s = 0; s < K; ++s) {
+                    if (st == s) { n_pos[s] += (unsigned long long)n; n_blk[s] += 1u; if (prev == s) n_stay[s] += 1u; }
+                }
+                if (prev != st) atomicAdd(&h_trans[prev * K + st], 1ull);
+            }
         }
 #pragma unroll
         for (int s = 0; s < K; ++s) {
@@ -404,6 +420,26 @@ __global__ __launch_bounds__(256) void hml_k_counts(int16_t* __restrict__ q, con
             partial[((uint64_t)g * K + s) * 2 + 1] = acc_q[s];
         }
     }
+    // fold the per-lane counters: wavefront sums, then one LDS update per wavefront and state
+    if (!direct) {
+#pragma unroll
+    for (int s = 0; s < K; ++s) {
+        unsigned long long np = n_pos[s];
+        uint32_t nb = n_blk[s], ns = n_stay[s];
+#pragma unroll
+        for (int m = 1; m < 64; m <<= 1) {
+            const uint32_t lo = __shfl_xor((uint32_t)np, m), hi = __shfl_xor((uint32_t)(np >> 32), m);
+            np += ((unsigned long long)hi << 32) | lo;
+            nb += __shfl_xor(nb, m);
+            ns += __shfl_xor(ns, m);
+        }
+        if (lane == 0) {
+            atomicAdd(&h_occ[s], np);
+            atomicAdd(&h_trans[s * K + s], np - (unsigned long long)nb + (unsigned long long)ns);
+        }
+    }
+    }
+    __syncthreads();
     const int slot = (int)(g % HML_CNT_SPLIT);
     for (int i = tid; i < K * K; i += 256)
         if (h_trans[i]) atomicAdd(&mdl->trans[slot][i], h_trans[i]);

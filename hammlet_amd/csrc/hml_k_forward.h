@@ -97,6 +97,124 @@ __global__ __launch_bounds__(256) void hml_k_stats_emission(const float2* __rest
 }
 
 // ------------------------------------------------------------------------------------------
+// Tiled form of the two kernels above for weakly compressed sweeps (millions of blocks, forward chunks of 16 or more
+// blocks).  Same values bit for bit; three differences in how they are produced:
+//  * stores: the chunk-transposed layout puts consecutive blocks of one chunk into different planes, so a block-per-lane
+//    store scatters 4-byte words.  A workgroup takes a tile of whole chunks, keeps the tile's terms in LDS in the
+//    layout's own order ([state][row in chunk][chunk], pitch + 1 against bank conflicts) and writes every
+//    (row, state) plane segment as one run of consecutive floats.
+//  * the quotient (2 mu Sx - Sxx) / (2 var) is taken as a product with the double reciprocal; the product is within
+//    2 ulp of the correctly rounded quotient, so both round to the same float unless the product lies within 4 ulp of
+//    the midpoint of two floats (or is tiny / not finite): only then is the division carried out.
+//  * g = expf((N-1) logA_s) comes from a per-workgroup table for N <= 64 (the same function on the same argument).
+template <int K>
+struct hml_emit_tile {
+    static constexpr int BLOCKS = (K <= 8) ? 512 : 256;   // blocks per tile: whole chunks for L <= 64, LDS < 64 KB
+    static constexpr int MAXL = 64;
+    static constexpr int GTAB = 64;
+};
+
+template <int K>
+__device__ __forceinline__ void hml_emit_values_fast(const hml_emit_params<K>& p, const double (&rvar)[K], const float* __restrict__ gtab,
+                                                     hml_model* mdl, uint32_t b, float sx, float sq, uint32_t n,
+                                                     float* __restrict__ eprobe, int mixture, float (&ev)[K], float (&gv)[K]) {
+    const float N = (float)n;
+    float E[K];
+    float maxE = -3.40282346638528859812e+38f;
+#pragma unroll
+    for (int s = 0; s < K; ++s) {
+        const double num = 2.0 * (double)p.mu[s] * (double)sx - (double)sq;
+        double ipd = num * rvar[s];
+        const uint64_t bits = hml_d2u(ipd);
+        const uint32_t low = (uint32_t)bits & 0x1fffffffu;
+        const uint32_t ex = (uint32_t)(bits >> 52) & 0x7ffu;
+        const bool close = (low - 0x0ffffffcu) <= 8u;                  // within 4 ulp of a float midpoint
+        if (close || ex < 923u || ex > 1150u) {                        // |ip| < 2^-100, > 2^127, inf/NaN (0 is decided by the product)
+            if (ipd != 0.0 || close) ipd = num / (2.0 * (double)p.var[s]);
+        }
+        const float ip = (float)ipd;
+        if (!hml_isfinite(ip)) hml_raise(mdl, HML_DEVERR_IP_NOT_FINITE, ip);
+        float e = (0.0f + ip) - N * p.logN[s];
+        if (p.self) e += (N - 1.0f) * p.logA[s];
+        E[s] = e;
+        maxE = (e < maxE) ? maxE : e;
+    }
+#pragma unroll
+    for (int s = 0; s < K; ++s) {
+        if (eprobe) eprobe[(uint64_t)b * K + s] = E[s];
+        ev[s] = hml_expf(E[s] - maxE);
+        gv[s] = 1.0f;
+        if (!mixture && p.self) gv[s] = (n <= (uint32_t)hml_emit_tile<K>::GTAB) ? gtab[(n - 1u) * K + s] : hml_expf((N - 1.0f) * p.logA[s]);
+    }
+}
+
+// STATS = true: block statistics from the integral array first (hml_k_stats_emission); false: from bstat (hml_k_emission)
+template <int K, bool STATS>
+__global__ __launch_bounds__(256) void hml_k_emission_tiled(const float2* __restrict__ ia, const uint32_t* __restrict__ starts,
+                                                            hml_model* __restrict__ mdl, float2* __restrict__ bstat,
+                                                            float* __restrict__ em, float* __restrict__ gsc,
+                                                            float* __restrict__ eprobe, int mixture, const hml_layout lay) {
+    constexpr int TB = hml_emit_tile<K>::BLOCKS;
+    constexpr int GT = hml_emit_tile<K>::GTAB;
+    __shared__ float sm_e[K * TB + K * 64 + 64];     // [s][r][cl] with pitch cpt + 1 (cpt = chunks per tile <= TB)
+    __shared__ float sm_g[K * TB + K * 64 + 64];
+    __shared__ float gtab[GT * K];
+    const uint32_t B = mdl->B;
+    hml_emit_params<K> p;
+    hml_emit_load<K>(p, mdl, mixture);
+    double rvar[K];
+#pragma unroll
+    for (int s = 0; s < K; ++s) rvar[s] = 1.0 / (2.0 * (double)p.var[s]);
+    for (int i = threadIdx.x; i < GT * K; i += 256) {
+        const int n1 = i / K, s = i % K;   // n - 1
+        gtab[i] = hml_expf((float)n1 * mdl->logA[s]);
+    }
+    const uint32_t Lr = 1u << lay.lshift;
+    if (Lr > (uint32_t)hml_emit_tile<K>::MAXL) return;   // (the host launches the plain kernels for longer chunks)
+    const uint32_t cpt = (uint32_t)TB >> lay.lshift;       // chunks per tile
+    const uint32_t pitch = cpt + 1u;
+    const uint32_t n_tiles = (B + TB - 1u) / TB;
+    __syncthreads();
+    for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const uint32_t b0 = tile * TB;
+#pragma unroll
+        for (int j = 0; j < TB / 256; ++j) {
+            const uint32_t bl = (uint32_t)j * 256u + threadIdx.x;
+            const uint32_t b = b0 + bl;
+            if (b < B) {
+                const uint32_t st = starts[b], en = starts[b + 1];
+                float sx, sq;
+                if (STATS) { hml_block_stats_one(ia, st, en, sx, sq); bstat[b] = make_float2(sx, sq); }
+                else { const float2 v = bstat[b]; sx = v.x; sq = v.y; }
+                float ev[K], gv[K];
+                hml_emit_values_fast<K>(p, rvar, gtab, mdl, b, sx, sq, en - st, eprobe, mixture, ev, gv);
+                const uint32_t r = bl & (Lr - 1u), cl = bl >> lay.lshift;
+#pragma unroll
+                for (int s = 0; s < K; ++s) {
+                    sm_e[((uint32_t)s * Lr + r) * pitch + cl] = ev[s];
+                    sm_g[((uint32_t)s * Lr + r) * pitch + cl] = gv[s];
+                }
+            }
+        }
+        __syncthreads();
+        // write-out: for every (row, state) the tile's chunks are consecutive floats in the plane
+        const uint32_t c0 = b0 >> lay.lshift;
+        const uint32_t nrs = Lr * (uint32_t)K;
+        for (uint32_t e = threadIdx.x; e < nrs * cpt; e += 256u) {
+            const uint32_t cl = e % cpt, rs = e / cpt;
+            const uint32_t r = rs / (uint32_t)K, s = rs % (uint32_t)K;
+            const uint32_t b = b0 + (cl << lay.lshift) + r;
+            if (b < B) {
+                const uint64_t g = ((uint64_t)r * (uint32_t)K + s) * lay.cstride + c0 + cl;
+                em[g] = sm_e[(s * Lr + r) * pitch + cl];
+                if (!mixture) gsc[g] = sm_g[(s * Lr + r) * pitch + cl];
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // K6b forward - the forward filter (reference src/StateSequence/ForwardBackward.hpp:86-123):
 //   f_j = e_t(j) * sum_i alpha_{t-1}(i) A(i,j)   (i in order, float)
 //   Z   = sum_j f_j                               (j in order, float)
