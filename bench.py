@@ -82,6 +82,7 @@ def main():
     ap.add_argument("--breakdown", action="store_true", help="extra profiled pass: per-kernel-family times")
     ap.add_argument("--no-stream-leg", action="store_true", help="skip the second leg (float weight stream instead of the summary)")
     ap.add_argument("--no-two-chain-leg", action="store_true", help="skip the third leg (two chains sharing one GPU)")
+    ap.add_argument("--no-uncompressed-leg", action="store_true", help="skip the fourth leg (same trace, weights x 1e9: every position its own block)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -278,6 +279,37 @@ def main():
                                      "note": "aggregate of two independent chains on one GPU; the headline value is one chain per GPU"}
         for ch in pair:
             ch.close()
+        chain = None
+
+    # fourth leg: SURVEY 8d's stress case C3u - the same trace with the breakpoint weights multiplied by 1e9, so that
+    # every position is its own block (B = T): the regime in which the trellis itself, not the block scan, is the load
+    if not args.no_uncompressed_leg and world == 1 and args.workload == "c3_1e8_k5_dynamic":
+        if chain is not None:
+            chain.close()
+        ch = hammlet_amd.Chain(device=local_rank, seed=args.seed, chain_id=rank)
+        ch.load(x)
+        ch.scale_weights(1e9)
+        ch.set_model(K, ch.autoprior(0.2, 0.9))
+        ch.sample_prior()
+        ch.set_recording(marginals=False)
+        n_u = max(5, min(20, args.steps))
+        ch.iterate("F", 6, 0)
+        ch.sync()
+        u0 = ch.stats()
+        barrier()
+        t0 = time.perf_counter()
+        ch.iterate("F", n_u, 0)
+        ch.sync()
+        barrier()
+        t1 = time.perf_counter()
+        u1 = ch.stats()
+        bu = u1["block_updates"] - u0["block_updates"]
+        Bu = bu / n_u
+        out["uncompressed_c3u"] = {"value": bu / (t1 - t0), "unit": "block-updates/s", "steps": n_u, "ms_per_step": 1e3 * (t1 - t0) / n_u,
+                                   "blocks_per_sweep": Bu, "forward_refits": u1["forward_refits"] - u0["forward_refits"],
+                                   "sweep_frac": (4.0 * T + Bu * (36 + 8 * K)) / ((t1 - t0) / n_u) / 1e9 / HBM_PEAK_GBS,
+                                   "note": "B = T: instruction-bound (about 1000 VALU instructions per block), DESIGN.md 3a"}
+        ch.close()
         chain = None
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

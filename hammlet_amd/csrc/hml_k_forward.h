@@ -26,13 +26,31 @@ __device__ __forceinline__ bool hml_isfinite(float x) { return (hml_f2u(x) & 0x7
 template <int K>
 struct hml_emit_params {
     float mu[K], var[K], logN[K], logA[K];
+    double rvar[K];   // 1 / (2 var), from the parameter kernel
     bool self;
 };
+
+// (float)((2.0 mu Sx - Sxx) / (2.0 var)) - the reference's inner product (EFD.hpp:23-33), double inside - with the
+// quotient taken as a product with the double reciprocal: the product is within 2 ulp of the correctly rounded
+// quotient, so both round to the same float unless the product lies within 4 ulp of the midpoint of two floats (or is
+// tiny / not finite); only then is the division carried out.
+__device__ __forceinline__ float hml_inner_product(float mu, float var, double rvar, float sx, float sq) {
+    const double num = 2.0 * (double)mu * (double)sx - (double)sq;
+    double ipd = num * rvar;
+    const uint64_t bits = hml_d2u(ipd);
+    const uint32_t low = (uint32_t)bits & 0x1fffffffu;
+    const uint32_t ex = (uint32_t)(bits >> 52) & 0x7ffu;
+    const bool close = (low - 0x0ffffffcu) <= 8u;                  // within 4 ulp of a float midpoint
+    if (close || ex < 923u || ex > 1150u) {                        // |ip| < 2^-100, > 2^127, inf/NaN (0 is decided by the product)
+        if (ipd != 0.0 || close) ipd = num / (2.0 * (double)var);
+    }
+    return (float)ipd;
+}
 
 template <int K>
 __device__ __forceinline__ void hml_emit_load(hml_emit_params<K>& p, const hml_model* mdl, int mixture) {
 #pragma unroll
-    for (int s = 0; s < K; ++s) { p.mu[s] = mdl->mu[s]; p.var[s] = mdl->var[s]; p.logN[s] = mdl->logN[s]; p.logA[s] = mdl->logA[s]; }
+    for (int s = 0; s < K; ++s) { p.mu[s] = mdl->mu[s]; p.var[s] = mdl->var[s]; p.logN[s] = mdl->logN[s]; p.logA[s] = mdl->logA[s]; p.rvar[s] = mdl->rvar[s]; }
     p.self = mdl->self_trans != 0 && !mixture;
 }
 
@@ -44,8 +62,7 @@ __device__ __forceinline__ void hml_emit_block(const hml_emit_params<K>& p, hml_
     float maxE = -3.40282346638528859812e+38f;   // numeric_limits<float>::lowest()
 #pragma unroll
     for (int s = 0; s < K; ++s) {
-        const double ipd = (2.0 * (double)p.mu[s] * (double)sx - (double)sq) / (2.0 * (double)p.var[s]);
-        const float ip = (float)ipd;
+        const float ip = hml_inner_product(p.mu[s], p.var[s], p.rvar[s], sx, sq);
         if (!hml_isfinite(ip)) hml_raise(mdl, HML_DEVERR_IP_NOT_FINITE, ip);
         float e = (0.0f + ip) - N * p.logN[s];
         if (p.self) e += (N - 1.0f) * p.logA[s];
@@ -98,14 +115,11 @@ __global__ __launch_bounds__(256) void hml_k_stats_emission(const float2* __rest
 
 // ------------------------------------------------------------------------------------------
 // Tiled form of the two kernels above for weakly compressed sweeps (millions of blocks, forward chunks of 16 or more
-// blocks).  Same values bit for bit; three differences in how they are produced:
+// blocks).  Same values bit for bit; two differences in how they are produced:
 //  * stores: the chunk-transposed layout puts consecutive blocks of one chunk into different planes, so a block-per-lane
 //    store scatters 4-byte words.  A workgroup takes a tile of whole chunks, keeps the tile's terms in LDS in the
 //    layout's own order ([state][row in chunk][chunk], pitch + 1 against bank conflicts) and writes every
 //    (row, state) plane segment as one run of consecutive floats.
-//  * the quotient (2 mu Sx - Sxx) / (2 var) is taken as a product with the double reciprocal; the product is within
-//    2 ulp of the correctly rounded quotient, so both round to the same float unless the product lies within 4 ulp of
-//    the midpoint of two floats (or is tiny / not finite): only then is the division carried out.
 //  * g = expf((N-1) logA_s) comes from a per-workgroup table for N <= 64 (the same function on the same argument).
 template <int K>
 struct hml_emit_tile {
@@ -115,7 +129,7 @@ struct hml_emit_tile {
 };
 
 template <int K>
-__device__ __forceinline__ void hml_emit_values_fast(const hml_emit_params<K>& p, const double (&rvar)[K], const float* __restrict__ gtab,
+__device__ __forceinline__ void hml_emit_values_fast(const hml_emit_params<K>& p, const float* __restrict__ gtab,
                                                      hml_model* mdl, uint32_t b, float sx, float sq, uint32_t n,
                                                      float* __restrict__ eprobe, int mixture, float (&ev)[K], float (&gv)[K]) {
     const float N = (float)n;
@@ -123,16 +137,7 @@ __device__ __forceinline__ void hml_emit_values_fast(const hml_emit_params<K>& p
     float maxE = -3.40282346638528859812e+38f;
 #pragma unroll
     for (int s = 0; s < K; ++s) {
-        const double num = 2.0 * (double)p.mu[s] * (double)sx - (double)sq;
-        double ipd = num * rvar[s];
-        const uint64_t bits = hml_d2u(ipd);
-        const uint32_t low = (uint32_t)bits & 0x1fffffffu;
-        const uint32_t ex = (uint32_t)(bits >> 52) & 0x7ffu;
-        const bool close = (low - 0x0ffffffcu) <= 8u;                  // within 4 ulp of a float midpoint
-        if (close || ex < 923u || ex > 1150u) {                        // |ip| < 2^-100, > 2^127, inf/NaN (0 is decided by the product)
-            if (ipd != 0.0 || close) ipd = num / (2.0 * (double)p.var[s]);
-        }
-        const float ip = (float)ipd;
+        const float ip = hml_inner_product(p.mu[s], p.var[s], p.rvar[s], sx, sq);
         if (!hml_isfinite(ip)) hml_raise(mdl, HML_DEVERR_IP_NOT_FINITE, ip);
         float e = (0.0f + ip) - N * p.logN[s];
         if (p.self) e += (N - 1.0f) * p.logA[s];
@@ -162,9 +167,6 @@ __global__ __launch_bounds__(256) void hml_k_emission_tiled(const float2* __rest
     const uint32_t B = mdl->B;
     hml_emit_params<K> p;
     hml_emit_load<K>(p, mdl, mixture);
-    double rvar[K];
-#pragma unroll
-    for (int s = 0; s < K; ++s) rvar[s] = 1.0 / (2.0 * (double)p.var[s]);
     for (int i = threadIdx.x; i < GT * K; i += 256) {
         const int n1 = i / K, s = i % K;   // n - 1
         gtab[i] = hml_expf((float)n1 * mdl->logA[s]);
@@ -187,7 +189,7 @@ __global__ __launch_bounds__(256) void hml_k_emission_tiled(const float2* __rest
                 if (STATS) { hml_block_stats_one(ia, st, en, sx, sq); bstat[b] = make_float2(sx, sq); }
                 else { const float2 v = bstat[b]; sx = v.x; sq = v.y; }
                 float ev[K], gv[K];
-                hml_emit_values_fast<K>(p, rvar, gtab, mdl, b, sx, sq, en - st, eprobe, mixture, ev, gv);
+                hml_emit_values_fast<K>(p, gtab, mdl, b, sx, sq, en - st, eprobe, mixture, ev, gv);
                 const uint32_t r = bl & (Lr - 1u), cl = bl >> lay.lshift;
 #pragma unroll
                 for (int s = 0; s < K; ++s) {
