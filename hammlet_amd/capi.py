@@ -89,7 +89,7 @@ def load_library(path=None):
     global _lib
     if _lib is not None and path is None:
         return _lib
-    path = path or _build.LIB_PATH
+    path = path or os.environ.get("HML_LIBRARY") or _build.LIB_PATH   # HML_LIBRARY: A/B timing of two builds
     if not os.path.exists(path):
         raise HmlError(-1, "%s is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                            "(hipcc --offload-arch=gfx950); there is no CPU fallback" % path)

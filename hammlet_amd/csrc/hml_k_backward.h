@@ -361,22 +361,43 @@ __global__ __launch_bounds__(256) void hml_k_counts(int16_t* __restrict__ q, con
     // with one or two chunks per workgroup (strongly compressed sweeps) the fold at the end would cost more than it
     // saves: the counts then go straight to LDS
     const bool direct = nchunks <= 2u * HML_REDUCE_GROUPS;
+    // one chunk of loads ahead: the next chunk's words are requested before this chunk's reductions and barriers
+    struct in_t { unsigned long long m1, m0; uint32_t e1, e0, s1, s0; float2 v; int16_t q1, q0; };
+    auto fetch = [&](uint32_t c, in_t& r) {
+        const uint32_t b = c * HML_REDUCE_CHUNK + (uint32_t)tid;
+        r.m1 = r.m0 = 0ull; r.e1 = r.e0 = 0u; r.s1 = r.s0 = 0u; r.v = make_float2(0.0f, 0.0f); r.q1 = r.q0 = 0;
+        if (c < nchunks && b < B) {
+            if (FB) {
+                r.m1 = smap[b + 1]; r.e1 = entry[b / HML_BWD_CHUNK];
+                if (b != 0) { r.m0 = smap[b]; r.e0 = entry[(b - 1) / HML_BWD_CHUNK]; }
+            } else {
+                r.q1 = q[b];
+                if (b != 0) r.q0 = q[b - 1];
+            }
+            r.s1 = starts[b + 1]; r.s0 = starts[b];
+            r.v = bstat[b];
+        }
+    };
+    in_t nxt;
+    fetch(g, nxt);
     for (uint32_t c = g; c < nchunks; c += HML_REDUCE_GROUPS) {
         const uint32_t b = c * HML_REDUCE_CHUNK + (uint32_t)tid;
+        const in_t cur = nxt;
+        fetch(c + HML_REDUCE_GROUPS, nxt);
         int st = -1;
         double vx = 0.0, vq = 0.0;
         if (b < B) {
             int prev;
             if (FB) {
-                st = (int)((smap[b + 1] >> (4 * (unsigned)entry[b / HML_BWD_CHUNK])) & 15ull);
-                prev = (b == 0) ? 0 : (int)((smap[b] >> (4 * (unsigned)entry[(b - 1) / HML_BWD_CHUNK])) & 15ull);
+                st = (int)((cur.m1 >> (4 * cur.e1)) & 15ull);
+                prev = (b == 0) ? 0 : (int)((cur.m0 >> (4 * cur.e0)) & 15ull);
                 q[b] = (int16_t)st;
             } else {
-                st = q[b];
-                prev = (b == 0) ? 0 : (int)q[b - 1];
+                st = cur.q1;
+                prev = (b == 0) ? 0 : (int)cur.q0;
             }
-            const uint32_t n = starts[b + 1] - starts[b];
-            const float2 v = bstat[b];
+            const uint32_t n = cur.s1 - cur.s0;
+            const float2 v = cur.v;
             vx = (double)v.x; vq = (double)v.y;
             if (direct) {
                 atomicAdd(&h_trans[st * K + st], (unsigned long long)(n - 1u));
