@@ -965,7 +965,6 @@ int hml_set_parameters(hml_ctx* c, const float* mean_var, const float* A, const 
         if (!std::isfinite(var)) return set_err(HML_ERR_MODEL, "Variance(" + std::to_string(var) + ") must be set to a finite value!");
         if (var <= 0) return set_err(HML_ERR_MODEL, "Variance (" + std::to_string(var) + ") must be positive!");
         m.mu[k] = mean; m.var[k] = var; m.sd[k] = sqrtf(var);
-        m.rvar[k] = 1.0 / (2.0 * (double)var);
     }
     memcpy(m.A, A, (size_t)K * K * sizeof(float));
     memcpy(m.pi, pi, (size_t)K * sizeof(float));

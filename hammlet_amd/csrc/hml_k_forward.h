@@ -26,14 +26,15 @@ __device__ __forceinline__ bool hml_isfinite(float x) { return (hml_f2u(x) & 0x7
 template <int K>
 struct hml_emit_params {
     float mu[K], var[K], logN[K], logA[K];
-    double rvar[K];   // 1 / (2 var), from the parameter kernel
     bool self;
 };
 
 // (float)((2.0 mu Sx - Sxx) / (2.0 var)) - the reference's inner product (EFD.hpp:23-33), double inside - with the
 // quotient taken as a product with the double reciprocal: the product is within 2 ulp of the correctly rounded
 // quotient, so both round to the same float unless the product lies within 4 ulp of the midpoint of two floats (or is
-// tiny / not finite); only then is the division carried out.
+// tiny / not finite); only then is the division carried out.  Used by the tiled kernel of the weakly compressed
+// sweeps, where a lane converts hundreds of blocks; in the strongly compressed sweeps a lane converts one block and the
+// dependent reciprocal made the block kernel 2 us slower (measured), so hml_emit_block divides.
 __device__ __forceinline__ float hml_inner_product(float mu, float var, double rvar, float sx, float sq) {
     const double num = 2.0 * (double)mu * (double)sx - (double)sq;
     double ipd = num * rvar;
@@ -50,7 +51,7 @@ __device__ __forceinline__ float hml_inner_product(float mu, float var, double r
 template <int K>
 __device__ __forceinline__ void hml_emit_load(hml_emit_params<K>& p, const hml_model* mdl, int mixture) {
 #pragma unroll
-    for (int s = 0; s < K; ++s) { p.mu[s] = mdl->mu[s]; p.var[s] = mdl->var[s]; p.logN[s] = mdl->logN[s]; p.logA[s] = mdl->logA[s]; p.rvar[s] = mdl->rvar[s]; }
+    for (int s = 0; s < K; ++s) { p.mu[s] = mdl->mu[s]; p.var[s] = mdl->var[s]; p.logN[s] = mdl->logN[s]; p.logA[s] = mdl->logA[s]; }
     p.self = mdl->self_trans != 0 && !mixture;
 }
 
@@ -62,7 +63,8 @@ __device__ __forceinline__ void hml_emit_block(const hml_emit_params<K>& p, hml_
     float maxE = -3.40282346638528859812e+38f;   // numeric_limits<float>::lowest()
 #pragma unroll
     for (int s = 0; s < K; ++s) {
-        const float ip = hml_inner_product(p.mu[s], p.var[s], p.rvar[s], sx, sq);
+        const double ipd = (2.0 * (double)p.mu[s] * (double)sx - (double)sq) / (2.0 * (double)p.var[s]);
+        const float ip = (float)ipd;
         if (!hml_isfinite(ip)) hml_raise(mdl, HML_DEVERR_IP_NOT_FINITE, ip);
         float e = (0.0f + ip) - N * p.logN[s];
         if (p.self) e += (N - 1.0f) * p.logA[s];
@@ -115,11 +117,12 @@ __global__ __launch_bounds__(256) void hml_k_stats_emission(const float2* __rest
 
 // ------------------------------------------------------------------------------------------
 // Tiled form of the two kernels above for weakly compressed sweeps (millions of blocks, forward chunks of 16 or more
-// blocks).  Same values bit for bit; two differences in how they are produced:
+// blocks).  Same values bit for bit; three differences in how they are produced:
 //  * stores: the chunk-transposed layout puts consecutive blocks of one chunk into different planes, so a block-per-lane
 //    store scatters 4-byte words.  A workgroup takes a tile of whole chunks, keeps the tile's terms in LDS in the
 //    layout's own order ([state][row in chunk][chunk], pitch + 1 against bank conflicts) and writes every
 //    (row, state) plane segment as one run of consecutive floats.
+//  * the quotient of the inner product is a product with the double reciprocal (hml_inner_product);
 //  * g = expf((N-1) logA_s) comes from a per-workgroup table for N <= 64 (the same function on the same argument).
 template <int K>
 struct hml_emit_tile {
@@ -129,7 +132,7 @@ struct hml_emit_tile {
 };
 
 template <int K>
-__device__ __forceinline__ void hml_emit_values_fast(const hml_emit_params<K>& p, const float* __restrict__ gtab,
+__device__ __forceinline__ void hml_emit_values_fast(const hml_emit_params<K>& p, const double (&rvar)[K], const float* __restrict__ gtab,
                                                      hml_model* mdl, uint32_t b, float sx, float sq, uint32_t n,
                                                      float* __restrict__ eprobe, int mixture, float (&ev)[K], float (&gv)[K]) {
     const float N = (float)n;
@@ -137,7 +140,7 @@ __device__ __forceinline__ void hml_emit_values_fast(const hml_emit_params<K>& p
     float maxE = -3.40282346638528859812e+38f;
 #pragma unroll
     for (int s = 0; s < K; ++s) {
-        const float ip = hml_inner_product(p.mu[s], p.var[s], p.rvar[s], sx, sq);
+        const float ip = hml_inner_product(p.mu[s], p.var[s], rvar[s], sx, sq);
         if (!hml_isfinite(ip)) hml_raise(mdl, HML_DEVERR_IP_NOT_FINITE, ip);
         float e = (0.0f + ip) - N * p.logN[s];
         if (p.self) e += (N - 1.0f) * p.logA[s];
@@ -167,6 +170,9 @@ __global__ __launch_bounds__(256) void hml_k_emission_tiled(const float2* __rest
     const uint32_t B = mdl->B;
     hml_emit_params<K> p;
     hml_emit_load<K>(p, mdl, mixture);
+    double rvar[K];   // once per lane: a lane converts hundreds of blocks in this regime
+#pragma unroll
+    for (int s = 0; s < K; ++s) rvar[s] = 1.0 / (2.0 * (double)p.var[s]);
     for (int i = threadIdx.x; i < GT * K; i += 256) {
         const int n1 = i / K, s = i % K;   // n - 1
         gtab[i] = hml_expf((float)n1 * mdl->logA[s]);
@@ -189,7 +195,7 @@ __global__ __launch_bounds__(256) void hml_k_emission_tiled(const float2* __rest
                 if (STATS) { hml_block_stats_one(ia, st, en, sx, sq); bstat[b] = make_float2(sx, sq); }
                 else { const float2 v = bstat[b]; sx = v.x; sq = v.y; }
                 float ev[K], gv[K];
-                hml_emit_values_fast<K>(p, gtab, mdl, b, sx, sq, en - st, eprobe, mixture, ev, gv);
+                hml_emit_values_fast<K>(p, rvar, gtab, mdl, b, sx, sq, en - st, eprobe, mixture, ev, gv);
                 const uint32_t r = bl & (Lr - 1u), cl = bl >> lay.lshift;
 #pragma unroll
                 for (int s = 0; s < K; ++s) {

@@ -159,7 +159,6 @@ __global__ __launch_bounds__(1024) void hml_k_params(hml_model* __restrict__ mdl
         else if (v <= 0.0f) hml_raise(mdl, HML_DEVERR_VAR_NOT_POSITIVE, v);
         const float sd = HML_SQRTF(v);
         mdl->mu[k] = m; mdl->var[k] = v; mdl->sd[k] = sd;
-        mdl->rvar[k] = 1.0 / (2.0 * (double)v);
         if (mode == 0) {   // hml_derive's logNormalizer, from the registers instead of a round trip through memory
             mdl->logN[k] = hml_logf(sd) + m * m / (2 * v);
             s_var[k] = v;

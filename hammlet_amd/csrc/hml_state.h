@@ -54,7 +54,6 @@ struct hml_model {
     hml_key key;
     // ---- current parameters ----
     float mu[HML_MAX_K], var[HML_MAX_K], sd[HML_MAX_K];
-    double rvar[HML_MAX_K];      // 1 / (2.0 * var): the emission kernels multiply by it and divide only on close calls
     float logN[HML_MAX_K];       // theta.logNormalizer(s)          (EFD.hpp:35-38)
     float logA[HML_MAX_K];       // log A(s,s)                       (ForwardBackward.hpp:47-52)
     float A[HML_MAX_K * HML_MAX_K];   // row-major, stride K
