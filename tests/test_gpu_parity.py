@@ -434,3 +434,46 @@ def test_dense_forward_geometry_is_invisible_in_the_results(hml, monkeypatch, de
     assert np.array_equal(bits(o.forward_rows()), bits(g.forward_rows()))
     seg, cnt = g.marginals_rle()
     assert hml.marginals_text(seg, cnt) == o.text("marginals")
+
+
+@pytest.mark.parametrize("fn,K", [(30, 16), (31, 5)])
+def test_division_free_categorical_equals_the_literal_form(hml, fn, K):
+    """hml_categorical_k_fast decides `cp_i >= u` from running sums and hands close calls (and rows whose sum is not a
+    positive finite number) to the literal std::discrete_distribution form: the combined result must be the literal
+    one, which in turn is the host's (numpy double) evaluation - on rows with zeros, tiny and ordinary weights, and on
+    uniforms placed next to the cumulative probabilities."""
+    rng = np.random.default_rng(fn)
+    n = 300000
+    kind = rng.integers(0, 4, (n, K))
+    w = np.where(kind == 0, 0.0, np.where(kind == 1, rng.integers(0, 10 ** 6, (n, K)) * 2.0 ** -rng.integers(0, 120, (n, K)),
+                                          rng.integers(0, 1000, (n, K)) / 1000.0)).astype(np.float32)
+    w[: n // 50] = 0.0                                             # all-zero rows: every probability is NaN, index 0
+    u = rng.random(n).astype(np.float32)
+    sd = w.astype(np.float64)
+    S = np.zeros(n)
+    for i in range(K):
+        S = S + sd[:, i]
+    # half of the uniforms sit on (the float nearest to) a cumulative probability
+    with np.errstate(all="ignore"):
+        j = rng.integers(0, K, n)
+        cpj = np.zeros(n)
+        for i in range(K):
+            cpj = cpj + np.where(i <= j, sd[:, i] / S, 0.0)
+    near = (rng.random(n) < 0.5) & np.isfinite(cpj) & (cpj < 1.0) & (cpj > 0.0)
+    u[near] = cpj[near].astype(np.float32)
+    u = np.minimum(u, np.float32(0.99999994))
+    out = hml.debug_eval(fn, w.ravel(), np.repeat(u[:, None], K, 1).ravel()).reshape(n, K)
+    comb, lit, unsure = out[:, 0], out[:, 1], out[:, 2]
+    with np.errstate(all="ignore"):
+        cp = np.zeros(n)
+        res = np.full(n, K - 1)
+        done = np.zeros(n, bool)
+        for i in range(K):
+            cp = cp + sd[:, i] / S
+            c = np.ones(n) if i == K - 1 else cp
+            hit = ~done & ~(c < u.astype(np.float64))
+            res[hit] = i
+            done |= hit
+    assert np.array_equal(lit, res)
+    assert np.array_equal(comb, lit)
+    assert unsure.sum() >= n // 50                                # the close calls were exercised
