@@ -448,6 +448,11 @@ def test_division_free_categorical_equals_the_literal_form(hml, fn, K):
     w = np.where(kind == 0, 0.0, np.where(kind == 1, rng.integers(0, 10 ** 6, (n, K)) * 2.0 ** -rng.integers(0, 120, (n, K)),
                                           rng.integers(0, 1000, (n, K)) / 1000.0)).astype(np.float32)
     w[: n // 50] = 0.0                                             # all-zero rows: every probability is NaN, index 0
+    # rows of small integers that add up to 64: every cumulative probability is a float, so u can hit it exactly
+    m = n // 4
+    ints = rng.integers(0, 64 // K + 1, (m, K))
+    ints[:, K - 1] = 64 - ints[:, : K - 1].sum(1)
+    w[n - m:] = ints.astype(np.float32)
     u = rng.random(n).astype(np.float32)
     sd = w.astype(np.float64)
     S = np.zeros(n)
@@ -476,4 +481,4 @@ def test_division_free_categorical_equals_the_literal_form(hml, fn, K):
             done |= hit
     assert np.array_equal(lit, res)
     assert np.array_equal(comb, lit)
-    assert unsure.sum() >= n // 50                                # the close calls were exercised
+    assert unsure.sum() >= n // 50 + m // 8                       # all-zero rows and exact ties went to the literal form
