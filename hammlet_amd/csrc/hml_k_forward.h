@@ -404,6 +404,7 @@ struct hml_repair_lds {
     uint32_t tcount;
     uint32_t next_first_bad;                  // the first chunk of the next window became inconsistent
     uint32_t any_bad;
+    uint32_t any_marked, carry;               // this window holds a stale chunk / inherits one from the window before
 };
 
 template <int K>
@@ -437,8 +438,9 @@ __device__ void hml_fwd_repair(const float* __restrict__ em, const float* __rest
     for (uint32_t w0 = 0; w0 < C; w0 += win) {
         const uint32_t w1 = (w0 + win < C) ? w0 + win : C;
         for (int i = tid; i < HML_REPAIR_WINDOW_WORDS; i += nthr) { sh.bad[i] = 0u; sh.bad2[i] = 0u; }
+        if (tid == 0) { sh.any_marked = 0u; sh.carry = 0u; sh.any_bad = 0u; }
         __syncthreads();
-        if (tid == 0 && sh.next_first_bad) { sh.bad2[0] = 1u; sh.next_first_bad = 0u; }
+        if (tid == 0 && sh.next_first_bad) { sh.bad2[0] = 1u; sh.next_first_bad = 0u; sh.carry = 1u; }
         // ---- 1a. stale forward chunks of the listed backward chunks
         for (uint64_t i = (uint64_t)tid; i < (uint64_t)n_fail * nfper; i += (uint64_t)nthr) {
             const uint32_t cb = fail_list[i / nfper];
@@ -451,9 +453,11 @@ __device__ void hml_fwd_repair(const float* __restrict__ em, const float* __rest
             bool same = true;
 #pragma unroll
             for (int s = 0; s < K; ++s) same = same && (hml_f2u(entry[(uint64_t)f * K + s]) == hml_f2u(exitv[(uint64_t)(f - 1) * K + s]));
-            if (!same) atomicOr(&sh.bad[(f - w0) >> 5], 1u << ((f - w0) & 31u));
+            if (!same) { atomicOr(&sh.bad[(f - w0) >> 5], 1u << ((f - w0) & 31u)); sh.any_marked = 1u; }
         }
         __syncthreads();
+        // a window without a stale chunk (nearly all of them, when a few chunks among millions failed) is done
+        if (sh.any_marked == 0u && sh.carry == 0u) continue;   // workgroup-uniform
         // ---- 1b / 2a. recompute the marked chunks after a longer warm-up (one thread per chunk), check them and
         // their successors again (loads that bypass the L1), and escalate what is still inconsistent: 2W, 4W, 8W, 16W
         for (uint32_t factor = 2u; factor <= 16u; factor *= 2u) {
@@ -496,7 +500,7 @@ __device__ void hml_fwd_repair(const float* __restrict__ em, const float* __rest
             __syncthreads();
         }
         // ---- 2b. what is still inconsistent, serially
-        if (tid == 0) {
+        if (tid == 0 && (sh.any_bad != 0u || sh.carry != 0u)) {
             for (uint32_t wi = 0; wi < (w1 - w0 + 31u) / 32u; ++wi) {
                 uint32_t bits = sh.bad2[wi];
                 while (bits) {

@@ -227,16 +227,24 @@ __global__ __launch_bounds__(1024) void hml_k_params(hml_model* __restrict__ mdl
         hml_derive<K>(mdl, tid);
     }
     if (tid == 1023) {
-        // adapt the forward warm-up: double it whenever the serial repair had to run, shrink it slowly
-        // after 32 sweeps without a single refit (speed only - the rows are bit-exact for every W)
+        // adapt the forward warm-up (speed only - the rows are bit-exact for every W): double it when the repair step
+        // had real work - its serial pass ran, or it recomputed more than a handful of chunks - and shrink it slowly
+        // after 32 sweeps without a single refit (shrinking while a few chunks still fail was measured: the failure
+        // count has a cliff, sweeps with 10^5 refits follow)
         if (mode == 0) {
             uint32_t W = mdl->fwd_W;
-            if (mdl->fwd_serial_ran) { W = (2u * W < 1024u) ? 2u * W : 1024u; mdl->fwd_quiet = 0u; }
-            else if (mdl->forward_refits == mdl->fwd_refits_seen) {
+            const unsigned long long refits = mdl->forward_refits - mdl->fwd_refits_seen;
+            const unsigned long long serial = mdl->forward_serial - mdl->fwd_serial_seen;
+            // a handful: none while a sweep has fewer than 2^22 blocks (a repair is then a visible share of the sweep),
+            // one chunk in some thousands beyond
+            const unsigned long long handful = (mdl->B >> 22) ? (((unsigned long long)(mdl->B >> 16) > 16ull) ? (unsigned long long)(mdl->B >> 16) : 16ull) : 0ull;
+            if (serial != 0ull || refits > handful) { W = (2u * W < 1024u) ? 2u * W : 1024u; mdl->fwd_quiet = 0u; }
+            else if (refits == 0ull) {
                 if (++mdl->fwd_quiet >= 32u) { const uint32_t w2 = W - W / 4u; W = (w2 > mdl->fwd_W0) ? (w2 & ~7u) : mdl->fwd_W0; mdl->fwd_quiet = 0u; }
             } else mdl->fwd_quiet = 0u;
             mdl->fwd_W = W;
             mdl->fwd_refits_seen = mdl->forward_refits;
+            mdl->fwd_serial_seen = mdl->forward_serial;
             mdl->fwd_serial_ran = 0u;
         }
         mdl->fwd_mismatch = 0u;
