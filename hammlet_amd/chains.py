@@ -39,6 +39,26 @@ def dense_to_rle(dense):
     return (ends - starts), counts
 
 
+def max_segmentation(seg, cnt):
+    """Maximum-posterior-margin segmentation of (pooled) run-length marginals - the reference's post-processing tool
+    (reference src/tools/maxSegmentation.cpp:53-82) on tensors: arg-max state per segment (first maximum; state 0 for
+    an all-zero row), adjacent segments of equal state merged.  Returns (run lengths, run states) on seg's device."""
+    import torch
+    if cnt.shape[1] == 0:
+        state = torch.zeros(seg.shape[0], dtype=torch.int64, device=seg.device)
+    else:
+        best = cnt.max(dim=1, keepdim=True).values
+        # first column that reaches the maximum; a row without a positive count gives column 0 like the tool's `>`
+        first = (cnt == best).to(torch.int8).argmax(dim=1)
+        state = torch.where(best.flatten() > 0, first, torch.zeros_like(first))
+    keep = torch.ones_like(state, dtype=torch.bool)
+    keep[1:] = state[1:] != state[:-1]
+    starts = torch.nonzero(keep, as_tuple=False).flatten()
+    csum = torch.cat([torch.zeros(1, dtype=seg.dtype, device=seg.device), torch.cumsum(seg, 0)])
+    ends = torch.cat([starts[1:], torch.tensor([seg.shape[0]], device=seg.device, dtype=starts.dtype)])
+    return csum[ends] - csum[starts], state[starts]
+
+
 def pooled_marginals(chain, group=None, device=None):
     """Relabel this chain's marginals by ascending mean, export them densely on the GPU, pool them over
     all chains of the process group and return (segment lengths, counts) of the pooled marginals."""

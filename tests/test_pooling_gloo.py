@@ -72,6 +72,27 @@ def test_pooled_marginals_world2(tmp_path):
     assert set(np.flatnonzero(expect[K])) == set(starts)
 
 
+def test_max_segmentation_of_pooled_marginals_matches_the_tool():
+    """chains.max_segmentation on run-length tensors against the restated reference tool (pinned on the reference
+    tool's own outputs by tests/test_maxseg_cpu.py), on the committed golden marginals files"""
+    import glob
+    from hammlet_amd import chains
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    files = sorted(glob.glob(os.path.join(gold, "*", "marginals.csv"))) + sorted(glob.glob(os.path.join(gold, "maxseg", "*.marginals")))
+    assert len(files) > 15
+    for path in files:
+        text = open(path).read()
+        rows = [list(map(int, l.split())) for l in text.splitlines() if l.strip()]
+        if not rows:
+            continue
+        width = max(len(r) for r in rows) - 1
+        seg = torch.tensor([r[0] for r in rows], dtype=torch.int64)
+        cnt = torch.tensor([r[1:] + [0] * (width - len(r) + 1) for r in rows], dtype=torch.int32).reshape(len(rows), width)
+        ln, st = chains.max_segmentation(seg, cnt)
+        lines = (["0\t0\n"] if int(st[0]) != 0 else []) + ["%d\t%d\n" % (int(a), int(b)) for a, b in zip(ln, st)]
+        assert "".join(lines) == ol.max_segmentation_text(text), path
+
+
 def test_relabel_permutation():
     from hammlet_amd import chains
     assert list(chains.relabel_permutation([0.5, -1.0, 2.0])) == [1, 0, 2]
