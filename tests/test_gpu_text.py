@@ -99,3 +99,24 @@ def test_cli_reads_text_through_the_gpu_reader(hml, tmp_path):
                                                    "-o", str(tmp_path / (tag + "-")), ".csv"], check=True)
     for kind in ("marginals", "sequences", "parameters"):
         assert open(tmp_path / ("a-%s.csv" % kind)).read() == open(tmp_path / ("b-%s.csv" % kind)).read()
+
+
+def test_cli_reads_standard_input_and_concatenates_files(hml, tmp_path):
+    """no -f: the text comes from standard input (reference src/main.cpp:284-289); several -f files are read one after
+    the other (the man page's contract)"""
+    from hammlet_amd import build
+    x = ol.trace(24000, 3, 5)
+    whole, a, b = tmp_path / "whole.txt", tmp_path / "a.txt", tmp_path / "b.txt"
+    lines = ["%.9g" % v for v in x]
+    whole.write_text("\n".join(lines) + "\n")
+    a.write_text("\n".join(lines[:10000]))          # no newline at the end of the first file
+    b.write_text("\n".join(lines[10000:]) + "\n")
+    common = ["-a", "-R", "3", "-s", "3", "-i", "F", "20", "1", "-O", "M", "P", "-w"]
+    subprocess.run([build.CLI_PATH, "-f", str(whole)] + common + ["-o", str(tmp_path / "w-"), ".csv"], check=True)
+    with open(whole, "rb") as f:
+        subprocess.run([build.CLI_PATH] + common + ["-o", str(tmp_path / "s-"), ".csv"], check=True, stdin=f)
+    subprocess.run([build.CLI_PATH, "-f", str(a), str(b)] + common + ["-o", str(tmp_path / "c-"), ".csv"], check=True)
+    for kind in ("marginals", "parameters"):
+        want = open(tmp_path / ("w-%s.csv" % kind)).read()
+        assert open(tmp_path / ("s-%s.csv" % kind)).read() == want
+        assert open(tmp_path / ("c-%s.csv" % kind)).read() == want
