@@ -482,3 +482,20 @@ def test_division_free_categorical_equals_the_literal_form(hml, fn, K):
     assert np.array_equal(lit, res)
     assert np.array_equal(comb, lit)
     assert unsure.sum() >= n // 50 + m // 8                       # all-zero rows and exact ties went to the literal form
+
+
+@pytest.mark.parametrize("K", [7, 10, 16])
+def test_dense_geometry_with_many_states(hml, monkeypatch, K):
+    """the tiled emission kernel's tile size depends on K (512 blocks up to 8 states, 256 beyond), the count kernel's
+    per-lane counters and the two-level chain on K-sized maps: uncompressed trace, dense geometry from the first sweep"""
+    monkeypatch.setenv("HML_DENSE_MIN_BLOCKS", "1")
+    T = 70_000
+    x = ol.trace(T, 5, 13)
+    xx, o, g = make_pair(hml, T, K, 0, 31, x=x, weight_mult=1e9)
+    setup_model(o, g, K)
+    g._pending_prior = True
+    o.set_record(marginals=True)
+    run_both(o, g, [("F", 4, 2), ("M", 2, 1), "S", ("F", 2, 1)])
+    compare_state(o, g)
+    seg, cnt = g.marginals_rle()
+    assert hml.marginals_text(seg, cnt) == o.text("marginals")
