@@ -9,6 +9,7 @@ CSRC = os.path.join(PKG_DIR, "csrc")
 LIB_PATH = os.path.join(PKG_DIR, "libhammlet_hip.so")
 CLI_PATH = os.path.join(PKG_DIR, "hammlet")
 TOOL_PATH = os.path.join(PKG_DIR, "maxSegmentation")
+SORT_TOOL_PATH = os.path.join(PKG_DIR, "sortStates")
 
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC"]
 
@@ -94,6 +95,12 @@ def build_cli(force=False, verbose=False):
     tsrc = os.path.join(CSRC, "host", "maxSegmentation_main.cpp")
     if force or _newer(TOOL_PATH, [tsrc, os.path.join(REPO_DIR, "include", "hammlet", "Parser.hpp")]):
         cmd = ["g++", "-O2", "-std=c++17", "-o", TOOL_PATH, tsrc, "-I", os.path.join(REPO_DIR, "include")]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.run(cmd, check=True)
+    ssrc = os.path.join(CSRC, "host", "sortStates_main.cpp")
+    if force or _newer(SORT_TOOL_PATH, [ssrc]):
+        cmd = ["g++", "-O2", "-std=c++17", "-o", SORT_TOOL_PATH, ssrc]
         if verbose:
             print(" ".join(cmd))
         subprocess.run(cmd, check=True)

@@ -27,3 +27,16 @@ def test_restatement_and_host_tool_match_the_reference_tool(inp, want):
     assert got == expected
     got = subprocess.run([build.TOOL_PATH], check=True, capture_output=True, text=True, stdin=open(inp)).stdout
     assert got == expected
+
+
+SORT_PAIRS = [(p, os.path.join(os.path.dirname(p), "sortstates.txt")) for p in sorted(glob.glob(os.path.join(GOLD, "*", "parameters.csv")))]
+
+
+@pytest.mark.parametrize("inp,want", SORT_PAIRS, ids=[os.path.relpath(a, GOLD) for a, _ in SORT_PAIRS])
+def test_sort_states_tool_matches_the_reference_script(inp, want):
+    """hammlet_amd/sortStates against the output of the reference's bin/sortStates (tests/golden/make_sortstates_golden.py)"""
+    from hammlet_amd import build
+    build.build_cli()
+    assert len(SORT_PAIRS) >= 8
+    got = subprocess.run([build.SORT_TOOL_PATH, inp], check=True, capture_output=True, text=True).stdout
+    assert got == open(want).read()
