@@ -41,6 +41,7 @@ SIGNATURES = {
     "hml_text_buffer": (C.c_int, [_P, C.POINTER(_P), C.POINTER(C.c_uint64)]),
     "hml_text_commit": (C.c_int, [_P, C.c_uint64]),
     "hml_text_feed": (C.c_int, [_P, C.c_char_p, C.c_uint64]),
+    "hml_text_reserve": (C.c_int, [_P, C.c_uint64]),
     "hml_text_finish": (C.c_int, [_P, C.POINTER(C.c_uint64), C.POINTER(C.c_int)]),
     "hml_text_values": (C.c_int, [_P, _P]),
     "hml_text_counters": (C.c_int, [_P, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),

@@ -12,6 +12,16 @@
 
 #include "hml_k_text.h"
 
+// float vector whose resize() leaves new elements uninitialised: every element is overwritten by the device-to-host
+// copy, and touching 400 MB twice is a visible share of reading 10^8 values
+template <class T>
+struct hml_noinit_alloc : std::allocator<T> {
+    template <class U> struct rebind { typedef hml_noinit_alloc<U> other; };
+    template <class U> void construct(U* p) noexcept { ::new (static_cast<void*>(p)) U; }
+    template <class U, class... A> void construct(U* p, A&&... a) { ::new (static_cast<void*>(p)) U(std::forward<A>(a)...); }
+};
+typedef std::vector<float, hml_noinit_alloc<float>> hml_fvec;
+
 #define HML_TEXT_DEFAULT_CHUNK (64u << 20)
 #define HML_TEXT_IRR_CAP 65536u
 
@@ -32,7 +42,7 @@ struct hml_text {
     int cur = 0;                        // slot being filled
     uint64_t fill = 0;                  // bytes in h_in[cur]
     bool finished = false, stopped = false;
-    std::vector<float> values;
+    hml_fvec values;
     uint64_t bytes_in = 0, irregular_tokens = 0, host_chunks = 0;
 };
 
@@ -44,7 +54,8 @@ struct hml_membuf : std::streambuf {
 
 // `while ( input >> v )` over [b, e): appends the values; false if an extraction failed (the reference's reader
 // stops there), true if the text was consumed to its end
-bool hml_text_host_extract(const char* b, const char* e, std::vector<float>& out) {
+template <class Vec>
+bool hml_text_host_extract(const char* b, const char* e, Vec& out) {
     hml_membuf mb(b, e);
     std::istream is(&mb);
     float v = 0;
@@ -113,7 +124,7 @@ int hml_text_retire(hml_text* p, int slot) {
         return 0;
     }
     // general case: a token gave several values ("1.5-3"), none, or the extraction failed inside it
-    std::vector<float> chunk(p->values.begin() + at, p->values.end());
+    const hml_fvec chunk(p->values.begin() + at, p->values.end());
     p->values.resize(at);
     size_t from = 0;
     for (size_t i = 0; i < irr.size(); ++i) {
@@ -258,6 +269,12 @@ int hml_text_finish(hml_text* p, uint64_t* n_values, int* stopped) {
 int hml_text_values(hml_text* p, float* out) {
     if (!p || !p->finished) return set_err(HML_ERR_ARG, "text reader not finished");
     if (!p->values.empty()) memcpy(out, p->values.data(), p->values.size() * sizeof(float));
+    return 0;
+}
+
+int hml_text_reserve(hml_text* p, uint64_t n_values) {
+    if (!p) return set_err(HML_ERR_ARG, "null argument");
+    try { p->values.reserve(n_values); } catch (...) { return set_err(HML_ERR_ARG, "cannot reserve that many values"); }
     return 0;
 }
 

@@ -159,7 +159,12 @@ int main(int argc, const char* argv[]) {
                 if (verbose) cout << "Reading " + fname << endl << flush;
                 std::ifstream fin(fname);
                 if (!fin) throw std::runtime_error("Cannot read from input file " + fname + "!");
-                MaxletTransform(fin, inputValues, stats, nrDataDim);
+                // upper estimate of the number of values (the reference counts the lines, main.cpp:277): a value and
+                // its separator take at least two bytes
+                fin.seekg(0, std::ios::end);
+                const std::streamoff bytes = fin.tellg();
+                fin.seekg(0);
+                MaxletTransform(fin, inputValues, stats, nrDataDim, bytes > 0 ? (size_t)bytes / 2 + 1 : 0);
             }
         } else {
             if (verbose) cout << "Reading from standard input" << endl << flush;

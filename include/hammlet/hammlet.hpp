@@ -102,12 +102,13 @@ inline int& inputDevice() { static int dev = 0; return dev; }
 template <typename T>
 void MaxletTransform(std::istream& input, std::vector<real_t>& coeffs, std::vector<SufficientStatistics<T>>& suffstats,
                      const size_t nrDim = 1, const size_t reserveT = 0) {
-    (void)suffstats; (void)reserveT;
+    (void)suffstats;
     if (nrDim != 1) throw std::runtime_error("Only univariate data is supported by the MI355X path!");
     if (!input) throw std::runtime_error("Cannot read input file or stream!");
     hml_text* reader = nullptr;
     hml_check(hml_text_open(&reader, inputDevice(), 0));
     struct Closer { hml_text* r; ~Closer() { hml_text_close(r); } } closer{reader};
+    if (reserveT) hml_check(hml_text_reserve(reader, reserveT));
     for (;;) {
         char* buf = nullptr;
         uint64_t cap = 0;

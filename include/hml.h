@@ -68,6 +68,8 @@ void hml_text_close(hml_text* reader);
 int hml_text_buffer(hml_text* reader, char** buf, uint64_t* capacity);
 int hml_text_commit(hml_text* reader, uint64_t nbytes);
 int hml_text_feed(hml_text* reader, const char* bytes, uint64_t nbytes);
+/* optional: an upper estimate of the number of values (the reference's reserveT, src/wavelet.hpp:103,123-124) */
+int hml_text_reserve(hml_text* reader, uint64_t n_values);
 int hml_text_finish(hml_text* reader, uint64_t* n_values, int* stopped);
 int hml_text_values(hml_text* reader, float* out /* n_values */);
 /* bytes consumed, tokens resolved by the host, chunks that went through the host extraction entirely */
