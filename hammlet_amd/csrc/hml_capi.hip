@@ -105,7 +105,9 @@ struct hml_ctx {
     uint32_t* d_hB = nullptr;       // device view of h_B
     uint32_t B_hint = 0;
     // forward geometry
-    int fwdL = 4, fwdW = 24;
+    int fwdL = 4, fwdW = 12;   // W is the floor of the adaptive warm-up (measured: 12 beats 16 and 24 on C1-C4; 8 does not)
+    int fwdW_init = 24;        // where a chain starts and the floor of its first 512 sweeps: while the parameters are
+                               // still far from settled the filter forgets slowly (131 refits in sweeps 20-220 of C3 with a floor of 12)
     hml_layout lay = {2, 0};
     // weakly compressed sweeps (B_hint >= dense_min_blocks): longer forward chunks - the warm-up is a smaller share
     // of the work - in their own chunk-transposed layout; which geometry a sweep uses never changes its results
@@ -306,7 +308,7 @@ int hml_create(hml_ctx** out, int device, uint64_t seed, uint32_t chain_id, void
     *c->h_B = 0;
     HIPCHK(hipHostGetDevicePointer((void**)&c->d_hB, c->h_B, 0));
     if (const char* e = getenv("HML_FWD_CHUNK")) { int l = std::max(1, atoi(e)); int sh = 0; while ((1 << (sh + 1)) <= l && sh < 10) ++sh; c->fwdL = 1 << sh; }
-    if (const char* e = getenv("HML_FWD_WARMUP")) c->fwdW = std::max(0, atoi(e));
+    if (const char* e = getenv("HML_FWD_WARMUP")) c->fwdW = c->fwdW_init = std::max(0, atoi(e));
     if (const char* e = getenv("HML_FWD_CHUNK_DENSE")) { int l = std::max(1, atoi(e)); int sh = 0; while ((1 << (sh + 1)) <= l && sh < 10) ++sh; c->fwdL_dense = 1 << sh; }
     if (const char* e = getenv("HML_DENSE_MIN_BLOCKS")) c->dense_min_blocks = (uint32_t)strtoul(e, nullptr, 10);
     if (const char* e = getenv("HML_USE_GRAPH")) c->use_graph = atoi(e) != 0;
@@ -640,7 +642,8 @@ int hml_set_model(hml_ctx* c, int K, const float nig4[4], float a_off, float a_d
         for (int j = 0; j < K; ++j) { m.dirA[k * K + j] = (k == j) ? a_diag : a_off; m.A[k * K + j] = 1.0f / K; }
     }
     m.max_state_recorded = -1;
-    m.fwd_W = m.fwd_W0 = (uint32_t)c->fwdW;
+    m.fwd_W0 = (uint32_t)c->fwdW;
+    m.fwd_W = m.fwd_W_burnin = (uint32_t)std::max(c->fwdW, c->fwdW_init);
     m.n_spans = c->n_spans;
     // keep the block count of an earlier enumeration (autoprior) out of the model: B = 0
     HIPCHK(hipMemcpyAsync(c->d_mdl, &m, sizeof m, hipMemcpyHostToDevice, c->stream));
