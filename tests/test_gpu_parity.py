@@ -499,3 +499,18 @@ def test_dense_geometry_with_many_states(hml, monkeypatch, K):
     compare_state(o, g)
     seg, cnt = g.marginals_rle()
     assert hml.marginals_text(seg, cnt) == o.text("marginals")
+
+
+def test_graph_replay_of_the_sweep_gives_the_same_chain(hml, monkeypatch):
+    """HML_USE_GRAPH=1 (opt-in: measured slower than eager launches) replays a captured sweep for non-recording sweeps
+    and re-captures when the launch geometry moves; results are those of the eager loop"""
+    monkeypatch.setenv("HML_USE_GRAPH", "1")
+    T, K = 150000, 4
+    x, o, g = make_pair(hml, T, K, 5, 77)
+    setup_model(o, g, K)
+    g._pending_prior = True
+    o.set_record(marginals=True)
+    run_both(o, g, [("F", 25, 0), ("M", 6, 0), ("F", 8, 4), "S", ("F", 12, 0)])
+    compare_state(o, g)
+    seg, cnt = g.marginals_rle()
+    assert hml.marginals_text(seg, cnt) == o.text("marginals")
