@@ -7,7 +7,7 @@ that is already resident in HBM.  Workload = BASELINE.json's headline configurat
 5 states, dynamic blocks).  With N GPUs every rank runs an independent chain on the same trace
 (weak scaling, no data-path collective); value = block updates of all ranks / max-over-ranks time.
 
-    python bench.py --gpus 1 --steps 200 --warmup 20
+    python bench.py --gpus 1 --steps 1000 --warmup 50
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 """
 import argparse
@@ -74,8 +74,8 @@ def cpu_baseline(x, K, seed, budget_s=20.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--workload", default="c3_1e8_k5_dynamic", choices=sorted(WORKLOADS))
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
