@@ -104,6 +104,7 @@ struct hml_ctx {
     uint32_t* h_B = nullptr;        // pinned + mapped: the offsets kernel stores the block count here (grid sizing hint)
     uint32_t* d_hB = nullptr;       // device view of h_B
     uint32_t B_hint = 0;
+    bool hint_stale = true;         // the hint predates the current parameters (new model, prior draw, mode switch)
     // forward geometry
     int fwdL = 4, fwdW = 12;   // W is the floor of the adaptive warm-up (measured: 12 beats 16 and 24 on C1-C4; 8 does not)
     int fwdW_init = 24;        // where a chain starts and the floor of its first 512 sweeps: while the parameters are
@@ -650,6 +651,7 @@ int hml_set_model(hml_ctx* c, int K, const float nig4[4], float a_off, float a_d
     HIPCHK(hipStreamSynchronize(c->stream));
     c->model_set = true;
     c->dynamic = true;
+    c->hint_stale = true;
     // Theta's constructor samples once from the prior (src/Theta.hpp:126-127)
     HML_DISPATCH_K(K, hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_params<KK>), dim3(1), dim3(1024), 0, c->stream, c->d_mdl, c->d_partial, 2));
     KLAUNCH_CHECK();
@@ -662,6 +664,7 @@ int hml_sample_prior(hml_ctx* c) {
     HML_DISPATCH_K(c->K, hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_params<KK>), dim3(1), dim3(1024), 0, c->stream, c->d_mdl, c->d_partial, 1));
     KLAUNCH_CHECK();
     if (c->dynamic) c->blocks_valid = false;
+    c->hint_stale = true;
     return 0;
 }
 
@@ -682,7 +685,7 @@ int hml_set_dynamic(hml_ctx* c, int on) {
     hipLaunchKernelGGL(hml_k_set_dynamic, dim3(1), dim3(64), 0, c->stream, c->d_mdl, on ? 1 : 0, on ? 1 : 0);
     KLAUNCH_CHECK();
     c->dynamic = on != 0;
-    if (on) c->blocks_valid = false;
+    if (on) { c->blocks_valid = false; c->hint_stale = true; }
     return 0;
 }
 
@@ -724,6 +727,20 @@ static int sweep_k(hml_ctx* c, char method, bool record) {
     const bool mix = (method == HML_METHOD_MIXTURE);
     const uint32_t T = (uint32_t)c->T;
     bool emitted = false, fused = false;
+    // The block count of the sweep sizes the grids and picks the forward geometry, and the host only knows the count of
+    // an earlier sweep (it enqueues far ahead of the device).  Right after the parameters were replaced that count
+    // means nothing - the first sweeps of a weakly compressed chain then ran in the geometry of a strongly compressed
+    // one (177 ms instead of 19 ms each on C5, for as many sweeps as were enqueued at once) - so the block structure is
+    // enumerated once ahead of the sweep and waited for.
+    if (c->hint_stale && (c->dynamic || !c->blocks_valid)) {
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(s, &cap) == hipSuccess && cap == hipStreamCaptureStatusNone) {
+            launch_compact_pair(c, 0, 0.0f);
+            KLAUNCH_CHECK();
+            HIPCHK(hipStreamSynchronize(s));
+        }
+    }
+    c->hint_stale = false;
     // forward geometry of this sweep, fixed before its first launch
     refresh_hint(c);
     const bool dense_geo = c->B_hint >= c->dense_min_blocks;

@@ -342,6 +342,7 @@ __global__ __launch_bounds__(256) void hml_k_compact_scatter(const uint16_t* __r
         if (is_last && lane == 0) {
             const uint32_t B = off + cnt;
             mdl->B = B;
+            hml_warmup_for_many_blocks(mdl, B);
             starts[B] = T;
             // host-mapped word: lets the host size later grids without a copy in the stream
             if (host_B) __hip_atomic_store(host_B, B, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);

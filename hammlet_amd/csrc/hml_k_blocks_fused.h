@@ -232,6 +232,7 @@ __global__ __launch_bounds__(HML_FUSED_WAVES * 64, (K <= 6 ? 6 : 4)) void hml_k_
     if (last_wg && threadIdx.x == 0) {
         const uint32_t Bn = before_group + wg_total;
         mdl->B = Bn;
+        hml_warmup_for_many_blocks(mdl, Bn);
         *launch_gen = gen;   // every workgroup has read it: this one only got here after all of them published
         // host-mapped word: lets the host size later grids without a copy in the stream
         if (host_B) __hip_atomic_store(host_B, Bn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);

@@ -91,4 +91,13 @@ struct hml_model {
     unsigned long long fwd_refits_seen, fwd_serial_seen;
 };
 
+#if defined(__HIPCC__)
+// A young chain over millions of blocks (weakly compressed input: each block carries little evidence, the filter forgets
+// slowly) starts its forward pass with four times the usual warm-up instead of finding that level through repairs:
+// on C5 the first ten sweeps cost 203 ms each (3.6e5 refits) until the adaptation had raised W from 24 to 96.
+__device__ __forceinline__ void hml_warmup_for_many_blocks(hml_model* mdl, uint32_t B) {
+    if (B >= (1u << 22) && mdl->sweeps < 4ull && mdl->fwd_W < 4u * mdl->fwd_W_burnin) mdl->fwd_W = 4u * mdl->fwd_W_burnin;
+}
+#endif
+
 #endif
