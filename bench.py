@@ -67,8 +67,56 @@ def cpu_baseline(x, K, seed, budget_s=20.0):
     t = o.time_sweeps("F", n)
     blocks = o.total_blocks() - b0
     o.close()
-    return {"value": blocks / t, "unit": "block-updates/s", "cores": 1, "kind": "port",
-            "sample": "%d sweeps of the same %d-position trace (reference-mode CPU restatement, %.1f ms/sweep)" % (n, x.size, 1e3 * t / n)}
+    out = {"value": blocks / t, "unit": "block-updates/s", "cores": 1, "kind": "port",
+           "sample": "%d sweeps of the same %d-position trace (reference-mode CPU restatement, %.1f ms/sweep)" % (n, x.size, 1e3 * t / n)}
+    try:
+        ref = reference_binary_baseline(x, K, seed)
+        if ref:
+            out["reference_binary"] = ref
+    except Exception as e:   # the prebuilt binary is optional on the GPU box
+        out["reference_binary"] = {"error": str(e)[:200]}
+    return out
+
+
+def reference_binary_baseline(x, K, seed, prefix=10_000_000, sweeps=300):
+    """The UNMODIFIED reference binary (oracle/_ref/hammlet, prebuilt in the build container from the reference's own
+    main.cpp; absent -> None) on a bounded sample: the first 10^7 positions of the same trace as text, sweep time =
+    wall(-i F n 0) - wall(-i F 0 0) (start-up and text parsing cancel), block count from the restatement run with the
+    same seed on the same prefix (it reproduces the reference's files byte for byte, hence its block structures)."""
+    import subprocess
+    import tempfile
+    exe = os.path.join(REPO, "oracle", "_ref", "hammlet")
+    if not os.path.exists(exe):
+        return None
+    from tests import oracle_lib as ol
+    xp = np.ascontiguousarray(x[:prefix])
+    with tempfile.TemporaryDirectory() as tmp:
+        txt = os.path.join(tmp, "prefix.txt")
+        try:
+            import pandas as pd
+            pd.Series(xp).to_csv(txt, index=False, header=False, float_format="%.9g")
+        except Exception:
+            np.savetxt(txt, xp, fmt="%.9g")
+
+        def run(n):
+            t0 = time.perf_counter()
+            subprocess.run([exe, "-f", txt, "-a", "-s", str(K), "-R", str(seed), "-i", "F", str(n), "0", "-w",
+                            "-o", os.path.join(tmp, "ref-"), ".csv"], check=True, stdout=subprocess.DEVNULL)
+            return time.perf_counter() - t0
+        t_zero = run(0)
+        t_n = run(sweeps)
+    o = ol.OracleChain(K=K, seed=seed, rng=ol.RNG_MT, math=ol.MATH_LIBM, reduce=ol.REDUCE_REF)
+    o.load(xp)
+    o.autoprior()
+    o.init_model()
+    o.set_record(marginals=False)
+    o.time_sweeps("F", sweeps)
+    blocks = o.total_blocks()
+    o.close()
+    dt = max(t_n - t_zero, 1e-9)
+    return {"value": blocks / dt, "unit": "block-updates/s", "cores": 1, "kind": "reference",
+            "sample": "unmodified reference binary, first %d positions of the trace as text, %d sweeps: %.2f ms/sweep, "
+                      "%.0f blocks/sweep (start-up + text parsing %.1f s, subtracted)" % (xp.size, sweeps, 1e3 * dt / sweeps, blocks / sweeps, t_zero)}
 
 
 def main():
