@@ -106,7 +106,16 @@ void MaxletTransform(std::istream& input, std::vector<real_t>& coeffs, std::vect
     if (nrDim != 1) throw std::runtime_error("Only univariate data is supported by the MI355X path!");
     if (!input) throw std::runtime_error("Cannot read input file or stream!");
     hml_text* reader = nullptr;
-    hml_check(hml_text_open(&reader, inputDevice(), 0));
+    // staging buffers no larger than the input when its size is known (reserveT ~ bytes / 2): pinned memory is costly
+    // to allocate, and a 10^5-value file should not pay for two 64 MiB buffers
+    uint64_t chunk = 0;
+    if (reserveT) {
+        chunk = 2 * (uint64_t)reserveT + 4096;
+        chunk = (chunk + 4095) / 4096 * 4096;
+        if (chunk < (1u << 16)) chunk = 1u << 16;
+        if (chunk > (64u << 20)) chunk = 0;   // the default
+    }
+    hml_check(hml_text_open(&reader, inputDevice(), chunk));
     struct Closer { hml_text* r; ~Closer() { hml_text_close(r); } } closer{reader};
     if (reserveT) hml_check(hml_text_reserve(reader, reserveT));
     for (;;) {
