@@ -83,7 +83,9 @@ struct StreamSrc {
 };
 
 struct Config {
-    int K = 3;
+    int K = 3;                               // number of STATES (= P^D with the combinations mapping)
+    int D = 1;                               // data dimensions            "-s C P D"   (main.cpp:116-129)
+    int P = 0;                               // emission parameters (0: P = K, univariate "-s K")
     float e_var = 0.2f, e_p = 0.9f;          // -e normal VAR P           (main.cpp:46,206)
     float t_off = 0.5f, t_diag = 0.5f;       // -t OFFDIAG DIAG           (main.cpp:144-149)
     float pi_alpha = 0.5f;                   // -I                        (main.cpp:161)
@@ -135,7 +137,8 @@ public:
 
     // last sweep
     std::vector<uint32_t> starts;  // B+1 entries, starts[B] = T
-    std::vector<float> bs_s, bs_q; // per-block sums
+    std::vector<float> bs_s, bs_q; // per-block sums (dimension 0)
+    std::vector<float> bsd_s, bsd_q; // per-block sums of every dimension, [b * D + d]
     std::vector<int16_t> q;
     std::vector<float> trellis;    // (B+1)*K, rows as left by the backward pass would be; we keep forward rows (backward-ready)
     std::vector<float> lastE;      // B*K emission log-likelihood terms E_s (parity probe)
@@ -154,6 +157,22 @@ public:
 
     explicit Oracle(const Config& c) : cfg(c), mt((std::mt19937::result_type)c.seed), pseq(c.seed) {
         if (c.K < 2) throw std::runtime_error("Requested parameters would yield an HMM with less than 2 states!");
+        set_dims(c.D, c.P);
+    }
+
+    // Mapping with MappingType combinations (Mapping.hpp:53-137): state x -> for data dimension d the parameter
+    // (x / P^d) % P, i.e. reversed P-ary digits; nrStates = P^D (Mapping.hpp:25-48)
+    int nD() const { return cfg.D; }
+    int nP() const { return cfg.P > 0 ? cfg.P : cfg.K; }
+    int map_sd(int state, int d) const { int n = state; for (int i = 0; i < d; ++i) n /= nP(); return n % nP(); }
+    void set_dims(int D, int P) {
+        if (D <= 0) throw std::runtime_error("Number of data dimensions must be positive!");
+        cfg.D = D; cfg.P = P;
+        if (D > 1 || P > 0) {
+            long k = 1;
+            for (int d = 0; d < D; ++d) k *= nP();
+            if (k != cfg.K) throw std::runtime_error("number of states must be (number of parameters)^(data dimensions)");
+        }
     }
 
     // ---------------------------------------------------------------- math helpers
@@ -166,7 +185,10 @@ public:
     // integral array (IntegralArray.hpp:136-191, utils.hpp:15-76), pointers (BreakpointArray.hpp:130-184)
     void load(const float* x, size_t n, bool build_pointers = true) {
         if (n == 0) throw std::runtime_error("Input vector for breakpoint weights is empty!");
-        T = n;
+        const size_t D = (size_t)nD();
+        // values of the D dimensions of a position follow each other in the stream (wavelet.hpp:131-137)
+        if (n % D != 0) throw std::runtime_error("Input stream did not contain enough values to fill all dimensions at last position!");
+        T = n / D;
         maxlet(x);
         // noise estimate: f64 accumulation over odd indices in order
         double acc = 0; size_t cnt = 0;
@@ -181,27 +203,30 @@ public:
     }
 
     void maxlet(const float* x) {
-        // streaming stack form, literally as wavelet.hpp:131-176 (univariate)
+        // streaming stack form, literally as wavelet.hpp:131-176: the stack holds D values per node, the coefficient
+        // of a node is the largest detail coefficient over the dimensions (wavelet.hpp:146-158)
         coeffs.assign(T, 0.0f);
+        const size_t D = (size_t)nD();
         const float inf = std::numeric_limits<float>::infinity();
         const float sqrt2 = (float)std::sqrt(2.0);
         const float sqrt2half = (float)(sqrt2 / 2.0);
         std::vector<float> S;
-        S.reserve(64);
+        S.reserve(64 * D);
         for (size_t i = 0; i < T; ++i) {
-            S.push_back(x[i]);
+            for (size_t d = 0; d < D; ++d) S.push_back(x[i * D + d]);
             coeffs[i] = inf;
             size_t j = i, m = 1;
             float normalizer = sqrt2half;
             while ((j & m) > 0) {
-                size_t L = S.size() - 2, R = L + 1;
-                float d = std::abs(S[L] - S[R]);
-                float c = normalizer * d;
                 float maxCoeff = 0;
-                maxCoeff = std::max(maxCoeff, c);
-                S[L] += S[R];
+                size_t L = S.size() - 2 * D, R = L + D;
+                for (size_t d = 0; d < D; ++d) {
+                    maxCoeff = std::max(maxCoeff, normalizer * std::abs(S[L] - S[R]));
+                    S[L] += S[R];
+                    L++; R++;
+                }
                 coeffs[j] = maxCoeff;
-                S.pop_back();
+                for (size_t d = 0; d < D; ++d) S.pop_back();
                 j -= m;
                 m *= 2;
                 normalizer *= sqrt2half;
@@ -233,18 +258,24 @@ public:
     }
 
     void integral_array(const float* x) {
-        ia_s.resize(T + 1); ia_q.resize(T + 1);
-        for (size_t i = 0; i < T; ++i) { ia_s[i] = x[i]; ia_q[i] = x[i] * x[i]; }
-        ia_s[T] = 0; ia_q[T] = 0;
-        const size_t n = T + 1;
-        for (size_t a = 0; a < n; a += HML_CELLSIZE) {
-            size_t right = std::min(a + (size_t)HML_CELLSIZE, n) - 1;
-            if (a < right) {
-                float ss = ia_s[right], sq = ia_q[right], cs = 0, cq = 0;
-                for (size_t i = right - 1;; --i) {
-                    float y = ia_s[i] - cs, t = ss + y; cs = (t - ss) - y; ss = t; ia_s[i] = ss;
-                    float y2 = ia_q[i] - cq, t2 = sq + y2; cq = (t2 - sq) - y2; sq = t2; ia_q[i] = sq;
-                    if (i == a) break;
+        // one reverse Kahan cumulative sum per cell AND dimension (IntegralArray.hpp:172-186: stride nrDim over the
+        // interleaved array, i.e. independent per dimension); stored dimension-major: ia_s[d * (T + 1) + t]
+        const size_t D = (size_t)nD(), n = T + 1;
+        ia_s.resize(n * D); ia_q.resize(n * D);
+        for (size_t d = 0; d < D; ++d) {
+            float* is = &ia_s[d * n];
+            float* iq = &ia_q[d * n];
+            for (size_t i = 0; i < T; ++i) { const float v = x[i * D + d]; is[i] = v; iq[i] = v * v; }
+            is[T] = 0; iq[T] = 0;
+            for (size_t a = 0; a < n; a += HML_CELLSIZE) {
+                size_t right = std::min(a + (size_t)HML_CELLSIZE, n) - 1;
+                if (a < right) {
+                    float ss = is[right], sq = iq[right], cs = 0, cq = 0;
+                    for (size_t i = right - 1;; --i) {
+                        float y = is[i] - cs, t = ss + y; cs = (t - ss) - y; ss = t; is[i] = ss;
+                        float y2 = iq[i] - cq, t2 = sq + y2; cq = (t2 - sq) - y2; sq = t2; iq[i] = sq;
+                        if (i == a) break;
+                    }
                 }
             }
         }
@@ -288,13 +319,19 @@ public:
     }
 
     // addBlockStats (IntegralArray.hpp:104-124)
-    inline void block_stats(size_t start, size_t end, float& s, float& sq) const {
+    inline void block_stats(size_t start, size_t end, float& s, float& sq, size_t d = 0) const {
+        const float* is = &ia_s[d * (T + 1)];
+        const float* iq = &ia_q[d * (T + 1)];
         Kahan2 k;
-        k.add(ia_s[start], ia_q[start]);
+        k.add(is[start], iq[start]);
         for (size_t c = ((start + HML_CELLSIZE) / HML_CELLSIZE) * HML_CELLSIZE; c < end; c += HML_CELLSIZE)
-            k.add(ia_s[c], ia_q[c]);
-        if (end % HML_CELLSIZE != 0) k.sub(ia_s[end], ia_q[end]);
+            k.add(is[c], iq[c]);
+        if (end % HML_CELLSIZE != 0) k.sub(is[end], iq[end]);
         s = k.sum(); sq = k.sumSq();
+    }
+    // all dimensions of one block: out[d] / outq[d]
+    inline void block_stats_all(size_t start, size_t end, float* out, float* outq) const {
+        for (int d = 0; d < nD(); ++d) block_stats(start, end, out[d], outq[d], (size_t)d);
     }
 
     void enumerate_blocks(float threshold) {
@@ -304,8 +341,16 @@ public:
         while (s < T) { starts.push_back((uint32_t)s); s = next_end(s); }
         starts.push_back((uint32_t)T);
         size_t B = starts.size() - 1;
-        bs_s.resize(B); bs_q.resize(B);
-        for (size_t b = 0; b < B; ++b) block_stats(starts[b], starts[b + 1], bs_s[b], bs_q[b]);
+        fill_block_stats(B);
+    }
+    // bs_s/bs_q[b]: dimension 0 (probes of the univariate path); bsd_s/bsd_q[b * D + d]: every dimension
+    void fill_block_stats(size_t B) {
+        const size_t D = (size_t)nD();
+        bs_s.resize(B); bs_q.resize(B); bsd_s.resize(B * D); bsd_q.resize(B * D);
+        for (size_t b = 0; b < B; ++b) {
+            block_stats_all(starts[b], starts[b + 1], &bsd_s[b * D], &bsd_q[b * D]);
+            bs_s[b] = bsd_s[b * D]; bs_q[b] = bsd_q[b * D];
+        }
     }
 
     // ---------------------------------------------------------------- auto prior (A.8)
@@ -315,17 +360,21 @@ public:
         float muSum = 0, muSq = 0;
         size_t B = 0;
         size_t s = 0;
+        const int D = nD();
         while (s < T) {
             size_t e = next_end(s);
-            float bsum, bsq;
-            block_stats(s, e, bsum, bsq);
-            float m = bsum / (float)(e - s);
-            muSum += m;
-            muSq += m * m;
+            // one observation per block AND dimension (AutoPriors.hpp:100-104), N = nrBlocks * nrDim (:105)
+            for (int d = 0; d < D; ++d) {
+                float bsum, bsq;
+                block_stats(s, e, bsum, bsq, (size_t)d);
+                float m = bsum / (float)(e - s);
+                muSum += m;
+                muSq += m * m;
+            }
             ++B;
             s = e;
         }
-        double n = (double)B;
+        double n = (double)(B * (size_t)D);
         double blocksMean = (double)(float)(muSum / n);
         double avg = (double)(float)(muSum / n);
         double blocksVar = (double)(float)(muSq / n - (avg * avg));
@@ -354,9 +403,9 @@ public:
     void set_nig_prior(const float p[4]) { for (int i = 0; i < 4; ++i) nig_prior[i] = p[i]; reset_theta_post(); }
 
     void reset_theta_post() {
-        const int K = cfg.K;
-        post_alpha.assign(K, nig_prior[0]); post_beta.assign(K, nig_prior[1]);
-        post_mu0.assign(K, nig_prior[2]); post_nu.assign(K, nig_prior[3]);
+        const int P = nP();   // one prior per emission parameter (main.cpp:201-209)
+        post_alpha.assign(P, nig_prior[0]); post_beta.assign(P, nig_prior[1]);
+        post_mu0.assign(P, nig_prior[2]); post_nu.assign(P, nig_prior[3]);
     }
     void reset_dir_post() {
         const int K = cfg.K;
@@ -369,7 +418,7 @@ public:
     // Objects as built in main.cpp:152-166,354-362; Theta's constructor draws once (Theta.hpp:126-127).
     void init_model() {
         const int K = cfg.K;
-        mu.assign(K, NAN); var.assign(K, NAN); sd.assign(K, NAN);
+        mu.assign(nP(), NAN); var.assign(nP(), NAN); sd.assign(nP(), NAN);
         A.assign((size_t)K * K, NAN); pi.assign(K, NAN);
         reset_dir_post();
         reset_theta_post();
@@ -396,7 +445,7 @@ public:
     }
     template <class E>
     void draw_theta_std(E& eng) {
-        for (int k = 0; k < cfg.K; ++k) {
+        for (int k = 0; k < nP(); ++k) {
             std::gamma_distribution<float> gamma(post_alpha[k], 1.0 / post_beta[k]);
             float v = 1.0 / gamma(eng);
             std::normal_distribution<float> normal(post_mu0[k], std::sqrt(v / post_nu[k]));
@@ -405,7 +454,7 @@ public:
         }
     }
     void draw_theta() {
-        const int K = cfg.K;
+        const int K = nP();   // Theta::sample draws every PARAMETER in order (Theta.hpp:203-211)
         switch (cfg.rng) {
             case RNG_MT19937: draw_theta_std(mt); break;
             case RNG_PHILOX_SEQ: draw_theta_std(pseq); break;
@@ -496,7 +545,7 @@ public:
     // createBlocks(theta) (BreakpointArray.hpp:196-199, Theta.hpp:227-234)
     float threshold_from_theta() const {
         float mv = std::numeric_limits<float>::infinity();
-        for (int k = 0; k < cfg.K; ++k) mv = std::min(mv, var[k]);
+        for (int k = 0; k < nP(); ++k) mv = std::min(mv, var[k]);
         float l = m_logf((float)T);
         float arg = 2 * l * mv;
         return cfg.math == MATH_DEV ? HML_SQRTF(arg) : std::sqrt(arg);
@@ -537,13 +586,25 @@ public:
     inline float log_normalizer(int k) const {  // EFD.hpp:35-38
         return m_logf(sd[k]) + mu[k] * mu[k] / (2 * var[k]);
     }
+    // Theta::logNormalizer(state) (Theta.hpp:148-158): float sum over the state's parameters, in dimension order
+    inline float log_normalizer_state(int s) const {
+        float r = 0;
+        for (int d = 0; d < nD(); ++d) r += log_normalizer(map_sd(s, d));
+        return r;
+    }
+    // innerProduct(y, theta.value(), theta.mapping(s)) (EFD.hpp:83-93): float sum over the dimensions, from 0
+    inline float emission_ip_state(const float* bsum, const float* bsq, int s) const {
+        float r = 0;
+        for (int d = 0; d < nD(); ++d) r += emission_ip(bsum[d], bsq[d], map_sd(s, d));
+        return r;
+    }
 
     void sweep_fb(bool record) {
         const int K = cfg.K;
         std::vector<float> logA(K, 0.0f), logN(K);
         for (int s = 0; s < K; ++s) {
             if (cfg.self_trans) logA[s] = m_logf(A[(size_t)s * K + s]);
-            logN[s] = log_normalizer(s);
+            logN[s] = log_normalizer_state(s);
         }
         trellis.clear();
         trellis.insert(trellis.end(), pi.begin(), pi.end());
@@ -555,14 +616,14 @@ public:
         size_t t = 0;
         while (pos < T) {
             size_t end = next_end(pos);
-            float bsum, bsq;
-            block_stats(pos, end, bsum, bsq);
+            float bsum[HML_MAX_K], bsq[HML_MAX_K];
+            block_stats_all(pos, end, bsum, bsq);
             starts.push_back((uint32_t)pos);
             ++t;
             float maxE = std::numeric_limits<float>::lowest();
             float N = (float)(end - pos);
             for (int s = 0; s < K; ++s) {
-                float E = (0.0f + emission_ip(bsum, bsq, s)) - N * logN[s];
+                float E = emission_ip_state(bsum, bsq, s) - N * logN[s];
                 if (cfg.self_trans) E += (N - 1) * logA[s];
                 forward[s] = E;
                 maxE = std::max(E, maxE);
@@ -619,7 +680,7 @@ public:
     void sweep_mix(bool record) {
         const int K = cfg.K;
         std::vector<float> logN(K);
-        for (int s = 0; s < K; ++s) logN[s] = log_normalizer(s);
+        for (int s = 0; s < K; ++s) logN[s] = log_normalizer_state(s);
         starts.clear();
         q.clear();
         if (keep_probes) lastE.clear();
@@ -627,13 +688,13 @@ public:
         size_t pos = 0, b = 0;
         while (pos < T) {
             size_t end = next_end(pos);
-            float bsum, bsq;
-            block_stats(pos, end, bsum, bsq);
+            float bsum[HML_MAX_K], bsq[HML_MAX_K];
+            block_stats_all(pos, end, bsum, bsq);
             starts.push_back((uint32_t)pos);
             float maxE = std::numeric_limits<float>::lowest();
             const size_t N = end - pos;
             for (int s = 0; s < K; ++s) {
-                float E = (0.0f + emission_ip(bsum, bsq, s)) - N * logN[s];
+                float E = emission_ip_state(bsum, bsq, s) - N * logN[s];
                 wts[s] = E;
                 maxE = std::max(E, maxE);
             }
@@ -653,19 +714,17 @@ public:
     // posterior counting pass (ForwardBackward.hpp:170-211 / Mixture.hpp:113-141) and conjugate
     // updates (Conjugate.hpp:121-168,178-205)
     void count_pass(bool record, bool mixture) {
-        const int K = cfg.K;
+        const int K = cfg.K, P = nP(), D = nD();
         const size_t B = q.size();
-        std::vector<uint64_t> trans((size_t)K * K, 0), occ(K, 0), nterms(K, 0);
-        std::vector<float> sum_s(K, 0.0f), sum_q(K, 0.0f);
-        bs_s.resize(B); bs_q.resize(B);
-        for (size_t b = 0; b < B; ++b) block_stats(starts[b], starts[b + 1], bs_s[b], bs_q[b]);
+        std::vector<uint64_t> trans((size_t)K * K, 0), occ(K, 0), nterms(P, 0);
+        std::vector<float> sum_s(P, 0.0f), sum_q(P, 0.0f);
+        fill_block_stats(B);
         if (cfg.reduce == REDUCE_REF) {
-            std::vector<Kahan2> st(K);
+            std::vector<Kahan2> st(P);
             int prev = 0;
             for (size_t b = 0; b < B; ++b) {
                 const size_t n = starts[b + 1] - starts[b];
                 const int s = q[b];
-                const float bsum = bs_s[b], bsq = bs_q[b];
                 if (mixture) {
                     occ[s] += n;
                     trans[(size_t)s * K + s] += n - 1;
@@ -676,54 +735,63 @@ public:
                 }
                 // `+= 1` happens after the diagonal update in the reference
                 trans[(size_t)prev * K + s] += 1;
-                st[s].add(bsum, bsq);
-                nterms[s] += n;
+                // stats[mapping[state][d]].add(y.suffStat(d), N) for every dimension in order (ForwardBackward.hpp:189-192)
+                for (int d = 0; d < D; ++d) {
+                    const int pp = map_sd(s, d);
+                    st[pp].add(bsd_s[b * D + d], bsd_q[b * D + d]);
+                    nterms[pp] += n;
+                }
                 prev = s;
             }
-            for (int s = 0; s < K; ++s) { sum_s[s] = st[s].sum(); sum_q[s] = st[s].sumSq(); }
+            for (int pp = 0; pp < P; ++pp) { sum_s[pp] = st[pp].sum(); sum_q[pp] = st[pp].sumSq(); }
         } else {
             // device order: chunk partials (pairwise tree over 64-lane groups, 4 groups per chunk in order),
-            // groups accumulate their chunks in increasing order, final pairwise tree over groups.
+            // groups accumulate their chunks in increasing order, final pairwise tree over groups.  A lane's term for
+            // parameter p is the sum, in dimension order, of the block's statistics of the dimensions mapped to p.
             const size_t nchunks = (B + kReduceChunk - 1) / kReduceChunk;
-            std::vector<double> gs((size_t)kReduceGroups * K, 0.0), gq((size_t)kReduceGroups * K, 0.0);
+            std::vector<double> gs((size_t)kReduceGroups * P, 0.0), gq((size_t)kReduceGroups * P, 0.0);
             std::vector<double> ls(64), lq(64);
             for (size_t c = 0; c < nchunks; ++c) {
                 const size_t g = c % kReduceGroups;
-                for (int s = 0; s < K; ++s) {
+                for (int pp = 0; pp < P; ++pp) {
                     double cs = 0.0, cq = 0.0;
                     for (int wv = 0; wv < kReduceChunk / 64; ++wv) {
                         for (int l = 0; l < 64; ++l) {
                             size_t b = c * kReduceChunk + (size_t)wv * 64 + l;
-                            if (b < B && q[b] == s) { ls[l] = (double)bs_s[b]; lq[l] = (double)bs_q[b]; }
-                            else { ls[l] = 0.0; lq[l] = 0.0; }
+                            ls[l] = 0.0; lq[l] = 0.0;
+                            if (b < B) {
+                                if (D == 1) { if (q[b] == pp) { ls[l] = (double)bsd_s[b]; lq[l] = (double)bsd_q[b]; } }
+                                else for (int d = 0; d < D; ++d) if (map_sd(q[b], d) == pp) { ls[l] = ls[l] + (double)bsd_s[b * D + d]; lq[l] = lq[l] + (double)bsd_q[b * D + d]; }
+                            }
                         }
                         for (int stride = 1; stride < 64; stride <<= 1)
                             for (int l = 0; l < 64; l += 2 * stride) { ls[l] = ls[l] + ls[l + stride]; lq[l] = lq[l] + lq[l + stride]; }
                         cs = cs + ls[0]; cq = cq + lq[0];
                     }
-                    gs[g * K + s] = gs[g * K + s] + cs;
-                    gq[g * K + s] = gq[g * K + s] + cq;
+                    gs[g * P + pp] = gs[g * P + pp] + cs;
+                    gq[g * P + pp] = gq[g * P + pp] + cq;
                 }
             }
-            for (int s = 0; s < K; ++s) {
-                std::vector<double> a(kReduceGroups), b2(kReduceGroups);
-                for (int g = 0; g < kReduceGroups; ++g) { a[g] = gs[(size_t)g * K + s]; b2[g] = gq[(size_t)g * K + s]; }
+            for (int pp = 0; pp < P; ++pp) {
+                std::vector<double> a2(kReduceGroups), b2(kReduceGroups);
+                for (int g = 0; g < kReduceGroups; ++g) { a2[g] = gs[(size_t)g * P + pp]; b2[g] = gq[(size_t)g * P + pp]; }
                 for (int stride = 1; stride < kReduceGroups; stride <<= 1)
-                    for (int g = 0; g < kReduceGroups; g += 2 * stride) { a[g] = a[g] + a[g + stride]; b2[g] = b2[g] + b2[g + stride]; }
-                sum_s[s] = (float)a[0]; sum_q[s] = (float)b2[0];
+                    for (int g = 0; g < kReduceGroups; g += 2 * stride) { a2[g] = a2[g] + a2[g + stride]; b2[g] = b2[g] + b2[g + stride]; }
+                sum_s[pp] = (float)a2[0]; sum_q[pp] = (float)b2[0];
             }
             int prev = 0;
             for (size_t b = 0; b < B; ++b) {
                 const size_t n = starts[b + 1] - starts[b];
                 const int s = q[b];
                 occ[s] += n; trans[(size_t)s * K + s] += n - 1; trans[(size_t)prev * K + s] += 1;
-                nterms[s] += n; prev = s;
+                for (int d = 0; d < D; ++d) nterms[map_sd(s, d)] += n;
+                prev = s;
             }
         }
         if (record) record_sweep();
-        // tau_theta.addObservation (Conjugate.hpp:121-168)
-        for (int p = 0; p < K; ++p) {
-            if (nterms[p] > 0) nig_update(p, sum_s[p], sum_q[p], nterms[p]);
+        // tau_theta.addObservation per parameter (ForwardBackward.hpp:202-207, Conjugate.hpp:121-168)
+        for (int pp = 0; pp < P; ++pp) {
+            if (nterms[pp] > 0) nig_update(pp, sum_s[pp], sum_q[pp], nterms[pp]);
         }
         for (int i = 0; i < K; ++i) for (int j2 = 0; j2 < K; ++j2) dirA[(size_t)i * K + j2] += (float)trans[(size_t)i * K + j2];
         for (int i = 0; i < K; ++i) dirPi[i] += (float)occ[i];
@@ -793,7 +861,7 @@ public:
     }
     void append_params() {
         // Theta::str -> concat(Observation<NormalParam>::str) (Theta.hpp:215-219, Observation.hpp:205-210)
-        for (int k = 0; k < cfg.K; ++k) {
+        for (int k = 0; k < nP(); ++k) {
             if (k) out_params += "\t";
             out_params += std::to_string(mu[k]) + "\t" + std::to_string(var[k]);
         }

@@ -40,6 +40,8 @@ void* orc_create(int K, float e_var, float e_p, float t_off, float t_diag, float
     } catch (std::exception& e) { g_err = e.what(); return nullptr; }
 }
 void orc_destroy(void* h) { delete (Oracle*)h; }
+// "-s C P D": P emission parameters shared by K = P^D states over D interleaved data dimensions (before orc_load)
+int orc_set_dims(void* h, int D, int P) { ORC_TRY ((Oracle*)h)->set_dims(D, P); ORC_END }
 
 int orc_load(void* h, const float* x, uint64_t T, int build_pointers) {
     ORC_TRY ((Oracle*)h)->load(x, T, build_pointers != 0); ORC_END

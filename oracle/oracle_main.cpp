@@ -48,7 +48,18 @@ int main(int argc, const char* argv[]) {
             }
         }
         Config cfg;
-        cfg.K = std::stoi(toks(a, "-s", "3")[0]);
+        {   // "-s K" or "-s C P [D]" (main.cpp:114-137): K = P^D states with the combinations mapping
+            auto st = toks(a, "-s", "3");
+            if (st.size() == 1) cfg.K = std::stoi(st[0]);
+            else {
+                if (st[0] != "C" && st[0] != "combinations") throw std::runtime_error("Unknown mapping type " + st[0] + "!");
+                cfg.P = std::stoi(st[1]);
+                cfg.D = st.size() >= 3 ? std::stoi(st[2]) : 1;
+                long k = 1;
+                for (int d = 0; d < cfg.D; ++d) k *= cfg.P;
+                cfg.K = (int)k;
+            }
+        }
         auto e = toks(a, "-e", "normal 0.2 0.9");
         cfg.e_var = std::stof(e[1]); cfg.e_p = std::stof(e[2]);
         if (!a.count("-a")) throw std::runtime_error("Manual theta priors not implemented, use -a!");

@@ -45,7 +45,27 @@ CASES = {
     "t65536": (65536, 3, 25, "-s 3 -R 5 -i F 20 2", ["marginals", "blocks", "parameters"]),
     "t65537": (65537, 3, 26, "-s 3 -R 6 -i F 20 2", ["marginals", "blocks", "parameters"]),
     "t131071": (131071, 4, 27, "-s 4 -R 7 -i F 20 4", ["marginals", "parameters", "compression"]),
+    # multivariate / shared parameters ("-s C P D": K = P^D states, D interleaved data dimensions).
+    # Trace: dimension d is the univariate generator with data seed + d; the values of a position follow each other.
+    "mv_c22": (30000, 2, 51, "-s C 2 2 -R 5 -i F 50 1", ["marginals", "sequences", "parameters", "blocks", "compression"]),
+    "mv_c32_mixed": (30000, 3, 52, "-s C 3 2 -R 6 -i M 20 1 S P F 30 2 D F 10 1", ["marginals", "sequences", "parameters", "compression"]),
+    "mv_c23": (20000, 2, 53, "-s C 2 3 -R 7 -i F 30 1", ["marginals", "parameters", "blocks"]),
+    "mv_c42_no_self": (70000, 4, 54, "-s C 4 2 -R 8 -S -m 1.3 -i F 20 2", ["marginals", "parameters", "compression"]),
 }
+
+
+def case_dims(flags):
+    """data dimensions of a case: the third token of `-s C P D` (1 for `-s K`)"""
+    t = flags.split()
+    i = t.index("-s")
+    return int(t[i + 3]) if t[i + 1] in ("C", "combinations") and i + 3 < len(t) and t[i + 3].isdigit() else 1
+
+
+def case_trace(T, K, dseed, flags):
+    D = case_dims(flags)
+    if D == 1:
+        return ol.trace(T, K, dseed)
+    return np.stack([ol.trace(T, K, dseed + d) for d in range(D)], axis=1).reshape(-1)
 
 
 def main():
@@ -54,7 +74,7 @@ def main():
     manifest = {}
     for name, (T, K, dseed, flags, outs) in CASES.items():
         # the data K (levels of the trace) is the first case field; `-s` in flags is the model's K
-        x = ol.trace(T, K, dseed)
+        x = case_trace(T, K, dseed, flags)
         d = os.path.join(HERE, name)
         os.makedirs(d, exist_ok=True)
         with tempfile.TemporaryDirectory() as tmp:
@@ -68,7 +88,7 @@ def main():
                     g.write(f.read())
             with open(os.path.join(d, "stdout.txt"), "w") as g:
                 g.write(r.stdout)
-        manifest[name] = {"T": T, "trace_levels": K, "data_seed": dseed, "flags": flags, "outputs": outs}
+        manifest[name] = {"T": T, "trace_levels": K, "data_seed": dseed, "flags": flags, "outputs": outs, "dims": case_dims(flags)}
         print(name, "ok")
     # `-g` prints the parser state (Parser::print, reference src/Parser.hpp:242-269): golden for the host-side parser
     with tempfile.TemporaryDirectory() as tmp:
