@@ -45,6 +45,8 @@ SIGNATURES = {
     "hml_text_finish": (C.c_int, [_P, C.POINTER(C.c_uint64), C.POINTER(C.c_int)]),
     "hml_text_values": (C.c_int, [_P, _P]),
     "hml_text_counters": (C.c_int, [_P, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "hml_set_dimensions": (C.c_int, [_P, C.c_int, C.c_int]),
+    "hml_get_dimensions": (C.c_int, [_P, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "hml_noise_sigma": (C.c_int, [_P, C.POINTER(C.c_double)]),
     "hml_scale_weights": (C.c_int, [_P, C.c_float]),
     "hml_autoprior": (C.c_int, [_P, C.c_float, C.c_float, _P]),
@@ -184,6 +186,8 @@ class Chain:
         self.h = h
         self.K = None
         self.T = None
+        self.D = 1          # data dimensions / emission parameters ("-s C P D"); P = None: P = K
+        self.P = None
         self._cb = None
 
     def close(self):
@@ -198,9 +202,14 @@ class Chain:
             pass
 
     # ---- construction -------------------------------------------------------------------
+    def set_dimensions(self, D, P):
+        """D data dimensions (their values follow each other in x), P emission parameters shared by P**D states"""
+        _check(self.lib.hml_set_dimensions(self.h, D, P))
+        self.D, self.P = D, P
+
     def load(self, x):
         x = np.ascontiguousarray(x, np.float32)
-        self.T = int(x.size)
+        self.T = int(x.size) // self.D
         _check(self.lib.hml_load_observations(self.h, x.ctypes.data, x.size))
 
     def load_device(self, ptr, T):
@@ -281,7 +290,7 @@ class Chain:
         return q
 
     def theta(self):
-        t = np.empty(2 * self.K, np.float32)
+        t = np.empty(2 * (self.P or self.K), np.float32)
         _check(self.lib.hml_get_theta(self.h, t.ctypes.data))
         return t
 

@@ -59,6 +59,7 @@ struct hml_ctx {
     uint32_t chain = 0;
     uint64_t T = 0;
     int K = 0;
+    int D = 1, P = 0;              // data dimensions / emission parameters ("-s C P D"; P = 0: univariate, P = K)
     bool loaded = false, model_set = false;
     bool dynamic = true;
     bool blocks_valid = false;     // starts/bstat describe the current threshold
@@ -358,18 +359,30 @@ static int build_keys(hml_ctx* c) {
     return 0;
 }
 
-static int build_from_device_x(hml_ctx* c, const float* d_x, const float* h_x) {
+__global__ void hml_k_max_inplace(float* __restrict__ a, const float* __restrict__ b, uint64_t n) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) { const float x = a[i], y = b[i]; a[i] = (x < y) ? y : x; }   // std::max(x, y)
+}
+
+// d_x[d], h_x[d]: the observations of dimension d (T values each), on the device and on the host
+static int build_from_device_x(hml_ctx* c, const float* const* d_x, const float* const* h_x) {
     const uint64_t T = c->T;
+    const int D = c->D;
     // noise estimate (src/main.cpp:303-311): f64 accumulation, in index order, of the finest-level
-    // maxlet coefficients c[t] = sqrt2half * |x[t-1] - x[t]| at odd t (wavelet.hpp:139-150, level 1)
+    // maxlet coefficients c[t] = max over the dimensions of sqrt2half * |x[t-1] - x[t]| at odd t
+    // (wavelet.hpp:139-158, level 1)
     {
         const float sqrt2 = (float)std::sqrt(2.0);
         const float sqrt2half = (float)(sqrt2 / 2.0);
         double acc = 0; uint64_t cnt = 0;
         for (uint64_t i = 1; i < T; i += 2) {
-            const float d = std::abs(h_x[i - 1] - h_x[i]);
-            const float cf = sqrt2half * d;
-            acc += (0.0f < cf) ? cf : 0.0f;
+            float mx = 0.0f;
+            for (int d = 0; d < D; ++d) {
+                const float df = std::abs(h_x[d][i - 1] - h_x[d][i]);
+                const float cf = sqrt2half * df;
+                mx = (mx < cf) ? cf : mx;
+            }
+            acc += mx;
             cnt++;
         }
         acc /= cnt;
@@ -378,8 +391,8 @@ static int build_from_device_x(hml_ctx* c, const float* d_x, const float* h_x) {
     }
     HIPCHK(hipMalloc(&c->d_w, T * sizeof(float)));
     HIPCHK(hipMalloc(&c->d_coeff, T * sizeof(float)));
-    HIPCHK(hipMalloc(&c->d_ia, (T + 1) * sizeof(float2)));
-    // K1: levels 10 at a time
+    HIPCHK(hipMalloc(&c->d_ia, (T + 1) * (uint64_t)D * sizeof(float2)));
+    // K1: levels 10 at a time, one dimension after the other; the coefficient is the maximum over the dimensions
     {
         float h_norm[64];
         const float sqrt2 = (float)std::sqrt(2.0);
@@ -390,34 +403,45 @@ static int build_from_device_x(hml_ctx* c, const float* d_x, const float* h_x) {
         float* d_norm = nullptr;
         HIPCHK(hipMalloc(&d_norm, sizeof h_norm));
         HIPCHK(hipMemcpyAsync(d_norm, h_norm, sizeof h_norm, hipMemcpyHostToDevice, c->stream));
-        uint64_t n = T;
-        int base = 0;
-        const float* in = d_x;
-        float *bufA = nullptr, *bufB = nullptr;
+        float *bufA = nullptr, *bufB = nullptr, *d_other = nullptr;
         const uint64_t n1 = T >> HML_MAXLET_LOG_TILE;
         HIPCHK(hipMalloc(&bufA, std::max<uint64_t>(n1, 1) * sizeof(float)));
         HIPCHK(hipMalloc(&bufB, std::max<uint64_t>(n1 >> HML_MAXLET_LOG_TILE, 1) * sizeof(float)));
-        float* outb = bufA;
-        while (true) {
-            const uint64_t tiles = (n + HML_MAXLET_TILE - 1) / HML_MAXLET_TILE;
-            hipLaunchKernelGGL(hml_k_maxlet, dim3((unsigned)tiles), dim3(256), 0, c->stream, in, n, base, c->d_coeff, T, outb, d_norm);
-            KLAUNCH_CHECK();
-            base += HML_MAXLET_LOG_TILE;
-            if (base >= 40 || (1ull << base) >= T) break;   // no discontinuity position left below T
-            n = T >> base;                                   // complete elements of the next level (>= 1)
-            in = outb;
-            outb = (outb == bufA) ? bufB : bufA;
+        if (D > 1) HIPCHK(hipMalloc(&d_other, T * sizeof(float)));
+        for (int d = 0; d < D; ++d) {
+            float* coeff_out = d == 0 ? c->d_coeff : d_other;
+            uint64_t n = T;
+            int base = 0;
+            const float* in = d_x[d];
+            float* outb = bufA;
+            while (true) {
+                const uint64_t tiles = (n + HML_MAXLET_TILE - 1) / HML_MAXLET_TILE;
+                hipLaunchKernelGGL(hml_k_maxlet, dim3((unsigned)tiles), dim3(256), 0, c->stream, in, n, base, coeff_out, T, outb, d_norm);
+                KLAUNCH_CHECK();
+                base += HML_MAXLET_LOG_TILE;
+                if (base >= 40 || (1ull << base) >= T) break;   // no discontinuity position left below T
+                n = T >> base;                                   // complete elements of the next level (>= 1)
+                in = outb;
+                outb = (outb == bufA) ? bufB : bufA;
+            }
+            if (d > 0) {
+                hipLaunchKernelGGL(hml_k_max_inplace, dim3(grid_for(T, 256, 1, 65536)), dim3(256), 0, c->stream, c->d_coeff, d_other, T);
+                KLAUNCH_CHECK();
+            }
         }
         HIPCHK(hipStreamSynchronize(c->stream));
         hipFree(bufA); hipFree(bufB); hipFree(d_norm);
+        if (d_other) hipFree(d_other);
     }
     hipLaunchKernelGGL(hml_k_weights, dim3(grid_for(T, 256, 1, 65536)), dim3(256), 0, c->stream, c->d_coeff, c->d_w, T, 1.0f);
     KLAUNCH_CHECK();
     if (int r = build_keys(c)) return r;
     {
         const uint64_t cells = (T + 1 + HML_CELLSIZE - 1) / HML_CELLSIZE;
-        hipLaunchKernelGGL(hml_k_integral, dim3((unsigned)((cells + 3) / 4)), dim3(256), 0, c->stream, d_x, c->d_ia, T);
-        KLAUNCH_CHECK();
+        for (int d = 0; d < D; ++d) {
+            hipLaunchKernelGGL(hml_k_integral, dim3((unsigned)((cells + 3) / 4)), dim3(256), 0, c->stream, d_x[d], c->d_ia + (uint64_t)d * (T + 1), T);
+            KLAUNCH_CHECK();
+        }
     }
     // block-structure buffers
     c->n_spans = (uint32_t)((T + HML_SPAN - 1) / HML_SPAN);
@@ -433,29 +457,59 @@ static int build_from_device_x(hml_ctx* c, const float* d_x, const float* h_x) {
         HIPCHK(hipMemsetAsync(c->d_launch_gen, 0, sizeof(uint32_t), c->stream));
         if (getenv("HML_FUSED_DEBUG")) { HIPCHK(hipMalloc(&c->d_dbg, 4096 * 4 * 8)); HIPCHK(hipMemset(c->d_dbg, 0, 4096 * 4 * 8)); }
     }
-    HIPCHK(hipMalloc(&c->d_bstat, T * sizeof(float2)));
+    HIPCHK(hipMalloc(&c->d_bstat, T * (uint64_t)D * sizeof(float2)));
     HIPCHK(hipStreamSynchronize(c->stream));
     c->loaded = true;
     return 0;
 }
 
-int hml_load_observations(hml_ctx* c, const float* x, uint64_t T) {
+// "-s C P D" (reference src/main.cpp:114-137, src/Mapping.hpp:53-137): D data dimensions whose values follow each other
+// in the observation stream, P emission parameters shared by the K = P^D states.  Before the observations are loaded.
+int hml_set_dimensions(hml_ctx* c, int D, int P) {
+    if (!c) return set_err(HML_ERR_ARG, "null context");
+    if (c->loaded) return set_err(HML_ERR_ARG, "dimensions must be set before the observations are loaded");
+    if (D <= 0) return set_err(HML_ERR_MODEL, "Number of data dimensions must be positive!");
+    if (P <= 0) return set_err(HML_ERR_MODEL, "Number of parameters must be positive!");
+    if (D > HML_MAX_D) return set_err(HML_ERR_ARG, "at most 4 data dimensions are supported");
+    long k = 1;
+    for (int d = 0; d < D; ++d) { k *= P; if (k > HML_MAX_K) return set_err(HML_ERR_ARG, "number of states must be in [2,16]"); }
+    if (k <= 1) return set_err(HML_ERR_MODEL, "Requested parameters would yield an HMM with less than 2 states!");
+    c->D = D; c->P = P;
+    return 0;
+}
+
+// x: T * D values, the D dimensions of a position one after the other (T values when D = 1)
+int hml_load_observations(hml_ctx* c, const float* x, uint64_t n_values) {
     if (!c || !x) return set_err(HML_ERR_ARG, "null argument");
-    if (T == 0) return set_err(HML_ERR_ARG, "Input vector for breakpoint weights is empty!");
+    if (n_values == 0) return set_err(HML_ERR_ARG, "Input vector for breakpoint weights is empty!");
+    const uint64_t D = (uint64_t)c->D;
+    if (n_values % D != 0) return set_err(HML_ERR_MODEL, "Input stream did not contain enough values to fill all dimensions at last position!");
+    const uint64_t T = n_values / D;
     if (T >= 0xffffffffull) return set_err(HML_ERR_ARG, "at most 2^32-2 positions are supported");
     if (c->loaded) return set_err(HML_ERR_ARG, "observations already loaded");
     if (int r = ctx_bind(c)) return r;
     c->T = T;
     float* d_x = nullptr;
-    HIPCHK(hipMalloc(&d_x, T * sizeof(float)));
-    HIPCHK(hipMemcpyAsync(d_x, x, T * sizeof(float), hipMemcpyHostToDevice, c->stream));
-    int r = build_from_device_x(c, d_x, x);
+    HIPCHK(hipMalloc(&d_x, n_values * sizeof(float)));
+    std::vector<float> planes;             // dimension-major copy when D > 1
+    const float* h_dim[HML_MAX_D];
+    const float* d_dim[HML_MAX_D];
+    if (D == 1) { h_dim[0] = x; }
+    else {
+        planes.resize(n_values);
+        for (uint64_t t = 0; t < T; ++t) for (uint64_t d = 0; d < D; ++d) planes[d * T + t] = x[t * D + d];
+        for (uint64_t d = 0; d < D; ++d) h_dim[d] = planes.data() + d * T;
+    }
+    HIPCHK(hipMemcpyAsync(d_x, D == 1 ? x : planes.data(), n_values * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    for (uint64_t d = 0; d < D; ++d) d_dim[d] = d_x + d * T;
+    int r = build_from_device_x(c, d_dim, h_dim);
     hipFree(d_x);
     return r;
 }
 
 int hml_load_observations_device(hml_ctx* c, const void* x_dev, uint64_t T) {
     if (!c || !x_dev) return set_err(HML_ERR_ARG, "null argument");
+    if (c->D != 1) return set_err(HML_ERR_ARG, "device input is univariate");
     if (T == 0) return set_err(HML_ERR_ARG, "Input vector for breakpoint weights is empty!");
     if (T >= 0xffffffffull) return set_err(HML_ERR_ARG, "at most 2^32-2 positions are supported");
     if (c->loaded) return set_err(HML_ERR_ARG, "observations already loaded");
@@ -463,7 +517,9 @@ int hml_load_observations_device(hml_ctx* c, const void* x_dev, uint64_t T) {
     c->T = T;
     std::vector<float> h(T);
     HIPCHK(hipMemcpy(h.data(), x_dev, T * sizeof(float), hipMemcpyDeviceToHost));
-    return build_from_device_x(c, (const float*)x_dev, h.data());
+    const float* h_dim[1] = {h.data()};
+    const float* d_dim[1] = {(const float*)x_dev};
+    return build_from_device_x(c, d_dim, h_dim);
 }
 
 int hml_noise_sigma(hml_ctx* c, double* sigma) {
@@ -517,8 +573,9 @@ static int launch_compact(hml_ctx* c, bool use_override, float thr) {
     {
         ProfScope ps(c, "block_stats");
         const uint32_t hint = c->B_hint ? c->B_hint : (uint32_t)std::min<uint64_t>(c->T, 1u << 20);
-        hipLaunchKernelGGL(hml_k_block_stats, dim3(grid_for(hint, 256, 64, 16384)), dim3(256), 0, c->stream, c->d_ia,
-                           c->d_starts, c->d_mdl, c->d_bstat);
+        for (int d = 0; d < c->D; ++d)   // the same enumeration for every dimension (dimension-major planes)
+            hipLaunchKernelGGL(hml_k_block_stats, dim3(grid_for(hint, 256, 64, 16384)), dim3(256), 0, c->stream,
+                               c->d_ia + (uint64_t)d * (c->T + 1), c->d_starts, c->d_mdl, c->d_bstat + (uint64_t)d * c->T);
     }
     KLAUNCH_CHECK();
     return 0;
@@ -549,17 +606,22 @@ int hml_autoprior(hml_ctx* c, float s2, float p, float out4[4]) {
     refresh_hint(c);
     const uint32_t B = *c->h_B;
     std::vector<uint32_t> st(B + 1);
-    std::vector<float2> bs(B);
+    const int D = c->D;
+    std::vector<float2> bs((size_t)B * D);
     HIPCHK(hipMemcpy(st.data(), c->d_starts, (B + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(bs.data(), c->d_bstat, B * sizeof(float2), hipMemcpyDeviceToHost));
-    // block means in block order, float accumulation (SufficientStatistics<Normal>::addObs)
+    for (int d = 0; d < D; ++d)
+        HIPCHK(hipMemcpy(bs.data() + (size_t)d * B, c->d_bstat + (uint64_t)d * c->T, B * sizeof(float2), hipMemcpyDeviceToHost));
+    // block means in block order, every dimension of a block in turn (AutoPriors.hpp:100-104), float accumulation
+    // (SufficientStatistics<Normal>::addObs); N = nrBlocks * nrDim (AutoPriors.hpp:105)
     float muSum = 0, muSq = 0;
     for (uint32_t b = 0; b < B; ++b) {
-        const float m = bs[b].x / (float)(st[b + 1] - st[b]);
-        muSum += m;
-        muSq += m * m;
+        for (int d = 0; d < D; ++d) {
+            const float m = bs[(size_t)d * B + b].x / (float)(st[b + 1] - st[b]);
+            muSum += m;
+            muSq += m * m;
+        }
     }
-    const double n = (double)B;
+    const double n = (double)((uint64_t)B * (uint64_t)D);
     const double blocksMean = (double)(float)(muSum / n);
     const double avg = (double)(float)(muSum / n);
     const double blocksVar = (double)(float)(muSq / n - (avg * avg));
@@ -588,6 +650,11 @@ int hml_set_model(hml_ctx* c, int K, const float nig4[4], float a_off, float a_d
     if (K < 2) return set_err(HML_ERR_MODEL, "Requested parameters would yield an HMM with less than 2 states!");
     if (K > HML_MAX_K) return set_err(HML_ERR_ARG, "number of states must be in [2,16]");
     if (c->model_set) return set_err(HML_ERR_ARG, "model already set");
+    if (c->P > 0) {
+        long k = 1;
+        for (int d = 0; d < c->D; ++d) k *= c->P;
+        if (k != K) return set_err(HML_ERR_ARG, "number of states must be (number of parameters)^(data dimensions)");
+    }
     if (!(nig4[0] > 0)) return set_err(HML_ERR_MODEL, "Alpha (" + std::to_string(nig4[0]) + ") must be positive!");
     if (!(nig4[1] > 0)) return set_err(HML_ERR_MODEL, "Beta (" + std::to_string(nig4[1]) + ") must be positive!");
     if (!(nig4[3] > 0)) return set_err(HML_ERR_MODEL, "Nu (" + std::to_string(nig4[3]) + ")must be positive!");
@@ -633,6 +700,11 @@ int hml_set_model(hml_ctx* c, int K, const float nig4[4], float a_off, float a_d
     hml_model m;
     memset(&m, 0, sizeof m);
     m.K = K; m.self_trans = self_trans ? 1 : 0; m.dynamic = 1; m.T = (uint32_t)T;
+    m.D = c->D; m.P = c->P > 0 ? c->P : K; m.stat_stride = T;
+    for (int st = 0; st < K; ++st) {   // reversed P-ary digits (Mapping.hpp:92-103)
+        int nn = st;
+        for (int d = 0; d < HML_MAX_D; ++d) { m.map[st][d] = (uint8_t)(d < c->D ? nn % m.P : 0); nn /= m.P; }
+    }
     for (int i = 0; i < 4; ++i) m.nig_prior[i] = nig4[i];
     m.a_off = a_off; m.a_diag = a_diag; m.pi_alpha = pi_alpha;
     m.key = hml_make_key(c->seed, c->chain);
@@ -747,7 +819,7 @@ static int sweep_k(hml_ctx* c, char method, bool record) {
     const int L = dense_geo ? c->fwdL_dense : c->fwdL;
     const hml_layout lay = dense_geo ? c->lay_dense : c->lay;
     if (c->dynamic || !c->blocks_valid) {
-        if (c->use_keys && !(!c->summary_always && c->B_hint && (uint64_t)c->B_hint * 24u > c->T)) {
+        if (c->D == 1 && c->use_keys && !(!c->summary_always && c->B_hint && (uint64_t)c->B_hint * 24u > c->T)) {
             // K4 + K5 + K6a in one launch (hml_k_blocks_fused.h); weak compression takes the float stream below
             ProfScope ps(c, "blocks_compact", 1);
             const uint32_t n_wg = (uint32_t)(((uint64_t)T + HML_FUSED_POSITIONS - 1) / HML_FUSED_POSITIONS);
@@ -762,7 +834,11 @@ static int sweep_k(hml_ctx* c, char method, bool record) {
             refresh_hint(c);
             const uint32_t h0 = c->B_hint ? c->B_hint : (uint32_t)std::min<uint64_t>(c->T, 1u << 20);
             ProfScope ps(c, "stats_emission");
-            if (dense_geo && L <= hml_emit_tile<KK>::MAXL)
+            if (c->D > 1)
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_emission_mv<KK, true>), dim3(grid_for(h0, 256, 64, 16384)), dim3(256), 0, s,
+                                   c->d_ia, c->d_starts, c->d_mdl, c->d_bstat, c->d_em, c->d_gsc, c->probes ? c->d_eprobe : nullptr,
+                                   mix ? 1 : 0, lay);
+            else if (dense_geo && L <= hml_emit_tile<KK>::MAXL)
                 hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_emission_tiled<KK, true>), dim3(grid_for(h0, hml_emit_tile<KK>::BLOCKS, 64, 65536)),
                                    dim3(256), 0, s, c->d_ia, c->d_starts, c->d_mdl, c->d_bstat, c->d_em, c->d_gsc,
                                    c->probes ? c->d_eprobe : nullptr, mix ? 1 : 0, lay);
@@ -780,7 +856,10 @@ static int sweep_k(hml_ctx* c, char method, bool record) {
     const int gB = grid_for(hint, 256, 64, 16384);
     if (!emitted) {
         ProfScope ps(c, "emission");
-        if (dense_geo && L <= hml_emit_tile<KK>::MAXL)
+        if (c->D > 1)
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_emission_mv<KK, false>), dim3(gB), dim3(256), 0, s, c->d_ia, c->d_starts, c->d_mdl,
+                               c->d_bstat, c->d_em, c->d_gsc, c->probes ? c->d_eprobe : nullptr, mix ? 1 : 0, lay);
+        else if (dense_geo && L <= hml_emit_tile<KK>::MAXL)
             hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_emission_tiled<KK, false>), dim3(grid_for(hint, hml_emit_tile<KK>::BLOCKS, 64, 65536)),
                                dim3(256), 0, s, c->d_ia, c->d_starts, c->d_mdl, c->d_bstat, c->d_em, c->d_gsc,
                                c->probes ? c->d_eprobe : nullptr, mix ? 1 : 0, lay);
@@ -823,6 +902,10 @@ static int sweep_k(hml_ctx* c, char method, bool record) {
         }
         {
             ProfScope ps(c, "counts");
+            if (c->D > 1)
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_counts<KK, true, true>), dim3(HML_REDUCE_GROUPS), dim3(256), 0, s, c->d_q,
+                                   c->d_starts, c->d_bstat, c->d_mdl, c->d_partial, c->d_smap, c->d_bentry);
+            else
             hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_counts<KK, true>), dim3(HML_REDUCE_GROUPS), dim3(256), 0, s, c->d_q,
                                c->d_starts, c->d_bstat, c->d_mdl, c->d_partial, c->d_smap, c->d_bentry);
         }
@@ -833,6 +916,11 @@ static int sweep_k(hml_ctx* c, char method, bool record) {
         }
         {
             ProfScope ps(c, "counts");
+            if (c->D > 1)
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_counts<KK, false, true>), dim3(HML_REDUCE_GROUPS), dim3(256), 0, s, c->d_q,
+                                   c->d_starts, c->d_bstat, c->d_mdl, c->d_partial, (const unsigned long long*)nullptr,
+                                   (const uint8_t*)nullptr);
+            else
             hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_counts<KK, false>), dim3(HML_REDUCE_GROUPS), dim3(256), 0, s, c->d_q,
                                c->d_starts, c->d_bstat, c->d_mdl, c->d_partial, (const unsigned long long*)nullptr,
                                (const uint8_t*)nullptr);
@@ -965,7 +1053,13 @@ int hml_get_states(hml_ctx* c, int16_t* q) {
 int hml_get_theta(hml_ctx* c, float* mean_var) {
     NEED_MODEL();
     hml_model m; if (int r = fetch_model(c, &m)) return r;
-    for (int k = 0; k < c->K; ++k) { mean_var[2 * k] = m.mu[k]; mean_var[2 * k + 1] = m.var[k]; }
+    for (int k = 0; k < m.P; ++k) { mean_var[2 * k] = m.mu[k]; mean_var[2 * k + 1] = m.var[k]; }   // one pair per parameter
+    return 0;
+}
+int hml_get_dimensions(hml_ctx* c, int* D, int* P) {
+    if (!c) return set_err(HML_ERR_ARG, "null context");
+    if (D) *D = c->D;
+    if (P) *P = c->P > 0 ? c->P : c->K;
     return 0;
 }
 int hml_get_transitions(hml_ctx* c, float* A, float* pi) {
@@ -979,7 +1073,7 @@ int hml_set_parameters(hml_ctx* c, const float* mean_var, const float* A, const 
     NEED_MODEL();
     hml_model m; if (int r = fetch_model(c, &m)) return r;
     const int K = c->K;
-    for (int k = 0; k < K; ++k) {
+    for (int k = 0; k < m.P; ++k) {
         const float mean = mean_var[2 * k], var = mean_var[2 * k + 1];
         if (!std::isfinite(mean)) return set_err(HML_ERR_MODEL, "Mean (" + std::to_string(mean) + ") must be set to a finite value!");
         if (!std::isfinite(var)) return set_err(HML_ERR_MODEL, "Variance(" + std::to_string(var) + ") must be set to a finite value!");

@@ -334,7 +334,9 @@ __device__ __forceinline__ double hml_shfl_xor_f64(double v, int m) {
 
 // FB = true: the states come straight from the backward maps (q_b = S_{b+1}(entry[chunk])) and are
 // written to q[] on the way; FB = false (mixture sweeps): q[] was written by the mixture kernel.
-template <int K, bool FB>
+// MV = true ("-s C P D"): the floating-point sums are per emission PARAMETER; a lane's term for parameter p is the sum,
+// in dimension order, of its block's statistics of the dimensions that the block's state maps to p.
+template <int K, bool FB, bool MV = false>
 __global__ __launch_bounds__(256) void hml_k_counts(int16_t* __restrict__ q, const uint32_t* __restrict__ starts,
                                                     const float2* __restrict__ bstat, hml_model* __restrict__ mdl,
                                                     double* __restrict__ partial /*[GROUPS][K][2]*/,
@@ -350,6 +352,8 @@ __global__ __launch_bounds__(256) void hml_k_counts(int16_t* __restrict__ q, con
     if (tid < K) h_occ[tid] = 0ull;
     __syncthreads();
     double acc_s[K], acc_q[K];   // only thread 0 uses them
+#pragma unroll
+    for (int s = 0; s < K; ++s) { acc_s[s] = 0.0; acc_q[s] = 0.0; }
     // integer counts: every lane keeps, per state, the positions and blocks it saw in that state and the blocks that
     // stayed in it (registers, no cross-lane traffic in the loop); only changes of state - rare - go to LDS.  From
     // these: occ[s] = positions, trans[s][s] = positions - blocks + stayed, trans[p][s] (p != s) from the LDS counters.
@@ -411,9 +415,25 @@ __global__ __launch_bounds__(256) void hml_k_counts(int16_t* __restrict__ q, con
                 if (prev != st) atomicAdd(&h_trans[prev * K + st], 1ull);
             }
         }
+        double mvx[HML_MAX_D], mvq[HML_MAX_D];
+        int mvmap[HML_MAX_D];
+        int nD = 1;
+        if (MV) {
+            nD = mdl->D;
+            for (int dd = 0; dd < HML_MAX_D; ++dd) { mvx[dd] = 0.0; mvq[dd] = 0.0; mvmap[dd] = -1; }
+            if (b < B) {
+                mvx[0] = vx; mvq[0] = vq;
+                for (int dd = 1; dd < nD; ++dd) { const float2 v2 = bstat[(uint64_t)dd * mdl->stat_stride + b]; mvx[dd] = (double)v2.x; mvq[dd] = (double)v2.y; }
+                for (int dd = 0; dd < nD; ++dd) mvmap[dd] = mdl->map[st][dd];
+            }
+        }
 #pragma unroll
         for (int s = 0; s < K; ++s) {
             double a = (st == s) ? vx : 0.0, d = (st == s) ? vq : 0.0;
+            if (MV) {
+                a = 0.0; d = 0.0;
+                for (int dd = 0; dd < nD; ++dd) if (mvmap[dd] == s) { a = a + mvx[dd]; d = d + mvq[dd]; }
+            }
 #pragma unroll
             for (int m = 1; m < 64; m <<= 1) {
                 a = a + hml_shfl_xor_f64(a, m);

@@ -116,6 +116,62 @@ __global__ __launch_bounds__(256) void hml_k_stats_emission(const float2* __rest
 }
 
 // ------------------------------------------------------------------------------------------
+// Multivariate / shared-parameter form ("-s C P D", reference src/Mapping.hpp, src/EFD.hpp:83-93, src/Theta.hpp:148-158):
+// the statistics of the D data dimensions lie in planes `stat_stride` apart, state s uses parameter map[s][d] for
+// dimension d, and
+//   E_s = sum_d fl32( (2.0 mu_p Sx_d - Sxx_d) / (2.0 var_p) )  (float running sum from 0, dimension order, p = map[s][d])
+//         - N * logNs[s]  [+ (N-1) logA_s]
+// One thread per block.  STATS: block statistics from the integral arrays first, else from the bstat planes.
+template <int K, bool STATS>
+__global__ __launch_bounds__(256) void hml_k_emission_mv(const float2* __restrict__ ia, const uint32_t* __restrict__ starts,
+                                                         hml_model* __restrict__ mdl, float2* __restrict__ bstat,
+                                                         float* __restrict__ em, float* __restrict__ gsc,
+                                                         float* __restrict__ eprobe, int mixture, const hml_layout lay) {
+    const uint32_t B = mdl->B;
+    const int D = mdl->D;
+    const uint64_t T = mdl->T;
+    const bool self = mdl->self_trans != 0 && !mixture;
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t b = blockIdx.x * blockDim.x + threadIdx.x; b < B; b += stride) {
+        const uint32_t st = starts[b], en = starts[b + 1];
+        float sx[HML_MAX_D], sq[HML_MAX_D];
+        for (int d = 0; d < D; ++d) {
+            if (STATS) {
+                hml_block_stats_one(ia + (uint64_t)d * (T + 1u), st, en, sx[d], sq[d]);
+                bstat[(uint64_t)d * T + b] = make_float2(sx[d], sq[d]);
+            } else {
+                const float2 v = bstat[(uint64_t)d * T + b];
+                sx[d] = v.x; sq[d] = v.y;
+            }
+        }
+        const float N = (float)(en - st);
+        float E[K];
+        float maxE = -3.40282346638528859812e+38f;
+#pragma unroll
+        for (int s = 0; s < K; ++s) {
+            float r = 0.0f;
+            for (int d = 0; d < D; ++d) {
+                const int pp = mdl->map[s][d];
+                const double ipd = (2.0 * (double)mdl->mu[pp] * (double)sx[d] - (double)sq[d]) / (2.0 * (double)mdl->var[pp]);
+                const float ip = (float)ipd;
+                if (!hml_isfinite(ip)) hml_raise(mdl, HML_DEVERR_IP_NOT_FINITE, ip);
+                r += ip;
+            }
+            float e = r - N * mdl->logNs[s];
+            if (self) e += (N - 1.0f) * mdl->logA[s];
+            E[s] = e;
+            maxE = (e < maxE) ? maxE : e;
+        }
+#pragma unroll
+        for (int s = 0; s < K; ++s) {
+            if (eprobe) eprobe[(uint64_t)b * K + s] = E[s];
+            em[hml_bk(lay, b, K, s)] = hml_expf(E[s] - maxE);
+            if (!mixture) gsc[hml_bk(lay, b, K, s)] = self ? hml_expf((N - 1.0f) * mdl->logA[s]) : 1.0f;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // Tiled form of the two kernels above for weakly compressed sweeps (millions of blocks, forward chunks of 16 or more
 // blocks).  Same values bit for bit; three differences in how they are produced:
 //  * stores: the chunk-transposed layout puts consecutive blocks of one chunk into different planes, so a block-per-lane

@@ -15,15 +15,25 @@ struct hml_dev_src {
 // ForwardBackward.hpp:47-52, BreakpointArray.hpp:196-199 + Theta.hpp:227-234)
 template <int K>
 __device__ __forceinline__ void hml_derive(hml_model* mdl, int tid) {
-    if (tid < K) {
+    const int P = mdl->P, D = mdl->D;
+    if (tid < P) {
         const float m = mdl->mu[tid], v = mdl->var[tid], sd = mdl->sd[tid];
         mdl->logN[tid] = hml_logf(sd) + m * m / (2 * v);
+    }
+    if (tid < K) {
+        // theta.logNormalizer(state): float sum over the state's parameters, in dimension order (Theta.hpp:148-158)
+        float r = 0.0f;
+        for (int d = 0; d < D; ++d) {
+            const int pp = mdl->map[tid][d];
+            const float m = mdl->mu[pp], v = mdl->var[pp], sd = mdl->sd[pp];
+            r += hml_logf(sd) + m * m / (2 * v);
+        }
+        mdl->logNs[tid] = r;
         mdl->logA[tid] = hml_logf(mdl->A[tid * K + tid]);
     }
     if (tid == 0) {
         float mv = HML_INF_F;
-#pragma unroll
-        for (int k = 0; k < K; ++k) { const float v = mdl->var[k]; mv = (v < mv) ? v : mv; }   // std::min(result, var)
+        for (int k = 0; k < P; ++k) { const float v = mdl->var[k]; mv = (v < mv) ? v : mv; }   // std::min(result, var)
         const float l = hml_logf((float)mdl->T);
         const float arg = 2 * l * mv;
         const float t = HML_SQRTF(arg);
@@ -61,12 +71,13 @@ __global__ __launch_bounds__(1024) void hml_k_params(hml_model* __restrict__ mdl
     __shared__ unsigned long long s_trans[K * K];
     __shared__ unsigned long long s_occ[K];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    __shared__ float s_var[K];
+    __shared__ float s_var[K], s_logN[K];
+    const int P = mdl->P, D = mdl->D;
     const unsigned long long epoch = mdl->epoch;
     const hml_key key = mdl->key;
     // hyperparameters of this thread's variate, requested before the reductions below need the memory pipeline
     float hyp0 = 0.0f, hyp1 = 0.0f, hyp2 = 0.0f, hyp3 = 0.0f;
-    if (wave == 0 && lane < K) { hyp0 = mdl->nig_post[lane][0]; hyp1 = mdl->nig_post[lane][1]; hyp2 = mdl->nig_post[lane][2]; hyp3 = mdl->nig_post[lane][3]; }
+    if (wave == 0 && lane < P) { hyp0 = mdl->nig_post[lane][0]; hyp1 = mdl->nig_post[lane][1]; hyp2 = mdl->nig_post[lane][2]; hyp3 = mdl->nig_post[lane][3]; }
     if (wave == 1 && lane < K) hyp0 = mdl->dirPi[lane];
     if (tid >= 128 && tid < 128 + K * K) hyp0 = mdl->dirA[tid - 128];
 
@@ -122,10 +133,16 @@ __global__ __launch_bounds__(1024) void hml_k_params(hml_model* __restrict__ mdl
         __syncthreads();
     }
 
-    if (wave == 0 && lane < K) {
+    if (wave == 0 && lane < P) {
         const int k = lane;
         float alpha = hyp0, beta = hyp1, mu0 = hyp2, nu = hyp3;
-        const unsigned long long cnt = (mode == 0) ? s_occ[k] : 0ull;   // n_s == occupancy (exact integers)
+        // number of terms of parameter k: the positions of every (state, dimension) mapped to it - the occupancy of
+        // state k when D = 1 (exact integers)
+        unsigned long long cnt = 0ull;
+        if (mode == 0) {
+            if (D == 1) cnt = s_occ[k];
+            else for (int st = 0; st < K; ++st) for (int d = 0; d < D; ++d) if (mdl->map[st][d] == k) cnt += s_occ[st];
+        }
         if (mode == 0) { mdl->last_sum[k] = fin[k][0]; mdl->last_sumsq[k] = fin[k][1]; }
         if (cnt > 0ull) {
             // Conjugate<NormalInverseGammaParam>::addObservation (Conjugate.hpp:121-168)
@@ -160,7 +177,9 @@ __global__ __launch_bounds__(1024) void hml_k_params(hml_model* __restrict__ mdl
         const float sd = HML_SQRTF(v);
         mdl->mu[k] = m; mdl->var[k] = v; mdl->sd[k] = sd;
         if (mode == 0) {   // hml_derive's logNormalizer, from the registers instead of a round trip through memory
-            mdl->logN[k] = hml_logf(sd) + m * m / (2 * v);
+            const float ln = hml_logf(sd) + m * m / (2 * v);
+            mdl->logN[k] = ln;
+            s_logN[k] = ln;
             s_var[k] = v;
         }
 #pragma unroll
@@ -191,13 +210,18 @@ __global__ __launch_bounds__(1024) void hml_k_params(hml_model* __restrict__ mdl
             for (int d = 0; d < K; ++d) sum += graw[tid * K + d];
 #pragma unroll
             for (int d = 0; d < K; ++d) mdl->A[tid * K + d] = graw[tid * K + d] / sum;
-            if (mode == 0) mdl->logA[tid] = hml_logf(graw[tid * K + tid] / sum);   // hml_derive's logA
+            if (mode == 0) {
+                mdl->logA[tid] = hml_logf(graw[tid * K + tid] / sum);   // hml_derive's logA
+                float r = 0.0f;                                          // ... and the state's logNormalizer
+                for (int d = 0; d < D; ++d) r += s_logN[mdl->map[tid][d]];
+                mdl->logNs[tid] = r;
+            }
         }
         if (mode == 0 && tid == 65) {
             // hml_derive's threshold
             float mv = HML_INF_F;
 #pragma unroll
-            for (int k = 0; k < K; ++k) { const float v = s_var[k]; mv = (v < mv) ? v : mv; }   // std::min(result, var)
+            for (int k = 0; k < P; ++k) { const float v = s_var[k]; mv = (v < mv) ? v : mv; }   // std::min(result, var)
             const float l = hml_logf((float)mdl->T);
             const float arg = 2 * l * mv;
             const float t = HML_SQRTF(arg);

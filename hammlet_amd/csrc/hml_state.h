@@ -43,9 +43,17 @@ enum {
     HML_DEVERR_TOO_MANY_RECORDS = 11
 };
 
+#define HML_MAX_D 4            // data dimensions (K = P^D <= 16 with P >= 2)
+
 struct hml_model {
     // ---- configuration ----
     int32_t K;
+    // multivariate / shared parameters ("-s C P D", reference src/Mapping.hpp:53-137): K = P^D states over D interleaved
+    // data dimensions; state s uses parameter map[s][d] = (s / P^d) % P for dimension d.  D = 1: P = K, map[s][0] = s.
+    int32_t D, P;
+    uint8_t map[HML_MAX_K][HML_MAX_D];
+    float logNs[HML_MAX_K];      // theta.logNormalizer(state): sum over the state's parameters (Theta.hpp:148-158)
+    uint64_t stat_stride;        // elements between the per-dimension planes of the integral array / block statistics
     int32_t self_trans;
     int32_t dynamic;
     uint32_t T;

@@ -48,7 +48,7 @@ void hml_destroy(hml_ctx* ctx);
 /* MaxletTransform + noise estimate + HaarBreakpointWeights + Statistics<IntegralArray,Normal> +
  * Blocks<BreakpointArray> constructors (src/wavelet.hpp:68-188, src/main.cpp:303-318,340-341,
  * src/Statistics/IntegralArray.hpp:136-191, src/Blocks/BreakpointArray.hpp:130-184).
- * x: T host floats (hml_load_observations) or T device floats (hml_load_observations_device;
+ * x: T host floats (T * D with hml_set_dimensions; hml_load_observations) or T device floats (hml_load_observations_device;
  * sigma-hat is then computed from a host copy made internally). */
 int hml_load_observations(hml_ctx* ctx, const float* x, uint64_t T);
 int hml_load_observations_device(hml_ctx* ctx, const void* x_dev, uint64_t T);
@@ -74,6 +74,13 @@ int hml_text_finish(hml_text* reader, uint64_t* n_values, int* stopped);
 int hml_text_values(hml_text* reader, float* out /* n_values */);
 /* bytes consumed, tokens resolved by the host, chunks that went through the host extraction entirely */
 int hml_text_counters(hml_text* reader, uint64_t* bytes_in, uint64_t* irregular_tokens, uint64_t* host_chunks);
+
+/* "-s C P D" (src/main.cpp:114-137, src/Mapping.hpp:53-137): D data dimensions whose values follow each other in the
+ * observation stream and P emission parameters shared by K = P^D states (state s uses parameter (s / P^d) % P for
+ * dimension d).  Call before hml_load_observations (which then takes T * D values); hml_set_model's K must be P^D;
+ * hml_get_theta / hml_set_parameters carry P (mean, variance) pairs.  Default: D = 1, P = K. */
+int hml_set_dimensions(hml_ctx* ctx, int D, int P);
+int hml_get_dimensions(hml_ctx* ctx, int* D, int* P);
 
 /* stdEstimate of src/main.cpp:303-311 */
 int hml_noise_sigma(hml_ctx* ctx, double* sigma);

@@ -91,13 +91,13 @@ void orc_get_block_stats(void* h, float* s, float* q) {
 void orc_get_states(void* h, int16_t* q) { Oracle* o = (Oracle*)h; memcpy(q, o->q.data(), o->q.size() * 2); }
 void orc_get_theta(void* h, float* mean_var) {
     Oracle* o = (Oracle*)h;
-    for (int k = 0; k < o->cfg.K; ++k) { mean_var[2 * k] = o->mu[k]; mean_var[2 * k + 1] = o->var[k]; }
+    for (int k = 0; k < o->nP(); ++k) { mean_var[2 * k] = o->mu[k]; mean_var[2 * k + 1] = o->var[k]; }
 }
 void orc_get_A(void* h, float* A) { Oracle* o = (Oracle*)h; memcpy(A, o->A.data(), o->A.size() * 4); }
 void orc_get_pi(void* h, float* pi) { Oracle* o = (Oracle*)h; memcpy(pi, o->pi.data(), o->pi.size() * 4); }
 void orc_set_params(void* h, const float* mean_var, const float* A, const float* pi) {
     Oracle* o = (Oracle*)h; const int K = o->cfg.K;
-    for (int k = 0; k < K; ++k) o->set_theta(k, mean_var[2 * k], mean_var[2 * k + 1]);
+    for (int k = 0; k < o->nP(); ++k) o->set_theta(k, mean_var[2 * k], mean_var[2 * k + 1]);
     memcpy(o->A.data(), A, (size_t)K * K * 4); memcpy(o->pi.data(), pi, K * 4);
     o->sample_prior_pending = false;
 }

@@ -128,6 +128,13 @@ class OracleChain:
         if not self.h:
             raise RuntimeError(self.lib.orc_last_error().decode())
         self.T = 0
+        self.D, self.P = 1, None
+
+    def set_dimensions(self, D, P):
+        """`-s C P D`: D interleaved data dimensions, P emission parameters shared by P**D states (before load)"""
+        self.lib.orc_set_dims.argtypes = [_P, C.c_int, C.c_int]
+        self._chk(self.lib.orc_set_dims(self.h, D, P))
+        self.D, self.P = D, P
 
     def _chk(self, rc):
         if rc:
@@ -143,7 +150,7 @@ class OracleChain:
 
     def load(self, x, pointers=True):
         x = np.ascontiguousarray(x, np.float32)
-        self.T = x.size
+        self.T = x.size // self.D
         self._chk(self.lib.orc_load(self.h, x.ctypes.data, x.size, 1 if pointers else 0))
 
     def autoprior(self):
@@ -213,7 +220,7 @@ class OracleChain:
         return self._arr("orc_get_states", self.num_blocks(), np.int16)
 
     def theta(self):
-        return self._arr("orc_get_theta", 2 * self.K, np.float32)
+        return self._arr("orc_get_theta", 2 * (self.P or self.K), np.float32)
 
     def transitions(self):
         return self._arr("orc_get_A", self.K * self.K, np.float32).reshape(self.K, self.K), self._arr("orc_get_pi", self.K, np.float32)

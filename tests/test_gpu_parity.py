@@ -514,3 +514,41 @@ def test_graph_replay_of_the_sweep_gives_the_same_chain(hml, monkeypatch):
     compare_state(o, g)
     seg, cnt = g.marginals_rle()
     assert hml.marginals_text(seg, cnt) == o.text("marginals")
+
+
+def mv_trace(T, levels, D, seed):
+    """D-dimensional trace: dimension d is the univariate generator with data seed + d; values interleaved by position"""
+    return np.stack([ol.trace(T, levels, seed + d) for d in range(D)], axis=1).reshape(-1)
+
+
+@pytest.mark.parametrize("P,D,T,scheme", [
+    (2, 2, 60000, [("F", 12, 1)]),
+    (3, 2, 40000, [("M", 6, 1), "S", "P", ("F", 8, 2), "D", ("F", 4, 1)]),
+    (2, 3, 30000, [("F", 10, 1)]),
+    (4, 2, 70000, [("F", 6, 2)]),
+    (2, 4, 20000, [("M", 3, 1), ("F", 5, 1)]),
+])
+def test_multivariate_sweeps_match_checker(hml, P, D, T, scheme):
+    """`-s C P D` (reference src/Mapping.hpp): D interleaved data dimensions, P emission parameters
+    shared by P^D states - maxlet coefficients as the maximum over the dimensions, per-dimension integral arrays and
+    block statistics, emission terms summed over the dimensions through the mapping, per-parameter sufficient statistics
+    and conjugate updates.  The checker reproduces the reference binary byte for byte on such runs (tests/golden/mv_*);
+    the GPU must equal the checker in device mode, bit for bit."""
+    K = P ** D
+    x = mv_trace(T, min(P, 5), D, 61)
+    o = ol.OracleChain(K=K, seed=19, rng=ol.RNG_CTR, math=ol.MATH_DEV, reduce=ol.REDUCE_DEV)
+    o.set_dimensions(D, P)
+    o.load(x)
+    g = hml.Chain(device=0, seed=19)
+    g.set_dimensions(D, P)
+    g.load(x)
+    assert np.array_equal(bits(o.weights()), bits(g.weights()))
+    assert o.sigma_hat() == g.noise_sigma()
+    setup_model(o, g, K)
+    g._pending_prior = True
+    o.set_record(marginals=True)
+    run_both(o, g, scheme)
+    compare_state(o, g)
+    assert g.theta().size == 2 * P
+    seg, cnt = g.marginals_rle()
+    assert hml.marginals_text(seg, cnt) == o.text("marginals")
