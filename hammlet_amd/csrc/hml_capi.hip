@@ -469,11 +469,13 @@ int hml_set_dimensions(hml_ctx* c, int D, int P) {
     if (!c) return set_err(HML_ERR_ARG, "null context");
     if (c->loaded) return set_err(HML_ERR_ARG, "dimensions must be set before the observations are loaded");
     if (D <= 0) return set_err(HML_ERR_MODEL, "Number of data dimensions must be positive!");
-    if (P <= 0) return set_err(HML_ERR_MODEL, "Number of parameters must be positive!");
+    if (P < 0) return set_err(HML_ERR_MODEL, "Number of parameters must be positive!");
     if (D > HML_MAX_D) return set_err(HML_ERR_ARG, "at most 4 data dimensions are supported");
-    long k = 1;
-    for (int d = 0; d < D; ++d) { k *= P; if (k > HML_MAX_K) return set_err(HML_ERR_ARG, "number of states must be in [2,16]"); }
-    if (k <= 1) return set_err(HML_ERR_MODEL, "Requested parameters would yield an HMM with less than 2 states!");
+    if (P > 0) {   // P = 0: taken from hml_set_model's number of states (K = P^D)
+        long k = 1;
+        for (int d = 0; d < D; ++d) { k *= P; if (k > HML_MAX_K) return set_err(HML_ERR_ARG, "number of states must be in [2,16]"); }
+        if (k <= 1) return set_err(HML_ERR_MODEL, "Requested parameters would yield an HMM with less than 2 states!");
+    }
     c->D = D; c->P = P;
     return 0;
 }
@@ -650,6 +652,10 @@ int hml_set_model(hml_ctx* c, int K, const float nig4[4], float a_off, float a_d
     if (K < 2) return set_err(HML_ERR_MODEL, "Requested parameters would yield an HMM with less than 2 states!");
     if (K > HML_MAX_K) return set_err(HML_ERR_ARG, "number of states must be in [2,16]");
     if (c->model_set) return set_err(HML_ERR_ARG, "model already set");
+    if (c->D > 1 && c->P == 0) {   // the number of parameters follows from K = P^D
+        for (int pp = 2; pp <= K; ++pp) { long k = 1; for (int d = 0; d < c->D; ++d) k *= pp; if (k == K) { c->P = pp; break; } if (k > K) break; }
+        if (c->P == 0) return set_err(HML_ERR_ARG, "number of states must be (number of parameters)^(data dimensions)");
+    }
     if (c->P > 0) {
         long k = 1;
         for (int d = 0; d < c->D; ++d) k *= c->P;

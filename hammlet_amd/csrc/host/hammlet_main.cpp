@@ -30,7 +30,7 @@ static const char* kHelp =
     "  -O, -output-data M S P B C G   marginals sequences parameters blocks compression segments\n"
     "                    X            maxsegmentation: the maxSegmentation tool's output for the marginals (extension)\n"
     "  -w, -overwrite                 allow overwriting output files\n"
-    "  -s, -states K                  number of states (default 3)\n"
+    "  -s, -states K | C P D          number of states (default 3), or P parameters shared by P^D states over D dimensions\n"
     "  -e, -emissions normal VAR P    automatic prior: P(variance < VAR) = P (default normal 0.2 0.9)\n"
     "  -a, -auto-priors               (required) derive emission priors from the data\n"
     "  -t, -transitions OFF [DIAG]    Dirichlet prior of the transition rows (default 0.5 0.5)\n"
@@ -90,18 +90,17 @@ int main(int argc, const char* argv[]) {
         const int device = args.parse<int>("-device");
         const uint32_t chain = args.parse<uint32_t>("-chain");
 
-        // states: "-s K" (univariate); the multivariate "-s C P D" form is not on the MI355X path
-        size_t nrParams;
+        // states: "-s K", or "-s C P D": P emission parameters shared by P^D states over D data dimensions whose values
+        // follow each other in the input (reference main.cpp:114-137)
+        size_t nrParams, nrDataDim = 1;
         if (args.nrTokens("-s") == 1) {
             nrParams = args.parse<size_t>("-s", 0);
         } else {
             const string m = args.parse<string>("-s", 0);
             if (m != "C" && m != "combinations") throw std::runtime_error("Unknown mapping type " + m + "!");
             nrParams = args.parse<size_t>("-s", 1);
-            if (args.nrTokens("-s") >= 3 && args.parse<size_t>("-s", 2) != 1)
-                throw std::runtime_error("Only univariate data is supported by the MI355X path!");
+            if (args.nrTokens("-s") >= 3) nrDataDim = args.parse<size_t>("-s", 2);
         }
-        const size_t nrDataDim = 1;
         Mapping mapping(nrDataDim, nrParams, combinations);
         const size_t nrStates = mapping.nrStates();
 
@@ -171,7 +170,10 @@ int main(int argc, const char* argv[]) {
             MaxletTransform(std::cin, inputValues, stats, nrDataDim);
         }
         if (verbose) cout << "Output will be written to " + opref + "*" + osuff << endl << flush;
-        const size_t T = inputValues.size();
+        // (the reference counts the coefficients, one per position; here the vector still holds the D values of every position)
+        if (inputValues.size() % nrDataDim != 0)
+            throw std::runtime_error("Input stream did not contain enough values to fill all dimensions at last position!");
+        const size_t T = inputValues.size() / nrDataDim;
         if (verbose) cout << "Number of data points: " + std::to_string(T) << endl << flush;
 
         if (verbose) cout << "Calculating Haar breakpoint weights" << endl << flush;

@@ -103,7 +103,7 @@ template <typename T>
 void MaxletTransform(std::istream& input, std::vector<real_t>& coeffs, std::vector<SufficientStatistics<T>>& suffstats,
                      const size_t nrDim = 1, const size_t reserveT = 0) {
     (void)suffstats;
-    if (nrDim != 1) throw std::runtime_error("Only univariate data is supported by the MI355X path!");
+    if (nrDim <= 0) throw std::runtime_error("Number of dimensions must be positive!");
     if (!input) throw std::runtime_error("Cannot read input file or stream!");
     hml_text* reader = nullptr;
     // staging buffers no larger than the input when its size is known (reserveT ~ bytes / 2): pinned memory is costly
@@ -154,21 +154,22 @@ class Theta;
 template <>
 class Statistics<IntegralArray, Normal> {
     rng_t& mDev;
-    size_t mSize = 0;
+    size_t mSize = 0, mNrDim = 1;
     SufficientStatistics<Normal> mCurrent;
     friend class Emissions<Statistics<IntegralArray, Normal>, Blocks<BreakpointArray>>;
 
 public:
     Statistics(const Statistics&) = delete;
     // `values`: the vector MaxletTransform filled (swap-stolen like the reference's constructors)
-    Statistics(std::vector<real_t>& values, const size_t nrDim) : mDev(rng_t::current()) {
-        if (nrDim != 1) throw std::runtime_error("Only univariate data is supported by the MI355X path!");
+    // (with nrDim > 1 the values of a position's dimensions follow each other, reference src/wavelet.hpp:131-137)
+    Statistics(std::vector<real_t>& values, const size_t nrDim) : mDev(rng_t::current()), mNrDim(nrDim) {
         if (values.empty()) throw std::runtime_error("Input vector for breakpoint weights is empty!");
-        mSize = values.size();
+        if (nrDim > 1) hml_check(hml_set_dimensions(mDev.ctx(), (int)nrDim, 0));
+        mSize = values.size() / nrDim;
         hml_check(hml_load_observations(mDev.ctx(), values.data(), values.size()));
         std::vector<real_t>().swap(values);
     }
-    size_t nrDim() const { return 1; }
+    size_t nrDim() const { return mNrDim; }
     size_t size() const { return mSize; }
     const SufficientStatistics<Normal>& suffStat(size_t) const { return mCurrent; }
     double noiseEstimate() const { double s; hml_check(hml_noise_sigma(mDev.ctx(), &s)); return s; }   // main.cpp:303-311
@@ -262,17 +263,23 @@ std::vector<real_t> autoPrior(real_t s2, real_t p, E& y, const double /*noiseStd
     return out;
 }
 
-class Mapping {   // reference src/Mapping.hpp:53-137, univariate "combinations"
-    size_t mParams;
+class Mapping {   // reference src/Mapping.hpp:53-137, "combinations": nrParams^nrDataDim states
+    size_t mParams, mDims, mStates;
 
 public:
-    Mapping(size_t nrDataDim, size_t nrParams, MappingType) : mParams(nrParams) {
-        if (nrDataDim != 1) throw std::runtime_error("Only univariate data is supported by the MI355X path!");
-        if (nrParams <= 1) throw std::runtime_error("Requested parameters would yield an HMM with less than 2 states!");
+    Mapping(size_t nrDataDim, size_t nrParams, MappingType) : mParams(nrParams), mDims(nrDataDim), mStates(1) {
+        if (nrDataDim <= 0) throw std::runtime_error("Number of data dimensions must be positive!");
+        if (nrParams <= 0) throw std::runtime_error("Number of parameters must be positive!");
+        for (size_t d = 0; d < nrDataDim; ++d) mStates *= nrParams;
+        if (mStates <= 1) throw std::runtime_error("Requested parameters would yield an HMM with less than 2 states!");
     }
-    size_t nrStates() const { return mParams; }
+    size_t nrStates() const { return mStates; }
     size_t nrParams() const { return mParams; }
-    size_t nrDataDims() const { return 1; }
+    size_t nrDataDims() const { return mDims; }
+    size_t operator()(size_t state, size_t dim) const {   // parameter of `state` for data dimension `dim`
+        for (size_t d = 0; d < dim; ++d) state /= mParams;
+        return state % mParams;
+    }
 };
 
 // Hyper-parameter holders (reference src/ThetaHyperParam.hpp, TransitionHyperParam.hpp, InitialHyperParam.hpp):
@@ -330,20 +337,20 @@ public:
 // like the reference's constructor (Theta.hpp:126-127), draws once from the prior.
 template <>
 class Theta<NormalParam> {
-    rng_t& mDev; size_t mK;
+    rng_t& mDev; size_t mK, mP;   // states, emission parameters (mP^D = mK)
 public:
     Theta(const Theta&) = delete;
     template <typename H, typename TA, typename TP>
     Theta(ThetaHyperParam<H>& tau_theta, const TransitionHyperParam<TA>& tau_A, const InitialHyperParam<TP>& tau_pi,
           bool useSelfTransitions, rng_t& RNG)
-        : mDev(RNG), mK(tau_theta.nrParams()) {
+        : mDev(RNG), mK(tau_A.nrStates), mP(tau_theta.nrParams()) {
         hml_check(hml_set_model(mDev.ctx(), (int)mK, tau_theta.prior(0).data(), tau_A.off, tau_A.diag, tau_pi.alpha,
                                 useSelfTransitions ? 1 : 0));
     }
-    size_t nrParams() const { return mK; }
+    size_t nrParams() const { return mP; }
     size_t nrStates() const { return mK; }
     std::vector<real_t> meanVar() const {
-        std::vector<real_t> v(2 * mK);
+        std::vector<real_t> v(2 * mP);
         hml_check(hml_get_theta(mDev.ctx(), v.data()));
         return v;
     }
@@ -351,7 +358,7 @@ public:
     std::string str(const std::string& sep = "\t") const {
         const std::vector<real_t> v = meanVar();
         std::string s;
-        for (size_t k = 0; k < mK; ++k) {
+        for (size_t k = 0; k < mP; ++k) {
             if (k) s += sep;
             s += std::to_string(v[2 * k]) + "\t" + std::to_string(v[2 * k + 1]);
         }
@@ -360,7 +367,7 @@ public:
     real_t thresholdValue() const {   // Theta.hpp:227-234: smallest variance
         const std::vector<real_t> v = meanVar();
         real_t r = std::numeric_limits<real_t>::infinity();
-        for (size_t k = 0; k < mK; ++k) r = std::min(r, v[2 * k + 1]);
+        for (size_t k = 0; k < mP; ++k) r = std::min(r, v[2 * k + 1]);
         return r;
     }
     hml_ctx* ctx() const { return mDev.ctx(); }

@@ -78,7 +78,8 @@ int hml_text_counters(hml_text* reader, uint64_t* bytes_in, uint64_t* irregular_
 /* "-s C P D" (src/main.cpp:114-137, src/Mapping.hpp:53-137): D data dimensions whose values follow each other in the
  * observation stream and P emission parameters shared by K = P^D states (state s uses parameter (s / P^d) % P for
  * dimension d).  Call before hml_load_observations (which then takes T * D values); hml_set_model's K must be P^D;
- * hml_get_theta / hml_set_parameters carry P (mean, variance) pairs.  Default: D = 1, P = K. */
+ * hml_get_theta / hml_set_parameters carry P (mean, variance) pairs.  P = 0 here: taken from hml_set_model's K.
+ * Default: D = 1, P = K. */
 int hml_set_dimensions(hml_ctx* ctx, int D, int P);
 int hml_get_dimensions(hml_ctx* ctx, int* D, int* P);
 

@@ -72,3 +72,13 @@ def test_cli_errors_like_the_reference():
         assert again.returncode == 1 and "already exists! Use -w to allow overwrite!" in again.stderr
         r = subprocess.run([CLI, "-raw", raw, "-a", "-a"], capture_output=True, text=True)
         assert r.returncode == 1 and "Duplicate flag -a!" in r.stderr
+
+
+@pytest.mark.parametrize("P,D,T,flags", [(2, 2, 30001, "-R 4 -i F 30 1"), (3, 2, 20000, "-R 5 -i M 10 1 S P F 20 2"), (2, 3, 65537, "-R 6 -S -i F 15 1")])
+def test_cli_multivariate_files_equal_checker_files(P, D, T, flags):
+    """`-s C P D` through the driver: interleaved text input, P parameter pairs per line of the parameters file"""
+    x = np.stack([ol.trace(T, min(P, 5), 70 + d) for d in range(D)], axis=1).reshape(-1)
+    res, g_out, o_out = run_pair(x, ("-s C %d %d " % (P, D) + flags).split(), text_input=True)
+    for name, (g, o) in res.items():
+        assert g == o, name
+    assert len(res["parameters"][0].splitlines()[0].split("\t")) == 2 * P
