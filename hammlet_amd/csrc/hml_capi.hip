@@ -127,6 +127,17 @@ struct hml_ctx {
     std::vector<hipEvent_t> ev_pool;
 };
 
+// Live contexts per device.  The fused block kernel hands block offsets from workgroup to workgroup inside one launch
+// (a workgroup spins on the words of lower-numbered ones); that is safe while all lower-numbered workgroups are resident
+// or finished, which in-order dispatch guarantees for ONE kernel on the GPU.  With two chains sweeping the same GPU at
+// once the eight XCDs can fill up with the late workgroups of one launch and the early ones of the other, each waiting
+// for workgroups that cannot be dispatched (observed once under the profiler: two launches stalled for 27 s until the
+// firmware's time slicing untangled them).  So while more than one context is alive on a device every sweep takes the
+// scan + scatter pair, which has no such hand-off.
+#include <atomic>
+static std::atomic<int> g_live_ctx[64];
+static bool shares_device(const hml_ctx* c);
+
 // ------------------------------------------------------------------------------------------------
 static int ctx_bind(hml_ctx* c) {
     HIPCHK(hipSetDevice(c->device));
@@ -315,9 +326,12 @@ int hml_create(hml_ctx** out, int device, uint64_t seed, uint32_t chain_id, void
     if (const char* e = getenv("HML_DENSE_MIN_BLOCKS")) c->dense_min_blocks = (uint32_t)strtoul(e, nullptr, 10);
     if (const char* e = getenv("HML_USE_GRAPH")) c->use_graph = atoi(e) != 0;
     if (const char* e = getenv("HML_WEIGHT_KEYS")) c->use_keys = atoi(e) != 0;
+    if (device < 64) g_live_ctx[device].fetch_add(1);
     *out = c;
     return 0;
 }
+
+static bool shares_device(const hml_ctx* c) { return c->device < 64 && g_live_ctx[c->device].load() > 1; }
 
 static void free_all(hml_ctx* c) {
     void* ptrs[] = {c->d_group_word, c->d_launch_gen, c->d_summary, c->d_w, c->d_coeff, c->d_ia, c->d_stage, c->d_span_count, c->d_starts, c->d_bstat,
@@ -329,6 +343,7 @@ static void free_all(hml_ctx* c) {
 
 void hml_destroy(hml_ctx* c) {
     if (!c) return;
+    if (c->device < 64) g_live_ctx[c->device].fetch_sub(1);
     hipSetDevice(c->device);
     hipStreamSynchronize(c->stream);
     for (auto& kv : c->prof) for (auto& p : kv.second.pending) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
@@ -825,7 +840,7 @@ static int sweep_k(hml_ctx* c, char method, bool record) {
     const int L = dense_geo ? c->fwdL_dense : c->fwdL;
     const hml_layout lay = dense_geo ? c->lay_dense : c->lay;
     if (c->dynamic || !c->blocks_valid) {
-        if (c->D == 1 && c->use_keys && !(!c->summary_always && c->B_hint && (uint64_t)c->B_hint * 24u > c->T)) {
+        if (c->D == 1 && c->use_keys && !shares_device(c) && !(!c->summary_always && c->B_hint && (uint64_t)c->B_hint * 24u > c->T)) {
             // K4 + K5 + K6a in one launch (hml_k_blocks_fused.h); weak compression takes the float stream below
             ProfScope ps(c, "blocks_compact", 1);
             const uint32_t n_wg = (uint32_t)(((uint64_t)T + HML_FUSED_POSITIONS - 1) / HML_FUSED_POSITIONS);

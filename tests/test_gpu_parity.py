@@ -552,3 +552,35 @@ def test_multivariate_sweeps_match_checker(hml, P, D, T, scheme):
     assert g.theta().size == 2 * P
     seg, cnt = g.marginals_rle()
     assert hml.marginals_text(seg, cnt) == o.text("marginals")
+
+
+def test_fused_block_kernel_only_while_the_chain_has_the_gpu_to_itself(hml):
+    """The fused block kernel hands offsets from workgroup to workgroup inside a launch, which needs in-order dispatch of
+    ONE kernel; while a second context is alive on the device the sweeps take the scan + scatter pair instead (same
+    results).  Checked through the per-family launch counters."""
+    import gc
+    gc.collect()
+    T, K = 400000, 3
+    x = ol.trace(T, K, 8)
+
+    def run(chain):
+        chain.load(x)
+        chain.set_model(K, chain.autoprior(0.2, 0.9))
+        chain.sample_prior()
+        chain.profile_enable(2)
+        before = chain.profile_get("blocks_scatter")[1]
+        chain.iterate("F", 12, 0)
+        chain.sync()
+        chain.profile_enable(0)
+        return chain.profile_get("blocks_scatter")[1] - before, chain.states().copy(), chain.theta().copy()
+
+    a = hml.Chain(device=0, seed=3)
+    scat_alone, q_alone, th_alone = run(a)
+    a.close()
+    b = hml.Chain(device=0, seed=3)
+    other = hml.Chain(device=0, seed=4)          # a second live context on the same device
+    scat_shared, q_shared, th_shared = run(b)
+    other.close()
+    b.close()
+    assert scat_alone <= 1 and scat_shared >= 12          # (one enumeration ahead of the first sweep either way)
+    assert np.array_equal(q_alone, q_shared) and np.array_equal(bits(th_alone), bits(th_shared))
