@@ -10,6 +10,7 @@ LIB_PATH = os.path.join(PKG_DIR, "libhammlet_hip.so")
 CLI_PATH = os.path.join(PKG_DIR, "hammlet")
 TOOL_PATH = os.path.join(PKG_DIR, "maxSegmentation")
 SORT_TOOL_PATH = os.path.join(PKG_DIR, "sortStates")
+AVG_TOOL_PATH = os.path.join(PKG_DIR, "avg")
 
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC"]
 
@@ -95,6 +96,13 @@ def build_cli(force=False, verbose=False):
     tsrc = os.path.join(CSRC, "host", "maxSegmentation_main.cpp")
     if force or _newer(TOOL_PATH, [tsrc, os.path.join(REPO_DIR, "include", "hammlet", "Parser.hpp")]):
         cmd = ["g++", "-O2", "-std=c++17", "-o", TOOL_PATH, tsrc, "-I", os.path.join(REPO_DIR, "include")]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.run(cmd, check=True)
+    asrc = os.path.join(CSRC, "host", "avg_main.cpp")
+    if force or _newer(AVG_TOOL_PATH, [asrc, LIB_PATH]):
+        cmd = ["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-o", AVG_TOOL_PATH, asrc, "-I", os.path.join(REPO_DIR, "include"),
+               "-L", PKG_DIR, "-lhammlet_hip", "-Wl,-rpath,$ORIGIN"]
         if verbose:
             print(" ".join(cmd))
         subprocess.run(cmd, check=True)

@@ -120,3 +120,18 @@ def test_cli_reads_standard_input_and_concatenates_files(hml, tmp_path):
         want = open(tmp_path / ("w-%s.csv" % kind)).read()
         assert open(tmp_path / ("s-%s.csv" % kind)).read() == want
         assert open(tmp_path / ("c-%s.csv" % kind)).read() == want
+
+
+def test_avg_tool_matches_the_reference_tool(hml):
+    """hammlet_amd/avg (values through the GPU text reader, window sums in the reference's order) against the outputs of
+    the reference's src/tools/avg.cpp (tests/golden/avg, made by tests/golden/make_avg_golden.py)"""
+    import glob
+    from hammlet_amd import build
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    outs = sorted(glob.glob(os.path.join(gold, "avg", "*.out")))
+    assert len(outs) >= 10
+    for path in outs:
+        name, w = os.path.basename(path)[:-4].rsplit(".w", 1)
+        with open(os.path.join(gold, "text", name + ".txt"), "rb") as f:
+            got = subprocess.run([build.AVG_TOOL_PATH, w], stdin=f, check=True, capture_output=True).stdout
+        assert got == open(path, "rb").read(), (name, w)
