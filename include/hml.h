@@ -48,9 +48,10 @@ void hml_destroy(hml_ctx* ctx);
 /* MaxletTransform + noise estimate + HaarBreakpointWeights + Statistics<IntegralArray,Normal> +
  * Blocks<BreakpointArray> constructors (src/wavelet.hpp:68-188, src/main.cpp:303-318,340-341,
  * src/Statistics/IntegralArray.hpp:136-191, src/Blocks/BreakpointArray.hpp:130-184).
- * x: T host floats (T * D with hml_set_dimensions; hml_load_observations) or T device floats (hml_load_observations_device;
- * sigma-hat is then computed from a host copy made internally). */
-int hml_load_observations(hml_ctx* ctx, const float* x, uint64_t T);
+ * hml_load_observations: n_values = T host floats - T * D after hml_set_dimensions(D, .), the D values of a position one
+ * after the other.  hml_load_observations_device: T device floats (univariate; sigma-hat is then computed from a host copy
+ * made internally). */
+int hml_load_observations(hml_ctx* ctx, const float* x, uint64_t n_values);
 int hml_load_observations_device(hml_ctx* ctx, const void* x_dev, uint64_t T);
 
 /* Text input: the values that `while ( input >> v )` extracts from a whitespace-separated decimal stream
