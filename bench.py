@@ -186,7 +186,7 @@ def main():
 
     # headline leg: the library's default path - the block structure is recomputed in every sweep (dynamic blocks)
     chain, elapsed, blocks, st0, st1 = run_leg(weight_summary=True, profile_level=1)
-    scan_ms, scan_n = chain.profile_get("blocks_compact")      # HIP events around every 8th launch of the kernel
+    scan_ms, scan_n = chain.profile_get("blocks_compact")      # HIP events around every 32nd launch of the kernel
     null_ms, null_n = chain.profile_get("event_null")          # empty brackets recorded right behind them
 
     if dist is not None:

@@ -121,7 +121,7 @@ struct hml_ctx {
     bool rec_marginals = true;
     hml_record_cb cb = nullptr;
     void* cb_user = nullptr;
-    int profiling = 0;             // 0 off, 1 dominant kernel only (blocks_compact, every 8th launch), 2 every kernel family
+    int profiling = 0;             // 0 off, 1 dominant kernel only (blocks_compact, every 32nd launch), 2 every kernel family
     uint32_t prof_tick = 0;
     std::map<std::string, ProfAcc> prof;
     std::vector<hipEvent_t> ev_pool;
@@ -155,9 +155,9 @@ struct ProfScope {
     hml_ctx* c; const char* name; hipEvent_t a = nullptr, b = nullptr;
     bool on;
     ProfScope(hml_ctx* c_, const char* n, int level = 2) : c(c_), name(n), on(c_->profiling >= level) {
-        // level 1 (the bench's timed region): bracket every 8th launch only - two event records cost ~6 us of
+        // level 1 (the bench's timed region): bracket every 32nd launch only - two event records cost ~6 us of
         // stream time, a visible share of an 80 us sweep
-        if (on && c->profiling == 1 && (c->prof_tick++ & 7u) != 0u) on = false;
+        if (on && c->profiling == 1 && (c->prof_tick++ & 31u) != 0u) on = false;
         if (on) { a = ev_get(c); b = ev_get(c); hipEventRecord(a, c->stream); }
     }
     ~ProfScope() {
