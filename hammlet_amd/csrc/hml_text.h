@@ -57,7 +57,9 @@ HML_HD bool hml_is_space(uint32_t c) { return c == 32u || (c - 9u) <= 4u; }
 // w * 10^q -> float bits (sign applied by the caller); false = cannot be decided here
 HML_HD bool hml_decimal_to_float(uint64_t w, int q, uint32_t* bits) {
     if (w == 0) { *bits = 0; return true; }
-    while (w % 10u == 0u) { w /= 10u; ++q; }
+    // trailing zeros of w only matter when they bring the pair into the range of the first branch (or make a tie exact)
+    if (!(w < (1ull << 53) && q >= -22 && q <= 22))
+        while (w % 10u == 0u) { w /= 10u; ++q; }
     if (w < (1ull << 53) && q >= -22 && q <= 22) {
         const double dw = (double)w;
         const double d = q >= 0 ? dw * HML_P10_D[q] : dw / HML_P10_D[-q];
