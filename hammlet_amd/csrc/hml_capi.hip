@@ -108,7 +108,7 @@ struct hml_ctx {
     bool hint_stale = true;         // the hint predates the current parameters (new model, prior draw, mode switch)
     // forward geometry
     int fwdL = 4, fwdW = 12;   // W is the floor of the adaptive warm-up (measured: 12 beats 16 and 24 on C1-C4; 8 does not)
-    int fwdW_init = 24;        // where a chain starts and the floor of its first 512 sweeps: while the parameters are
+    int fwdW_init = 24;        // where a chain starts and the floor of its first 256 sweeps: while the parameters are
                                // still far from settled the filter forgets slowly (131 refits in sweeps 20-220 of C3 with a floor of 12)
     hml_layout lay = {2, 0};
     // weakly compressed sweeps (B_hint >= dense_min_blocks): longer forward chunks - the warm-up is a smaller share

@@ -264,7 +264,7 @@ __global__ __launch_bounds__(1024) void hml_k_params(hml_model* __restrict__ mdl
             const unsigned long long handful = (mdl->B >> 22) ? (((unsigned long long)(mdl->B >> 16) > 16ull) ? (unsigned long long)(mdl->B >> 16) : 16ull) : 0ull;
             if (serial != 0ull || refits > handful) { W = (2u * W < 1024u) ? 2u * W : 1024u; mdl->fwd_quiet = 0u; }
             else if (refits == 0ull) {
-                const uint32_t floorW = (mdl->sweeps < 512ull) ? mdl->fwd_W_burnin : mdl->fwd_W0;
+                const uint32_t floorW = (mdl->sweeps < 256ull) ? mdl->fwd_W_burnin : mdl->fwd_W0;
                 if (++mdl->fwd_quiet >= 32u) { const uint32_t w2 = W - W / 4u; W = (w2 > floorW) ? ((w2 & ~7u) > floorW ? (w2 & ~7u) : floorW) : floorW; mdl->fwd_quiet = 0u; }
             } else mdl->fwd_quiet = 0u;
             mdl->fwd_W = W;

@@ -95,7 +95,7 @@ struct hml_model {
     uint32_t fwd_mismatch;       // set by a verification round that found a stale chunk
     // adaptive warm-up length of the speculative forward pass (results never depend on it)
     uint32_t fwd_W, fwd_W0, fwd_serial_ran, fwd_quiet;
-    uint32_t fwd_W_burnin;       // floor during the first 512 sweeps of a chain (parameters still far from settled)
+    uint32_t fwd_W_burnin;       // floor during the first 256 sweeps of a chain (parameters still far from settled)
     unsigned long long fwd_refits_seen, fwd_serial_seen;
 };
 
