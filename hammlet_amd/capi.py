@@ -47,10 +47,12 @@ SIGNATURES = {
     "hml_text_counters": (C.c_int, [_P, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "hml_set_dimensions": (C.c_int, [_P, C.c_int, C.c_int]),
     "hml_get_dimensions": (C.c_int, [_P, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "hml_set_weights": (C.c_int, [_P, _P, C.c_uint64]),
     "hml_noise_sigma": (C.c_int, [_P, C.POINTER(C.c_double)]),
     "hml_scale_weights": (C.c_int, [_P, C.c_float]),
     "hml_autoprior": (C.c_int, [_P, C.c_float, C.c_float, _P]),
     "hml_set_model": (C.c_int, [_P, C.c_int, _P, C.c_float, C.c_float, C.c_float, C.c_int]),
+    "hml_set_self_transitions": (C.c_int, [_P, C.c_int]),
     "hml_sample_prior": (C.c_int, [_P]),
     "hml_set_static_blocks": (C.c_int, [_P]),
     "hml_set_dynamic": (C.c_int, [_P, C.c_int]),
@@ -78,6 +80,17 @@ SIGNATURES = {
     "hml_max_segmentation": (C.c_int, [_P, C.POINTER(C.c_uint64), _P, _P]),
     "hml_marginals_dense_device": (C.c_int, [_P, _P, _P]),
     "hml_recorded_sweeps": (C.c_int, [_P, C.POINTER(C.c_uint64)]),
+    "hml_categorical_draw": (C.c_int, [_P, _P, C.c_int, C.POINTER(C.c_uint32)]),
+    "hml_relabel_permutation": (C.c_int, [_P, _P]),
+    "hml_pool_payload_size": (C.c_int, [_P, C.POINTER(C.c_uint64)]),
+    "hml_pool_export": (C.c_int, [_P, _P, _P]),
+    "hml_pool_install": (C.c_int, [_P, _P]),
+    "hml_pool_unique_id": (C.c_int, [_P]),
+    "hml_pool_create": (C.c_int, [C.POINTER(_P), C.c_int, C.c_int, C.c_int, _P]),
+    "hml_pool_destroy": (None, [_P]),
+    "hml_pool_marginals": (C.c_int, [_P, _P, _P]),
+    "hml_pool_info": (C.c_int, [_P, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.POINTER(C.c_int)]),
+    "hml_allreduce_marginals": (C.c_int, [_P, C.c_int]),
     "hml_get_stats": (C.c_int, [_P, C.POINTER(HmlStats)]),
     "hml_profile_enable": (C.c_int, [_P, C.c_int]),
     "hml_profile_get": (C.c_int, [_P, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
@@ -224,6 +237,10 @@ class Chain:
     def scale_weights(self, m):
         _check(self.lib.hml_scale_weights(self.h, m))
 
+    def set_weights(self, w):
+        w = np.ascontiguousarray(w, np.float32)
+        _check(self.lib.hml_set_weights(self.h, w.ctypes.data, w.size))
+
     def autoprior(self, s2=0.2, p=0.9):
         out = np.empty(4, np.float32)
         _check(self.lib.hml_autoprior(self.h, s2, p, out.ctypes.data))
@@ -236,6 +253,9 @@ class Chain:
 
     def sample_prior(self):
         _check(self.lib.hml_sample_prior(self.h))
+
+    def set_self_transitions(self, on=True):
+        _check(self.lib.hml_set_self_transitions(self.h, 1 if on else 0))
 
     def set_static_blocks(self):
         _check(self.lib.hml_set_static_blocks(self.h))
@@ -277,11 +297,12 @@ class Chain:
         return s
 
     def block_stats(self):
+        """(sum x, sum x^2) of every block; with D > 1 data dimensions arrays of shape [D][B]"""
         B = self.num_blocks()
-        a = np.empty(B, np.float32)
-        b = np.empty(B, np.float32)
+        a = np.empty((self.D, B), np.float32)
+        b = np.empty((self.D, B), np.float32)
         _check(self.lib.hml_get_block_stats(self.h, a.ctypes.data, b.ctypes.data))
-        return a, b
+        return (a[0], b[0]) if self.D == 1 else (a, b)
 
     def states(self):
         B = self.num_blocks()
@@ -383,6 +404,31 @@ class Chain:
             p = perm.ctypes.data
         _check(self.lib.hml_marginals_dense_device(self.h, out_ptr, p))
 
+    # ---- chain-parallel pooling ---------------------------------------------------------
+    def relabel_permutation(self):
+        perm = np.empty(self.K, np.int32)
+        _check(self.lib.hml_relabel_permutation(self.h, perm.ctypes.data))
+        return perm
+
+    def pool_payload_size(self):
+        n = C.c_uint64()
+        _check(self.lib.hml_pool_payload_size(self.h, C.byref(n)))
+        return n.value
+
+    def pool_export(self, payload_ptr):
+        perm = np.empty(self.K, np.int32)
+        _check(self.lib.hml_pool_export(self.h, payload_ptr, perm.ctypes.data))
+        return perm
+
+    def pool_install(self, payload_ptr):
+        _check(self.lib.hml_pool_install(self.h, payload_ptr))
+
+    def categorical_draw(self, weights):
+        w = np.ascontiguousarray(weights, np.float32)
+        out = C.c_uint32()
+        _check(self.lib.hml_categorical_draw(self.h, w.ctypes.data, w.size, C.byref(out)))
+        return out.value
+
     def stats(self):
         s = HmlStats()
         _check(self.lib.hml_get_stats(self.h, C.byref(s)))
@@ -396,6 +442,54 @@ class Chain:
         n = C.c_uint64()
         _check(self.lib.hml_profile_get(self.h, name.encode(), C.byref(ms), C.byref(n)))
         return ms.value, n.value
+
+
+class Pool:
+    """RCCL communicator of the chain-parallel pooling (hml_pool_* of include/hml.h): one rank per process and GPU."""
+
+    def __init__(self, device, rank, n_ranks, unique_id):
+        self.lib = load_library()
+        h = _P()
+        buf = C.create_string_buffer(bytes(unique_id), 128)
+        _check(self.lib.hml_pool_create(C.byref(h), device, rank, n_ranks, C.cast(buf, _P)))
+        self.h = h
+
+    @staticmethod
+    def unique_id():
+        """ncclGetUniqueId: made by rank 0, handed to every rank by the launcher"""
+        lib = load_library()
+        buf = C.create_string_buffer(128)
+        _check(lib.hml_pool_unique_id(C.cast(buf, _P)))
+        return buf.raw
+
+    def marginals(self, chain):
+        """export + ncclAllReduce(sum, int32) + install: afterwards `chain` holds the pooled marginals"""
+        perm = np.empty(chain.K, np.int32)
+        _check(self.lib.hml_pool_marginals(self.h, chain.h, perm.ctypes.data))
+        return perm
+
+    def info(self):
+        r, n, ms, b, v = C.c_int(), C.c_int(), C.c_double(), C.c_uint64(), C.c_int()
+        _check(self.lib.hml_pool_info(self.h, C.byref(r), C.byref(n), C.byref(ms), C.byref(b), C.byref(v)))
+        return {"rank": r.value, "n_ranks": n.value, "last_allreduce_ms": ms.value, "last_bytes": b.value, "rccl_version": v.value}
+
+    def close(self):
+        if self.h:
+            self.lib.hml_pool_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def allreduce_marginals(chains):
+    """hml_allreduce_marginals: one process driving several chains (possibly on several GPUs)"""
+    lib = load_library()
+    arr = (_P * len(chains))(*[c.h for c in chains])
+    _check(lib.hml_allreduce_marginals(C.cast(arr, _P), len(chains)))
 
 
 def marginals_text(seg, cnt):

@@ -1,42 +1,70 @@
-"""Chain-parallel execution: independent Gibbs chains, one per GPU (one process per GPU), and the single
-collective of the design - a sum all-reduce (RCCL over xGMI when the backend is "nccl") that pools the
-chains' state marginals at the end.
+"""Chain-parallel execution: independent Gibbs chains, one per GPU (one process per GPU), and the single collective of
+the design - a sum all-reduce that pools the chains' state marginals at the end.
 
-The reference has nothing distributed (one process, one thread, src/main.cpp).  Chains never communicate
-while sampling; pooling needs (1) a common labelling of the states - every chain relabels its states by
-ascending emission mean, the idea of the reference's bin/sortStates:1-6 - and (2) one all-reduce over the
-dense [K+1][T] int32 array (K count rows + one row that is non-zero at segment boundaries).
+The product path is the C ABI: `hml_pool_create` / `hml_pool_marginals` (RCCL over xGMI inside libhammlet_hip.so,
+hammlet_amd.Pool here) or `hml_allreduce_marginals` for one process that drives several GPUs.  This module holds the
+launcher glue around it - how the ranks of a torch.distributed job obtain the RCCL id - and a tensor-level mirror of the
+payload algebra (`payload_from_dense`, `pool_payload`, `payload_to_rle`) that works on any backend, which is how the
+world-size-2 gloo test on CPU covers the N > 1 semantics (relabel, sum, cut at the union of the boundaries).
+
+The reference has nothing distributed (one process, one thread, src/main.cpp:108).  Pooling needs (1) a common
+labelling of the states - every chain relabels its states by ascending emission mean, the idea of the reference's
+bin/sortStates:1-6 - and (2) one all-reduce over the int32 payload [K+1][T+1] (+ K+1 words): K relabelled difference
+arrays of the recorded marginals, one row that is non-zero at segment boundaries, the number of recorded sweeps and
+which states were ever recorded (hammlet_amd/csrc/hml_k_pool.h).
 """
 import numpy as np
 
 
 def relabel_permutation(means):
-    """perm[new] = old such that the states are ordered by ascending mean (ties keep their order)."""
+    """perm[new] = old such that the states are ordered by ascending mean (ties keep their order); `means` may be
+    [K] or, for "-s C P D" states, [K][D] tuples of mapped parameter means compared in dimension order"""
     means = np.asarray(means, np.float64)
-    return np.argsort(means, kind="stable").astype(np.int32)
+    if means.ndim == 1:
+        return np.argsort(means, kind="stable").astype(np.int32)
+    return np.lexsort(tuple(means[:, d] for d in range(means.shape[1] - 1, -1, -1))).astype(np.int32)
 
 
-def pool_dense(dense, group=None):
-    """Sum all-reduce of a [K+1][T] int32 tensor over the process group (in place).  Works on any backend:
-    "nccl" (= RCCL on ROCm) for device tensors, "gloo" for the CPU tests."""
+def payload_from_dense(dense, boundary, perm, n_recorded):
+    """The int32 payload of one chain from dense per-position counts [K][T], a 0/1 boundary row [T], the relabelling
+    and the number of recorded sweeps - what hml_pool_export builds on the device from the difference arrays."""
+    dense = np.asarray(dense, np.int64)
+    K, T = dense.shape
+    d = dense[np.asarray(perm)]
+    diff = np.zeros((K + 1, T + 1), np.int64)
+    diff[:K, 0] = d[:, 0]
+    diff[:K, 1:T] = d[:, 1:] - d[:, :-1]
+    diff[K, :T] = np.asarray(boundary) != 0
+    diff[K, 0] = 1
+    used = (d != 0).any(axis=1).astype(np.int64)
+    return np.concatenate([diff.ravel(), [n_recorded], used]).astype(np.int32)
+
+
+def pool_payload(payload, group=None):
+    """Sum all-reduce of a payload tensor over the process group (in place).  Works on any backend: "nccl" (= RCCL on
+    ROCm) for device tensors, "gloo" for the CPU tests.  (The product path does this inside the library.)"""
     import torch.distributed as dist
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-        dist.all_reduce(dense, op=dist.ReduceOp.SUM, group=group)
-    return dense
+        dist.all_reduce(payload, op=dist.ReduceOp.SUM, group=group)
+    return payload
 
 
-def dense_to_rle(dense):
-    """Run-length form of pooled dense counts: cut at every position whose boundary row is non-zero.
-    Returns (segment lengths [M], counts [M][K]) as tensors on dense's device."""
+def payload_to_rle(payload, K, T):
+    """Run-length form of a pooled payload: prefix sums of the difference rows, cut wherever the boundary row is
+    non-zero; columns up to the highest state any chain recorded (reference src/StateMarginals.hpp:300-303).
+    Returns (segment lengths [M], counts [M][columns], recorded sweeps)."""
     import torch
-    K = dense.shape[0] - 1
-    T = dense.shape[1]
-    flags = dense[K] != 0
+    body = payload[: (K + 1) * (T + 1)].view(K + 1, T + 1)
+    tail = payload[(K + 1) * (T + 1):]
+    flags = body[K, :T] != 0
     flags[0] = True
     starts = torch.nonzero(flags, as_tuple=False).flatten()
-    ends = torch.cat([starts[1:], torch.tensor([T], device=dense.device, dtype=starts.dtype)])
-    counts = dense[:K, starts].t().contiguous()
-    return (ends - starts), counts
+    ends = torch.cat([starts[1:], torch.tensor([T], device=payload.device, dtype=starts.dtype)])
+    dense = torch.cumsum(body[:K, :T].to(torch.int64), dim=1)
+    used = torch.nonzero(tail[1:1 + K] != 0, as_tuple=False).flatten()
+    cols = int(used.max().item()) + 1 if used.numel() else 0
+    counts = dense[:cols, starts].t().contiguous()
+    return (ends - starts), counts, int(tail[0].item())
 
 
 def max_segmentation(seg, cnt):
@@ -59,16 +87,23 @@ def max_segmentation(seg, cnt):
     return csum[ends] - csum[starts], state[starts]
 
 
-def pooled_marginals(chain, group=None, device=None):
-    """Relabel this chain's marginals by ascending mean, export them densely on the GPU, pool them over
-    all chains of the process group and return (segment lengths, counts) of the pooled marginals."""
-    import torch
-    K, T = chain.K, chain.T
-    theta = chain.theta()
-    perm = relabel_permutation(theta[0::2])
-    dev = device if device is not None else torch.device("cuda", torch.cuda.current_device())
-    dense = torch.empty((K + 1, T), dtype=torch.int32, device=dev)
-    chain.marginals_dense_device(dense.data_ptr(), perm)
-    pool_dense(dense, group)
-    seg, cnt = dense_to_rle(dense)
+def make_pool(device, group=None):
+    """The RCCL communicator of this rank inside a torch.distributed job (one process per GPU): rank 0 creates the id,
+    the job's own backend broadcasts its 128 bytes, every rank joins (ncclCommInitRank).  Without an initialised
+    process group: a one-rank communicator."""
+    import torch.distributed as dist
+    from .capi import Pool
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+        box = [Pool.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0, group=group)
+        return Pool(device, rank, world, box[0])
+    return Pool(device, 0, 1, Pool.unique_id())
+
+
+def pooled_marginals(chain, pool):
+    """Pools the recorded marginals of all chains of the communicator (hml_pool_marginals) and returns the pooled
+    run-length marginals (segment lengths, counts) together with the permutation this chain applied."""
+    perm = pool.marginals(chain)
+    seg, cnt = chain.marginals_rle()
     return seg, cnt, perm

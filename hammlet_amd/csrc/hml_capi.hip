@@ -24,6 +24,7 @@
 #include "hml_synth_host.hpp"
 
 #include "hml_host_common.hpp"
+#include "hml_ctx.hpp"
 
 static thread_local std::string g_err;
 int hml_set_err(int code, const std::string& msg) { g_err = msg; return code; }
@@ -49,84 +50,6 @@ static int set_err(int code, const std::string& msg) { return hml_set_err(code, 
         default: return set_err(HML_ERR_ARG, "number of states must be in [2,16]"); \
     }
 
-struct ProfAcc { double ms = 0; uint64_t n = 0; std::vector<std::pair<hipEvent_t, hipEvent_t>> pending; };
-
-struct hml_ctx {
-    int device = 0;
-    hipStream_t stream = nullptr;
-    bool own_stream = false;
-    uint64_t seed = 0;
-    uint32_t chain = 0;
-    uint64_t T = 0;
-    int K = 0;
-    int D = 1, P = 0;              // data dimensions / emission parameters ("-s C P D"; P = 0: univariate, P = K)
-    bool loaded = false, model_set = false;
-    bool dynamic = true;
-    bool blocks_valid = false;     // starts/bstat describe the current threshold
-    double sigma = 0;
-    // construction
-    float* d_w = nullptr;
-    uint8_t* d_summary = nullptr;  // largest key of every 16-position group (what the scan streams)
-    int32_t key_base = 0;
-    double key_scale = 1.0;         // product of the weight multipliers applied so far
-    bool use_keys = true;
-    bool summary_always = false;    // option weight_keys = 2: never fall back to the float stream (tests)
-    float* d_coeff = nullptr;
-    float2* d_ia = nullptr;
-    // block structure
-    uint16_t* d_stage = nullptr;
-    uint32_t *d_span_count = nullptr, *d_starts = nullptr;
-    float2* d_bstat = nullptr;
-    uint32_t n_spans = 0;
-    uint32_t* d_coarse1 = nullptr;   // block count per group of HML_GROUP_SPANS spans
-    unsigned long long* d_group_word = nullptr;   // fused block kernel: {generation, starts, last start} per span group
-    uint32_t* d_launch_gen = nullptr;             // its launch generation
-    unsigned long long* d_dbg = nullptr;
-    // hipGraph replay of a non-recording sweep (launch-bound inner loop); re-captured when the grid hint moves
-    bool use_graph = false;
-    hipGraphExec_t graph_exec = nullptr;
-    char graph_method = 0;
-    uint32_t graph_hint = 0;
-    bool graph_dynamic = false, graph_valid_blocks = false;
-    // sweep buffers (allocated by set_model)
-    float *d_em = nullptr, *d_gsc = nullptr, *d_rows = nullptr, *d_eprobe = nullptr, *d_aprobe = nullptr;
-    float *d_entry = nullptr, *d_exitA = nullptr;
-    uint32_t* d_redo = nullptr;    // backward chunks that failed the forward verification (list for the repair step)
-    uint32_t* d_touched = nullptr; // backward chunks whose rows the repair recomputed, tagged with the sweep
-    uint32_t* d_fb = nullptr;
-    unsigned long long *d_smap = nullptr, *d_cmap = nullptr;
-    unsigned long long *d_scmap = nullptr, *d_super = nullptr;   // two-level chain (weakly compressed sweeps)
-    uint8_t *d_bentry = nullptr, *d_bentry2 = nullptr;
-    int16_t* d_q = nullptr;
-    double* d_partial = nullptr;
-    int32_t* d_diff = nullptr;
-    uint32_t* d_boundary = nullptr;
-    hml_model* d_mdl = nullptr;
-    uint32_t* h_B = nullptr;        // pinned + mapped: the offsets kernel stores the block count here (grid sizing hint)
-    uint32_t* d_hB = nullptr;       // device view of h_B
-    uint32_t B_hint = 0;
-    bool hint_stale = true;         // the hint predates the current parameters (new model, prior draw, mode switch)
-    // forward geometry
-    int fwdL = 4, fwdW = 12;   // W is the floor of the adaptive warm-up (measured: 12 beats 16 and 24 on C1-C4; 8 does not)
-    int fwdW_init = 24;        // where a chain starts and the floor of its first 256 sweeps: while the parameters are
-                               // still far from settled the filter forgets slowly (131 refits in sweeps 20-220 of C3 with a floor of 12)
-    hml_layout lay = {2, 0};
-    // weakly compressed sweeps (B_hint >= dense_min_blocks): longer forward chunks - the warm-up is a smaller share
-    // of the work - in their own chunk-transposed layout; which geometry a sweep uses never changes its results
-    int fwdL_dense = 16;
-    hml_layout lay_dense = {4, 0};
-    uint32_t dense_min_blocks = 1u << 22;
-    bool graph_dense = false;
-    bool probes = false;
-    bool rec_marginals = true;
-    hml_record_cb cb = nullptr;
-    void* cb_user = nullptr;
-    int profiling = 0;             // 0 off, 1 dominant kernel only (blocks_compact, every 32nd launch), 2 every kernel family
-    uint32_t prof_tick = 0;
-    std::map<std::string, ProfAcc> prof;
-    std::vector<hipEvent_t> ev_pool;
-};
-
 // Live contexts per device.  The fused block kernel hands block offsets from workgroup to workgroup inside one launch
 // (a workgroup spins on the words of lower-numbered ones); that is safe while all lower-numbered workgroups are resident
 // or finished, which in-order dispatch guarantees for ONE kernel on the GPU.  With two chains sweeping the same GPU at
@@ -143,6 +66,7 @@ static int ctx_bind(hml_ctx* c) {
     HIPCHK(hipSetDevice(c->device));
     return 0;
 }
+int hml_ctx_bind(hml_ctx* c) { return ctx_bind(c); }
 
 static hipEvent_t ev_get(hml_ctx* c) {
     if (!c->ev_pool.empty()) { hipEvent_t e = c->ev_pool.back(); c->ev_pool.pop_back(); return e; }
@@ -172,6 +96,13 @@ struct ProfScope {
             c->prof["event_null"].pending.push_back({n0, n1});
         }
     }
+};
+
+// device scratch that is released on every path out of a function
+struct DevScratch {
+    void* p = nullptr;
+    ~DevScratch() { if (p) hipFree(p); }
+    template <typename T> T* as() const { return static_cast<T*>(p); }
 };
 
 static int grid_for(uint64_t items, int per_block, int lo, int hi) {
@@ -204,6 +135,7 @@ static int fetch_model(hml_ctx* c, hml_model* out) {
     HIPCHK(hipStreamSynchronize(c->stream));
     return 0;
 }
+int hml_ctx_fetch_model(hml_ctx* c, hml_model* out) { return fetch_model(c, out); }
 
 static int check_device_error(hml_ctx* c) {
     hml_model m;
@@ -304,6 +236,21 @@ const char* hml_last_error(void) { return g_err.c_str(); }
 uint32_t hml_abi_version(void) { return 1; }
 const char* hml_device_arch(void) { return "gfx950"; }
 
+static void free_all(hml_ctx* c);
+
+// allocations of a fresh context; on failure the caller releases whatever was created
+static int create_inner(hml_ctx* c, void* stream) {
+    HIPCHK(hipSetDevice(c->device));
+    if (stream) { c->stream = (hipStream_t)stream; c->own_stream = false; }
+    else { HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)); c->own_stream = true; }
+    HIPCHK(hipMalloc(&c->d_mdl, sizeof(hml_model)));
+    HIPCHK(hipMemsetAsync(c->d_mdl, 0, sizeof(hml_model), c->stream));
+    HIPCHK(hipHostMalloc(&c->h_B, sizeof(uint32_t), hipHostMallocMapped));
+    *c->h_B = 0;
+    HIPCHK(hipHostGetDevicePointer((void**)&c->d_hB, c->h_B, 0));
+    return 0;
+}
+
 int hml_create(hml_ctx** out, int device, uint64_t seed, uint32_t chain_id, void* stream) {
     if (!out) return set_err(HML_ERR_ARG, "null output pointer");
     int n = 0;
@@ -312,20 +259,19 @@ int hml_create(hml_ctx** out, int device, uint64_t seed, uint32_t chain_id, void
     if (device < 0 || device >= n) return set_err(HML_ERR_ARG, "device index out of range");
     hml_ctx* c = new hml_ctx();
     c->device = device; c->seed = seed; c->chain = chain_id;
-    HIPCHK(hipSetDevice(device));
-    if (stream) { c->stream = (hipStream_t)stream; c->own_stream = false; }
-    else { HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)); c->own_stream = true; }
-    HIPCHK(hipMalloc(&c->d_mdl, sizeof(hml_model)));
-    HIPCHK(hipMemsetAsync(c->d_mdl, 0, sizeof(hml_model), c->stream));
-    HIPCHK(hipHostMalloc(&c->h_B, sizeof(uint32_t), hipHostMallocMapped));
-    *c->h_B = 0;
-    HIPCHK(hipHostGetDevicePointer((void**)&c->d_hB, c->h_B, 0));
+    if (int r = create_inner(c, stream)) {
+        free_all(c);
+        if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
+        delete c;
+        return r;
+    }
     if (const char* e = getenv("HML_FWD_CHUNK")) { int l = std::max(1, atoi(e)); int sh = 0; while ((1 << (sh + 1)) <= l && sh < 10) ++sh; c->fwdL = 1 << sh; }
     if (const char* e = getenv("HML_FWD_WARMUP")) c->fwdW = c->fwdW_init = std::max(0, atoi(e));
     if (const char* e = getenv("HML_FWD_CHUNK_DENSE")) { int l = std::max(1, atoi(e)); int sh = 0; while ((1 << (sh + 1)) <= l && sh < 10) ++sh; c->fwdL_dense = 1 << sh; }
     if (const char* e = getenv("HML_DENSE_MIN_BLOCKS")) c->dense_min_blocks = (uint32_t)strtoul(e, nullptr, 10);
     if (const char* e = getenv("HML_USE_GRAPH")) c->use_graph = atoi(e) != 0;
     if (const char* e = getenv("HML_WEIGHT_KEYS")) c->use_keys = atoi(e) != 0;
+    if (const char* e = getenv("HML_FUSED_BLOCKS")) c->fused_blocks = atoi(e) != 0;   // 0: a GPU shared with other processes
     if (device < 64) g_live_ctx[device].fetch_add(1);
     *out = c;
     return 0;
@@ -339,7 +285,9 @@ static void free_all(hml_ctx* c) {
                     c->d_smap, c->d_cmap, c->d_scmap, c->d_super, c->d_bentry2, c->d_bentry, c->d_q, c->d_partial, c->d_diff, c->d_boundary, c->d_mdl};
     for (void* p : ptrs) if (p) hipFree(p);
     if (c->h_B) hipHostFree(c->h_B);
+    c->h_B = nullptr;
 }
+
 
 void hml_destroy(hml_ctx* c) {
     if (!c) return;
@@ -383,6 +331,11 @@ __global__ void hml_k_max_inplace(float* __restrict__ a, const float* __restrict
 static int build_from_device_x(hml_ctx* c, const float* const* d_x, const float* const* h_x) {
     const uint64_t T = c->T;
     const int D = c->D;
+    {   // what an earlier load that failed half-way may have left behind
+        void** stale[] = {(void**)&c->d_w, (void**)&c->d_coeff, (void**)&c->d_ia, (void**)&c->d_summary, (void**)&c->d_stage, (void**)&c->d_span_count,
+                          (void**)&c->d_starts, (void**)&c->d_coarse1, (void**)&c->d_group_word, (void**)&c->d_launch_gen, (void**)&c->d_bstat};
+        for (void** q : stale) if (*q) { hipFree(*q); *q = nullptr; }
+    }
     // noise estimate (src/main.cpp:303-311): f64 accumulation, in index order, of the finest-level
     // maxlet coefficients c[t] = max over the dimensions of sqrt2half * |x[t-1] - x[t]| at odd t
     // (wavelet.hpp:139-158, level 1)
@@ -415,14 +368,15 @@ static int build_from_device_x(hml_ctx* c, const float* const* d_x, const float*
         h_norm[0] = 1.0f;
         float nrm = sqrt2half;
         for (int l = 1; l < 64; ++l) { h_norm[l] = nrm; nrm *= sqrt2half; }
-        float* d_norm = nullptr;
-        HIPCHK(hipMalloc(&d_norm, sizeof h_norm));
+        DevScratch s_norm, s_a, s_b, s_other;   // freed on every path out of this scope
+        HIPCHK(hipMalloc(&s_norm.p, sizeof h_norm));
+        float* d_norm = s_norm.as<float>();
         HIPCHK(hipMemcpyAsync(d_norm, h_norm, sizeof h_norm, hipMemcpyHostToDevice, c->stream));
-        float *bufA = nullptr, *bufB = nullptr, *d_other = nullptr;
         const uint64_t n1 = T >> HML_MAXLET_LOG_TILE;
-        HIPCHK(hipMalloc(&bufA, std::max<uint64_t>(n1, 1) * sizeof(float)));
-        HIPCHK(hipMalloc(&bufB, std::max<uint64_t>(n1 >> HML_MAXLET_LOG_TILE, 1) * sizeof(float)));
-        if (D > 1) HIPCHK(hipMalloc(&d_other, T * sizeof(float)));
+        HIPCHK(hipMalloc(&s_a.p, std::max<uint64_t>(n1, 1) * sizeof(float)));
+        HIPCHK(hipMalloc(&s_b.p, std::max<uint64_t>(n1 >> HML_MAXLET_LOG_TILE, 1) * sizeof(float)));
+        if (D > 1) HIPCHK(hipMalloc(&s_other.p, T * sizeof(float)));
+        float *bufA = s_a.as<float>(), *bufB = s_b.as<float>(), *d_other = s_other.as<float>();
         for (int d = 0; d < D; ++d) {
             float* coeff_out = d == 0 ? c->d_coeff : d_other;
             uint64_t n = T;
@@ -445,8 +399,6 @@ static int build_from_device_x(hml_ctx* c, const float* const* d_x, const float*
             }
         }
         HIPCHK(hipStreamSynchronize(c->stream));
-        hipFree(bufA); hipFree(bufB); hipFree(d_norm);
-        if (d_other) hipFree(d_other);
     }
     hipLaunchKernelGGL(hml_k_weights, dim3(grid_for(T, 256, 1, 65536)), dim3(256), 0, c->stream, c->d_coeff, c->d_w, T, 1.0f);
     KLAUNCH_CHECK();
@@ -506,8 +458,9 @@ int hml_load_observations(hml_ctx* c, const float* x, uint64_t n_values) {
     if (c->loaded) return set_err(HML_ERR_ARG, "observations already loaded");
     if (int r = ctx_bind(c)) return r;
     c->T = T;
-    float* d_x = nullptr;
-    HIPCHK(hipMalloc(&d_x, n_values * sizeof(float)));
+    DevScratch s_x;
+    HIPCHK(hipMalloc(&s_x.p, n_values * sizeof(float)));
+    float* d_x = s_x.as<float>();
     std::vector<float> planes;             // dimension-major copy when D > 1
     const float* h_dim[HML_MAX_D];
     const float* d_dim[HML_MAX_D];
@@ -519,9 +472,7 @@ int hml_load_observations(hml_ctx* c, const float* x, uint64_t n_values) {
     }
     HIPCHK(hipMemcpyAsync(d_x, D == 1 ? x : planes.data(), n_values * sizeof(float), hipMemcpyHostToDevice, c->stream));
     for (uint64_t d = 0; d < D; ++d) d_dim[d] = d_x + d * T;
-    int r = build_from_device_x(c, d_dim, h_dim);
-    hipFree(d_x);
-    return r;
+    return build_from_device_x(c, d_dim, h_dim);
 }
 
 int hml_load_observations_device(hml_ctx* c, const void* x_dev, uint64_t T) {
@@ -553,6 +504,20 @@ int hml_scale_weights(hml_ctx* c, float mult) {
     c->key_scale *= std::fabs((double)mult) > 0 ? std::fabs((double)mult) : 1.0;
     if (int r = build_keys(c)) return r;
     c->blocks_valid = false;
+    return 0;
+}
+
+int hml_set_weights(hml_ctx* c, const float* w, uint64_t T) {
+    if (!c || !c->loaded || !w) return set_err(HML_ERR_ARG, "no observations loaded");
+    if (T != c->T) return set_err(HML_ERR_MODEL, "Block structure and statistics have different number of data points!");
+    if (int r = ctx_bind(c)) return r;
+    HIPCHK(hipMemcpyAsync(c->d_w, w, T * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    // the key window stays centred on the noise estimate times the multipliers applied through hml_scale_weights: the
+    // window only decides how many groups the summary scan opens, never which positions start a block
+    if (int r = build_keys(c)) return r;
+    c->blocks_valid = false;
+    c->hint_stale = true;
     return 0;
 }
 
@@ -761,6 +726,19 @@ int hml_sample_prior(hml_ctx* c) {
     return 0;
 }
 
+__global__ __launch_bounds__(64) void hml_k_set_self_trans(hml_model* mdl, int on) {
+    if (threadIdx.x == 0) mdl->self_trans = on;
+}
+
+int hml_set_self_transitions(hml_ctx* c, int on) {
+    if (!c || !c->model_set) return set_err(HML_ERR_ARG, "model not set");
+    if (int r = ctx_bind(c)) return r;
+    hipLaunchKernelGGL(hml_k_set_self_trans, dim3(1), dim3(64), 0, c->stream, c->d_mdl, on ? 1 : 0);
+    KLAUNCH_CHECK();
+    if (c->graph_exec) { hipGraphExecDestroy(c->graph_exec); c->graph_exec = nullptr; }
+    return 0;
+}
+
 int hml_set_static_blocks(hml_ctx* c) {
     if (!c || !c->model_set) return set_err(HML_ERR_ARG, "model not set");
     if (int r = ctx_bind(c)) return r;
@@ -814,6 +792,8 @@ static int ensure_marginal_buffers(hml_ctx* c) {
 
 }  // extern "C"
 
+int hml_ctx_ensure_marginal_buffers(hml_ctx* c) { return ensure_marginal_buffers(c); }
+
 template <int KK>
 static int sweep_k(hml_ctx* c, char method, bool record) {
     hipStream_t s = c->stream;
@@ -840,7 +820,7 @@ static int sweep_k(hml_ctx* c, char method, bool record) {
     const int L = dense_geo ? c->fwdL_dense : c->fwdL;
     const hml_layout lay = dense_geo ? c->lay_dense : c->lay;
     if (c->dynamic || !c->blocks_valid) {
-        if (c->D == 1 && c->use_keys && !shares_device(c) && !(!c->summary_always && c->B_hint && (uint64_t)c->B_hint * 24u > c->T)) {
+        if (c->D == 1 && c->use_keys && c->fused_blocks && !shares_device(c) && !(!c->summary_always && c->B_hint && (uint64_t)c->B_hint * 24u > c->T)) {
             // K4 + K5 + K6a in one launch (hml_k_blocks_fused.h); weak compression takes the float stream below
             ProfScope ps(c, "blocks_compact", 1);
             const uint32_t n_wg = (uint32_t)(((uint64_t)T + HML_FUSED_POSITIONS - 1) / HML_FUSED_POSITIONS);
@@ -960,6 +940,11 @@ static int sweep_k(hml_ctx* c, char method, bool record) {
     return 0;
 }
 
+static int sweep_dispatch(hml_ctx* c, char method, bool record) {
+    HML_DISPATCH_K(c->K, return sweep_k<KK>(c, method, record));
+    return 0;
+}
+
 extern "C" {
 
 int hml_iterate(hml_ctx* c, char method, uint64_t iterations, uint64_t thinning) {
@@ -980,12 +965,18 @@ int hml_iterate(hml_ctx* c, char method, uint64_t iterations, uint64_t thinning)
                 if (c->graph_exec) { hipGraphExecDestroy(c->graph_exec); c->graph_exec = nullptr; }
                 hipGraph_t g = nullptr;
                 HIPCHK(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
-                int rr = 0;
-                HML_DISPATCH_K(c->K, rr = sweep_k<KK>(c, method, false));
-                HIPCHK(hipStreamEndCapture(c->stream, &g));
-                if (rr) return rr;
-                HIPCHK(hipGraphInstantiate(&c->graph_exec, g, nullptr, nullptr, 0));
+                // whatever happens below, the stream must leave capture mode (a failure in between would otherwise
+                // make every later call on this context fail) and a partial graph must not stay behind
+                int rr = sweep_dispatch(c, method, false);
+                const hipError_t ec = hipStreamEndCapture(c->stream, &g);
+                if (rr || ec != hipSuccess) {
+                    if (g) hipGraphDestroy(g);
+                    (void)hipGetLastError();
+                    return rr ? rr : set_err(HML_ERR_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(ec));
+                }
+                const hipError_t ei = hipGraphInstantiate(&c->graph_exec, g, nullptr, nullptr, 0);
                 hipGraphDestroy(g);
+                if (ei != hipSuccess) { c->graph_exec = nullptr; return set_err(HML_ERR_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(ei)); }
                 c->graph_method = method; c->graph_dynamic = c->dynamic; c->graph_hint = c->B_hint;
                 c->graph_dense = c->B_hint >= c->dense_min_blocks;
             }
@@ -1010,6 +1001,11 @@ int hml_set_option(hml_ctx* c, const char* name, int value) {
         if (c->loaded) return set_err(HML_ERR_ARG, "weight_keys must be set before the observations are loaded");
         c->use_keys = value != 0;
         c->summary_always = value == 2;
+        return 0;
+    }
+    if (std::string(name) == "fused_blocks") {
+        c->fused_blocks = value != 0;
+        if (c->graph_exec) { hipGraphExecDestroy(c->graph_exec); c->graph_exec = nullptr; }
         return 0;
     }
     return set_err(HML_ERR_ARG, std::string("unknown option ") + name);
@@ -1061,8 +1057,10 @@ int hml_get_block_stats(hml_ctx* c, float* sum, float* sum_sq) {
     NEED_LOADED();
     uint32_t b; if (int r = current_B(c, &b)) return r;
     std::vector<float2> v(b);
-    HIPCHK(hipMemcpy(v.data(), c->d_bstat, (uint64_t)b * sizeof(float2), hipMemcpyDeviceToHost));
-    for (uint32_t i = 0; i < b; ++i) { sum[i] = v[i].x; sum_sq[i] = v[i].y; }
+    for (int d = 0; d < c->D; ++d) {   // one plane per data dimension
+        HIPCHK(hipMemcpy(v.data(), c->d_bstat + (uint64_t)d * c->T, (uint64_t)b * sizeof(float2), hipMemcpyDeviceToHost));
+        for (uint32_t i = 0; i < b; ++i) { sum[(uint64_t)d * b + i] = v[i].x; sum_sq[(uint64_t)d * b + i] = v[i].y; }
+    }
     return 0;
 }
 int hml_get_states(hml_ctx* c, int16_t* q) {
@@ -1297,6 +1295,11 @@ int hml_marginals_dense_device(hml_ctx* c, void* out_dev, const int32_t* perm) {
     int32_t *d_cs = nullptr, *d_perm = nullptr;
     HIPCHK(hipMalloc(&d_cs, (uint64_t)K * n_chunks * sizeof(int32_t)));
     if (perm) {
+        uint32_t seen = 0u;
+        for (int k = 0; k < K; ++k) {
+            if (perm[k] < 0 || perm[k] >= K || ((seen >> perm[k]) & 1u)) { hipFree(d_cs); return set_err(HML_ERR_ARG, "perm is not a permutation of the K states"); }
+            seen |= 1u << perm[k];
+        }
         HIPCHK(hipMalloc(&d_perm, K * sizeof(int32_t)));
         HIPCHK(hipMemcpyAsync(d_perm, perm, K * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
     }
@@ -1309,6 +1312,36 @@ int hml_marginals_dense_device(hml_ctx* c, void* out_dev, const int32_t* perm) {
     HIPCHK(hipStreamSynchronize(c->stream));
     hipFree(d_cs);
     if (d_perm) hipFree(d_perm);
+    return 0;
+}
+
+int hml_relabel_permutation(hml_ctx* c, int32_t* perm) {
+    NEED_MODEL();
+    if (!perm) return set_err(HML_ERR_ARG, "null argument");
+    hml_model m; if (int r = fetch_model(c, &m)) return r;
+    const int K = c->K, D = m.D;
+    std::vector<int32_t> p(K);
+    for (int k = 0; k < K; ++k) p[k] = k;
+    // ascending tuple (mean of the parameter mapped to dimension 0, dimension 1, ...); stable: ties keep their order
+    std::stable_sort(p.begin(), p.end(), [&](int32_t a, int32_t b) {
+        for (int d = 0; d < D; ++d) {
+            const float ma = m.mu[m.map[a][d]], mb = m.mu[m.map[b][d]];
+            if (ma < mb) return true;
+            if (mb < ma) return false;
+        }
+        return false;
+    });
+    for (int k = 0; k < K; ++k) perm[k] = p[k];
+    return 0;
+}
+
+int hml_categorical_draw(hml_ctx* c, const float* weights, int K, uint32_t* index) {
+    if (!c || !weights || !index || K < 1) return set_err(HML_ERR_ARG, "invalid argument");
+    // std::discrete_distribution with one weight consumes no random number and returns 0 (libstdc++)
+    if (K == 1) { *index = 0; return 0; }
+    const uint64_t n = c->host_draws++;
+    const hml_u32x4 o = hml_stream4(hml_make_key(c->seed, c->chain), HML_KIND_HOST, n >> 32, (uint32_t)n, 0);
+    *index = (uint32_t)hml_categorical(weights, K, hml_canonical_f64(o.v[0], o.v[1]));
     return 0;
 }
 

@@ -1,0 +1,102 @@
+// The chain context behind `hml_ctx*` (include/hml.h), shared by the translation units of libhammlet_hip.so
+// (hml_capi.hip: the chain; hml_pool.hip: chain-parallel pooling over RCCL).
+#ifndef HML_CTX_HPP
+#define HML_CTX_HPP
+
+#include <hip/hip_runtime.h>
+
+#include <map>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "../../include/hml.h"
+#include "hml_host_common.hpp"
+#include "hml_state.h"
+
+struct ProfAcc { double ms = 0; uint64_t n = 0; std::vector<std::pair<hipEvent_t, hipEvent_t>> pending; };
+
+struct hml_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    uint64_t seed = 0;
+    uint32_t chain = 0;
+    uint64_t T = 0;
+    int K = 0;
+    int D = 1, P = 0;              // data dimensions / emission parameters ("-s C P D"; P = 0: univariate, P = K)
+    bool loaded = false, model_set = false;
+    bool dynamic = true;
+    bool blocks_valid = false;     // starts/bstat describe the current threshold
+    double sigma = 0;
+    // construction
+    float* d_w = nullptr;
+    uint8_t* d_summary = nullptr;  // largest key of every 16-position group (what the scan streams)
+    int32_t key_base = 0;
+    double key_scale = 1.0;         // product of the weight multipliers applied so far
+    bool use_keys = true;
+    bool fused_blocks = true;       // option fused_blocks: 0 forces the scan + scatter + statistics launches
+    uint64_t host_draws = 0;        // hml_categorical_draw calls so far (Philox sub-stream HOST)
+    bool summary_always = false;    // option weight_keys = 2: never fall back to the float stream (tests)
+    float* d_coeff = nullptr;
+    float2* d_ia = nullptr;
+    // block structure
+    uint16_t* d_stage = nullptr;
+    uint32_t *d_span_count = nullptr, *d_starts = nullptr;
+    float2* d_bstat = nullptr;
+    uint32_t n_spans = 0;
+    uint32_t* d_coarse1 = nullptr;   // block count per group of HML_GROUP_SPANS spans
+    unsigned long long* d_group_word = nullptr;   // fused block kernel: {generation, starts, last start} per span group
+    uint32_t* d_launch_gen = nullptr;             // its launch generation
+    unsigned long long* d_dbg = nullptr;
+    // hipGraph replay of a non-recording sweep (launch-bound inner loop); re-captured when the grid hint moves
+    bool use_graph = false;
+    hipGraphExec_t graph_exec = nullptr;
+    char graph_method = 0;
+    uint32_t graph_hint = 0;
+    bool graph_dynamic = false, graph_valid_blocks = false;
+    // sweep buffers (allocated by set_model)
+    float *d_em = nullptr, *d_gsc = nullptr, *d_rows = nullptr, *d_eprobe = nullptr, *d_aprobe = nullptr;
+    float *d_entry = nullptr, *d_exitA = nullptr;
+    uint32_t* d_redo = nullptr;    // backward chunks that failed the forward verification (list for the repair step)
+    uint32_t* d_touched = nullptr; // backward chunks whose rows the repair recomputed, tagged with the sweep
+    uint32_t* d_fb = nullptr;
+    unsigned long long *d_smap = nullptr, *d_cmap = nullptr;
+    unsigned long long *d_scmap = nullptr, *d_super = nullptr;   // two-level chain (weakly compressed sweeps)
+    uint8_t *d_bentry = nullptr, *d_bentry2 = nullptr;
+    int16_t* d_q = nullptr;
+    double* d_partial = nullptr;
+    int32_t* d_diff = nullptr;
+    uint32_t* d_boundary = nullptr;
+    hml_model* d_mdl = nullptr;
+    uint32_t* h_B = nullptr;        // pinned + mapped: the offsets kernel stores the block count here (grid sizing hint)
+    uint32_t* d_hB = nullptr;       // device view of h_B
+    uint32_t B_hint = 0;
+    bool hint_stale = true;         // the hint predates the current parameters (new model, prior draw, mode switch)
+    // forward geometry
+    int fwdL = 4, fwdW = 12;   // W is the floor of the adaptive warm-up (measured: 12 beats 16 and 24 on C1-C4; 8 does not)
+    int fwdW_init = 24;        // where a chain starts and the floor of its first 256 sweeps: while the parameters are
+                               // still far from settled the filter forgets slowly (131 refits in sweeps 20-220 of C3 with a floor of 12)
+    hml_layout lay = {2, 0};
+    // weakly compressed sweeps (B_hint >= dense_min_blocks): longer forward chunks - the warm-up is a smaller share
+    // of the work - in their own chunk-transposed layout; which geometry a sweep uses never changes its results
+    int fwdL_dense = 16;
+    hml_layout lay_dense = {4, 0};
+    uint32_t dense_min_blocks = 1u << 22;
+    bool graph_dense = false;
+    bool probes = false;
+    bool rec_marginals = true;
+    hml_record_cb cb = nullptr;
+    void* cb_user = nullptr;
+    int profiling = 0;             // 0 off, 1 dominant kernel only (blocks_compact, every 32nd launch), 2 every kernel family
+    uint32_t prof_tick = 0;
+    std::map<std::string, ProfAcc> prof;
+    std::vector<hipEvent_t> ev_pool;
+};
+
+// hml_capi.hip
+int hml_ctx_bind(hml_ctx* c);                         // hipSetDevice(ctx's device)
+int hml_ctx_fetch_model(hml_ctx* c, hml_model* out);  // synchronising copy of the device-resident model
+int hml_ctx_ensure_marginal_buffers(hml_ctx* c);
+
+#endif

@@ -1,0 +1,80 @@
+// Chain-parallel pooling of the state marginals: kernels that pack a chain's recorded marginals
+// into the all-reduce payload and unpack the pooled payload back into a chain context.
+//
+// A chain keeps its marginals as per-state DIFFERENCE arrays diff[K][T+1] (+1 where a recorded segment of the state
+// starts, -1 where it ends) and a bitmap of segment boundaries (hml_k_record, reference src/StateMarginals.hpp:51-137).
+// Both are additive over recorded sweeps - and therefore over chains once the states carry common labels - except
+// that +1/-1 of different sweeps can cancel at a boundary, so the boundaries travel as their own row:
+//   payload (int32): rows 0..K-1  diff[perm[r]][0..T]      relabelled difference arrays
+//                    row  K       1 at segment boundaries  (sum > 0 after the all-reduce <=> some chain cut there)
+//                    tail         [recorded sweeps, used[0..K-1]]   used[r] = relabelled state r was ever recorded
+// One ncclAllReduce(sum, int32) over the payload pools everything.
+#ifndef HML_K_POOL_H
+#define HML_K_POOL_H
+
+#include "hml_state.h"
+
+__global__ __launch_bounds__(256) void hml_k_pool_export(const int32_t* __restrict__ diff, const uint32_t* __restrict__ boundary,
+                                                         const hml_model* __restrict__ mdl, const int32_t* __restrict__ perm,
+                                                         uint32_t T, int K, int32_t* __restrict__ payload) {
+    const uint64_t T1 = (uint64_t)T + 1u;
+    const uint64_t n = (uint64_t)(K + 1) * T1;
+    int32_t* __restrict__ tail = payload + n;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i0 = (uint64_t)blockIdx.x * blockDim.x; i0 < n; i0 += stride) {   // workgroup-uniform trip count
+        const uint64_t i = i0 + threadIdx.x;
+        int32_t v = 0;
+        int r = -1;
+        if (i < n) {
+            r = (int)(i / T1);
+            const uint64_t t = i - (uint64_t)r * T1;
+            if (r < K) v = diff[(uint64_t)perm[r] * T1 + t];
+            else v = (t < T && (t == 0u || ((boundary[t >> 5] >> (t & 31u)) & 1u))) ? 1 : 0;
+            payload[i] = v;
+        }
+        // a state was recorded at least once iff its difference array is not identically zero (its prefix sums are
+        // the non-negative counts, and they start from zero)
+        const bool nz = (r >= 0 && r < K && v != 0);
+        if (__ballot(nz) != 0ull && nz) atomicOr(reinterpret_cast<unsigned int*>(tail + 1 + r), 1u);
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) tail[0] = (int32_t)mdl->n_recorded;
+}
+
+__global__ __launch_bounds__(256) void hml_k_pool_add(int32_t* __restrict__ acc, const int32_t* __restrict__ other, uint64_t n) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) acc[i] += other[i];
+}
+
+// pooled payload -> the context's difference arrays (states now carry the common labels)
+__global__ __launch_bounds__(256) void hml_k_pool_install_diff(const int32_t* __restrict__ payload, uint32_t T, int K,
+                                                               int32_t* __restrict__ diff) {
+    const uint64_t n = (uint64_t)K * ((uint64_t)T + 1u);
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) diff[i] = payload[i];
+}
+
+// ... and the boundary bitmap (one thread per 32-bit word) plus the recorded-sweep bookkeeping of the model
+__global__ __launch_bounds__(256) void hml_k_pool_install_boundary(const int32_t* __restrict__ payload, uint32_t T, int K,
+                                                                   uint32_t* __restrict__ boundary, hml_model* __restrict__ mdl) {
+    const uint64_t T1 = (uint64_t)T + 1u;
+    const int32_t* __restrict__ row = payload + (uint64_t)K * T1;
+    const uint64_t words = (T1 + 31u) / 32u;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; w < words; w += stride) {
+        uint32_t bits = 0u;
+        for (uint32_t j = 0; j < 32u; ++j) {
+            const uint64_t t = w * 32u + j;
+            if (t < T1 && row[t] != 0) bits |= 1u << j;
+        }
+        boundary[w] = bits;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        const int32_t* __restrict__ tail = payload + (uint64_t)(K + 1) * T1;
+        mdl->n_recorded = (unsigned long long)(uint32_t)tail[0];
+        int mx = -1;
+        for (int r = 0; r < K; ++r) if (tail[1 + r] != 0) mx = r;
+        mdl->max_state_recorded = mx;
+    }
+}
+
+#endif

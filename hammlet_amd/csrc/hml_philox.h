@@ -29,7 +29,8 @@ enum {
     HML_KIND_THETA = 3,
     HML_KIND_PI = 4,
     HML_KIND_TRANS = 5,
-    HML_KIND_DATA = 6
+    HML_KIND_DATA = 6,
+    HML_KIND_HOST = 7    // draws made by the host on a chain's behalf (Trellis::sample of the C++ surface); index = call number
 };
 
 typedef struct { uint32_t v[4]; } hml_u32x4;

@@ -1,0 +1,286 @@
+// libhammlet_hip.so, chain-parallel pooling (hml_pool_* / hml_allreduce_marginals of include/hml.h).
+// Chains shard across GPUs and never communicate while sampling; ONE collective at the end - ncclAllReduce(sum, int32)
+// over xGMI - pools their state marginals.  The reference has no counterpart (one process, one thread,
+// src/main.cpp:108); the common labelling of the states follows the idea of bin/sortStates:1-6.
+//
+// RCCL is bound at run time (dlopen of librccl.so.1 on the first pooling call): the library is 570 MB of code objects,
+// and a single-chain `hammlet` run - the reference's use - should not pay for mapping and registering it at start-up.
+// Its official header provides the types and prototypes; nothing of RCCL is re-declared here.
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <algorithm>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "hml_ctx.hpp"
+#include "hml_k_pool.h"
+
+static int set_err(int code, const std::string& msg) { return hml_set_err(code, msg); }
+
+namespace {
+
+struct RcclApi {
+    void* handle = nullptr;
+    decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+    decltype(&ncclCommInitRank) CommInitRank = nullptr;
+    decltype(&ncclCommInitAll) CommInitAll = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclAllReduce) AllReduce = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    decltype(&ncclGetVersion) GetVersion = nullptr;
+    std::string error;
+};
+
+RcclApi& rccl() {
+    static RcclApi api;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        const char* names[] = {getenv("HML_RCCL_LIBRARY"), "librccl.so.1", "librccl.so"};
+        for (const char* n : names) {
+            if (!n || !*n) continue;
+            api.handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+            if (api.handle) break;
+            api.error = dlerror();
+        }
+        if (!api.handle) return;
+        bool ok = true;
+        auto bind = [&](auto& fn, const char* sym) {
+            fn = reinterpret_cast<std::remove_reference_t<decltype(fn)>>(dlsym(api.handle, sym));
+            if (!fn) { ok = false; api.error = std::string("librccl: missing symbol ") + sym; }
+        };
+        bind(api.GetUniqueId, "ncclGetUniqueId");
+        bind(api.CommInitRank, "ncclCommInitRank");
+        bind(api.CommInitAll, "ncclCommInitAll");
+        bind(api.CommDestroy, "ncclCommDestroy");
+        bind(api.AllReduce, "ncclAllReduce");
+        bind(api.GroupStart, "ncclGroupStart");
+        bind(api.GroupEnd, "ncclGroupEnd");
+        bind(api.GetErrorString, "ncclGetErrorString");
+        bind(api.GetVersion, "ncclGetVersion");
+        if (!ok) { dlclose(api.handle); api.handle = nullptr; }
+    });
+    return api;
+}
+
+int need_rccl() {
+    RcclApi& r = rccl();
+    if (!r.handle) return set_err(HML_ERR_HIP, "RCCL is not available (librccl.so.1): " + r.error);
+    return 0;
+}
+
+#define NCCLCHK(call)                                                                                       \
+    do {                                                                                                    \
+        ncclResult_t r_ = (call);                                                                           \
+        if (r_ != ncclSuccess) return set_err(HML_ERR_HIP, std::string(#call) + ": " + rccl().GetErrorString(r_)); \
+    } while (0)
+
+uint64_t payload_count(const hml_ctx* c) { return (uint64_t)(c->K + 1) * (c->T + 1) + 1u + (uint64_t)c->K; }
+
+int grid_for(uint64_t items, int per_block, int hi) {
+    uint64_t g = (items + per_block - 1) / per_block;
+    return (int)std::max<uint64_t>(1, std::min<uint64_t>(g, (uint64_t)hi));
+}
+
+// relabelled difference arrays + boundary row + tail of one chain -> payload (device, payload_count(c) int32)
+int export_payload(hml_ctx* c, int32_t* payload, int32_t* perm_out) {
+    if (int r = hml_ctx_bind(c)) return r;
+    if (int r = hml_ctx_ensure_marginal_buffers(c)) return r;
+    std::vector<int32_t> perm(c->K);
+    if (int r = hml_relabel_permutation(c, perm.data())) return r;
+    if (perm_out) memcpy(perm_out, perm.data(), sizeof(int32_t) * c->K);
+    int32_t* d_perm = nullptr;
+    HIPCHK(hipMalloc(&d_perm, sizeof(int32_t) * c->K));
+    HIPCHK(hipMemcpyAsync(d_perm, perm.data(), sizeof(int32_t) * c->K, hipMemcpyHostToDevice, c->stream));
+    const uint64_t n = payload_count(c);
+    HIPCHK(hipMemsetAsync(payload + (n - 1u - (uint64_t)c->K), 0, sizeof(int32_t) * (1u + (uint64_t)c->K), c->stream));
+    hipLaunchKernelGGL(hml_k_pool_export, dim3(grid_for(n, 256, 1 << 16)), dim3(256), 0, c->stream, c->d_diff, c->d_boundary, c->d_mdl,
+                       d_perm, (uint32_t)c->T, c->K, payload);
+    KLAUNCH_CHECK();
+    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipFree(d_perm));
+    return 0;
+}
+
+int install_payload(hml_ctx* c, const int32_t* payload) {
+    if (int r = hml_ctx_bind(c)) return r;
+    if (int r = hml_ctx_ensure_marginal_buffers(c)) return r;
+    const uint64_t T1 = c->T + 1;
+    hipLaunchKernelGGL(hml_k_pool_install_diff, dim3(grid_for((uint64_t)c->K * T1, 256, 1 << 16)), dim3(256), 0, c->stream, payload,
+                       (uint32_t)c->T, c->K, c->d_diff);
+    hipLaunchKernelGGL(hml_k_pool_install_boundary, dim3(grid_for((T1 + 31) / 32, 256, 1 << 16)), dim3(256), 0, c->stream, payload,
+                       (uint32_t)c->T, c->K, c->d_boundary, c->d_mdl);
+    KLAUNCH_CHECK();
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+}  // namespace
+
+struct hml_pool {
+    ncclComm_t comm = nullptr;
+    int device = 0, rank = 0, n_ranks = 1;
+    hipStream_t stream = nullptr;
+    int32_t* d_payload = nullptr;
+    uint64_t capacity = 0;       // int32 elements
+    double last_ms = 0;
+    uint64_t last_bytes = 0;
+};
+
+extern "C" {
+
+int hml_pool_unique_id(void* id) {
+    if (!id) return set_err(HML_ERR_ARG, "null argument");
+    if (int r = need_rccl()) return r;
+    static_assert(sizeof(ncclUniqueId) == HML_POOL_ID_BYTES, "ncclUniqueId size");
+    ncclUniqueId u;
+    NCCLCHK(rccl().GetUniqueId(&u));
+    memcpy(id, &u, sizeof u);
+    return 0;
+}
+
+int hml_pool_create(hml_pool** out, int device, int rank, int n_ranks, const void* id) {
+    if (!out || !id) return set_err(HML_ERR_ARG, "null argument");
+    if (n_ranks < 1 || rank < 0 || rank >= n_ranks) return set_err(HML_ERR_ARG, "rank out of range");
+    if (int r = need_rccl()) return r;
+    HIPCHK(hipSetDevice(device));
+    hml_pool* p = new hml_pool();
+    p->device = device; p->rank = rank; p->n_ranks = n_ranks;
+    ncclUniqueId u;
+    memcpy(&u, id, sizeof u);
+    ncclResult_t rc = rccl().CommInitRank(&p->comm, n_ranks, u, rank);
+    if (rc != ncclSuccess) { delete p; return set_err(HML_ERR_HIP, std::string("ncclCommInitRank: ") + rccl().GetErrorString(rc)); }
+    if (hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking) != hipSuccess) {
+        rccl().CommDestroy(p->comm);
+        delete p;
+        return set_err(HML_ERR_HIP, "hipStreamCreateWithFlags failed");
+    }
+    *out = p;
+    return 0;
+}
+
+void hml_pool_destroy(hml_pool* p) {
+    if (!p) return;
+    hipSetDevice(p->device);
+    if (p->stream) hipStreamSynchronize(p->stream);
+    if (p->comm) rccl().CommDestroy(p->comm);
+    if (p->d_payload) hipFree(p->d_payload);
+    if (p->stream) hipStreamDestroy(p->stream);
+    delete p;
+}
+
+int hml_pool_info(hml_pool* p, int* rank, int* n_ranks, double* last_allreduce_ms, uint64_t* last_bytes, int* rccl_version) {
+    if (!p) return set_err(HML_ERR_ARG, "null pool");
+    if (rank) *rank = p->rank;
+    if (n_ranks) *n_ranks = p->n_ranks;
+    if (last_allreduce_ms) *last_allreduce_ms = p->last_ms;
+    if (last_bytes) *last_bytes = p->last_bytes;
+    if (rccl_version) { int v = 0; rccl().GetVersion(&v); *rccl_version = v; }
+    return 0;
+}
+
+int hml_pool_payload_size(hml_ctx* c, uint64_t* n_int32) {
+    if (!c || !c->model_set || !n_int32) return set_err(HML_ERR_ARG, "model not set");
+    *n_int32 = payload_count(c);
+    return 0;
+}
+
+int hml_pool_export(hml_ctx* c, void* payload_dev, int32_t* perm_out) {
+    if (!c || !c->model_set || !payload_dev) return set_err(HML_ERR_ARG, "model not set");
+    return export_payload(c, (int32_t*)payload_dev, perm_out);
+}
+
+int hml_pool_install(hml_ctx* c, const void* payload_dev) {
+    if (!c || !c->model_set || !payload_dev) return set_err(HML_ERR_ARG, "model not set");
+    return install_payload(c, (const int32_t*)payload_dev);
+}
+
+int hml_pool_marginals(hml_pool* p, hml_ctx* c, int32_t* perm_out) {
+    if (!p || !c || !c->model_set) return set_err(HML_ERR_ARG, "model not set");
+    if (c->device != p->device) return set_err(HML_ERR_ARG, "the chain lives on another device than the communicator's rank");
+    HIPCHK(hipSetDevice(p->device));
+    const uint64_t n = payload_count(c);
+    if (p->capacity < n) {
+        if (p->d_payload) HIPCHK(hipFree(p->d_payload));
+        p->d_payload = nullptr; p->capacity = 0;
+        HIPCHK(hipMalloc(&p->d_payload, n * sizeof(int32_t)));
+        p->capacity = n;
+    }
+    if (int r = export_payload(c, p->d_payload, perm_out)) return r;
+    hipEvent_t e0, e1;
+    HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+    HIPCHK(hipEventRecord(e0, p->stream));
+    NCCLCHK(rccl().AllReduce(p->d_payload, p->d_payload, (size_t)n, ncclInt32, ncclSum, p->comm, p->stream));
+    HIPCHK(hipEventRecord(e1, p->stream));
+    HIPCHK(hipStreamSynchronize(p->stream));
+    float ms = 0;
+    hipEventElapsedTime(&ms, e0, e1);
+    hipEventDestroy(e0); hipEventDestroy(e1);
+    p->last_ms = ms; p->last_bytes = n * sizeof(int32_t);
+    return install_payload(c, p->d_payload);
+}
+
+// One process driving n chains (hammlet -chains N): contexts that share a device are summed on that device first, the
+// per-device sums go through one grouped ncclAllReduce over a communicator of the distinct devices (ncclCommInitAll;
+// a single device still forms a one-rank communicator), and every context receives the pooled marginals.
+int hml_allreduce_marginals(hml_ctx* const* ctxs, int n) {
+    if (!ctxs || n < 1) return set_err(HML_ERR_ARG, "no contexts");
+    for (int i = 0; i < n; ++i) {
+        if (!ctxs[i] || !ctxs[i]->model_set) return set_err(HML_ERR_ARG, "model not set");
+        if (ctxs[i]->K != ctxs[0]->K || ctxs[i]->T != ctxs[0]->T) return set_err(HML_ERR_ARG, "chains of different shape cannot be pooled");
+    }
+    if (int r = need_rccl()) return r;
+    const uint64_t cnt = payload_count(ctxs[0]);
+    std::map<int, std::vector<int>> by_dev;
+    for (int i = 0; i < n; ++i) by_dev[ctxs[i]->device].push_back(i);
+    std::vector<int> devs;
+    std::vector<int32_t*> bufs;
+    int rc = 0;
+    auto cleanup = [&]() { for (size_t k = 0; k < bufs.size(); ++k) { hipSetDevice(devs[k]); hipFree(bufs[k]); } };
+    for (auto& kv : by_dev) {
+        HIPCHK(hipSetDevice(kv.first));
+        int32_t *acc = nullptr, *tmp = nullptr;
+        if (hipMalloc(&acc, cnt * sizeof(int32_t)) != hipSuccess) { cleanup(); return set_err(HML_ERR_HIP, "out of device memory for the pooling payload"); }
+        devs.push_back(kv.first); bufs.push_back(acc);
+        for (size_t j = 0; j < kv.second.size() && !rc; ++j) {
+            hml_ctx* c = ctxs[kv.second[j]];
+            if (j == 0) { rc = export_payload(c, acc, nullptr); continue; }
+            if (!tmp && hipMalloc(&tmp, cnt * sizeof(int32_t)) != hipSuccess) { rc = set_err(HML_ERR_HIP, "out of device memory for the pooling payload"); break; }
+            rc = export_payload(c, tmp, nullptr);
+            if (!rc) {
+                hipLaunchKernelGGL(hml_k_pool_add, dim3(grid_for(cnt, 256, 1 << 16)), dim3(256), 0, c->stream, acc, tmp, cnt);
+                if (hipStreamSynchronize(c->stream) != hipSuccess) rc = set_err(HML_ERR_HIP, "pooling kernel failed");
+            }
+        }
+        if (tmp) hipFree(tmp);
+        if (rc) { cleanup(); return rc; }
+    }
+    const int nd = (int)devs.size();
+    std::vector<ncclComm_t> comms(nd);
+    {
+        ncclResult_t r = rccl().CommInitAll(comms.data(), nd, devs.data());
+        if (r != ncclSuccess) { cleanup(); return set_err(HML_ERR_HIP, std::string("ncclCommInitAll: ") + rccl().GetErrorString(r)); }
+    }
+    ncclResult_t r = rccl().GroupStart();
+    for (int k = 0; k < nd && r == ncclSuccess; ++k) {
+        hipSetDevice(devs[k]);
+        r = rccl().AllReduce(bufs[k], bufs[k], (size_t)cnt, ncclInt32, ncclSum, comms[k], ctxs[by_dev[devs[k]][0]]->stream);
+    }
+    ncclResult_t r2 = rccl().GroupEnd();
+    if (r == ncclSuccess) r = r2;
+    for (int k = 0; k < nd; ++k) { hipSetDevice(devs[k]); hipStreamSynchronize(ctxs[by_dev[devs[k]][0]]->stream); }
+    for (int k = 0; k < nd; ++k) rccl().CommDestroy(comms[k]);
+    if (r != ncclSuccess) { cleanup(); return set_err(HML_ERR_HIP, std::string("ncclAllReduce: ") + rccl().GetErrorString(r)); }
+    for (int k = 0; k < nd && !rc; ++k)
+        for (int i : by_dev[devs[k]]) { rc = install_payload(ctxs[i], bufs[k]); if (rc) break; }
+    cleanup();
+    return rc;
+}
+
+}  // extern "C"

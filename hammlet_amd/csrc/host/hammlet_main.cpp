@@ -142,8 +142,7 @@ int main(int argc, const char* argv[]) {
 
         // ---- input
         inputDevice() = device;
-        vector<real_t> inputValues;
-        vector<SufficientStatistics<Normal>> stats;
+        vector<real_t> inputValues;   // the observations (the device computes coefficients, weights and statistics)
         if (args.isSet("-raw")) {
             const string fname = args.parse<string>("-raw");
             std::ifstream fin(fname, std::ios::binary);
@@ -163,11 +162,11 @@ int main(int argc, const char* argv[]) {
                 fin.seekg(0, std::ios::end);
                 const std::streamoff bytes = fin.tellg();
                 fin.seekg(0);
-                MaxletTransform(fin, inputValues, stats, nrDataDim, bytes > 0 ? (size_t)bytes / 2 + 1 : 0);
+                readValues(fin, inputValues, nrDataDim, bytes > 0 ? (size_t)bytes / 2 + 1 : 0);
             }
         } else {
             if (verbose) cout << "Reading from standard input" << endl << flush;
-            MaxletTransform(std::cin, inputValues, stats, nrDataDim);
+            readValues(std::cin, inputValues, nrDataDim);
         }
         if (verbose) cout << "Output will be written to " + opref + "*" + osuff << endl << flush;
         // (the reference counts the coefficients, one per position; here the vector still holds the D values of every position)
@@ -176,8 +175,8 @@ int main(int argc, const char* argv[]) {
         const size_t T = inputValues.size() / nrDataDim;
         if (verbose) cout << "Number of data points: " + std::to_string(T) << endl << flush;
 
+        if (inputValues.empty()) throw std::runtime_error("Cannot compute Haar breakpoint weights, vector is empty!");
         if (verbose) cout << "Calculating Haar breakpoint weights" << endl << flush;
-        HaarBreakpointWeights(inputValues);
 
         // the device context: created once every argument has been parsed and the input has been read (and before
         // `records`, whose destructor fetches the marginals from it)
@@ -239,8 +238,7 @@ int main(int argc, const char* argv[]) {
                 continue;
             } else if (method == "D") {
                 if (verbose) cout << "Setting block structure to dynamic" << endl << flush;
-                hml_check(hml_set_dynamic(RNG.ctx(), 1));
-                dynamic = true;
+                dynamic = true;   // (sampleHMM switches the device back to per-sweep recompression)
                 i++;
                 continue;
             } else {

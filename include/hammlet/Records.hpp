@@ -56,7 +56,7 @@ public:
     ~Records() {
         try { close(); } catch (...) {}
     }
-    void attach(hml_ctx* ctx) { mCtx = ctx; }
+    void attach(hml_ctx* ctx) { mCtx = ctx; }   // sampleHMM / StateSequence::sample do this; the marginals are fetched from it at close()
 
     void setRecordMarginals(bool b, bool overwrite = false) { setRecordX(mMarginalsFile, "marginals", mRecordMarginals, b, overwrite); }
     void setRecordBlocks(bool b, bool overwrite = false) { setRecordX(mBlocksFile, "blocks", mRecordBlocks, b, overwrite); }
@@ -70,9 +70,9 @@ public:
     bool recordsMarginals() const { return mRecordMarginals || mRecordMaxSeg; }
     bool needsPerSweepData() const { return mRecordBlocks || mRecordCompression || mRecordSequences || mRecordTheta || mRecordSegments; }
 
-    // one recorded sweep: Records::record(state, N) for every block in order + Records::record(theta)
-    template <typename ThetaT>
-    void recordSweep(hml_ctx* ctx, const ThetaT& theta) {
+    // one recorded sweep: Records::record(state, N) for every block in order (reference src/Records.hpp:155-235) ...
+    void recordStates(hml_ctx* ctx) {
+        if (!(mRecordBlocks || mRecordCompression || mRecordSequences || mRecordSegments)) return;
         uint64_t B = 0;
         hml_check(hml_get_num_blocks(ctx, &B));
         std::vector<uint32_t> starts(B + 1);
@@ -95,7 +95,16 @@ public:
         if (mRecordSequences) mSequenceFile << "\n";
         if (mRecordCompression) mCompressionsFile << ((double)mSize) / ((double)B) << std::endl;
         if (mRecordSegments) mSegmentFile << mBoundaries.size() << "\t" << mBoundaries.size() * 2 << std::endl;
+    }
+    // ... and Records::record(theta) (src/Records.hpp:196-203): the parameters line of the sweep
+    template <typename ThetaT>
+    void record(const ThetaT& theta) {
         if (mRecordTheta) mThetaFile << theta.str() << std::endl;
+    }
+    template <typename ThetaT>
+    void recordSweep(hml_ctx* ctx, const ThetaT& theta) {
+        recordStates(ctx);
+        record(theta);
     }
 
     void close() {

@@ -84,6 +84,11 @@ int hml_text_counters(hml_text* reader, uint64_t* bytes_in, uint64_t* irregular_
 int hml_set_dimensions(hml_ctx* ctx, int D, int P);
 int hml_get_dimensions(hml_ctx* ctx, int* D, int* P);
 
+/* Blocks<BreakpointArray>(vector<real_t>& weights) (src/Blocks/BreakpointArray.hpp:130-184, src/main.cpp:341): replaces
+ * the breakpoint weights the device computed by the caller's T host values - for drivers that, like the reference's,
+ * hold the weights on the host between HaarBreakpointWeights and the Blocks constructor (and may have changed them). */
+int hml_set_weights(hml_ctx* ctx, const float* w, uint64_t T);
+
 /* stdEstimate of src/main.cpp:303-311 */
 int hml_noise_sigma(hml_ctx* ctx, double* sigma);
 
@@ -100,6 +105,10 @@ int hml_autoprior(hml_ctx* ctx, float s2, float p, float out4[4]);
  * Like Theta's constructor (src/Theta.hpp:126-127) this draws theta once from the prior. */
 int hml_set_model(hml_ctx* ctx, int K, const float nig4[4], float a_off, float a_diag, float pi_alpha,
                   int self_trans);
+
+/* useSelfTransitions, the last argument of StateSequence::sample / sampleHMM (src/StateSequence.hpp:64, src/HMM.hpp:75):
+ * a driver in the reference's shape only states it when it samples, after the model objects exist. */
+int hml_set_self_transitions(hml_ctx* ctx, int on);
 
 /* theta.sample(tau_theta); pi.sample(tau_pi); A.sample(tau_A) from the priors
  * (src/main.cpp:393-401, and again after a "P" token). */
@@ -133,6 +142,9 @@ int hml_set_recording(hml_ctx* ctx, int marginals, hml_record_cb cb, void* user)
  * below 24 positions per block stream the floats instead); 2: the summary at any compression; 0: always stream all T
  * float weights.  Same block structures every way (exact). */
 int hml_set_option(hml_ctx* ctx, const char* name, int value);
+/* "fused_blocks" (any time), 1 (default): dynamic sweeps take the fused block kernel (block scan + block statistics +
+ * emission terms in one launch; its workgroups hand block offsets to each other inside the launch); 0: always the
+ * scan + scatter + statistics launches, which share nothing inside a launch.  Same results. */
 
 /* wait for all enqueued work; surfaces model errors raised on the device */
 int hml_sync(hml_ctx* ctx);
@@ -141,7 +153,7 @@ int hml_sync(hml_ctx* ctx);
  * theta/A/pi values; src/Emissions.hpp:66-99, src/StateSequence.hpp:71-74) ---- */
 int hml_get_num_blocks(hml_ctx* ctx, uint64_t* B);
 int hml_get_blocks(hml_ctx* ctx, uint32_t* starts /* B+1, last = T */);
-int hml_get_block_stats(hml_ctx* ctx, float* sum /*B*/, float* sum_sq /*B*/);
+int hml_get_block_stats(hml_ctx* ctx, float* sum /*D*B, dimension-major*/, float* sum_sq /*D*B*/);
 int hml_get_states(hml_ctx* ctx, int16_t* q /*B*/);
 int hml_get_theta(hml_ctx* ctx, float* mean_var /*2K: mean0,var0,mean1,...*/);
 int hml_get_transitions(hml_ctx* ctx, float* A /*K*K row-major*/, float* pi /*K*/);
@@ -175,6 +187,42 @@ int hml_max_segmentation(hml_ctx* ctx, uint64_t* n_runs, uint64_t* run_len /*n_r
  * chain-parallel pooling all-reduces over RCCL. */
 int hml_marginals_dense_device(hml_ctx* ctx, void* out_dev, const int32_t* perm);
 int hml_recorded_sweeps(hml_ctx* ctx, uint64_t* n);
+
+/* Trellis::sample(t) (src/Trellis.hpp:61-66): one draw of std::discrete_distribution over K weights - p_i = w_i / sum in
+ * double, first i whose cumulative probability reaches u - with u from the chain's Philox key (sub-stream HOST,
+ * one counter step per call).  Runs on the host (shared arithmetic of the kernels, hml_dist.h). */
+int hml_categorical_draw(hml_ctx* ctx, const float* weights, int K, uint32_t* index);
+
+/* ---- chain-parallel pooling.  Chains shard across GPUs and never communicate while sampling;
+ * one ncclAllReduce(sum, int32) over xGMI pools their recorded state marginals at the end.  The reference has no
+ * counterpart (one process, one thread, src/main.cpp:108). ---- */
+/* Common labels: perm[new] = old with the states ordered by ascending emission mean of the current theta - for
+ * "-s C P D" by the tuple of the means of their mapped parameters, in dimension order; ties keep their order.  (The
+ * idea of bin/sortStates:1-6, which orders states by their last sampled mean.) */
+int hml_relabel_permutation(hml_ctx* ctx, int32_t* perm /*K*/);
+/* The payload one chain contributes: int32 [K+1][T+1] - rows 0..K-1 the relabelled per-state difference arrays of the
+ * recorded marginals, row K = 1 at recorded segment boundaries - followed by [recorded sweeps, used[0..K-1]].
+ * hml_pool_export fills a device buffer of hml_pool_payload_size elements, hml_pool_install makes a (summed) payload
+ * the context's marginals: hml_marginals_rle, hml_max_segmentation, hml_marginals_dense_device and hml_recorded_sweeps
+ * then describe the pooled chains.  Any transport may sum the payloads in between. */
+int hml_pool_payload_size(hml_ctx* ctx, uint64_t* n_int32);
+int hml_pool_export(hml_ctx* ctx, void* payload_dev, int32_t* perm_out_or_null);
+int hml_pool_install(hml_ctx* ctx, const void* payload_dev);
+/* RCCL transport, one process per GPU: rank 0 creates the id (ncclGetUniqueId) and the launcher hands its
+ * HML_POOL_ID_BYTES bytes to every rank; hml_pool_create is ncclCommInitRank (collective).  hml_pool_marginals =
+ * export + ncclAllReduce(sum, int32) on the pool's stream + install (collective; every rank ends with the same
+ * pooled marginals).  RCCL is loaded on the first of these calls (librccl.so.1). */
+typedef struct hml_pool hml_pool;
+#define HML_POOL_ID_BYTES 128
+int hml_pool_unique_id(void* id /*HML_POOL_ID_BYTES*/);
+int hml_pool_create(hml_pool** out, int device, int rank, int n_ranks, const void* id);
+void hml_pool_destroy(hml_pool* pool);
+int hml_pool_marginals(hml_pool* pool, hml_ctx* ctx, int32_t* perm_out_or_null);
+int hml_pool_info(hml_pool* pool, int* rank, int* n_ranks, double* last_allreduce_ms, uint64_t* last_bytes, int* rccl_version);
+/* One process driving n chains, e.g. one per GPU (`hammlet -chains N`): contexts sharing a device are summed there,
+ * the per-device sums go through one grouped ncclAllReduce (ncclCommInitAll over the distinct devices), every context
+ * receives the pooled marginals. */
+int hml_allreduce_marginals(hml_ctx* const* ctxs, int n);
 
 /* ---- counters for measurement ---- */
 typedef struct {

@@ -133,12 +133,17 @@ def test_sweeps_match_checker(hml, T, K, scheme):
 
 def test_first_sweep_probes(hml):
     """Kernel-level probes: E_s bit-exact vs the checker in device-math mode, within 1e-6 relative of the
-    libm reference mode; forward rows bit-exact (the speculative chunked filter equals the sequential one)."""
+    libm reference mode (BASELINE.json's tolerance for the emission log-likelihoods); forward rows bit-exact (the
+    speculative chunked filter equals the sequential one).  The reference-math checker is given the very parameters
+    the GPU sweep started from, so all three enumerate the same blocks and the comparison is never skipped."""
     T, K = 100000, 5
     x, o, g = make_pair(hml, T, K, 9, 3)
     setup_model(o, g, K)
     o.token("F")
     g.sample_prior()
+    theta0 = g.theta()
+    A0, pi0 = g.transitions()
+    assert np.array_equal(bits(theta0), bits(o.theta()))
     o.set_probes(True)
     g.enable_probes(True)
     o.iterate("F", 1, 0)
@@ -147,18 +152,20 @@ def test_first_sweep_probes(hml):
     Eo, Eg = o.loglik(), g.block_loglik()
     assert np.array_equal(bits(Eo), bits(Eg))
     assert np.array_equal(bits(o.forward_rows()), bits(g.forward_rows()))
-    # reference-math checker on the same parameters
+    # reference-math checker (glibc expf/logf, sequential float Kahan sums) on the same parameters
     r = ol.OracleChain(K=K, seed=3, rng=ol.RNG_CTR, math=ol.MATH_LIBM, reduce=ol.REDUCE_REF)
     r.load(x)
     r.autoprior()
     r.init_model()
     r.token("F")
+    r.set_params(theta0, A0, pi0)
     r.set_probes(True)
     r.iterate("F", 1, 0)
     Er = r.loglik()
-    if Er.shape == Eg.shape:
-        rel = np.abs(Er - Eg) / np.maximum(np.abs(Er), 1e-30)
-        assert rel.max() <= 1e-6
+    assert np.array_equal(r.blocks(), g.blocks())
+    assert Er.shape == Eg.shape and Er.size > 0
+    rel = np.abs(Er.astype(np.float64) - Eg) / np.maximum(np.abs(Er), 1e-30)
+    assert rel.max() <= 1e-6, rel.max()
 
 
 @pytest.mark.parametrize("fn,name", [(0, "expf"), (1, "logf"), (2, "pow"), (3, "sqrtf"), (4, "div"), (5, "gamma"), (6, "normal"),
@@ -201,9 +208,8 @@ def test_gamma_lanes_independent(hml):
     assert np.array_equal(bits(together), bits(host))
 
 
-def test_dense_marginals_export_and_pooling_path(hml):
-    """hml_marginals_dense_device (the buffer the chains all-reduce) against the checker's dense counts,
-    with the relabelling permutation applied; world size 1, so pooling is the identity."""
+def test_dense_marginals_export(hml):
+    """hml_marginals_dense_device against the checker's dense counts, with a relabelling permutation applied."""
     import torch
     from hammlet_amd import chains
     T, K = 60000, 4
@@ -216,8 +222,7 @@ def test_dense_marginals_export_and_pooling_path(hml):
     g.sync()
     dense_o = o.marginals_dense()
     perm = chains.relabel_permutation(g.theta()[0::2])
-    seg, cnt, perm2 = chains.pooled_marginals(g)
-    assert np.array_equal(perm, perm2)
+    assert np.array_equal(perm, g.relabel_permutation())
     buf = torch.empty((K + 1, T), dtype=torch.int32, device="cuda")
     g.marginals_dense_device(buf.data_ptr(), perm)
     got = buf.cpu().numpy()
@@ -225,8 +230,6 @@ def test_dense_marginals_export_and_pooling_path(hml):
     lens = [int(l.split("\t")[0]) for l in o.text("marginals").strip().split("\n")]
     starts = np.cumsum([0] + lens[:-1])
     assert np.array_equal(np.flatnonzero(got[K]), starts)
-    assert np.array_equal(seg.cpu().numpy(), np.asarray(lens))
-    assert np.array_equal(cnt.cpu().numpy(), dense_o[perm][:, starts].T)
     assert np.all(got[:K].sum(0) == 8)
 
 

@@ -1,0 +1,148 @@
+"""Chain-parallel pooling through the C ABI on the GPU: the RCCL path with a one-rank communicator (RCCL
+is initialised and ncclAllReduce runs on the box), `hml_allreduce_marginals` for one process driving several chains,
+the export/install pair with an external sum, and the relabelling rule - each against the CPU checker's chains."""
+import numpy as np
+import pytest
+
+from tests import oracle_lib as ol
+
+pytestmark = pytest.mark.gpu
+
+T, K = 60000, 4
+
+
+def checker_chain(x, chain, seed=21, sweeps=(24, 3)):
+    o = ol.OracleChain(K=K, seed=seed, chain=chain, rng=ol.RNG_CTR, math=ol.MATH_DEV, reduce=ol.REDUCE_DEV)
+    o.load(x)
+    o.autoprior()
+    o.init_model()
+    o.token("F")
+    o.iterate("F", *sweeps)
+    lens = [int(l.split("\t")[0]) for l in o.text("marginals").strip().split("\n")]
+    bnd = np.zeros(T, np.int32)
+    bnd[np.cumsum([0] + lens[:-1])] = 1
+    return o.marginals_dense(), o.theta()[0::2].copy(), bnd
+
+
+def gpu_chain(hml, x, chain, seed=21, sweeps=(24, 3)):
+    g = hml.Chain(device=0, seed=seed, chain_id=chain)
+    g.load(x)
+    g.set_model(K, g.autoprior(0.2, 0.9))
+    g.sample_prior()
+    g.iterate("F", *sweeps)
+    g.sync()
+    return g
+
+
+def expected_pooled(x, chain_ids):
+    from hammlet_amd import chains
+    dense = np.zeros((K, T), np.int64)
+    bnd = np.zeros(T, np.int64)
+    perms = []
+    for c in chain_ids:
+        d, means, b = checker_chain(x, c)
+        perm = chains.relabel_permutation(means)
+        perms.append(perm)
+        dense += d[perm]
+        bnd += b
+    starts = np.flatnonzero(bnd)
+    seg = np.diff(np.append(starts, T))
+    cols = int(np.flatnonzero(dense.any(axis=1)).max()) + 1
+    return seg, dense[:cols, starts].T, perms
+
+
+def test_one_rank_rccl_communicator_pools_through_the_c_entry_point(hml):
+    """hml_pool_unique_id + hml_pool_create (ncclCommInitRank, one rank) + hml_pool_marginals (export, ncclAllReduce,
+    install): the chain afterwards holds its own marginals under the common labels."""
+    x = ol.trace(T, K, 3)
+    g = gpu_chain(hml, x, 0)
+    pool = hml.Pool(0, 0, 1, hml.Pool.unique_id())
+    perm = pool.marginals(g)
+    info = pool.info()
+    assert info["n_ranks"] == 1 and info["rccl_version"] > 0
+    assert info["last_bytes"] == 4 * ((K + 1) * (T + 1) + 1 + K)
+    seg_e, cnt_e, perms = expected_pooled(x, [0])
+    assert np.array_equal(perm, perms[0])
+    seg, cnt = g.marginals_rle()
+    assert np.array_equal(seg, seg_e) and np.array_equal(cnt, cnt_e)
+    assert g.recorded_sweeps() == 8
+    pool.close()
+    g.close()
+
+
+def test_allreduce_marginals_of_three_chains_on_one_device(hml):
+    """hml_allreduce_marginals (what `hammlet -chains N` calls): chains that share a device are summed there, the sum
+    goes through a one-device RCCL communicator, every context ends with the pooled marginals."""
+    x = ol.trace(T, K, 3)
+    hml.Chain(device=0).close()
+    cs = [gpu_chain(hml, x, c) for c in (0, 1, 2)]
+    hml.allreduce_marginals(cs)
+    seg_e, cnt_e, _ = expected_pooled(x, [0, 1, 2])
+    for g in cs:
+        seg, cnt = g.marginals_rle()
+        assert np.array_equal(seg, seg_e) and np.array_equal(cnt, cnt_e)
+        assert g.recorded_sweeps() == 3 * 8
+        assert np.all(cnt.sum(1) == 24)
+    ln, st = cs[0].max_segmentation()
+    assert int(ln.sum()) == T
+    for g in cs:
+        g.close()
+
+
+def test_export_external_sum_install_equals_the_library_path(hml):
+    """hml_pool_export / hml_pool_install with the sum done by the caller (any transport may stand in between)"""
+    import torch
+    x = ol.trace(T, K, 3)
+    a, b = gpu_chain(hml, x, 0), gpu_chain(hml, x, 1)
+    n = a.pool_payload_size()
+    assert n == (K + 1) * (T + 1) + 1 + K
+    pa = torch.empty(n, dtype=torch.int32, device="cuda")
+    pb = torch.empty(n, dtype=torch.int32, device="cuda")
+    a.pool_export(pa.data_ptr())
+    b.pool_export(pb.data_ptr())
+    pa += pb
+    torch.cuda.synchronize()
+    a.pool_install(pa.data_ptr())
+    seg_e, cnt_e, _ = expected_pooled(x, [0, 1])
+    seg, cnt = a.marginals_rle()
+    assert np.array_equal(seg, seg_e) and np.array_equal(cnt, cnt_e)
+    # the tensor-level mirror used by the CPU (gloo) test reads the same payload
+    from hammlet_amd import chains
+    s2, c2, nrec = chains.payload_to_rle(pa, K, T)
+    assert nrec == 16 and np.array_equal(s2.cpu().numpy(), seg_e) and np.array_equal(c2.cpu().numpy(), cnt_e)
+    a.close()
+    b.close()
+
+
+def test_relabelling_of_shared_parameter_states_and_permutation_checks(hml):
+    """`-s C 2 2`: four states over two parameters - the permutation has K entries (ascending tuples of mapped
+    means); hml_marginals_dense_device rejects an array that is not a permutation of the K states."""
+    import torch
+    Tm = 30000
+    x = np.stack([ol.trace(Tm, 2, 61 + d) for d in range(2)], axis=1).reshape(-1)
+    g = hml.Chain(device=0, seed=19)
+    g.set_dimensions(2, 2)
+    g.load(x)
+    g.set_model(4, g.autoprior(0.2, 0.9))
+    g.sample_prior()
+    g.iterate("F", 12, 2)
+    g.sync()
+    perm = g.relabel_permutation()
+    assert sorted(perm.tolist()) == [0, 1, 2, 3]
+    mu = g.theta()[0::2]
+    tuples = [(mu[s % 2], mu[s // 2]) for s in perm]
+    assert tuples == sorted(tuples)
+    buf = torch.empty((5, Tm), dtype=torch.int32, device="cuda")
+    g.marginals_dense_device(buf.data_ptr(), perm)
+    assert int(buf[:4].sum(0).min().item()) == 6 and int(buf[:4].sum(0).max().item()) == 6
+    with pytest.raises(hml.HmlError):
+        g.marginals_dense_device(buf.data_ptr(), np.array([0, 1, 1, 3], np.int32))
+    with pytest.raises(hml.HmlError):
+        g.marginals_dense_device(buf.data_ptr(), np.array([0, 1, 2, 7], np.int32))
+    a, b = g.block_stats()
+    assert a.shape == (2, g.num_blocks()) and b.shape == a.shape       # one plane per data dimension
+    # pooling a multivariate chain with itself through the one-process entry point
+    hml.allreduce_marginals([g])
+    seg, cnt = g.marginals_rle()
+    assert int(seg.sum()) == Tm and np.all(cnt.sum(1) == 6)
+    g.close()

@@ -2,6 +2,7 @@
 import ctypes as C
 
 import numpy as np
+import pytest
 
 from tests import oracle_lib as ol
 
@@ -91,3 +92,30 @@ def test_depth_trace_is_deterministic_and_plausible():
     assert 29.0 < dip.mean() < 31.0            # depth 15 x copy number 2
     assert 1.0 < dip.var() / dip.mean() < 2.5  # over-dispersed relative to Poisson
     assert set(np.unique(st)).issubset({0, 1, 2, 3, 4})
+
+
+@pytest.mark.parametrize("T,K,dseed,seed", [(100000, 5, 9, 3), (60000, 3, 1, 1), (50000, 10, 4, 7), (30000, 16, 2, 11)])
+def test_emission_terms_of_device_math_within_1e6_of_reference_math(T, K, dseed, seed):
+    """BASELINE.json's tolerance: emission log-likelihoods within 1e-6 relative.  E_s of one sweep computed with the
+    device's arithmetic (hml_math.h) against glibc's, on the same parameters and therefore the same block structure."""
+    x = ol.trace(T, K, dseed)
+    res = []
+    params = None
+    for math, red in ((ol.MATH_DEV, ol.REDUCE_DEV), (ol.MATH_LIBM, ol.REDUCE_REF)):
+        o = ol.OracleChain(K=K, seed=seed, rng=ol.RNG_CTR, math=math, reduce=red)
+        o.load(x)
+        o.autoprior()
+        o.init_model()
+        o.token("F")
+        if params is None:
+            params = (o.theta(), *o.transitions())
+        else:
+            o.set_params(*params)
+        o.set_probes(True)
+        o.iterate("F", 1, 0)
+        res.append((o.blocks(), o.loglik()))
+    assert np.array_equal(res[0][0], res[1][0])
+    Ed, Er = res[0][1], res[1][1]
+    assert Ed.shape == Er.shape and Ed.size >= K
+    rel = np.abs(Er.astype(np.float64) - Ed) / np.maximum(np.abs(Er), 1e-30)
+    assert rel.max() <= 1e-6, rel.max()

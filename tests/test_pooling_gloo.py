@@ -1,5 +1,6 @@
 """Chain-parallel pooling on CPU: world_size 2 over gloo.  Each rank runs its own chain (the CPU checker,
-chain id = rank), relabels by ascending mean, all-reduces the dense [K+1][T] counts and checks the pooled
+chain id = rank), relabels by ascending mean, builds the payload the library's hml_pool_export builds on the device
+(relabelled difference arrays + boundary row + recorded sweeps + used states), all-reduces it and checks the pooled
 result against the sum computed directly from both chains."""
 import os
 import socket
@@ -13,6 +14,7 @@ import torch.multiprocessing as mp
 from tests import oracle_lib as ol
 
 T, K = 20000, 3
+N_RECORDED = 15
 
 
 def chain_dense(rank):
@@ -38,11 +40,12 @@ def worker(rank, world, port, out):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     dense, means, bnd = chain_dense(rank)
     perm = chains.relabel_permutation(means)
-    t = torch.from_numpy(np.concatenate([dense[perm], bnd[None, :]], 0).astype(np.int32))
-    chains.pool_dense(t)
-    seg, cnt = chains.dense_to_rle(t)
+    # the payload of hml_pool_export (relabelled difference arrays, boundary row, recorded sweeps, used states)
+    t = torch.from_numpy(chains.payload_from_dense(dense, bnd, perm, N_RECORDED))
+    chains.pool_payload(t)
+    seg, cnt, n_rec = chains.payload_to_rle(t, K, T)
     if rank == 0:
-        np.savez(out, dense=t.numpy(), seg=seg.numpy(), cnt=cnt.numpy())
+        np.savez(out, payload=t.numpy(), seg=seg.numpy(), cnt=cnt.numpy(), n_rec=n_rec)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -63,13 +66,32 @@ def test_pooled_marginals_world2(tmp_path):
         assert np.all(np.diff(means[perm]) >= 0)
         expect[:K] += dense[perm]
         expect[K] += bnd
-    assert np.array_equal(got["dense"], expect)
-    # pooled row sums = chains x recorded sweeps; segments tile [0, T)
-    assert np.all(got["dense"][:K].sum(0) == 2 * 15)
+    body = got["payload"][: (K + 1) * (T + 1)].reshape(K + 1, T + 1)
+    # prefix sums of the pooled difference rows are the sums of the relabelled dense counts
+    assert np.array_equal(np.cumsum(body[:K, :T], axis=1), expect[:K])
+    assert np.all(body[:K, T] == 0)
+    assert int(got["n_rec"]) == 2 * N_RECORDED
+    # pooled row sums = chains x recorded sweeps; segments tile [0, T) and are cut at the union of the chains' boundaries
+    assert np.all(expect[:K].sum(0) == 2 * N_RECORDED)
     assert got["seg"].sum() == T
     starts = np.concatenate([[0], np.cumsum(got["seg"])[:-1]])
     assert np.array_equal(got["cnt"], expect[:K, starts].T)
     assert set(np.flatnonzero(expect[K])) == set(starts)
+
+
+def test_payload_round_trip_and_unused_states():
+    """payload_from_dense / payload_to_rle: a state no chain recorded is not printed (reference
+    src/StateMarginals.hpp:300-303), an interior unused state is a zero column"""
+    from hammlet_amd import chains
+    dense = np.zeros((4, 12), np.int64)
+    dense[0, :5] = 3
+    dense[2, 5:] = 3
+    bnd = np.zeros(12, np.int32)
+    bnd[[0, 5, 9]] = 1
+    t = torch.from_numpy(chains.payload_from_dense(dense, bnd, np.arange(4), 3))
+    seg, cnt, n = chains.payload_to_rle(t, 4, 12)
+    assert n == 3 and seg.tolist() == [5, 4, 3]
+    assert cnt.tolist() == [[3, 0, 0], [0, 0, 3], [0, 0, 3]]
 
 
 def test_max_segmentation_of_pooled_marginals_matches_the_tool():
@@ -97,3 +119,7 @@ def test_relabel_permutation():
     from hammlet_amd import chains
     assert list(chains.relabel_permutation([0.5, -1.0, 2.0])) == [1, 0, 2]
     assert list(chains.relabel_permutation([1.0, 1.0, 0.0])) == [2, 0, 1]
+    # "-s C 2 2": state s maps to parameters (s % 2, s / 2); tuples compared in dimension order
+    mu = np.array([0.7, -0.3])
+    tuples = np.array([[mu[s % 2], mu[s // 2]] for s in range(4)])
+    assert list(chains.relabel_permutation(tuples)) == [3, 1, 2, 0]
