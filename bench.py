@@ -34,20 +34,53 @@ WORKLOADS = {
 }
 
 
-PMC_FILE = "profiles/round1_pmc_hbm_traffic.json"
+PMC_FILE = "profiles/round2_pmc_hbm_traffic.json"
+
+# kernel families timed by the library's event brackets (hml_profile_enable) -> the kernel each one launches in the
+# default dynamic sweep (names as rocprofv3 prints them, without template arguments)
+FAMILY_KERNEL = {
+    "blocks_compact": "hml_k_blocks_fused",
+    "forward": "hml_k_forward",
+    "backward_maps": "hml_k_backward_maps",
+    "backward_chain": "hml_k_backward_chain",
+    "counts": "hml_k_counts",
+    "params": "hml_k_params",
+}
 
 
-def pmc_traffic(workload, which="scan_kernel"):
-    """HBM bytes per launch of a kernel from the committed rocprofv3 --pmc passes of this same command
-    (FETCH_SIZE doubled per the gfx950 correction for wide coalesced reads + WRITE_SIZE; tools/pmc_summary.py);
-    PMC counters cannot be collected from inside the timed run, so the JSON line quotes the profile."""
+def pmc_table(workload):
+    """Per-kernel memory traffic from the committed rocprofv3 --pmc passes of this same command (separate FETCH_SIZE and
+    WRITE_SIZE passes, tools/pmc_summary.py): bytes per launch = 2 x FETCH_SIZE + WRITE_SIZE (the gfx950 correction of
+    MI355X_MICROARCH.md for FETCH_SIZE).  Counters cannot be collected from inside the timed run, so the JSON line
+    quotes the profile; Infinity-Cache hits are counted in FETCH_SIZE, so the figure is an upper bound on HBM bytes."""
     try:
         if workload != "c3_1e8_k5_dynamic":
-            return None
+            return {}
         with open(os.path.join(REPO, PMC_FILE)) as f:
-            return json.load(f)[which]["hbm_bytes_per_launch_corrected"]
+            return json.load(f)["kernels"]
     except Exception:
-        return None
+        return {}
+
+
+def pmc_traffic(workload, kernel):
+    """bytes per launch of `kernel` (name without template arguments)"""
+    for name, k in pmc_table(workload).items():
+        if name.split("<")[0] == kernel:
+            return k["bytes_fetch_doubled"]
+    return None
+
+
+def host_cpu():
+    model, n = "unknown", os.cpu_count() or 0
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    model = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    return model, n
 
 
 def cpu_baseline(x, K, seed, budget_s=20.0):
@@ -67,8 +100,10 @@ def cpu_baseline(x, K, seed, budget_s=20.0):
     t = o.time_sweeps("F", n)
     blocks = o.total_blocks() - b0
     o.close()
-    out = {"value": blocks / t, "unit": "block-updates/s", "cores": 1, "kind": "port",
-           "sample": "%d sweeps of the same %d-position trace (reference-mode CPU restatement, %.1f ms/sweep)" % (n, x.size, 1e3 * t / n)}
+    model, total = host_cpu()
+    out = {"value": blocks / t, "unit": "block-updates/s", "cores": 1, "kind": "port", "host_cpu": model, "host_cores": total,
+           "sample": "%d sweeps of the same %d-position trace (reference-mode CPU restatement, %.1f ms/sweep); one thread, "
+                     "like the reference (src/main.cpp:108)" % (n, x.size, 1e3 * t / n)}
     try:
         ref = reference_binary_baseline(x, K, seed)
         if ref:
@@ -114,8 +149,8 @@ def reference_binary_baseline(x, K, seed, prefix=10_000_000, sweeps=300):
     blocks = o.total_blocks()
     o.close()
     dt = max(t_n - t_zero, 1e-9)
-    return {"value": blocks / dt, "unit": "block-updates/s", "cores": 1, "kind": "reference",
-            "sample": "unmodified reference binary, first %d positions of the trace as text, %d sweeps: %.2f ms/sweep, "
+    return {"value": blocks / dt, "unit": "block-updates/s", "cores": 1, "kind": "reference", "sample_positions": int(xp.size),
+            "sample": "unmodified reference binary, first %d positions of the trace as text (a bounded sample: not the 10^8 trace), %d sweeps: %.2f ms/sweep, "
                       "%.0f blocks/sweep (start-up + text parsing %.1f s, subtracted)" % (xp.size, sweeps, 1e3 * dt / sweeps, blocks / sweeps, t_zero)}
 
 
@@ -202,23 +237,27 @@ def main():
     out = None
     if rank == 0:
         B_avg = blocks / max(1, args.steps)
-        # an event pair measures ~3 us with nothing in between on this stack (marker packets + barrier): the
+        # an event pair measures ~3-5 us with nothing in between on this stack (marker packets + barrier): the
         # kernel's duration is the bracket minus the empty bracket (both reported; rocprofv3 agrees with the net)
         scan_raw_s = (scan_ms / max(1, scan_n)) * 1e-3
         null_s = (null_ms / max(1, null_n)) * 1e-3
         scan_avg_s = max(scan_raw_s - null_s, 1e-9)
         # The timed kernel is hml_k_blocks_fused: block starts from the weights, their order, block statistics,
-        # emission terms.  Algorithmic bytes per SURVEY.md section 8d, the part of bytes_iter this launch covers:
-        # the weight stream at 4 B/position + per block one 32-bit start and two 8-byte integral-array gathers.
-        # The kernel itself streams a one-byte-per-16-positions summary of the weights and opens only the groups
-        # that can hold a block start (DESIGN.md "K4"), so it physically moves far fewer bytes: `traffic` (PMC)
-        # shows that, and `physical_*` prices the kernel against an estimate of the bytes it really touches
-        # (T/16 summary + per block: one 64-byte weight line, two 64-byte integral-array sectors, 12 + 8K written).
-        scan_bytes = 4.0 * T + 20.0 * B_avg
-        achieved = scan_bytes / scan_avg_s / 1e9 if scan_avg_s > 0 else 0.0
-        phys_bytes = T / 16.0 + B_avg * (64.0 + 128.0 + 12.0 + 8.0 * K)
-        phys_achieved = phys_bytes / scan_avg_s / 1e9 if scan_avg_s > 0 else 0.0
+        # emission terms.  It streams a one-byte-per-16-positions summary of the weights and opens only the groups
+        # that can hold a block start (DESIGN.md "K4"), so it moves far fewer bytes than the 4 B/position weight stream
+        # of SURVEY.md 8d.  `frac` prices it on the bytes the memory system really moved for it - the PMC counters of the
+        # committed profile of this command (2 x FETCH_SIZE + WRITE_SIZE per launch) - and is therefore a fraction of
+        # peak (<= 1); it is small because the kernel is bound by latency (three dependent memory round trips and one
+        # inter-workgroup hand-off), not by bandwidth.  The algorithmic figure of SURVEY 8d (4 T + 20 B: weight stream +
+        # one start and two integral-array gathers per block) is reported separately as what the launch REPLACES.
+        algo_bytes = 4.0 * T + 20.0 * B_avg
+        phys_bytes = T / 16.0 + B_avg * (64.0 + 128.0 + 12.0 + 8.0 * K)     # estimate, used when no profile is committed
+        traffic = pmc_traffic(args.workload, FAMILY_KERNEL["blocks_compact"])
+        moved = traffic if traffic else phys_bytes
+        achieved = moved / scan_avg_s / 1e9
         sweep_bytes = 4.0 * T + B_avg * (36 + 8 * K)   # SURVEY.md 8d bytes_iter
+        frac = achieved / HBM_PEAK_GBS
+        assert frac <= 1.0, "a roofline fraction above 1 means the byte count is not what the kernel moves"
         out = {
             "metric": "block-updates/sec (Gibbs sweep) + HBM GB/s, 10^8 pos / 5 states",
             "value": blocks_all / elapsed,
@@ -234,20 +273,54 @@ def main():
             "data": "synthetic",
             "config": {"workload": args.workload, "positions": T, "states": K, "blocks_per_sweep": B_avg,
                        "compression": T / max(B_avg, 1.0), "block_structure": "dynamic", "chains": world,
-                       "parallelism": "chain-parallel x%d" % world},
+                       "parallelism": "chain-parallel x%d" % world,
+                       "cpu_baseline_sample": "port: the same 10^8 trace; reference binary: its first 10^7 positions"},
             "roofline": {"bound": "hbm", "kernel": "hml_k_blocks_fused (block scan + block statistics + emission terms)",
-                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": pmc_traffic(args.workload), "traffic_source": PMC_FILE, "kernel_avg_us": 1e6 * scan_avg_s, "kernel_bracket_us": 1e6 * scan_raw_s,
+                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": frac,
+                         "traffic": traffic, "traffic_source": PMC_FILE if traffic else None,
+                         "bytes_priced": "pmc: 2*FETCH_SIZE + WRITE_SIZE per launch" if traffic else "estimate (no committed profile)",
+                         "kernel_avg_us": 1e6 * scan_avg_s, "kernel_bracket_us": 1e6 * scan_raw_s,
                          "empty_bracket_us": 1e6 * null_s, "launches": scan_n,
-                         "bytes_per_launch": scan_bytes, "physical_bytes_per_launch": phys_bytes,
-                         "physical_achieved": phys_achieved, "physical_frac": phys_achieved / HBM_PEAK_GBS,
-                         "sweep_frac": sweep_bytes / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS},
+                         "limiter": "latency: three dependent memory round trips + one inter-workgroup hand-off per launch",
+                         "algorithmic_bytes_per_launch": algo_bytes,
+                         "algorithmic_equivalent_gbs": algo_bytes / scan_avg_s / 1e9,
+                         "algorithmic_speedup_vs_peak_float_stream": algo_bytes / scan_avg_s / 1e9 / HBM_PEAK_GBS,
+                         "sweep_frac": sweep_bytes / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS,
+                         "sweep_frac_note": "SURVEY.md 8d: algorithmic bytes of a whole sweep (4 T + B (36 + 8 K)) / sweep time / 8 TB/s"},
             "forward_refits": st1["forward_refits"] - st0["forward_refits"],
             "forward_serial": st1["forward_serial"] - st0["forward_serial"],
         }
+        assert out["roofline"]["sweep_frac"] <= 1.0
+
+    # per-kernel table (not part of the timed region): every launch of 200 further sweeps bracketed by HIP events on the
+    # chain's stream, next to the PMC traffic of the committed profile
+    if rank == 0 and world == 1:
+        names = list(FAMILY_KERNEL)
+        before = {nm: chain.profile_get(nm) for nm in names + ["event_null"]}
+        chain.profile_enable(2)
+        n_extra = 200
+        chain.iterate("F", n_extra, 0)
+        chain.sync()
+        chain.profile_enable(0)
+        table = {}
+        for nm in names:
+            ms, n = chain.profile_get(nm)
+            dn = n - before[nm][1]
+            if dn <= 0:
+                continue
+            us = 1e3 * (ms - before[nm][0]) / dn
+            tr = pmc_traffic(args.workload, FAMILY_KERNEL[nm])
+            row = {"bracket_us": round(us, 2), "launches_per_sweep": round(dn / n_extra, 2), "traffic": tr}
+            net = max(us - 1e6 * null_s, 0.5)
+            row["kernel_us"] = round(net, 2)
+            if tr:
+                row["frac"] = round(tr / (net * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)
+                assert row["frac"] <= 1.0
+            table[FAMILY_KERNEL[nm]] = row
+        out["kernels"] = table
 
     if args.breakdown and rank == 0:
-        names = ("blocks_compact", "blocks_scatter", "stats_emission", "forward", "forward_fix", "backward", "counts", "params")
+        names = ("blocks_compact", "blocks_scatter", "stats_emission", "forward", "backward_maps", "backward_chain", "counts", "params")
         before = {nm: chain.profile_get(nm) for nm in names}
         chain.profile_enable(2)
         chain.iterate("F", min(50, args.steps), 0)
@@ -259,19 +332,26 @@ def main():
             fam[nm] = round(1e3 * (ms - before[nm][0]) / max(1, n - before[nm][1]), 2)
         out["kernel_us_per_sweep"] = fam
 
-    # chain-parallel pooling (not timed): a few recorded sweeps, relabel by ascending mean, one RCCL all-reduce
+    # chain-parallel pooling (not timed): a few recorded sweeps, then the library's own collective - every rank joins
+    # an RCCL communicator (hml_pool_create) and hml_pool_marginals relabels, all-reduces and installs the pooled marginals
     if world > 1:
         from hammlet_amd import chains
+        pool = chains.make_pool(local_rank)
         chain.set_recording(marginals=True)
         chain.iterate("F", 10, 5)
         chain.sync()
         barrier()
         tp0 = time.perf_counter()
-        seg, cnt, _ = chains.pooled_marginals(chain)
+        seg, cnt, _ = chains.pooled_marginals(chain, pool)
         barrier()
         if rank == 0:
-            out["pooling"] = {"all_reduce_bytes": int((K + 1) * T * 4), "seconds_incl_dense_export": time.perf_counter() - tp0,
-                              "pooled_segments": int(seg.numel()), "counts_per_position": int(cnt[0].sum().item())}
+            info = pool.info()
+            out["pooling"] = {"transport": "RCCL ncclAllReduce(sum, int32) inside libhammlet_hip.so (hml_pool_marginals)",
+                              "rccl_version": info["rccl_version"], "all_reduce_bytes": info["last_bytes"],
+                              "all_reduce_ms": info["last_allreduce_ms"],
+                              "seconds_incl_export_and_install": time.perf_counter() - tp0,
+                              "pooled_segments": int(len(seg)), "counts_per_position": int(cnt[0].sum())}
+        pool.close()
 
     # second leg: the same chain with the float weight stream (option weight_keys = 0): every sweep reads all T
     # float weights - the one genuinely bandwidth-bound kernel of the path, priced against the HBM roofline
@@ -286,7 +366,7 @@ def main():
             out["float_stream"] = {"value": bl2 / el2, "unit": "block-updates/s", "ms_per_step": 1e3 * el2 / args.steps,
                                    "roofline": {"bound": "hbm", "kernel": "hml_k_compact_scan (all T float weights)",
                                                 "achieved": f_bytes / f_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                                "frac": f_bytes / f_s / 1e9 / HBM_PEAK_GBS, "traffic": pmc_traffic(args.workload, "float_scan_kernel"),
+                                                "frac": f_bytes / f_s / 1e9 / HBM_PEAK_GBS, "traffic": pmc_traffic(args.workload, "hml_k_compact_scan"),
                                                 "kernel_avg_us": 1e6 * f_s,
                                                 "bytes_per_launch": f_bytes, "launches": f_n},
                                    "note": "same chain, same results; the default path above replaces this stream by the group summary"}

@@ -87,7 +87,7 @@ def build_cli(force=False, verbose=False):
         return None
     if force or _newer(CLI_PATH, _sources()):
         build_library(force=False, verbose=verbose)
-        cmd = ["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-o", CLI_PATH, src, "-I", os.path.join(REPO_DIR, "include"),
+        cmd = ["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-pthread", "-o", CLI_PATH, src, "-I", os.path.join(REPO_DIR, "include"),
                "-L", PKG_DIR, "-lhammlet_hip", "-Wl,-rpath,$ORIGIN"]
         if verbose:
             print(" ".join(cmd))

@@ -32,6 +32,7 @@ SIGNATURES = {
     "hml_last_error": (C.c_char_p, []),
     "hml_abi_version": (C.c_uint32, []),
     "hml_device_arch": (C.c_char_p, []),
+    "hml_device_count": (C.c_int, [C.POINTER(C.c_int)]),
     "hml_create": (C.c_int, [C.POINTER(_P), C.c_int, C.c_uint64, C.c_uint32, _P]),
     "hml_destroy": (None, [_P]),
     "hml_load_observations": (C.c_int, [_P, _P, C.c_uint64]),

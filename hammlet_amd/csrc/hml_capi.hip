@@ -235,6 +235,11 @@ extern "C" {
 const char* hml_last_error(void) { return g_err.c_str(); }
 uint32_t hml_abi_version(void) { return 1; }
 const char* hml_device_arch(void) { return "gfx950"; }
+int hml_device_count(int* n) {
+    if (!n) return set_err(HML_ERR_ARG, "null argument");
+    HIPCHK(hipGetDeviceCount(n));
+    return 0;
+}
 
 static void free_all(hml_ctx* c);
 
@@ -879,10 +884,13 @@ static int sweep_k(hml_ctx* c, char method, bool record) {
         {
             // backward maps (verifies the forward chunks on the way), then one workgroup: repair if a check failed,
             // and the chain over the chunk maps
-            ProfScope ps(c, "backward");
             const uint64_t bch = ((uint64_t)hint + HML_BWD_CHUNK - 1) / HML_BWD_CHUNK;
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_backward_maps<KK>), dim3(grid_for(bch * 64, 256, 16, 1 << 18)), dim3(256), 0,
-                               s, c->d_rows, c->d_mdl, c->d_smap, c->d_cmap, lay, c->d_entry, c->d_exitA, c->d_redo, L);
+            {
+                ProfScope ps(c, "backward_maps");
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_backward_maps<KK>), dim3(grid_for(bch * 64, 256, 16, 1 << 18)), dim3(256), 0,
+                                   s, c->d_rows, c->d_mdl, c->d_smap, c->d_cmap, lay, c->d_entry, c->d_exitA, c->d_redo, L);
+            }
+            ProfScope ps(c, "backward_chain");
             if (!dense_geo) {
                 hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_backward_chain<KK>), dim3(1), dim3(1024), 0, s, c->d_cmap, c->d_mdl,
                                    c->d_bentry, c->d_em, c->d_gsc, c->d_rows, c->probes ? c->d_aprobe : nullptr, c->d_entry,
@@ -912,7 +920,7 @@ static int sweep_k(hml_ctx* c, char method, bool record) {
         }
     } else {
         {
-            ProfScope ps(c, "backward");
+            ProfScope ps(c, "mixture");
             hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_mixture<KK>), dim3(gB), dim3(256), 0, s, c->d_em, c->d_mdl, c->d_q, lay);
         }
         {

@@ -4,11 +4,20 @@
 // files runs on the GPU through libhammlet_hip.so.
 //
 // Extensions (not in the reference): `-O X` writes PREFIXmaxsegmentationSUFFIX; -raw FILE reads float32 values instead of text; -device N selects
-// the GPU; -chain N selects the Philox sub-key of an independent chain.
+// the GPU; -chain N selects the Philox sub-key of an independent chain; -chains N runs N independent chains (sub-keys
+// chain .. chain+N-1), chain k on GPU (device + k) mod #GPUs in its own host thread, and pools their recorded marginals
+// with one all-reduce over RCCL before PREFIXmarginalsSUFFIX is written (hml_allreduce_marginals); the per-sweep side
+// files of chain k >= 1 are PREFIXchainK.{sequences,...}SUFFIX.
+#include <condition_variable>
 #include <ctime>
+#include <exception>
 #include <fstream>
 #include <iostream>
+#include <map>
+#include <memory>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "hammlet/Parser.hpp"
@@ -39,7 +48,154 @@ static const char* kHelp =
     "  -R, -random-seed N             seed (default: time)\n"
     "  -i, -iterations SCHEME         tokens: M n t | F n t | S | D | P (default M 500 0 S P F 200 0 F 300 3)\n"
     "  -m, -weight-multiplier F       multiply breakpoint weights (default 1)\n"
+    "  -device N  -chain N            GPU and Philox sub-key of the chain (extensions)\n"
+    "  -chains N                      N independent chains, one per GPU, marginals pooled over RCCL (extension)\n"
     "  -v, -verbose   -g, -arguments   -h, -help\n";
+
+// one entry of the sampling scheme (-i)
+struct Step {
+    string method;
+    size_t iterations = 0, thinning = 0;
+    bool incomplete = false;
+};
+
+// everything a chain needs besides the observations
+struct Job {
+    size_t T = 0, nrDataDim = 1, nrStates = 0, seed = 0;
+    string opref, osuff;
+    bool overwrite = false, useSelfTrans = true;
+    real_t weightMultiplier = 1, trans = 0.5, selfTrans = 0.5, initialAlpha = 0.5;
+    vector<vector<real_t>> thetaParams;
+    vector<Step> scheme;
+    std::map<string, bool> outputs;
+};
+
+// Meeting point of the chain threads of `-chains N` and the main thread: a chain arrives with its context once its
+// scheme has run, the main thread pools the marginals of all of them (hml_allreduce_marginals) and lets them go on to
+// write their files - or tells them not to when a chain failed.
+class Rendezvous {
+    std::mutex mMutex;
+    std::condition_variable mCv;
+    const int mExpected;
+    vector<hml_ctx*> mCtx;
+    int mAbandoned = 0;
+    bool mReleased = false, mOk = false;
+
+public:
+    explicit Rendezvous(int n) : mExpected(n), mCtx(n, nullptr) {}
+    // chain side: true = the marginals were pooled, write them
+    bool arrive(int index, hml_ctx* ctx) {
+        std::unique_lock<std::mutex> lock(mMutex);
+        mCtx[index] = ctx;
+        mCv.notify_all();
+        mCv.wait(lock, [&] { return mReleased; });
+        return mOk;
+    }
+    void abandon() {
+        std::lock_guard<std::mutex> lock(mMutex);
+        ++mAbandoned;
+        mCv.notify_all();
+    }
+    // main side
+    vector<hml_ctx*> waitForAll() {
+        std::unique_lock<std::mutex> lock(mMutex);
+        auto arrived = [&] { int n = 0; for (hml_ctx* c : mCtx) n += c != nullptr; return n; };
+        mCv.wait(lock, [&] { return arrived() + mAbandoned >= mExpected; });
+        vector<hml_ctx*> out;
+        if (mAbandoned == 0) out = mCtx;
+        return out;
+    }
+    void release(bool ok) {
+        std::lock_guard<std::mutex> lock(mMutex);
+        mReleased = true;
+        mOk = ok;
+        mCv.notify_all();
+    }
+};
+
+// One chain from its device context to its output files.  `index` > 0 (chains of `-chains N` beyond the first): the
+// per-sweep side files carry the infix "chainK." and the (pooled) marginals are left to chain 0.
+static void runChain(const Job& job, vector<real_t>& inputValues, bool steal, int device, uint32_t chainId, int index, bool verbose,
+                     Rendezvous* rendezvous) {
+    inputDevice() = device;
+    rng_t RNG(job.seed, device, chainId);
+    Transitions<DirichletVector> A(job.nrStates, RNG);
+    Initial<Dirichlet> pi(job.nrStates, RNG);
+    TransitionHyperParam<DirichletParamVector> tau_A(job.nrStates, job.trans, job.selfTrans);
+    InitialHyperParam<DirichletParam> tau_pi(job.nrStates, job.initialAlpha);
+    Mapping mapping(job.nrDataDim, job.thetaParams.size(), combinations);
+
+    const string prefix = index == 0 ? job.opref : job.opref + "chain" + std::to_string(index) + ".";
+    Records records(job.T, prefix, job.osuff, job.nrStates);
+    auto wants = [&](const char* o) { return job.outputs.at(o); };
+    records.setRecordStateSequence(wants("sequences"), job.overwrite);
+    records.setRecordTheta(wants("parameters"), job.overwrite);
+    records.setRecordBlocks(wants("blocks"), job.overwrite);
+    records.setRecordCompression(wants("compression"), job.overwrite);
+    records.setRecordSegments(wants("segments"), job.overwrite);
+    if (index == 0) {
+        records.setRecordMarginals(wants("marginals"), job.overwrite);
+        records.setRecordMaxSegmentation(wants("maxsegmentation"), job.overwrite);
+    } else {
+        records.setRecordMarginals(false);
+        records.setAccumulateMarginals(wants("marginals") || wants("maxsegmentation"));   // for the pool
+    }
+
+    typedef Statistics<IntegralArray, Normal> S;
+    typedef Blocks<BreakpointArray> B;
+    // upload + maxlet transform + weights + integral array (GPU); a lone chain takes the vector, several share it
+    std::unique_ptr<S> iaHolder(steal ? new S(inputValues, job.nrDataDim) : new S(static_cast<const vector<real_t>&>(inputValues), job.nrDataDim, S::keepInput));
+    S& ia = *iaHolder;
+    B waveletBlocks(ia);
+    if (job.weightMultiplier != 1) waveletBlocks.scaleWeights(job.weightMultiplier);
+    Emissions<S, B> y(ia, waveletBlocks);
+    records.attach(y.ctx());
+
+    vector<vector<real_t>> thetaParams = job.thetaParams;
+    const double stdEstimate = ia.noiseEstimate();
+    thetaParams[0] = autoPrior(thetaParams[0][0], thetaParams[0][1], y, stdEstimate);
+    for (auto& p : thetaParams) p = thetaParams[0];
+    ThetaHyperParam<NormalInverseGammaParam> tau_theta(thetaParams);
+    Theta<NormalInverseGamma> theta(tau_theta, tau_A, tau_pi, job.useSelfTrans, RNG);
+
+    // the scheme (reference main.cpp:383-452): a pending prior draw happens when the next token starts, whatever it is
+    bool samplePrior = true, dynamic = true;
+    if (verbose) cout << "Setting block structure to dynamic" << endl << flush;
+    for (const Step& st : job.scheme) {
+        if (samplePrior) {
+            if (verbose) cout << "Sampling prior" << endl << flush;
+            hml_check(hml_sample_prior(RNG.ctx()));
+            samplePrior = false;
+        }
+        if (st.method == "P") { samplePrior = true; continue; }
+        if (st.method == "S") {
+            if (verbose) cout << "Setting block structure to static" << endl << flush;
+            y.createBlocks(theta);
+            dynamic = false;
+            continue;
+        }
+        if (st.method == "D") {
+            if (verbose) cout << "Setting block structure to dynamic" << endl << flush;
+            dynamic = true;   // (sampleHMM switches the device back to per-sweep recompression)
+            continue;
+        }
+        if (st.incomplete) throw std::runtime_error("Incomplete command line for -i!");
+        if (st.method == "F") {
+            if (verbose) cout << "Sampling Forward-Backward" << endl << flush;
+            StateSequence<ForwardBackward> q(RNG);
+            sampleHMM(y, q, theta, tau_theta, A, tau_A, pi, tau_pi, mapping, st.iterations, st.thinning, records, dynamic, job.useSelfTrans);
+        } else if (st.method == "M") {
+            if (verbose) cout << "Sampling mixture" << endl << flush;
+            StateSequence<Mixture> q(RNG);
+            sampleHMM(y, q, theta, tau_theta, A, tau_A, pi, tau_pi, mapping, st.iterations, st.thinning, records, dynamic, job.useSelfTrans);
+        } else {
+            throw std::runtime_error("Unknown sampling type " + st.method + "!");
+        }
+    }
+    hml_check(hml_sync(RNG.ctx()));
+    if (rendezvous && !rendezvous->arrive(index, RNG.ctx())) records.discardMarginals();   // pooling failed elsewhere
+    records.close();
+}
 
 int main(int argc, const char* argv[]) {
     try {
@@ -64,6 +220,7 @@ int main(int argc, const char* argv[]) {
         args.registerFlags({"-raw"});
         args.registerFlags({"-device"}, "0");
         args.registerFlags({"-chain"}, "0");
+        args.registerFlags({"-chains"}, "1");
         args.parseArgs();
 
         if (args.isSet("-g")) args.print();
@@ -89,6 +246,8 @@ int main(int argc, const char* argv[]) {
         const size_t rng_seed = args.parse<size_t>("-R", 0);
         const int device = args.parse<int>("-device");
         const uint32_t chain = args.parse<uint32_t>("-chain");
+        const int nrChains = args.parse<int>("-chains");
+        if (nrChains < 1) throw std::runtime_error("Number of chains must be positive!");
 
         // states: "-s K", or "-s C P D": P emission parameters shared by P^D states over D data dimensions whose values
         // follow each other in the input (reference main.cpp:114-137)
@@ -178,89 +337,73 @@ int main(int argc, const char* argv[]) {
         if (inputValues.empty()) throw std::runtime_error("Cannot compute Haar breakpoint weights, vector is empty!");
         if (verbose) cout << "Calculating Haar breakpoint weights" << endl << flush;
 
-        // the device context: created once every argument has been parsed and the input has been read (and before
-        // `records`, whose destructor fetches the marginals from it)
-        rng_t RNG(rng_seed, device, chain);
-        Transitions<DirichletVector> A(nrStates, RNG);
-        Initial<Dirichlet> pi(nrStates, RNG);
-
-        Records records(T, opref, osuff, nrStates);
-        records.setRecordStateSequence(outputArgs.isSet("sequences"), overwrite);
-        records.setRecordTheta(outputArgs.isSet("parameters"), overwrite);
-        records.setRecordBlocks(outputArgs.isSet("blocks"), overwrite);
-        records.setRecordCompression(outputArgs.isSet("compression"), overwrite);
-        records.setRecordMarginals(outputArgs.isSet("marginals"), overwrite);
-        records.setRecordSegments(outputArgs.isSet("segments"), overwrite);
-        records.setRecordMaxSegmentation(outputArgs.isSet("maxsegmentation"), overwrite);
-
-        typedef Statistics<IntegralArray, Normal> S;
-        typedef Blocks<BreakpointArray> B;
-        S ia(inputValues, nrDataDim);          // upload + maxlet transform + weights + integral array (GPU)
-        B waveletBlocks(ia);
-        if (weightMultiplier != 1) waveletBlocks.scaleWeights(weightMultiplier);
-        Emissions<S, B> y(ia, waveletBlocks);
-        records.attach(y.ctx());
-
-        const double stdEstimate = ia.noiseEstimate();
-        thetaParams[0] = autoPrior(thetaParams[0][0], thetaParams[0][1], y, stdEstimate);
-        for (auto& p : thetaParams) p = thetaParams[0];
-        ThetaHyperParam<NormalInverseGammaParam> tau_theta(thetaParams);
-        Theta<NormalInverseGamma> theta(tau_theta, tau_A, tau_pi, useSelfTrans, RNG);
-
-        // ---- sampling scheme (reference main.cpp:368-454)
-        size_t nrTokens = 0;
-        for (const string& c : args.tokens("-i"))
-            if (c != "P" && c != "S" && c != "D") nrTokens++;
-        if (nrTokens % 3 != 0)
-            throw std::runtime_error("Parameters for -i, excluding \"P\", \"S\" and \"D\", must be multiples of 3!");
-        nrTokens = args.nrTokens("-i");
-
-        bool samplePrior = true;
-        bool dynamic = true;
-        if (verbose) cout << "Setting block structure to dynamic" << endl << flush;
-        for (size_t i = 0; i < nrTokens;) {
-            const string method = args.parse<string>("-i", i);
-            if (samplePrior) {
-                if (verbose) cout << "Sampling prior" << endl << flush;
-                hml_check(hml_sample_prior(RNG.ctx()));
-                samplePrior = false;
-            }
-            size_t iterations = 0, thinning = 0;
-            if (method == "P") {
-                samplePrior = true;
-                i++;
-                continue;
-            } else if (method == "S") {
-                if (verbose) cout << "Setting block structure to static" << endl << flush;
-                y.createBlocks(theta);
-                dynamic = false;
-                i++;
-                continue;
-            } else if (method == "D") {
-                if (verbose) cout << "Setting block structure to dynamic" << endl << flush;
-                dynamic = true;   // (sampleHMM switches the device back to per-sweep recompression)
-                i++;
-                continue;
-            } else {
-                if (i + 2 >= nrTokens) throw std::runtime_error("Incomplete command line for -i!");
-                iterations = args.parse<size_t>("-i", i + 1);
-                thinning = args.parse<size_t>("-i", i + 2);
-                i += 3;
-            }
-            if (method == "F") {
-                if (verbose) cout << "Sampling Forward-Backward" << endl << flush;
-                StateSequence<ForwardBackward> q(RNG);
-                sampleHMM(y, q, theta, tau_theta, A, tau_A, pi, tau_pi, mapping, iterations, thinning, records, dynamic, useSelfTrans);
-            } else if (method == "M") {
-                if (verbose) cout << "Sampling mixture" << endl << flush;
-                StateSequence<Mixture> q(RNG);
-                sampleHMM(y, q, theta, tau_theta, A, tau_A, pi, tau_pi, mapping, iterations, thinning, records, dynamic, useSelfTrans);
-            } else {
-                throw std::runtime_error("Unknown sampling type " + method + "!");
+        // ---- sampling scheme, read once (reference main.cpp:364-377 validates the triples before anything runs; an
+        // incomplete triple or an unknown method only fails when the loop reaches it, main.cpp:424-451)
+        {
+            size_t n = 0;
+            for (const string& c : args.tokens("-i"))
+                if (c != "P" && c != "S" && c != "D") n++;
+            if (n % 3 != 0) throw std::runtime_error("Parameters for -i, excluding \"P\", \"S\" and \"D\", must be multiples of 3!");
+        }
+        vector<Step> scheme;
+        {
+            const size_t nrTokens = args.nrTokens("-i");
+            for (size_t i = 0; i < nrTokens;) {
+                Step st;
+                st.method = args.parse<string>("-i", i);
+                if (st.method == "P" || st.method == "S" || st.method == "D") { i++; }
+                else if (i + 2 >= nrTokens) { st.incomplete = true; i = nrTokens; }
+                else {
+                    // (conversion errors surface here, before the first sweep; the reference parses them when the token is reached)
+                    st.iterations = args.parse<size_t>("-i", i + 1);
+                    st.thinning = args.parse<size_t>("-i", i + 2);
+                    i += 3;
+                }
+                scheme.push_back(st);
             }
         }
-        hml_check(hml_sync(RNG.ctx()));
-        records.close();
+
+        Job job;
+        job.T = T; job.nrDataDim = nrDataDim; job.nrStates = nrStates; job.seed = rng_seed;
+        job.opref = opref; job.osuff = osuff; job.overwrite = overwrite;
+        job.weightMultiplier = weightMultiplier; job.useSelfTrans = useSelfTrans;
+        job.thetaParams = thetaParams; job.trans = trans; job.selfTrans = selfTrans; job.initialAlpha = initialAlpha;
+        job.scheme = scheme;
+        for (const char* o : {"sequences", "parameters", "blocks", "compression", "marginals", "segments", "maxsegmentation"})
+            job.outputs[o] = outputArgs.isSet(o);
+
+        if (nrChains <= 1) {
+            // the device context is created once every argument has been parsed and the input has been read
+            runChain(job, inputValues, /*steal*/ true, device, chain, /*index*/ 0, verbose, nullptr);
+        } else {
+            // ---- chain-parallel (extension): chain k on GPU (device + k) mod #GPUs, each driven by its own host thread;
+            // nothing is exchanged while sampling; the recorded marginals are pooled by one all-reduce (RCCL) at the end
+            int nDev = 1;
+            hml_check(hml_device_count(&nDev));
+            Rendezvous rv(nrChains);
+            vector<std::thread> threads;
+            vector<std::exception_ptr> errors(nrChains);
+            for (int k = 0; k < nrChains; ++k)
+                threads.emplace_back([&, k] {
+                    try {
+                        runChain(job, inputValues, /*steal*/ false, (device + k) % nDev, chain + (uint32_t)k, k, verbose && k == 0, &rv);
+                    } catch (...) {
+                        errors[k] = std::current_exception();
+                        rv.abandon();
+                    }
+                });
+            // all chains have sampled (or one has failed): pool, then let them write their files
+            vector<hml_ctx*> ctxs = rv.waitForAll();
+            std::exception_ptr poolError;
+            if ((int)ctxs.size() == nrChains) {
+                if (verbose) cout << "Pooling the marginals of " << nrChains << " chains" << endl << flush;
+                try { hml_check(hml_allreduce_marginals(ctxs.data(), nrChains)); } catch (...) { poolError = std::current_exception(); }
+            }
+            rv.release(poolError == nullptr && (int)ctxs.size() == nrChains);
+            for (auto& t : threads) t.join();
+            for (auto& e : errors) if (e) std::rethrow_exception(e);
+            if (poolError) std::rethrow_exception(poolError);
+        }
         if (verbose) cout << "Exit HaMMLET" << endl << flush;
         return 0;
     } catch (std::exception& e) {

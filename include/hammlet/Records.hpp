@@ -33,7 +33,7 @@ class Records {
     std::string mPrefix, mSuffix;
     hml_ctx* mCtx = nullptr;
     bool mRecordMarginals = true, mRecordBlocks = false, mRecordCompression = false, mRecordSequences = false,
-         mRecordTheta = false, mRecordSegments = false, mRecordMaxSeg = false;
+         mRecordTheta = false, mRecordSegments = false, mRecordMaxSeg = false, mAccumulate = false;
     std::ofstream mMarginalsFile, mSequenceFile, mBlocksFile, mThetaFile, mCompressionsFile, mSegmentFile, mMaxSegFile;
     bool mClosed = false;
     std::set<uint32_t> mBoundaries;   // only maintained when the segments file is requested
@@ -67,7 +67,11 @@ public:
 
     void setRecordMaxSegmentation(bool b, bool overwrite = false) { setRecordX(mMaxSegFile, "maxsegmentation", mRecordMaxSeg, b, overwrite); }
 
-    bool recordsMarginals() const { return mRecordMarginals || mRecordMaxSeg; }
+    // chains whose marginals only feed a pool: accumulated on the device, written by another chain's Records
+    void setAccumulateMarginals(bool b) { mAccumulate = b; }
+    // give up the marginals files (a pooling step failed): they are closed empty
+    void discardMarginals() { mCtx = nullptr; mRecordMarginals = false; mRecordMaxSeg = false; }
+    bool recordsMarginals() const { return mRecordMarginals || mRecordMaxSeg || mAccumulate; }
     bool needsPerSweepData() const { return mRecordBlocks || mRecordCompression || mRecordSequences || mRecordTheta || mRecordSegments; }
 
     // one recorded sweep: Records::record(state, N) for every block in order (reference src/Records.hpp:155-235) ...

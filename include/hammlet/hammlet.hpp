@@ -64,7 +64,7 @@ inline void hml_check(int rc) {
 //    device draw: the first call that is not yet covered by a device draw triggers it, the other two are covered by it.
 class rng_t {
     hml_ctx* mCtx = nullptr;
-    static rng_t*& currentSlot() { static rng_t* cur = nullptr; return cur; }
+    static rng_t*& currentSlot() { static thread_local rng_t* cur = nullptr; return cur; }   // per host thread: one chain each
 
     // deferred model
     std::vector<real_t> mNig;
@@ -148,7 +148,7 @@ public:
 };
 
 // GPU index used by objects that exist before the chain's context does (the text reader); set by the driver.
-inline int& inputDevice() { static int dev = 0; return dev; }
+inline int& inputDevice() { static thread_local int dev = 0; return dev; }
 
 // readValues: every value that `while ( input >> v )` extracts (reference src/wavelet.hpp:131), converted on the GPU
 // chunk by chunk (hml_text_*; tokens the device cannot decide with proof go through the stream extraction on the host,
@@ -251,6 +251,14 @@ public:
         mSize = values.size() / nrDim;
         hml_check(hml_load_observations(mDev.ctx(), values.data(), values.size()));
         std::vector<real_t>().swap(values);
+    }
+    // several chains over the same observations (`hammlet -chains N`): the vector stays with the caller
+    enum KeepInput { keepInput };
+    Statistics(const std::vector<real_t>& values, const size_t nrDim, KeepInput) : mDev(rng_t::current()), mNrDim(nrDim) {
+        if (values.empty()) throw std::runtime_error("Input vector for breakpoint weights is empty!");
+        if (nrDim > 1) hml_check(hml_set_dimensions(mDev.ctx(), (int)nrDim, 0));
+        mSize = values.size() / nrDim;
+        hml_check(hml_load_observations(mDev.ctx(), values.data(), values.size()));
     }
     // the reference's shape (src/main.cpp:340, src/Statistics/IntegralArray.hpp:136-191): the per-position statistics
     // MaxletTransform produced (swap-stolen).  The device already holds the integral arrays when MaxletTransform put

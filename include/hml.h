@@ -39,6 +39,8 @@ const char* hml_last_error(void);
 /* Library/ABI version and the GPU architecture the kernels were compiled for ("gfx950"). */
 uint32_t hml_abi_version(void);
 const char* hml_device_arch(void);
+/* number of GPUs this process can use (hipGetDeviceCount) */
+int hml_device_count(int* n);
 
 /* rng_t RNG(seed) (src/main.cpp:107-108) + one chain's device state.  `stream` may be NULL
  * (a private stream is created) or a hipStream_t owned by the caller. */
@@ -236,8 +238,8 @@ typedef struct {
 int hml_get_stats(hml_ctx* ctx, hml_stats* out);
 
 /* HIP-event timing of one named kernel family accumulated since the last reset (milliseconds and
- * launches); name is one of "blocks_compact", "block_stats", "emission", "forward", "backward",
- * "counts", "params", "marginals", "blocks_offsets".  level 0 = off, 1 = only the dominant kernel
+ * launches); name is one of "blocks_compact", "blocks_scatter", "block_stats", "stats_emission", "emission", "forward",
+ * "backward_maps", "backward_chain", "mixture", "counts", "params", "marginals", "event_null".  level 0 = off, 1 = only the dominant kernel
  * ("blocks_compact", two events per sweep), 2 = every family. */
 int hml_profile_enable(hml_ctx* ctx, int level);
 int hml_profile_get(hml_ctx* ctx, const char* name, double* total_ms, uint64_t* launches);

@@ -82,3 +82,44 @@ def test_cli_multivariate_files_equal_checker_files(P, D, T, flags):
     for name, (g, o) in res.items():
         assert g == o, name
     assert len(res["parameters"][0].splitlines()[0].split("\t")) == 2 * P
+
+
+def test_cli_chains_pools_marginals_over_rccl(tmp_path):
+    """`hammlet -chains 3` (extension): three independent chains (Philox sub-keys 0, 1, 2) in their own host threads, the
+    recorded marginals pooled by hml_allreduce_marginals (RCCL) before PREFIXmarginalsSUFFIX is written.  Expected result
+    from three single-chain runs of the same driver: relabel each by ascending last mean, sum the dense counts, cut at
+    the union of the boundaries."""
+    from hammlet_amd import chains
+    T, K = 50000, 3
+    x = ol.trace(T, K, 6)
+    raw = str(tmp_path / "in.f32")
+    x.tofile(raw)
+    common = ["-raw", raw, "-a", "-s", str(K), "-R", "5", "-i", "F", "40", "4", "-w"]
+    r = subprocess.run([CLI] + common + ["-chains", "3", "-o", str(tmp_path / "pool-"), ".csv", "-O", "marginals", "parameters", "maxsegmentation"],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    dense = np.zeros((K, T), np.int64)
+    bnd = np.zeros(T, np.int64)
+    for k in range(3):
+        pre = str(tmp_path / ("one%d-" % k))
+        s = subprocess.run([CLI] + common + ["-chain", str(k), "-o", pre, ".csv", "-O", "marginals", "parameters"], capture_output=True, text=True)
+        assert s.returncode == 0, s.stderr
+        # the pooled run's per-chain side files are those of the single-chain runs
+        side = "pool-parameters.csv" if k == 0 else "pool-chain%d.parameters.csv" % k
+        assert open(str(tmp_path / side)).read() == open(pre + "parameters.csv").read()
+        rows = [list(map(int, l.split("\t"))) for l in open(pre + "marginals.csv").read().strip().split("\n")]
+        last = [float(v) for v in open(pre + "parameters.csv").read().strip().split("\n")[-1].split("\t")]
+        perm = chains.relabel_permutation(np.array(last[0::2], np.float32))
+        seg = np.array([r_[0] for r_ in rows])
+        cnt = np.array([r_[1:] + [0] * (K + 1 - len(r_)) for r_ in rows])
+        starts = np.concatenate([[0], np.cumsum(seg)[:-1]])
+        dense += np.repeat(cnt, seg, axis=0).T[perm]
+        bnd[starts] = 1
+    starts = np.flatnonzero(bnd)
+    seg = np.diff(np.append(starts, T))
+    cols = int(np.flatnonzero(dense.any(axis=1)).max()) + 1
+    want = "".join("%d\t%s\n" % (n, "\t".join(str(v) for v in dense[:cols, s])) for n, s in zip(seg, starts))
+    got = open(str(tmp_path / "pool-marginals.csv")).read()
+    assert got == want
+    assert all(sum(map(int, l.split("\t")[1:])) == 30 for l in got.strip().split("\n"))
+    assert open(str(tmp_path / "pool-maxsegmentation.csv")).read() == ol.max_segmentation_text(got)
