@@ -38,6 +38,8 @@
 #include "../hammlet_amd/csrc/hml_math.h"
 #include "../hammlet_amd/csrc/hml_philox.h"
 
+#include "philox_seq_engine.hpp"
+
 namespace hml_oracle {
 
 enum RngMode { RNG_MT19937 = 0, RNG_PHILOX_SEQ = 1, RNG_CTR = 2, RNG_MT19937_RESTATED = 3 };
@@ -47,21 +49,6 @@ enum ReduceMode { REDUCE_REF = 0, REDUCE_DEV = 1 };
 // fixed geometry of the device-order reduction (must equal the constants in the HIP kernels)
 static const int kReduceChunk = 256;    // blocks per chunk
 static const int kReduceGroups = 1024;  // chunk c is accumulated by group c % kReduceGroups
-
-// A sequential 32-bit engine whose n-th output is word n of Philox sub-stream (kind 0).
-struct PhiloxSeqEngine {
-    typedef uint32_t result_type;
-    hml_key key;
-    uint64_t n;
-    hml_u32x4 buf;
-    explicit PhiloxSeqEngine(uint64_t seed = 0) : key(hml_make_key(seed, 0)), n(0) {}
-    static constexpr result_type min() { return 0; }
-    static constexpr result_type max() { return 0xffffffffu; }
-    result_type operator()() {
-        if ((n & 3) == 0) buf = hml_philox4x32_10((uint32_t)(n >> 2), (uint32_t)(n >> 34), 0, 0, key.k0, key.k1);
-        return buf.v[n++ & 3];
-    }
-};
 
 struct libm_math {
     static float logf_(float x) { return std::log(x); }
