@@ -30,6 +30,15 @@ static thread_local std::string g_err;
 int hml_set_err(int code, const std::string& msg) { g_err = msg; return code; }
 static int set_err(int code, const std::string& msg) { return hml_set_err(code, msg); }
 
+// -DHML_ONLY_K=5: development builds that instantiate the sweep for one number of states only (the full library takes
+// minutes to compile; tools/dev_build.py)
+#ifdef HML_ONLY_K
+#define HML_DISPATCH_K(KV, ...)                                                   \
+    switch (KV) {                                                                 \
+        case HML_ONLY_K: { constexpr int KK = HML_ONLY_K; __VA_ARGS__; } break;   \
+        default: return set_err(HML_ERR_ARG, "this development build only knows one number of states"); \
+    }
+#else
 #define HML_DISPATCH_K(KV, ...)                                                   \
     switch (KV) {                                                                 \
         case 2: { constexpr int KK = 2; __VA_ARGS__; } break;                     \
@@ -49,6 +58,7 @@ static int set_err(int code, const std::string& msg) { return hml_set_err(code, 
         case 16: { constexpr int KK = 16; __VA_ARGS__; } break;                   \
         default: return set_err(HML_ERR_ARG, "number of states must be in [2,16]"); \
     }
+#endif
 
 // Live contexts per device.  The fused block kernel hands block offsets from workgroup to workgroup inside one launch
 // (a workgroup spins on the words of lower-numbered ones); that is safe while all lower-numbered workgroups are resident
@@ -250,8 +260,8 @@ static int create_inner(hml_ctx* c, void* stream) {
     else { HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)); c->own_stream = true; }
     HIPCHK(hipMalloc(&c->d_mdl, sizeof(hml_model)));
     HIPCHK(hipMemsetAsync(c->d_mdl, 0, sizeof(hml_model), c->stream));
-    HIPCHK(hipHostMalloc(&c->h_B, sizeof(uint32_t), hipHostMallocMapped));
-    *c->h_B = 0;
+    HIPCHK(hipHostMalloc(&c->h_B, 2 * sizeof(uint32_t), hipHostMallocMapped));
+    c->h_B[0] = 0; c->h_B[1] = 0;
     HIPCHK(hipHostGetDevicePointer((void**)&c->d_hB, c->h_B, 0));
     return 0;
 }
@@ -276,7 +286,8 @@ int hml_create(hml_ctx** out, int device, uint64_t seed, uint32_t chain_id, void
     if (const char* e = getenv("HML_DENSE_MIN_BLOCKS")) c->dense_min_blocks = (uint32_t)strtoul(e, nullptr, 10);
     if (const char* e = getenv("HML_USE_GRAPH")) c->use_graph = atoi(e) != 0;
     if (const char* e = getenv("HML_WEIGHT_KEYS")) c->use_keys = atoi(e) != 0;
-    if (const char* e = getenv("HML_FUSED_BLOCKS")) c->fused_blocks = atoi(e) != 0;   // 0: a GPU shared with other processes
+    if (const char* e = getenv("HML_FUSED_BLOCKS")) { c->fused_blocks = atoi(e) != 0; c->fused_keep = atoi(e) == 2; }   // 0: a GPU shared with other processes
+    if (const char* e = getenv("HML_FUSED_SPIN_LIMIT")) c->fused_spin_limit = (uint32_t)strtoul(e, nullptr, 10);
     if (device < 64) g_live_ctx[device].fetch_add(1);
     *out = c;
     return 0;
@@ -285,7 +296,7 @@ int hml_create(hml_ctx** out, int device, uint64_t seed, uint32_t chain_id, void
 static bool shares_device(const hml_ctx* c) { return c->device < 64 && g_live_ctx[c->device].load() > 1; }
 
 static void free_all(hml_ctx* c) {
-    void* ptrs[] = {c->d_group_word, c->d_launch_gen, c->d_summary, c->d_w, c->d_coeff, c->d_ia, c->d_stage, c->d_span_count, c->d_starts, c->d_bstat,
+    void* ptrs[] = {c->d_group_word, c->d_summary, c->d_w, c->d_coeff, c->d_ia, c->d_stage, c->d_span_count, c->d_starts, c->d_bstat,
                     c->d_em, c->d_gsc, c->d_rows, c->d_eprobe, c->d_aprobe, c->d_entry, c->d_exitA, c->d_redo, c->d_touched, c->d_fb, c->d_coarse1,
                     c->d_smap, c->d_cmap, c->d_scmap, c->d_super, c->d_bentry2, c->d_bentry, c->d_q, c->d_partial, c->d_diff, c->d_boundary, c->d_mdl};
     for (void* p : ptrs) if (p) hipFree(p);
@@ -338,7 +349,7 @@ static int build_from_device_x(hml_ctx* c, const float* const* d_x, const float*
     const int D = c->D;
     {   // what an earlier load that failed half-way may have left behind
         void** stale[] = {(void**)&c->d_w, (void**)&c->d_coeff, (void**)&c->d_ia, (void**)&c->d_summary, (void**)&c->d_stage, (void**)&c->d_span_count,
-                          (void**)&c->d_starts, (void**)&c->d_coarse1, (void**)&c->d_group_word, (void**)&c->d_launch_gen, (void**)&c->d_bstat};
+                          (void**)&c->d_starts, (void**)&c->d_coarse1, (void**)&c->d_group_word, (void**)&c->d_bstat};
         for (void** q : stale) if (*q) { hipFree(*q); *q = nullptr; }
     }
     // noise estimate (src/main.cpp:303-311): f64 accumulation, in index order, of the finest-level
@@ -422,11 +433,9 @@ static int build_from_device_x(hml_ctx* c, const float* const* d_x, const float*
     HIPCHK(hipMalloc(&c->d_starts, (T + 1) * sizeof(uint32_t)));
     HIPCHK(hipMalloc(&c->d_coarse1, ((c->n_spans + HML_GROUP_SPANS - 1) / HML_GROUP_SPANS + 1u) * sizeof(uint32_t)));
     {
-        const uint64_t n_groups = (c->n_spans + HML_GROUP_SPANS - 1) / HML_GROUP_SPANS;
-        HIPCHK(hipMalloc(&c->d_group_word, (n_groups + 1) * sizeof(unsigned long long)));
-        HIPCHK(hipMalloc(&c->d_launch_gen, sizeof(uint32_t)));
-        HIPCHK(hipMemsetAsync(c->d_group_word, 0, (n_groups + 1) * sizeof(unsigned long long), c->stream));
-        HIPCHK(hipMemsetAsync(c->d_launch_gen, 0, sizeof(uint32_t), c->stream));
+        const uint64_t n_tiles = (T + HML_FUSED_SUB_POSITIONS - 1) / HML_FUSED_SUB_POSITIONS;   // (tiles of one batch: the most there can be)
+        HIPCHK(hipMalloc(&c->d_group_word, (n_tiles + 1) * sizeof(unsigned long long)));
+        HIPCHK(hipMemsetAsync(c->d_group_word, 0, (n_tiles + 1) * sizeof(unsigned long long), c->stream));
         if (getenv("HML_FUSED_DEBUG")) { HIPCHK(hipMalloc(&c->d_dbg, 4096 * 4 * 8)); HIPCHK(hipMemset(c->d_dbg, 0, 4096 * 4 * 8)); }
     }
     HIPCHK(hipMalloc(&c->d_bstat, T * (uint64_t)D * sizeof(float2)));
@@ -799,6 +808,31 @@ static int ensure_marginal_buffers(hml_ctx* c) {
 
 int hml_ctx_ensure_marginal_buffers(hml_ctx* c) { return ensure_marginal_buffers(c); }
 
+// Tile size and grid of the fused block kernel: the smallest number of 2^17-position batches per workgroup with which
+// the whole grid is resident at once (the workgroups wait for lower-numbered ones inside the launch).  False when even
+// the largest tile does not fit: those traces take the scan + scatter launches.
+template <int KK>
+static bool fused_geometry(hml_ctx* c, uint32_t* n_sub, uint32_t* n_wg) {
+    if (c->fused_slots == 0) {
+        int per_cu = 0, cus = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, hml_k_blocks_fused<KK>, HML_FUSED_WAVES * 64, 0) != hipSuccess ||
+            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device) != hipSuccess || per_cu <= 0 || cus <= 0) {
+            (void)hipGetLastError();
+            c->fused_slots = -1;
+        } else {
+            c->fused_slots = per_cu * cus;
+        }
+        if (const char* e = getenv("HML_FUSED_SLOTS")) c->fused_slots = atoi(e);   // (tests: force larger tiles / an oversized grid)
+    }
+    if (c->fused_slots <= 0) return false;
+    const uint64_t batches = (c->T + HML_FUSED_SUB_POSITIONS - 1) / HML_FUSED_SUB_POSITIONS;
+    const uint64_t m = (batches + (uint64_t)c->fused_slots - 1) / (uint64_t)c->fused_slots;
+    if (m > HML_FUSED_MAX_SUB) return false;
+    *n_sub = (uint32_t)m;
+    *n_wg = (uint32_t)((c->T + m * HML_FUSED_SUB_POSITIONS - 1) / (m * HML_FUSED_SUB_POSITIONS));
+    return true;
+}
+
 template <int KK>
 static int sweep_k(hml_ctx* c, char method, bool record) {
     hipStream_t s = c->stream;
@@ -825,13 +859,18 @@ static int sweep_k(hml_ctx* c, char method, bool record) {
     const int L = dense_geo ? c->fwdL_dense : c->fwdL;
     const hml_layout lay = dense_geo ? c->lay_dense : c->lay;
     if (c->dynamic || !c->blocks_valid) {
-        if (c->D == 1 && c->use_keys && c->fused_blocks && !shares_device(c) && !(!c->summary_always && c->B_hint && (uint64_t)c->B_hint * 24u > c->T)) {
-            // K4 + K5 + K6a in one launch (hml_k_blocks_fused.h); weak compression takes the float stream below
+        // the fused block kernel: univariate chains that have the GPU to themselves, unless compression is weak (the
+        // float stream is the better access pattern then), the kernel reported a bounded wait that expired (someone
+        // else is using the GPU: h_B[1]), or the trace is too long for a resident grid (hml_fused_geometry)
+        uint32_t n_sub = 0u, n_wg = 0u;
+        if (c->h_B[1] && !c->fused_keep) c->fused_blocks = false;
+        if (c->D == 1 && c->use_keys && c->fused_blocks && !shares_device(c) &&
+            !(!c->summary_always && c->B_hint && (uint64_t)c->B_hint * 24u > c->T) && fused_geometry<KK>(c, &n_sub, &n_wg)) {
+            // K4 + K5 + K6a in one launch (hml_k_blocks_fused.h)
             ProfScope ps(c, "blocks_compact", 1);
-            const uint32_t n_wg = (uint32_t)(((uint64_t)T + HML_FUSED_POSITIONS - 1) / HML_FUSED_POSITIONS);
             hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_blocks_fused<KK>), dim3(n_wg), dim3(HML_FUSED_WAVES * 64), 0, s, c->d_summary, c->d_w, c->d_ia,
-                               T, c->d_mdl, c->key_base, c->d_group_word, c->d_launch_gen, c->d_starts, c->d_bstat, c->d_em,
-                               c->d_gsc, c->probes ? c->d_eprobe : nullptr, mix ? 1 : 0, lay, c->d_hB, c->d_dbg);
+                               T, c->d_mdl, c->key_base, c->d_group_word, c->d_stage, c->d_starts, c->d_bstat, c->d_em,
+                               c->d_gsc, c->probes ? c->d_eprobe : nullptr, mix ? 1 : 0, lay, c->d_hB, n_sub, c->fused_spin_limit, c->d_dbg, c->d_mdl);
             fused = true;
         } else {
             launch_compact_pair(c, 0, 0.0f);
@@ -1013,6 +1052,7 @@ int hml_set_option(hml_ctx* c, const char* name, int value) {
     }
     if (std::string(name) == "fused_blocks") {
         c->fused_blocks = value != 0;
+        c->fused_keep = value == 2;
         if (c->graph_exec) { hipGraphExecDestroy(c->graph_exec); c->graph_exec = nullptr; }
         return 0;
     }
@@ -1026,7 +1066,7 @@ int hml_sync(hml_ctx* c) {
     if (c->d_dbg) {
         std::vector<unsigned long long> h(4096 * 4);
         hipMemcpy(h.data(), c->d_dbg, h.size() * 8, hipMemcpyDeviceToHost);
-        const uint32_t n = (uint32_t)((c->T + HML_FUSED_POSITIONS - 1) / HML_FUSED_POSITIONS);
+        const uint32_t n = (uint32_t)std::min<uint64_t>(4096, (c->T + HML_FUSED_SUB_POSITIONS - 1) / HML_FUSED_SUB_POSITIONS);
         unsigned long long t0 = ~0ull; for (uint32_t i = 0; i < n; ++i) if (h[i * 4]) t0 = std::min(t0, h[i * 4]);
         double mx[4] = {0, 0, 0, 0}, av[4] = {0, 0, 0, 0};
         for (uint32_t i = 0; i < n; ++i) for (int k = 0; k < 4; ++k) { const double d = (double)(h[i * 4 + k] - t0) * 0.01; mx[k] = std::max(mx[k], d); av[k] += d / n; }
@@ -1359,6 +1399,7 @@ int hml_get_stats(hml_ctx* c, hml_stats* out) {
     out->sweeps = m.sweeps; out->block_updates = m.block_updates; out->uniform_fallbacks = m.uniform_fallbacks;
     out->forward_refits = m.forward_refits; out->forward_serial = m.forward_serial;
     out->forward_warmup = m.fwd_W;
+    out->fused_fallbacks = m.fused_fallbacks;
     return 0;
 }
 

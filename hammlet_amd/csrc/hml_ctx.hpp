@@ -46,8 +46,10 @@ struct hml_ctx {
     float2* d_bstat = nullptr;
     uint32_t n_spans = 0;
     uint32_t* d_coarse1 = nullptr;   // block count per group of HML_GROUP_SPANS spans
-    unsigned long long* d_group_word = nullptr;   // fused block kernel: {generation, starts, last start} per span group
-    uint32_t* d_launch_gen = nullptr;             // its launch generation
+    unsigned long long* d_group_word = nullptr;   // fused block kernel: {generation, starts, last start} per tile
+    int fused_slots = 0;                          // workgroups of it that are resident at once (occupancy x compute units; 0: not asked yet)
+    uint32_t fused_spin_limit = 4096;             // polls of a tile word before the waiting thread computes the word itself
+    bool fused_keep = false;                      // option fused_blocks = 2 (tests): keep the kernel after it reported trouble
     unsigned long long* d_dbg = nullptr;
     // hipGraph replay of a non-recording sweep (launch-bound inner loop); re-captured when the grid hint moves
     bool use_graph = false;
@@ -69,7 +71,8 @@ struct hml_ctx {
     int32_t* d_diff = nullptr;
     uint32_t* d_boundary = nullptr;
     hml_model* d_mdl = nullptr;
-    uint32_t* h_B = nullptr;        // pinned + mapped: the offsets kernel stores the block count here (grid sizing hint)
+    uint32_t* h_B = nullptr;        // pinned + mapped, two words: [0] the block count of the latest enumeration (grid sizing hint),
+                                    // [1] set by the fused block kernel when a bounded wait expired
     uint32_t* d_hB = nullptr;       // device view of h_B
     uint32_t B_hint = 0;
     bool hint_stale = true;         // the hint predates the current parameters (new model, prior draw, mode switch)

@@ -26,15 +26,15 @@ __device__ __forceinline__ bool hml_isfinite(float x) { return (hml_f2u(x) & 0x7
 template <int K>
 struct hml_emit_params {
     float mu[K], var[K], logN[K], logA[K];
+    double rvar[K];   // 1 / (2 var), from the model (computed once per parameter draw)
     bool self;
 };
 
 // (float)((2.0 mu Sx - Sxx) / (2.0 var)) - the reference's inner product (EFD.hpp:23-33), double inside - with the
 // quotient taken as a product with the double reciprocal: the product is within 2 ulp of the correctly rounded
 // quotient, so both round to the same float unless the product lies within 4 ulp of the midpoint of two floats (or is
-// tiny / not finite); only then is the division carried out.  Used by the tiled kernel of the weakly compressed
-// sweeps, where a lane converts hundreds of blocks; in the strongly compressed sweeps a lane converts one block and the
-// dependent reciprocal made the block kernel 2 us slower (measured), so hml_emit_block divides.
+// tiny / not finite); only then is the division carried out.  The reciprocal 1 / (2 var) comes from the model (the
+// parameter kernel computes it once per draw), so no lane pays for a division in the common case.
 __device__ __forceinline__ float hml_inner_product(float mu, float var, double rvar, float sx, float sq) {
     const double num = 2.0 * (double)mu * (double)sx - (double)sq;
     double ipd = num * rvar;
@@ -51,20 +51,19 @@ __device__ __forceinline__ float hml_inner_product(float mu, float var, double r
 template <int K>
 __device__ __forceinline__ void hml_emit_load(hml_emit_params<K>& p, const hml_model* mdl, int mixture) {
 #pragma unroll
-    for (int s = 0; s < K; ++s) { p.mu[s] = mdl->mu[s]; p.var[s] = mdl->var[s]; p.logN[s] = mdl->logN[s]; p.logA[s] = mdl->logA[s]; }
+    for (int s = 0; s < K; ++s) { p.mu[s] = mdl->mu[s]; p.var[s] = mdl->var[s]; p.logN[s] = mdl->logN[s]; p.logA[s] = mdl->logA[s]; p.rvar[s] = mdl->rvar2[s]; }
     p.self = mdl->self_trans != 0 && !mixture;
 }
 
+// the terms of one block in registers: E_s, e_s = expf(E_s - max E), g_s = expf((N-1) logA_s) (1 without self-transitions)
 template <int K>
-__device__ __forceinline__ void hml_emit_block(const hml_emit_params<K>& p, hml_model* mdl, uint32_t b, float sx, float sq,
-                                               float N, float* __restrict__ em, float* __restrict__ gsc,
-                                               float* __restrict__ eprobe, int mixture, const hml_layout lay) {
-    float E[K];
+__device__ __forceinline__ void hml_emit_compute(const hml_emit_params<K>& p, hml_model* mdl, float sx, float sq, float N, int mixture,
+                                                 float (&E)[K], float (&ev)[K], float (&gv)[K]) {
     float maxE = -3.40282346638528859812e+38f;   // numeric_limits<float>::lowest()
 #pragma unroll
     for (int s = 0; s < K; ++s) {
-        const double ipd = (2.0 * (double)p.mu[s] * (double)sx - (double)sq) / (2.0 * (double)p.var[s]);
-        const float ip = (float)ipd;
+        // (float)((2.0 mu Sx - Sxx) / (2.0 var)) through the reciprocal; divides only where the product could round differently
+        const float ip = hml_inner_product(p.mu[s], p.var[s], p.rvar[s], sx, sq);
         if (!hml_isfinite(ip)) hml_raise(mdl, HML_DEVERR_IP_NOT_FINITE, ip);
         float e = (0.0f + ip) - N * p.logN[s];
         if (p.self) e += (N - 1.0f) * p.logA[s];
@@ -73,10 +72,30 @@ __device__ __forceinline__ void hml_emit_block(const hml_emit_params<K>& p, hml_
     }
 #pragma unroll
     for (int s = 0; s < K; ++s) {
-        if (eprobe) eprobe[(uint64_t)b * K + s] = E[s];
-        em[hml_bk(lay, b, K, s)] = hml_expf(E[s] - maxE);
-        if (!mixture) gsc[hml_bk(lay, b, K, s)] = p.self ? hml_expf((N - 1.0f) * p.logA[s]) : 1.0f;
+        ev[s] = hml_expf(E[s] - maxE);
+        gv[s] = (!mixture && p.self) ? hml_expf((N - 1.0f) * p.logA[s]) : 1.0f;
     }
+}
+
+template <int K>
+__device__ __forceinline__ void hml_emit_store(uint32_t b, const float (&E)[K], const float (&ev)[K], const float (&gv)[K],
+                                               float* __restrict__ em, float* __restrict__ gsc, float* __restrict__ eprobe,
+                                               int mixture, const hml_layout lay) {
+#pragma unroll
+    for (int s = 0; s < K; ++s) {
+        if (eprobe) eprobe[(uint64_t)b * K + s] = E[s];
+        em[hml_bk(lay, b, K, s)] = ev[s];
+        if (!mixture) gsc[hml_bk(lay, b, K, s)] = gv[s];
+    }
+}
+
+template <int K>
+__device__ __forceinline__ void hml_emit_block(const hml_emit_params<K>& p, hml_model* mdl, uint32_t b, float sx, float sq,
+                                               float N, float* __restrict__ em, float* __restrict__ gsc,
+                                               float* __restrict__ eprobe, int mixture, const hml_layout lay) {
+    float E[K], ev[K], gv[K];
+    hml_emit_compute<K>(p, mdl, sx, sq, N, mixture, E, ev, gv);
+    hml_emit_store<K>(b, E, ev, gv, em, gsc, eprobe, mixture, lay);
 }
 
 template <int K>
@@ -226,9 +245,9 @@ __global__ __launch_bounds__(256) void hml_k_emission_tiled(const float2* __rest
     const uint32_t B = mdl->B;
     hml_emit_params<K> p;
     hml_emit_load<K>(p, mdl, mixture);
-    double rvar[K];   // once per lane: a lane converts hundreds of blocks in this regime
+    double rvar[K];
 #pragma unroll
-    for (int s = 0; s < K; ++s) rvar[s] = 1.0 / (2.0 * (double)p.var[s]);
+    for (int s = 0; s < K; ++s) rvar[s] = p.rvar[s];
     for (int i = threadIdx.x; i < GT * K; i += 256) {
         const int n1 = i / K, s = i % K;   // n - 1
         gtab[i] = hml_expf((float)n1 * mdl->logA[s]);

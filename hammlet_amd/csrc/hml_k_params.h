@@ -19,6 +19,7 @@ __device__ __forceinline__ void hml_derive(hml_model* mdl, int tid) {
     if (tid < P) {
         const float m = mdl->mu[tid], v = mdl->var[tid], sd = mdl->sd[tid];
         mdl->logN[tid] = hml_logf(sd) + m * m / (2 * v);
+        mdl->rvar2[tid] = 1.0 / (2.0 * (double)v);
     }
     if (tid < K) {
         // theta.logNormalizer(state): float sum over the state's parameters, in dimension order (Theta.hpp:148-158)
@@ -176,6 +177,7 @@ __global__ __launch_bounds__(1024) void hml_k_params(hml_model* __restrict__ mdl
         else if (v <= 0.0f) hml_raise(mdl, HML_DEVERR_VAR_NOT_POSITIVE, v);
         const float sd = HML_SQRTF(v);
         mdl->mu[k] = m; mdl->var[k] = v; mdl->sd[k] = sd;
+        mdl->rvar2[k] = 1.0 / (2.0 * (double)v);
         if (mode == 0) {   // hml_derive's logNormalizer, from the registers instead of a round trip through memory
             const float ln = hml_logf(sd) + m * m / (2 * v);
             mdl->logN[k] = ln;

@@ -62,6 +62,7 @@ struct hml_model {
     hml_key key;
     // ---- current parameters ----
     float mu[HML_MAX_K], var[HML_MAX_K], sd[HML_MAX_K];
+    double rvar2[HML_MAX_K];     // 1 / (2 var): the emission kernels multiply by it instead of dividing (hml_inner_product)
     float logN[HML_MAX_K];       // theta.logNormalizer(s)          (EFD.hpp:35-38)
     float logA[HML_MAX_K];       // log A(s,s)                       (ForwardBackward.hpp:47-52)
     float A[HML_MAX_K * HML_MAX_K];   // row-major, stride K
@@ -85,6 +86,7 @@ struct hml_model {
     // ---- counters ----
     unsigned long long epoch;
     unsigned long long sweeps, block_updates, uniform_fallbacks, forward_refits, forward_serial;
+    unsigned long long fused_fallbacks;   // words of the fused block kernel that a waiting workgroup had to compute itself
     unsigned long long n_recorded;
     int32_t max_state_recorded;
     // ---- errors ----

@@ -145,8 +145,11 @@ int hml_set_recording(hml_ctx* ctx, int marginals, hml_record_cb cb, void* user)
  * float weights.  Same block structures every way (exact). */
 int hml_set_option(hml_ctx* ctx, const char* name, int value);
 /* "fused_blocks" (any time), 1 (default): dynamic sweeps take the fused block kernel (block scan + block statistics +
- * emission terms in one launch; its workgroups hand block offsets to each other inside the launch); 0: always the
- * scan + scatter + statistics launches, which share nothing inside a launch.  Same results. */
+ * emission terms in one launch; its workgroups hand block offsets to each other inside the launch, with a bounded
+ * wait: when the GPU is shared and a wait expires the waiting workgroup computes the missing word itself, and the chain
+ * takes the other path from the next sweep on); 0: always the scan + scatter + statistics launches, which share
+ * nothing inside a launch - the setting for a GPU that several processes use; 2: like 1, but keep the kernel after an
+ * expired wait (tests).  Same results every way.  Environment: HML_FUSED_BLOCKS. */
 
 /* wait for all enqueued work; surfaces model errors raised on the device */
 int hml_sync(hml_ctx* ctx);
@@ -234,6 +237,7 @@ typedef struct {
     uint64_t forward_refits;    /* chunks whose speculative forward pass had to be redone  */
     uint64_t forward_serial;    /* chunks finished by the sequential fallback              */
     uint64_t forward_warmup;     /* current (adaptive) warm-up length of the speculative forward pass */
+    uint64_t fused_fallbacks;    /* tile words of the fused block kernel computed by a waiting workgroup (bounded wait expired) */
 } hml_stats;
 int hml_get_stats(hml_ctx* ctx, hml_stats* out);
 

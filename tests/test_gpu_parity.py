@@ -587,3 +587,59 @@ def test_fused_block_kernel_only_while_the_chain_has_the_gpu_to_itself(hml):
     b.close()
     assert scat_alone <= 1 and scat_shared >= 12          # (one enumeration ahead of the first sweep either way)
     assert np.array_equal(q_alone, q_shared) and np.array_equal(bits(th_alone), bits(th_shared))
+
+
+@pytest.mark.parametrize("slots,spin,weight_keys", [(1, None, 1), (2, None, 1), (3, None, 2), (100000, None, 1), (2, 0, 2), (100000, 0, 2), (1, 0, 1)])
+def test_fused_block_kernel_tile_sizes_and_bounded_wait(hml, monkeypatch, slots, spin, weight_keys):
+    """The fused block kernel sizes its tiles so that the grid is resident (HML_FUSED_SLOTS stands in for the occupancy
+    query: 1 -> one workgroup walks the whole trace in several batches, a huge value -> one batch per workgroup), and its
+    wait for the words of lower-numbered workgroups is bounded: with HML_FUSED_SPIN_LIMIT = 0 every word that is not
+    there at the first look is computed by the waiting thread itself (`fused_blocks` = 2 keeps the kernel in use
+    afterwards).  Every variant must give the checker's chain, bit for bit; depth data (compression ~1.4, weight_keys = 2)
+    makes the per-wavefront lists overflow into the staging array."""
+    monkeypatch.setenv("HML_FUSED_SLOTS", str(slots))
+    if spin is not None:
+        monkeypatch.setenv("HML_FUSED_SPIN_LIMIT", str(spin))
+    T, K = 400_003, 5
+    x = ol.synth_depth(T, seed=11) if weight_keys == 2 else ol.trace(T, K, 21)
+    o = ol.OracleChain(K=K, seed=5, rng=ol.RNG_CTR, math=ol.MATH_DEV, reduce=ol.REDUCE_DEV)
+    o.load(x)
+    g = hml.Chain(device=0, seed=5)
+    g.set_option("weight_keys", weight_keys)
+    g.set_option("fused_blocks", 2)
+    g.load(x)
+    setup_model(o, g, K)
+    g._pending_prior = True
+    o.set_record(marginals=True)
+    g.profile_enable(2)
+    run_both(o, g, [("F", 12, 3), ("M", 3, 1), ("F", 4, 2)])
+    g.profile_enable(0)
+    compare_state(o, g)
+    seg, cnt = g.marginals_rle()
+    assert hml.marginals_text(seg, cnt) == o.text("marginals")
+    assert g.profile_get("blocks_compact")[1] >= 19          # the fused kernel ran in (nearly) every sweep
+    assert g.profile_get("blocks_scatter")[1] <= 1
+    st = g.stats()
+    if spin == 0 and slots > 1:
+        assert st["fused_fallbacks"] > 0
+    if spin is None:
+        assert st["fused_fallbacks"] == 0
+
+
+def test_fused_block_kernel_retires_itself_after_an_expired_wait(hml, monkeypatch):
+    """default option (fused_blocks = 1): the first expired wait makes the chain take the scan + scatter launches from
+    the next sweep on - the situation of a GPU shared with another process"""
+    monkeypatch.setenv("HML_FUSED_SPIN_LIMIT", "0")
+    monkeypatch.setenv("HML_FUSED_SLOTS", "100000")
+    T, K = 400_003, 5
+    x, o, g = make_pair(hml, T, K, 21, 5)
+    setup_model(o, g, K)
+    g._pending_prior = True
+    g.profile_enable(2)
+    run_both(o, g, [("F", 10, 0)])
+    g.sync()
+    run_both(o, g, [("F", 10, 0)])
+    g.profile_enable(0)
+    compare_state(o, g)
+    assert g.stats()["fused_fallbacks"] > 0
+    assert g.profile_get("blocks_scatter")[1] >= 10
