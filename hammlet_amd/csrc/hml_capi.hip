@@ -953,6 +953,9 @@ static int sweep_k(hml_ctx* c, char method, bool record) {
             if (c->D > 1)
                 hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_counts<KK, true, true>), dim3(HML_REDUCE_GROUPS), dim3(256), 0, s, c->d_q,
                                    c->d_starts, c->d_bstat, c->d_mdl, c->d_partial, c->d_smap, c->d_bentry);
+            else if (dense_geo)   // hundreds of chunks per workgroup: one wavefront per chunk (same tree, bit for bit)
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_counts_dense<KK, true>), dim3(HML_REDUCE_GROUPS), dim3(256), 0, s, c->d_q,
+                                   c->d_starts, c->d_bstat, c->d_mdl, c->d_partial, c->d_smap, c->d_bentry);
             else
             hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_counts<KK, true>), dim3(HML_REDUCE_GROUPS), dim3(256), 0, s, c->d_q,
                                c->d_starts, c->d_bstat, c->d_mdl, c->d_partial, c->d_smap, c->d_bentry);
@@ -966,6 +969,10 @@ static int sweep_k(hml_ctx* c, char method, bool record) {
             ProfScope ps(c, "counts");
             if (c->D > 1)
                 hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_counts<KK, false, true>), dim3(HML_REDUCE_GROUPS), dim3(256), 0, s, c->d_q,
+                                   c->d_starts, c->d_bstat, c->d_mdl, c->d_partial, (const unsigned long long*)nullptr,
+                                   (const uint8_t*)nullptr);
+            else if (dense_geo)
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_counts_dense<KK, false>), dim3(HML_REDUCE_GROUPS), dim3(256), 0, s, c->d_q,
                                    c->d_starts, c->d_bstat, c->d_mdl, c->d_partial, (const unsigned long long*)nullptr,
                                    (const uint8_t*)nullptr);
             else

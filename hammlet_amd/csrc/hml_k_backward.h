@@ -321,15 +321,47 @@ __global__ __launch_bounds__(256) void hml_k_mixture(const float* __restrict__ e
 // K8 state_reduce - the count pass (reference src/StateSequence/ForwardBackward.hpp:170-200,
 // Mixture.hpp:113-128): K x K transition counts ([s][s] += N-1, [prev][s] += 1, prev_0 = 0),
 // occupancies, per-state (sum x, sum x^2, n).  Counts are exact integers (device atomics).  The
-// floating-point sums use a FIXED tree so that the result does not depend on scheduling:
-//   chunk (256 blocks, one workgroup pass) = 4 wavefront butterflies added in wavefront order,
-//   group g accumulates chunks g, g+1024, ... in order, the parameter kernel adds the 1024 groups
-//   in a pairwise tree.  Doubles throughout; the CPU checker mirrors the same tree.
+// floating-point sums use a FIXED tree so that the result does not depend on scheduling: block b belongs
+// to chunk c = b / 256, wavefront w = (b / 64) % 4, lane l = b % 64 and group g = c % 1024; accumulator
+// (g, w, l) adds its blocks' terms in increasing block order (registers, no cross-lane traffic in the
+// loop), then a pairwise tree over the 64 lanes, the four wavefronts in order, and - in the parameter
+// kernel - a pairwise tree over the 1024 groups.  Doubles throughout; the CPU checker mirrors the tree.
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ double hml_shfl_xor_f64(double v, int m) {
     const unsigned long long u = hml_d2u(v);
     const unsigned lo = __shfl_xor((unsigned)u, m), hi = __shfl_xor((unsigned)(u >> 32), m);
     return hml_u2d(((unsigned long long)hi << 32) | lo);
+}
+
+// Pairwise tree over the 64 lanes of a wavefront on DPP lane exchanges (pairs, quads, half rows, rows: the partner lane
+// always holds the sibling subtree's sum, and IEEE addition is commutative, so the result is exactly the tree
+// ((l0 + l1) + (l2 + l3)) + ... of the CPU checker), finished with the four row sums read into scalars.
+__device__ __forceinline__ double hml_dpp_f64(double v, int ctrl_quad1, int which) {
+    // lane exchange of a double through DPP: which = 0 quad_perm [1,0,3,2], 1 quad_perm [2,3,0,1], 2 row_half_mirror, 3 row_mirror
+    const unsigned long long u = hml_d2u(v);
+    int lo = (int)(unsigned)u, hi = (int)(unsigned)(u >> 32);
+    (void)ctrl_quad1;
+    switch (which) {
+        case 0: lo = __builtin_amdgcn_update_dpp(lo, lo, 0xB1, 0xF, 0xF, false); hi = __builtin_amdgcn_update_dpp(hi, hi, 0xB1, 0xF, 0xF, false); break;
+        case 1: lo = __builtin_amdgcn_update_dpp(lo, lo, 0x4E, 0xF, 0xF, false); hi = __builtin_amdgcn_update_dpp(hi, hi, 0x4E, 0xF, 0xF, false); break;
+        case 2: lo = __builtin_amdgcn_update_dpp(lo, lo, 0x141, 0xF, 0xF, false); hi = __builtin_amdgcn_update_dpp(hi, hi, 0x141, 0xF, 0xF, false); break;
+        default: lo = __builtin_amdgcn_update_dpp(lo, lo, 0x140, 0xF, 0xF, false); hi = __builtin_amdgcn_update_dpp(hi, hi, 0x140, 0xF, 0xF, false); break;
+    }
+    return hml_u2d(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo);
+}
+__device__ __forceinline__ double hml_readlane_f64(double v, int src) {
+    const unsigned long long u = hml_d2u(v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)u, src), hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(u >> 32), src);
+    return hml_u2d(((unsigned long long)hi << 32) | lo);
+}
+// pairwise tree over the 64 lanes (the value lane 0 of hml_k_counts' xor butterfly ends with), wave-uniform result
+__device__ __forceinline__ double hml_wave_tree_f64(double a) {
+    a = a + hml_dpp_f64(a, 0, 0);
+    a = a + hml_dpp_f64(a, 0, 1);
+    a = a + hml_dpp_f64(a, 0, 2);
+    a = a + hml_dpp_f64(a, 0, 3);
+    const double r0 = hml_readlane_f64(a, 0), r1 = hml_readlane_f64(a, 16), r2 = hml_readlane_f64(a, 32), r3 = hml_readlane_f64(a, 48);
+    return (r0 + r1) + (r2 + r3);
 }
 
 // FB = true: the states come straight from the backward maps (q_b = S_{b+1}(entry[chunk])) and are
@@ -351,7 +383,7 @@ __global__ __launch_bounds__(256) void hml_k_counts(int16_t* __restrict__ q, con
     for (int i = tid; i < K * K; i += 256) h_trans[i] = 0ull;
     if (tid < K) h_occ[tid] = 0ull;
     __syncthreads();
-    double acc_s[K], acc_q[K];   // only thread 0 uses them
+    double acc_s[K], acc_q[K];   // this lane's terms, accumulated in block order
 #pragma unroll
     for (int s = 0; s < K; ++s) { acc_s[s] = 0.0; acc_q[s] = 0.0; }
     // integer counts: every lane keeps, per state, the positions and blocks it saw in that state and the blocks that
@@ -365,7 +397,7 @@ __global__ __launch_bounds__(256) void hml_k_counts(int16_t* __restrict__ q, con
     // with one or two chunks per workgroup (strongly compressed sweeps) the fold at the end would cost more than it
     // saves: the counts then go straight to LDS
     const bool direct = nchunks <= 2u * HML_REDUCE_GROUPS;
-    // one chunk of loads ahead: the next chunk's words are requested before this chunk's reductions and barriers
+    // one chunk of loads ahead
     struct in_t { unsigned long long m1, m0; uint32_t e1, e0, s1, s0; float2 v; int16_t q1, q0; };
     auto fetch = [&](uint32_t c, in_t& r) {
         const uint32_t b = c * HML_REDUCE_CHUNK + (uint32_t)tid;
@@ -388,10 +420,8 @@ __global__ __launch_bounds__(256) void hml_k_counts(int16_t* __restrict__ q, con
         const uint32_t b = c * HML_REDUCE_CHUNK + (uint32_t)tid;
         const in_t cur = nxt;
         fetch(c + HML_REDUCE_GROUPS, nxt);
-        int st = -1;
-        double vx = 0.0, vq = 0.0;
         if (b < B) {
-            int prev;
+            int st, prev;
             if (FB) {
                 st = (int)((cur.m1 >> (4 * cur.e1)) & 15ull);
                 prev = (b == 0) ? 0 : (int)((cur.m0 >> (4 * cur.e0)) & 15ull);
@@ -401,8 +431,6 @@ __global__ __launch_bounds__(256) void hml_k_counts(int16_t* __restrict__ q, con
                 prev = (b == 0) ? 0 : (int)cur.q0;
             }
             const uint32_t n = cur.s1 - cur.s0;
-            const float2 v = cur.v;
-            vx = (double)v.x; vq = (double)v.y;
             if (direct) {
                 atomicAdd(&h_trans[st * K + st], (unsigned long long)(n - 1u));
                 atomicAdd(&h_trans[prev * K + st], 1ull);
@@ -414,51 +442,44 @@ __global__ __launch_bounds__(256) void hml_k_counts(int16_t* __restrict__ q, con
                 }
                 if (prev != st) atomicAdd(&h_trans[prev * K + st], 1ull);
             }
-        }
-        double mvx[HML_MAX_D], mvq[HML_MAX_D];
-        int mvmap[HML_MAX_D];
-        int nD = 1;
-        if (MV) {
-            nD = mdl->D;
-            for (int dd = 0; dd < HML_MAX_D; ++dd) { mvx[dd] = 0.0; mvq[dd] = 0.0; mvmap[dd] = -1; }
-            if (b < B) {
-                mvx[0] = vx; mvq[0] = vq;
-                for (int dd = 1; dd < nD; ++dd) { const float2 v2 = bstat[(uint64_t)dd * mdl->stat_stride + b]; mvx[dd] = (double)v2.x; mvq[dd] = (double)v2.y; }
-                for (int dd = 0; dd < nD; ++dd) mvmap[dd] = mdl->map[st][dd];
-            }
-        }
-#pragma unroll
-        for (int s = 0; s < K; ++s) {
-            double a = (st == s) ? vx : 0.0, d = (st == s) ? vq : 0.0;
             if (MV) {
-                a = 0.0; d = 0.0;
-                for (int dd = 0; dd < nD; ++dd) if (mvmap[dd] == s) { a = a + mvx[dd]; d = d + mvq[dd]; }
-            }
+                // the term for parameter p: the block's statistics of the dimensions mapped to p, added in dimension order
+                const int nD = mdl->D;
 #pragma unroll
-            for (int m = 1; m < 64; m <<= 1) {
-                a = a + hml_shfl_xor_f64(a, m);
-                d = d + hml_shfl_xor_f64(d, m);
+                for (int s = 0; s < K; ++s) {
+                    double ts = 0.0, tq = 0.0;
+                    bool any = false;
+                    for (int dd = 0; dd < nD; ++dd) {
+                        if (mdl->map[st][dd] == s) {
+                            const float2 v2 = (dd == 0) ? cur.v : bstat[(uint64_t)dd * mdl->stat_stride + b];
+                            ts = ts + (double)v2.x; tq = tq + (double)v2.y; any = true;
+                        }
+                    }
+                    if (any) { acc_s[s] = acc_s[s] + ts; acc_q[s] = acc_q[s] + tq; }
+                }
+            } else {
+                const double vx = (double)cur.v.x, vq = (double)cur.v.y;
+#pragma unroll
+                for (int s = 0; s < K; ++s)
+                    if (st == s) { acc_s[s] = acc_s[s] + vx; acc_q[s] = acc_q[s] + vq; }
             }
-            if (lane == 0) { wsum[wave][s][0] = a; wsum[wave][s][1] = d; }
         }
-        __syncthreads();
-        if (tid == 0) {
-#pragma unroll
-            for (int s = 0; s < K; ++s) {
-                double cs = 0.0, cq = 0.0;
-#pragma unroll
-                for (int wv = 0; wv < 4; ++wv) { cs = cs + wsum[wv][s][0]; cq = cq + wsum[wv][s][1]; }
-                acc_s[s] = acc_s[s] + cs;
-                acc_q[s] = acc_q[s] + cq;
-            }
-        }
-        __syncthreads();
     }
+    // the tree: pairwise over the 64 lanes of a wavefront, the four wavefronts in order
+#pragma unroll
+    for (int s = 0; s < K; ++s) {
+        const double a = hml_wave_tree_f64(acc_s[s]), d = hml_wave_tree_f64(acc_q[s]);
+        if (lane == 0) { wsum[wave][s][0] = a; wsum[wave][s][1] = d; }
+    }
+    __syncthreads();
     if (tid == 0) {
 #pragma unroll
         for (int s = 0; s < K; ++s) {
-            partial[((uint64_t)g * K + s) * 2 + 0] = acc_s[s];
-            partial[((uint64_t)g * K + s) * 2 + 1] = acc_q[s];
+            double cs = 0.0, cq = 0.0;
+#pragma unroll
+            for (int wv = 0; wv < 4; ++wv) { cs = cs + wsum[wv][s][0]; cq = cq + wsum[wv][s][1]; }
+            partial[((uint64_t)g * K + s) * 2 + 0] = cs;
+            partial[((uint64_t)g * K + s) * 2 + 1] = cq;
         }
     }
     // fold the per-lane counters: wavefront sums, then one LDS update per wavefront and state
@@ -479,6 +500,122 @@ __global__ __launch_bounds__(256) void hml_k_counts(int16_t* __restrict__ q, con
             atomicAdd(&h_trans[s * K + s], np - (unsigned long long)nb + (unsigned long long)ns);
         }
     }
+    }
+    __syncthreads();
+    const int slot = (int)(g % HML_CNT_SPLIT);
+    for (int i = tid; i < K * K; i += 256)
+        if (h_trans[i]) atomicAdd(&mdl->trans[slot][i], h_trans[i]);
+    if (tid < K && h_occ[tid]) atomicAdd(&mdl->occ[slot][tid], h_occ[tid]);
+}
+
+// ------------------------------------------------------------------------------------------
+// K8 for sweeps with many blocks (weakly compressed input: hundreds of 256-block chunks per workgroup), univariate: the
+// same sums and the same tree as hml_k_counts, as a streaming loop - per-lane integer counters always (registers;
+// changes of state - rare - in LDS), loads one chunk ahead, nothing but the lane's own accumulators in the loop.
+// ------------------------------------------------------------------------------------------
+template <int K, bool FB>
+__global__ __launch_bounds__(256) void hml_k_counts_dense(int16_t* __restrict__ q, const uint32_t* __restrict__ starts,
+                                                          const float2* __restrict__ bstat, hml_model* __restrict__ mdl,
+                                                          double* __restrict__ partial /*[GROUPS][K][2]*/,
+                                                          const unsigned long long* __restrict__ smap,
+                                                          const uint8_t* __restrict__ entry) {
+    __shared__ unsigned long long h_trans[K * K];
+    __shared__ unsigned long long h_occ[K];
+    __shared__ double wsum[4][K][2];
+    const uint32_t B = mdl->B;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t g = blockIdx.x;
+    for (int i = tid; i < K * K; i += 256) h_trans[i] = 0ull;
+    if (tid < K) h_occ[tid] = 0ull;
+    __syncthreads();
+    double acc_s[K], acc_q[K];   // this lane's terms, accumulated in block order
+#pragma unroll
+    for (int s = 0; s < K; ++s) { acc_s[s] = 0.0; acc_q[s] = 0.0; }
+    unsigned long long n_pos[K];
+    uint32_t n_blk[K], n_stay[K];
+#pragma unroll
+    for (int s = 0; s < K; ++s) { n_pos[s] = 0ull; n_blk[s] = 0u; n_stay[s] = 0u; }
+    const uint32_t nchunks = (B + HML_REDUCE_CHUNK - 1u) / HML_REDUCE_CHUNK;
+    struct in_t { unsigned long long m1, m0; uint32_t e1, e0, s1, s0; float2 v; int16_t q1, q0; };
+    auto fetch = [&](uint32_t b, in_t& r) {
+        r.m1 = r.m0 = 0ull; r.e1 = r.e0 = 0u; r.s1 = r.s0 = 0u; r.v = make_float2(0.0f, 0.0f); r.q1 = r.q0 = 0;
+        if (b < B) {
+            if (FB) {
+                r.m1 = smap[b + 1]; r.e1 = entry[b / HML_BWD_CHUNK];
+                if (b != 0) { r.m0 = smap[b]; r.e0 = entry[(b - 1) / HML_BWD_CHUNK]; }
+            } else {
+                r.q1 = q[b];
+                if (b != 0) r.q0 = q[b - 1];
+            }
+            r.s1 = starts[b + 1]; r.s0 = starts[b];
+            r.v = bstat[b];
+        }
+    };
+    // workgroup g owns chunks g, g + GROUPS, g + 2 GROUPS, ...; wavefront w streams quarter w of each of them, every lane
+    // adding its block's term to its own accumulator - no tree, no barrier in the loop
+    {
+        in_t nxt;
+        fetch(g * HML_REDUCE_CHUNK + (uint32_t)tid, nxt);
+        for (uint32_t c = g; c < nchunks; c += HML_REDUCE_GROUPS) {
+            const uint32_t b = c * HML_REDUCE_CHUNK + (uint32_t)tid;
+            const in_t cur = nxt;
+            if (c + HML_REDUCE_GROUPS < nchunks) fetch(b + HML_REDUCE_GROUPS * HML_REDUCE_CHUNK, nxt);
+            if (b < B) {
+                int st, prev;
+                if (FB) {
+                    st = (int)((cur.m1 >> (4 * cur.e1)) & 15ull);
+                    prev = (b == 0) ? 0 : (int)((cur.m0 >> (4 * cur.e0)) & 15ull);
+                    q[b] = (int16_t)st;
+                } else {
+                    st = cur.q1;
+                    prev = (b == 0) ? 0 : (int)cur.q0;
+                }
+                const uint32_t n = cur.s1 - cur.s0;
+                const double vx = (double)cur.v.x, vq = (double)cur.v.y;
+#pragma unroll
+                for (int s = 0; s < K; ++s) {
+                    if (st == s) {
+                        n_pos[s] += (unsigned long long)n; n_blk[s] += 1u;
+                        if (prev == s) n_stay[s] += 1u;
+                        acc_s[s] = acc_s[s] + vx; acc_q[s] = acc_q[s] + vq;
+                    }
+                }
+                if (prev != st) atomicAdd(&h_trans[prev * K + st], 1ull);
+            }
+        }
+    }
+#pragma unroll
+    for (int s = 0; s < K; ++s) {
+        const double a = hml_wave_tree_f64(acc_s[s]), d = hml_wave_tree_f64(acc_q[s]);
+        if (lane == 0) { wsum[wave][s][0] = a; wsum[wave][s][1] = d; }
+    }
+    __syncthreads();
+    if (tid == 0) {
+#pragma unroll
+        for (int s = 0; s < K; ++s) {
+            double cs = 0.0, cq = 0.0;
+#pragma unroll
+            for (int wv = 0; wv < 4; ++wv) { cs = cs + wsum[wv][s][0]; cq = cq + wsum[wv][s][1]; }
+            partial[((uint64_t)g * K + s) * 2 + 0] = cs;
+            partial[((uint64_t)g * K + s) * 2 + 1] = cq;
+        }
+    }
+    // fold the per-lane counters: wavefront sums, then one LDS update per wavefront and state
+#pragma unroll
+    for (int s = 0; s < K; ++s) {
+        unsigned long long np = n_pos[s];
+        uint32_t nb = n_blk[s], ns = n_stay[s];
+#pragma unroll
+        for (int m = 1; m < 64; m <<= 1) {
+            const uint32_t lo = __shfl_xor((uint32_t)np, m), hi = __shfl_xor((uint32_t)(np >> 32), m);
+            np += ((unsigned long long)hi << 32) | lo;
+            nb += __shfl_xor(nb, m);
+            ns += __shfl_xor(ns, m);
+        }
+        if (lane == 0) {
+            atomicAdd(&h_occ[s], np);
+            atomicAdd(&h_trans[s * K + s], np - (unsigned long long)nb + (unsigned long long)ns);
+        }
     }
     __syncthreads();
     const int slot = (int)(g % HML_CNT_SPLIT);

@@ -732,32 +732,45 @@ public:
             }
             for (int pp = 0; pp < P; ++pp) { sum_s[pp] = st[pp].sum(); sum_q[pp] = st[pp].sumSq(); }
         } else {
-            // device order: chunk partials (pairwise tree over 64-lane groups, 4 groups per chunk in order),
-            // groups accumulate their chunks in increasing order, final pairwise tree over groups.  A lane's term for
-            // parameter p is the sum, in dimension order, of the block's statistics of the dimensions mapped to p.
+            // device order (hml_k_counts): block b belongs to chunk c = b / 256, wavefront w = (b / 64) % 4, lane l = b % 64 and
+            // group g = c % 1024.  Accumulator (g, w, l) adds the terms of its blocks in increasing block order (a lane's
+            // term for parameter p is the sum, in dimension order, of the block's statistics of the dimensions mapped to
+            // p; blocks in other states add nothing); then a pairwise tree over the 64 lanes, the four wavefronts in
+            // order, and a final pairwise tree over the groups.
             const size_t nchunks = (B + kReduceChunk - 1) / kReduceChunk;
             std::vector<double> gs((size_t)kReduceGroups * P, 0.0), gq((size_t)kReduceGroups * P, 0.0);
-            std::vector<double> ls(64), lq(64);
-            for (size_t c = 0; c < nchunks; ++c) {
-                const size_t g = c % kReduceGroups;
-                for (int pp = 0; pp < P; ++pp) {
-                    double cs = 0.0, cq = 0.0;
-                    for (int wv = 0; wv < kReduceChunk / 64; ++wv) {
-                        for (int l = 0; l < 64; ++l) {
-                            size_t b = c * kReduceChunk + (size_t)wv * 64 + l;
-                            ls[l] = 0.0; lq[l] = 0.0;
-                            if (b < B) {
-                                if (D == 1) { if (q[b] == pp) { ls[l] = (double)bsd_s[b]; lq[l] = (double)bsd_q[b]; } }
-                                else for (int d = 0; d < D; ++d) if (map_sd(q[b], d) == pp) { ls[l] = ls[l] + (double)bsd_s[b * D + d]; lq[l] = lq[l] + (double)bsd_q[b * D + d]; }
-                            }
+            {
+                // (groups beyond the number of chunks stay empty: their sums are the +0.0 the vectors start with)
+                const size_t active = nchunks < (size_t)kReduceGroups ? nchunks : (size_t)kReduceGroups;
+                const size_t nacc = active * (kReduceChunk / 64) * 64;
+                std::vector<double> as(nacc * P, 0.0), aq(nacc * P, 0.0);
+                for (size_t b = 0; b < B; ++b) {
+                    const size_t c = b / kReduceChunk, g = c % kReduceGroups, wl = b % kReduceChunk;   // wl = w * 64 + l
+                    double* ps = &as[(g * kReduceChunk + wl) * P];
+                    double* pq = &aq[(g * kReduceChunk + wl) * P];
+                    if (D == 1) { ps[q[b]] = ps[q[b]] + (double)bsd_s[b]; pq[q[b]] = pq[q[b]] + (double)bsd_q[b]; }
+                    else {
+                        for (int pp = 0; pp < P; ++pp) {
+                            double ts = 0.0, tq = 0.0;
+                            bool any = false;
+                            for (int d = 0; d < D; ++d) if (map_sd(q[b], d) == pp) { ts = ts + (double)bsd_s[b * D + d]; tq = tq + (double)bsd_q[b * D + d]; any = true; }
+                            if (any) { ps[pp] = ps[pp] + ts; pq[pp] = pq[pp] + tq; }
                         }
-                        for (int stride = 1; stride < 64; stride <<= 1)
-                            for (int l = 0; l < 64; l += 2 * stride) { ls[l] = ls[l] + ls[l + stride]; lq[l] = lq[l] + lq[l + stride]; }
-                        cs = cs + ls[0]; cq = cq + lq[0];
                     }
-                    gs[g * P + pp] = gs[g * P + pp] + cs;
-                    gq[g * P + pp] = gq[g * P + pp] + cq;
                 }
+                std::vector<double> ls(64), lq(64);
+                for (size_t g = 0; g < active; ++g)
+                    for (int pp = 0; pp < P; ++pp) {
+                        double cs = 0.0, cq = 0.0;
+                        for (int wv = 0; wv < kReduceChunk / 64; ++wv) {
+                            for (int l = 0; l < 64; ++l) { ls[l] = as[(g * kReduceChunk + wv * 64 + l) * P + pp]; lq[l] = aq[(g * kReduceChunk + wv * 64 + l) * P + pp]; }
+                            for (int stride = 1; stride < 64; stride <<= 1)
+                                for (int l = 0; l < 64; l += 2 * stride) { ls[l] = ls[l] + ls[l + stride]; lq[l] = lq[l] + lq[l + stride]; }
+                            cs = cs + ls[0]; cq = cq + lq[0];
+                        }
+                        gs[g * P + pp] = cs;
+                        gq[g * P + pp] = cq;
+                    }
             }
             for (int pp = 0; pp < P; ++pp) {
                 std::vector<double> a2(kReduceGroups), b2(kReduceGroups);
