@@ -19,6 +19,7 @@
 #include "hml_k_forward.h"
 #include "hml_k_marginals.h"
 #include "hml_k_segment.h"
+#include "hml_k_trellis.h"
 #include "hml_k_params.h"
 #include "hml_state.h"
 #include "hml_synth_host.hpp"
@@ -287,6 +288,8 @@ int hml_create(hml_ctx** out, int device, uint64_t seed, uint32_t chain_id, void
     if (const char* e = getenv("HML_USE_GRAPH")) c->use_graph = atoi(e) != 0;
     if (const char* e = getenv("HML_WEIGHT_KEYS")) c->use_keys = atoi(e) != 0;
     if (const char* e = getenv("HML_FUSED_BLOCKS")) { c->fused_blocks = atoi(e) != 0; c->fused_keep = atoi(e) == 2; }   // 0: a GPU shared with other processes
+    if (const char* e = getenv("HML_TRELLIS_FUSED")) c->tre_fused = atoi(e) != 0;
+    if (const char* e = getenv("HML_TRELLIS_L")) { const int l = atoi(e); c->tre_L = (l >= 256) ? 256u : (l >= 128) ? 128u : (l >= 64) ? 64u : (l > 0 ? 32u : 0u); }
     if (const char* e = getenv("HML_FUSED_SPIN_LIMIT")) c->fused_spin_limit = (uint32_t)strtoul(e, nullptr, 10);
     if (device < 64) g_live_ctx[device].fetch_add(1);
     *out = c;
@@ -298,7 +301,8 @@ static bool shares_device(const hml_ctx* c) { return c->device < 64 && g_live_ct
 static void free_all(hml_ctx* c) {
     void* ptrs[] = {c->d_group_word, c->d_summary, c->d_w, c->d_coeff, c->d_ia, c->d_stage, c->d_span_count, c->d_starts, c->d_bstat,
                     c->d_em, c->d_gsc, c->d_rows, c->d_eprobe, c->d_aprobe, c->d_entry, c->d_exitA, c->d_redo, c->d_touched, c->d_fb, c->d_coarse1,
-                    c->d_smap, c->d_cmap, c->d_scmap, c->d_super, c->d_bentry2, c->d_bentry, c->d_q, c->d_partial, c->d_diff, c->d_boundary, c->d_mdl};
+                    c->d_smap, c->d_cmap, c->d_scmap, c->d_super, c->d_bentry2, c->d_bentry, c->d_q, c->d_partial, c->d_diff, c->d_boundary, c->d_mdl,
+                    c->d_redo2, c->d_tre_bitmap};
     for (void* p : ptrs) if (p) hipFree(p);
     if (c->h_B) hipHostFree(c->h_B);
     c->h_B = nullptr;
@@ -683,7 +687,8 @@ int hml_set_model(hml_ctx* c, int K, const float nig4[4], float a_off, float a_d
     HIPCHK(hipMalloc(&c->d_exitA, maxChunks * K * sizeof(float)));
     HIPCHK(hipMalloc(&c->d_fb, maxChunks * sizeof(uint32_t)));
     HIPCHK(hipMalloc(&c->d_smap, (T + 2) * sizeof(unsigned long long)));
-    const uint64_t bchunks = (T + HML_BWD_CHUNK - 1) / HML_BWD_CHUNK + 1;
+    // per-chunk arrays serve the backward chunks of 64 rows and the fused trellis path's forward chunks of 16 or 32
+    const uint64_t bchunks = (T + 15) / 16 + 1;
     HIPCHK(hipMalloc(&c->d_cmap, bchunks * sizeof(unsigned long long)));
     HIPCHK(hipMalloc(&c->d_bentry, bchunks));
     HIPCHK(hipMalloc(&c->d_scmap, bchunks * sizeof(unsigned long long)));
@@ -693,6 +698,8 @@ int hml_set_model(hml_ctx* c, int K, const float nig4[4], float a_off, float a_d
     HIPCHK(hipMemsetAsync(c->d_redo, 0, bchunks * sizeof(uint32_t), c->stream));
     HIPCHK(hipMalloc(&c->d_touched, bchunks * sizeof(uint32_t)));
     HIPCHK(hipMemsetAsync(c->d_touched, 0, bchunks * sizeof(uint32_t), c->stream));
+    HIPCHK(hipMalloc(&c->d_redo2, bchunks * sizeof(uint32_t)));
+    HIPCHK(hipMalloc(&c->d_tre_bitmap, (bchunks / 32 + 2) * sizeof(uint32_t)));
     HIPCHK(hipMalloc(&c->d_q, T * sizeof(int16_t)));
     HIPCHK(hipMalloc(&c->d_partial, (uint64_t)HML_REDUCE_GROUPS * K * 2 * sizeof(double)));
     HIPCHK(hipMemsetAsync(c->d_partial, 0, (uint64_t)HML_REDUCE_GROUPS * K * 2 * sizeof(double), c->stream));
@@ -715,6 +722,7 @@ int hml_set_model(hml_ctx* c, int K, const float nig4[4], float a_off, float a_d
         for (int j = 0; j < K; ++j) { m.dirA[k * K + j] = (k == j) ? a_diag : a_off; m.A[k * K + j] = 1.0f / K; }
     }
     m.max_state_recorded = -1;
+    m.tre_fused = (c->tre_fused && c->D == 1) ? 1u : 0u;
     m.fwd_W0 = (uint32_t)c->fwdW;
     m.fwd_W = m.fwd_W_burnin = (uint32_t)std::max(c->fwdW, c->fwdW_init);
     m.n_spans = c->n_spans;
@@ -856,6 +864,8 @@ static int sweep_k(hml_ctx* c, char method, bool record) {
     // forward geometry of this sweep, fixed before its first launch
     refresh_hint(c);
     const bool dense_geo = c->B_hint >= c->dense_min_blocks;
+    // weakly compressed univariate FB sweeps: emission terms, filter and candidate maps fused per tile (hml_k_trellis.h)
+    const bool trellis = dense_geo && !mix && c->D == 1 && c->tre_fused;
     const int L = dense_geo ? c->fwdL_dense : c->fwdL;
     const hml_layout lay = dense_geo ? c->lay_dense : c->lay;
     if (c->dynamic || !c->blocks_valid) {
@@ -875,7 +885,7 @@ static int sweep_k(hml_ctx* c, char method, bool record) {
         } else {
             launch_compact_pair(c, 0, 0.0f);
         }
-        if (!fused) {
+        if (!fused && !trellis) {
             refresh_hint(c);
             const uint32_t h0 = c->B_hint ? c->B_hint : (uint32_t)std::min<uint64_t>(c->T, 1u << 20);
             ProfScope ps(c, "stats_emission");
@@ -899,7 +909,7 @@ static int sweep_k(hml_ctx* c, char method, bool record) {
     refresh_hint(c);
     const uint32_t hint = c->B_hint ? c->B_hint : (uint32_t)std::min<uint64_t>(c->T, 1u << 20);
     const int gB = grid_for(hint, 256, 64, 16384);
-    if (!emitted) {
+    if (!emitted && !trellis) {
         ProfScope ps(c, "emission");
         if (c->D > 1)
             hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_emission_mv<KK, false>), dim3(gB), dim3(256), 0, s, c->d_ia, c->d_starts, c->d_mdl,
@@ -912,7 +922,52 @@ static int sweep_k(hml_ctx* c, char method, bool record) {
         hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_emission<KK>), dim3(gB), dim3(256), 0, s, c->d_bstat, c->d_starts, c->d_mdl,
                            c->d_em, c->d_gsc, c->probes ? c->d_eprobe : nullptr, mix ? 1 : 0, lay);
     }
-    if (!mix) {
+    if (trellis) {
+        // chunk length by the number of blocks: the warm-up (emission terms included) is paid once per chunk, and a
+        // wavefront takes 64 chunks - long chunks where there are enough blocks to fill the machine with wavefronts anyway
+        uint32_t TL = c->tre_L ? c->tre_L : (hint >= (1u << 26) ? 128u : hint >= (1u << 24) ? 64u : (uint32_t)HML_TRE_MIN_L);
+        const uint64_t tchunks = ((uint64_t)hint + TL - 1) / TL;
+        const uint64_t tgroups = (tchunks + HML_TRE_NCH - 1) / HML_TRE_NCH;
+        float* ep = c->probes ? c->d_eprobe : nullptr;
+        float* ap = c->probes ? c->d_aprobe : nullptr;
+        {
+            ProfScope ps(c, "trellis");
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_trellis_tile<KK>), dim3(grid_for(tgroups, 1, 16, 1 << 20)), dim3(64), 0, s,
+                               c->d_ia, c->d_starts, c->d_mdl, c->d_mdl, c->d_bstat, c->d_smap, c->d_cmap, c->d_entry, c->d_exitA, c->d_fb, ep, ap, TL);
+        }
+        {
+            // verification, four rounds of parallel refits from the predecessors' end vectors (the lists of stale chunks
+            // alternate between d_redo and d_redo2), then the sequential finisher: each exits at once when its list is empty
+            ProfScope ps(c, "trellis_repair");
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_trellis_verify<KK>), dim3(grid_for(tchunks, 256, 16, 1 << 14)), dim3(256), 0, s, c->d_mdl,
+                               c->d_entry, c->d_exitA, c->d_redo, TL);
+            int in_a = 1;
+            for (uint32_t round = 0; round < 4u; ++round, in_a ^= 1) {
+                uint32_t* lin = in_a ? c->d_redo : c->d_redo2;
+                uint32_t* lout = in_a ? c->d_redo2 : c->d_redo;
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_trellis_refit<KK>), dim3(1024), dim3(64), 0, s, c->d_ia, c->d_starts, c->d_mdl, c->d_smap,
+                                   c->d_cmap, c->d_entry, c->d_exitA, c->d_fb, ep, ap, lin, in_a, TL);
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_trellis_verify_list<KK>), dim3(64), dim3(256), 0, s, c->d_mdl, c->d_entry, c->d_exitA,
+                                   lin, lout, c->d_touched, in_a, round, TL);
+            }
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_trellis_serial<KK>), dim3(1), dim3(256), 0, s, c->d_ia, c->d_starts, c->d_mdl, c->d_smap,
+                               c->d_cmap, c->d_entry, c->d_exitA, c->d_fb, ep, ap, in_a ? c->d_redo : c->d_redo2, in_a, c->d_tre_bitmap, TL);
+        }
+        {
+            ProfScope ps(c, "backward_chain");
+            const uint64_t supers = (tchunks + 63) / 64;
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_trellis_super<KK>), dim3(grid_for(supers * 64, 256, 16, 1 << 16)), dim3(256), 0, s, c->d_cmap,
+                               c->d_mdl, c->d_scmap, c->d_super, TL);
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_trellis_chain<KK>), dim3(1), dim3(1024), 0, s, c->d_super, c->d_mdl, c->d_bentry2, TL);
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_trellis_states<KK>), dim3(grid_for(tgroups, 1, 16, 1 << 20)), dim3(64), 0, s, c->d_smap,
+                               c->d_scmap, c->d_bentry2, c->d_mdl, c->d_q, TL);
+        }
+        {
+            ProfScope ps(c, "counts");
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_counts_dense<KK, false>), dim3(HML_REDUCE_GROUPS), dim3(256), 0, s, c->d_q,
+                               c->d_starts, c->d_bstat, c->d_mdl, c->d_partial, (const unsigned long long*)nullptr, (const uint8_t*)nullptr);
+        }
+    } else if (!mix) {
         const uint64_t chunks = ((uint64_t)hint + L - 1) / L;
         const int gF = grid_for(chunks, 256, 16, 1 << 20);
         {

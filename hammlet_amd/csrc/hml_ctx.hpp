@@ -61,6 +61,10 @@ struct hml_ctx {
     float *d_em = nullptr, *d_gsc = nullptr, *d_rows = nullptr, *d_eprobe = nullptr, *d_aprobe = nullptr;
     float *d_entry = nullptr, *d_exitA = nullptr;
     uint32_t* d_redo = nullptr;    // backward chunks that failed the forward verification (list for the repair step)
+    uint32_t* d_redo2 = nullptr;   // second list of stale chunks and the bitmap of the sequential finisher (fused trellis path)
+    uint32_t* d_tre_bitmap = nullptr;
+    uint32_t tre_L = 0;            // its chunk length (0: chosen from the number of blocks; HML_TRELLIS_L)
+    bool tre_fused = true;         // weakly compressed FB sweeps take the fused trellis kernels (HML_TRELLIS_FUSED=0: the separate ones)
     uint32_t* d_touched = nullptr; // backward chunks whose rows the repair recomputed, tagged with the sweep
     uint32_t* d_fb = nullptr;
     unsigned long long *d_smap = nullptr, *d_cmap = nullptr;

@@ -264,6 +264,16 @@ __global__ __launch_bounds__(1024) void hml_k_params(hml_model* __restrict__ mdl
             // a handful: none while a sweep has fewer than 2^22 blocks (a repair is then a visible share of the sweep),
             // one chunk in some thousands beyond
             const unsigned long long handful = (mdl->B >> 22) ? (((unsigned long long)(mdl->B >> 16) > 16ull) ? (unsigned long long)(mdl->B >> 16) : 16ull) : 0ull;
+            if (mdl->tre_fused && (mdl->B >> 22)) {
+                // fused trellis path: a stale chunk costs one wavefront ~0.1 ms, in parallel with all the others, while
+                // every block pays for the warm-up - so the warm-up follows the refit count down to a few per
+                // ten thousand chunks instead of insisting on none: +8 above B / 2^17 refits (or a sequential finish),
+                // -8 below B / 2^20
+                const unsigned long long hi = (unsigned long long)(mdl->B >> 17) + 16ull, lo = (unsigned long long)(mdl->B >> 20) + 2ull;
+                if (serial != 0ull || refits > hi) W = (W + 8u < 64u) ? W + 8u : 64u;
+                else if (refits < lo) W = (W > 16u) ? W - 8u : 8u;
+                if (W > 64u) W = 64u;
+            } else
             if (serial != 0ull || refits > handful) { W = (2u * W < 1024u) ? 2u * W : 1024u; mdl->fwd_quiet = 0u; }
             else if (refits == 0ull) {
                 const uint32_t floorW = (mdl->sweeps < 256ull) ? mdl->fwd_W_burnin : mdl->fwd_W0;
@@ -275,6 +285,7 @@ __global__ __launch_bounds__(1024) void hml_k_params(hml_model* __restrict__ mdl
             mdl->fwd_serial_ran = 0u;
         }
         mdl->fwd_mismatch = 0u;
+        mdl->fwd_mismatch2 = 0u;
         mdl->epoch = epoch + 1ull;
         if (mode == 0) { mdl->sweeps += 1ull; mdl->block_updates += (unsigned long long)mdl->B; }
     }

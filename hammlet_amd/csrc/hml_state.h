@@ -95,9 +95,12 @@ struct hml_model {
     unsigned long long err_count;
     // ---- scratch for the forward fix-up ----
     uint32_t fwd_mismatch;       // set by a verification round that found a stale chunk
+    uint32_t fwd_mismatch2;      // the fused trellis path alternates between two lists of stale chunks (refit rounds)
     // adaptive warm-up length of the speculative forward pass (results never depend on it)
     uint32_t fwd_W, fwd_W0, fwd_serial_ran, fwd_quiet;
     uint32_t fwd_W_burnin;       // floor during the first 256 sweeps of a chain (parameters still far from settled)
+    uint32_t tre_fused;          // weakly compressed FB sweeps take the fused trellis kernels (hml_k_trellis.h): stale chunks are
+                                 // refitted in parallel there, so the warm-up follows a different rule (hml_k_params)
     unsigned long long fwd_refits_seen, fwd_serial_seen;
 };
 
@@ -106,7 +109,7 @@ struct hml_model {
 // slowly) starts its forward pass with four times the usual warm-up instead of finding that level through repairs:
 // on C5 the first ten sweeps cost 203 ms each (3.6e5 refits) until the adaptation had raised W from 24 to 96.
 __device__ __forceinline__ void hml_warmup_for_many_blocks(hml_model* mdl, uint32_t B) {
-    if (B >= (1u << 22) && mdl->sweeps < 4ull && mdl->fwd_W < 4u * mdl->fwd_W_burnin) mdl->fwd_W = 4u * mdl->fwd_W_burnin;
+    if (B >= (1u << 22) && !mdl->tre_fused && mdl->sweeps < 4ull && mdl->fwd_W < 4u * mdl->fwd_W_burnin) mdl->fwd_W = 4u * mdl->fwd_W_burnin;
 }
 #endif
 

@@ -643,3 +643,47 @@ def test_fused_block_kernel_retires_itself_after_an_expired_wait(hml, monkeypatc
     compare_state(o, g)
     assert g.stats()["fused_fallbacks"] > 0
     assert g.profile_get("blocks_scatter")[1] >= 10
+
+
+@pytest.mark.parametrize("chunk,fused", [(32, 1), (128, 1), (256, 1), (32, 0)])
+def test_fused_trellis_repair_paths_on_twin_states(hml, monkeypatch, chunk, fused):
+    """The fused trellis kernels of weakly compressed sweeps (hml_k_trellis.h; HML_TRELLIS_FUSED=0 runs the separate
+    kernels for comparison) on the adversarial twin-state parameters: an uncompressed trace on which the filter hardly
+    forgets, so most chunks are stale after the first pass, the parallel refits run four rounds and the sequential
+    finisher walks long chains - and forward rows, states and parameters must still be the checker's, bit for bit, for
+    every chunk length."""
+    monkeypatch.setenv("HML_DENSE_MIN_BLOCKS", "1")
+    monkeypatch.setenv("HML_TRELLIS_L", str(chunk))
+    monkeypatch.setenv("HML_TRELLIS_FUSED", str(fused))
+    T, K = 300_000, 3
+    x = ol.trace(T, 3, 1)
+    xx, o, g = make_pair(hml, T, K, 0, 1, x=x, weight_mult=1e9)
+    setup_model(o, g, K)
+    o.token("F")
+    g.sample_prior()
+    mv = np.array([-1.0, 0.04, 0.5, 0.04, 0.5, 0.04], np.float32)    # states 1 and 2 are twins
+    A = np.array([[0.999, 0.0005, 0.0005], [0.0005, 0.9994, 0.0001], [0.0005, 0.0001, 0.9994]], np.float32)
+    pi = np.array([0.2, 0.5, 0.3], np.float32)
+    o.set_params(mv, A, pi)
+    g.set_parameters(mv, A, pi)
+    o.set_probes(True)
+    g.enable_probes(True)
+    s0 = g.stats()
+    o.iterate("F", 1, 0)
+    g.iterate("F", 1, 0)
+    g.sync()
+    s1 = g.stats()
+    assert len(g.blocks()) - 1 == T
+    assert np.array_equal(bits(o.loglik()), bits(g.block_loglik()))
+    assert np.array_equal(bits(o.forward_rows()), bits(g.forward_rows()))
+    assert np.array_equal(o.states(), g.states())
+    assert s1["forward_refits"] > s0["forward_refits"]
+    if fused:
+        assert s1["forward_serial"] > s0["forward_serial"]          # runs of stale chunks longer than the four parallel rounds
+    o.set_record(marginals=True)
+    o.iterate("F", 4, 2)
+    g.iterate("F", 4, 2)
+    g.sync()
+    compare_state(o, g)
+    seg, cnt = g.marginals_rle()
+    assert hml.marginals_text(seg, cnt) == o.text("marginals")
