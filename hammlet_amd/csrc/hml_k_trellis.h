@@ -26,6 +26,8 @@
 #ifndef HML_K_TRELLIS_H
 #define HML_K_TRELLIS_H
 
+#include <type_traits>
+
 #include "hml_k_backward.h"
 #include "hml_k_forward.h"
 
@@ -39,6 +41,21 @@
 __device__ __forceinline__ uint32_t hml_tre_warmup(const hml_model* mdl) {
     const uint32_t w = (mdl->fwd_W < (uint32_t)HML_TRE_HALO) ? mdl->fwd_W : (uint32_t)HML_TRE_HALO;
     return (w + (uint32_t)HML_TRE_R - 1u) / (uint32_t)HML_TRE_R * (uint32_t)HML_TRE_R;
+}
+
+// candidate maps in memory: 4 bits per state, so 32 bits hold a map of up to 8 states (half the traffic of the first pass's
+// stores and of the states kernel's loads); 64 bits beyond
+template <int K>
+struct hml_tre_map {
+    typedef typename std::conditional<(K <= 8), uint32_t, unsigned long long>::type stored;
+};
+template <int K>
+__device__ __forceinline__ void hml_tre_store_cand(unsigned long long* __restrict__ cand, uint32_t t, unsigned long long m) {
+    reinterpret_cast<typename hml_tre_map<K>::stored*>(cand)[t] = (typename hml_tre_map<K>::stored)m;
+}
+template <int K>
+__device__ __forceinline__ unsigned long long hml_tre_load_cand(const unsigned long long* __restrict__ cand, uint64_t t) {
+    return (unsigned long long)reinterpret_cast<const typename hml_tre_map<K>::stored*>(cand)[t];
 }
 
 // E_s and e_s = expf(E_s - max E) of one block (hml_emit_compute without the rescale factors)
@@ -217,7 +234,7 @@ __global__ __launch_bounds__(64) void hml_k_trellis_tile(const float2* __restric
                                 row[s] = row[s] * ((n <= (uint32_t)HML_TRE_GTAB) ? gtab[(n - 1u) * K + s] : hml_expf(((float)n - 1.0f) * p.logA[s]));
                         }
                         const unsigned long long cm = hml_tre_cand<K>(row, cx.A, mdl, t, B, epoch, key);
-                        cand[t] = cm;
+                        hml_tre_store_cand<K>(cand, t, cm);
                         sm_c[c * PITCH + r] = cm;
                     }
                 }
@@ -343,7 +360,7 @@ __device__ void hml_tre_chunk_sequential(const hml_emit_params<K>& p, const hml_
             for (int s = 0; s < K; ++s) row[s] = row[s] * hml_expf(((float)n - 1.0f) * p.logA[s]);   // (the table holds this very value)
         }
         const unsigned long long cm = hml_tre_cand<K>(row, cx.A, mdl, t, B, epoch, key);
-        cand[t] = cm;
+        hml_tre_store_cand<K>(cand, t, cm);
         m = hml_map_compose<K>(m, cm);
     }
     fmap[f] = m;
@@ -439,7 +456,7 @@ __global__ __launch_bounds__(64) void hml_k_trellis_refit(const float2* __restri
                     for (int s = 0; s < K; ++s) row[s] = row[s] * hml_expf(((float)nb - 1.0f) * p.logA[s]);   // (the first pass's table holds this very value)
                 }
                 const unsigned long long cm = hml_tre_cand<K>(row, cx.A, mdl, t, B, epoch, key);
-                cand[t] = cm;
+                hml_tre_store_cand<K>(cand, t, cm);
                 sm_m[lane] = cm;
             }
             __syncthreads();
@@ -571,9 +588,11 @@ template <int K>
 __global__ __launch_bounds__(64) void hml_k_trellis_states(const unsigned long long* __restrict__ cand, const unsigned long long* __restrict__ scmap,
                                                            const uint8_t* __restrict__ entry2, const hml_model* __restrict__ mdl,
                                                            int16_t* __restrict__ q, uint32_t L) {
+    typedef typename hml_tre_map<K>::stored map_t;
     constexpr int RB = 32, PITCH = RB + 1;
-    __shared__ unsigned long long sm_m[HML_TRE_NCH * PITCH];
+    __shared__ map_t sm_m[HML_TRE_NCH * PITCH];
     __shared__ int16_t sm_q[HML_TRE_NCH * (RB + 2)];
+    const map_t* __restrict__ cm = reinterpret_cast<const map_t*>(cand);
     const uint32_t B = mdl->B;
     const uint32_t NC = (B + L - 1u) / L;
     const uint32_t n_groups = (NC + (uint32_t)HML_TRE_NCH - 1u) / (uint32_t)HML_TRE_NCH;
@@ -591,24 +610,31 @@ __global__ __launch_bounds__(64) void hml_k_trellis_states(const unsigned long l
         const uint64_t first = (uint64_t)f * L;
         const uint64_t last = active ? ((first + L < B) ? first + L : (uint64_t)B) : first;
         for (int rel0 = (int)L - RB; rel0 >= 0; rel0 -= RB) {   // batches from the chunks' ends down (L is a multiple of 32)
-#pragma unroll 4
+            // lane = (chunk, row): half a wavefront reads one chunk's 32 consecutive maps; all 32 loads of a lane in flight
+            map_t v[RB];
+#pragma unroll
             for (int k = 0; k < RB; ++k) {
                 const int slot = k * 64 + lane;
                 const int c = slot / RB, r = slot % RB;
                 const uint64_t b = (uint64_t)(f0 + (uint32_t)c) * L + (uint32_t)rel0 + (uint32_t)r;   // row t = b + 1
-                if (f0 + (uint32_t)c < NC && b < B) sm_m[c * PITCH + r] = cand[b + 1u];
+                v[k] = (f0 + (uint32_t)c < NC && b < B) ? cm[b + 1u] : (map_t)0;
+            }
+#pragma unroll
+            for (int k = 0; k < RB; ++k) {
+                const int slot = k * 64 + lane;
+                sm_m[(slot / RB) * PITCH + (slot % RB)] = v[k];
             }
             __syncthreads();
             if (active) {
                 for (int r = RB - 1; r >= 0; --r) {
                     const uint64_t b = first + (uint32_t)rel0 + (uint32_t)r;
                     if (b >= last) continue;
-                    x = (unsigned)((sm_m[lane * PITCH + r] >> (4u * x)) & 15ull);   // q_t = cand_t(q_{t+1})
+                    x = (unsigned)(((unsigned long long)sm_m[lane * PITCH + r] >> (4u * x)) & 15ull);   // q_t = cand_t(q_{t+1})
                     sm_q[lane * (RB + 2) + r] = (int16_t)x;
                 }
             }
             __syncthreads();
-#pragma unroll 4
+#pragma unroll 8
             for (int k = 0; k < RB; ++k) {
                 const int slot = k * 64 + lane;
                 const int c = slot / RB, r = slot % RB;

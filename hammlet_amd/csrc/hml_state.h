@@ -110,6 +110,9 @@ struct hml_model {
 // on C5 the first ten sweeps cost 203 ms each (3.6e5 refits) until the adaptation had raised W from 24 to 96.
 __device__ __forceinline__ void hml_warmup_for_many_blocks(hml_model* mdl, uint32_t B) {
     if (B >= (1u << 22) && !mdl->tre_fused && mdl->sweeps < 4ull && mdl->fwd_W < 4u * mdl->fwd_W_burnin) mdl->fwd_W = 4u * mdl->fwd_W_burnin;
+    // the fused trellis path starts a young chain at its longest first-pass warm-up and lets the refit count walk it down
+    // (hml_k_params): starting low would put a million chunks through the refit rounds in the first sweeps
+    if (B >= (1u << 22) && mdl->tre_fused && mdl->sweeps < 4ull && mdl->fwd_W < 64u) mdl->fwd_W = 64u;
 }
 #endif
 
