@@ -1137,6 +1137,14 @@ int hml_sync(hml_ctx* c) {
           fprintf(stderr, "   late starters: %u, first index %u\n", late, first_late); }
         for (uint32_t i : {0u, n / 4, n / 2, n - 1}) fprintf(stderr, "   wg %u: %.2f %.2f %.2f %.2f\n", i, (h[i*4]-t0)*0.01, (h[i*4+1]-t0)*0.01, (h[i*4+2]-t0)*0.01, (h[i*4+3]-t0)*0.01);
     }
+    if (c->model_set && getenv("HML_PARAMS_DEBUG")) {
+        hml_model m;
+        if (fetch_model(c, &m) == 0) {
+            fprintf(stderr, "[params dbg] us since the kernel's start: accumulators read %.2f | tree %.2f | theta drawn %.2f | A gammas %.2f | barrier %.2f | end %.2f\n",
+                    (m.dbg_t[1] - m.dbg_t[0]) * 0.01, (m.dbg_t[2] - m.dbg_t[0]) * 0.01, (m.dbg_t[3] - m.dbg_t[0]) * 0.01, (m.dbg_t[4] - m.dbg_t[0]) * 0.01,
+                    (m.dbg_t[5] - m.dbg_t[0]) * 0.01, (m.dbg_t[6] - m.dbg_t[0]) * 0.01);
+        }
+    }
     if (c->model_set) return check_device_error(c);
     return 0;
 }

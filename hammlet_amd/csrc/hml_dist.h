@@ -70,7 +70,10 @@ struct hml_normal_f32 {
     bool have;
     HML_HDM hml_normal_f32() : saved(0.0f), have(false) {}
     template <class Src>
-    HML_HDM float draw(Src& src, float mean, float stddev) {
+    HML_HDM float draw(Src& src, float mean, float stddev) { return draw_std(src) * stddev + mean; }
+    // the variate before `* stddev + mean` (callers that learn mean and stddev later apply them themselves: same operations)
+    template <class Src>
+    HML_HDM float draw_std(Src& src) {
         float ret;
         if (have) {
             have = false;
@@ -87,7 +90,7 @@ struct hml_normal_f32 {
             have = true;
             ret = y * mult;
         }
-        return ret * stddev + mean;
+        return ret;
     }
 };
 
@@ -97,8 +100,10 @@ struct hml_normal_f32 {
 // tests is written here as ONE loop with explicit state: hipcc (ROCm 7.2, -O3) mis-executes the
 // nested form on gfx950 when the lanes of a wavefront leave the loops at different trip counts
 // (tests/test_gpu_parity.py::test_gamma_lanes_independent keeps watch).
+// hml_gamma_core_f32: everything but the final `* beta` - the rejection loop depends on alpha only, so a caller that learns
+// beta later (the parameter kernel: beta needs the sweep's sums, alpha only its counts) can run it ahead.
 template <class M, class Src>
-HML_HD float hml_gamma_f32(Src& src, float alpha, float beta) {
+HML_HD float hml_gamma_core_f32(Src& src, float alpha) {
     const float malpha = alpha < 1.0f ? alpha + 1.0f : alpha;
     const float a1 = malpha - 1.0f / 3.0f;
     const float a2 = 1.0f / M::sqrtf_(9.0f * a1);
@@ -134,10 +139,15 @@ HML_HD float hml_gamma_f32(Src& src, float alpha, float beta) {
             accepted = !(c1 && c2);
         }
     }
-    if (alpha == malpha) return a1 * v * beta;
+    if (alpha == malpha) return a1 * v;
     float u = hml_canonical_f32(src);
     while (u == 0.0f) u = hml_canonical_f32(src);
-    return M::powf_(u, 1.0f / alpha) * a1 * v * beta;
+    return M::powf_(u, 1.0f / alpha) * a1 * v;
+}
+
+template <class M, class Src>
+HML_HD float hml_gamma_f32(Src& src, float alpha, float beta) {
+    return hml_gamma_core_f32<M>(src, alpha) * beta;   // (a1 * v * beta and powf * a1 * v * beta associate from the left)
 }
 
 #endif

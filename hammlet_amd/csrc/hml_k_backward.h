@@ -371,7 +371,7 @@ __device__ __forceinline__ double hml_wave_tree_f64(double a) {
 template <int K, bool FB, bool MV = false>
 __global__ __launch_bounds__(256) void hml_k_counts(int16_t* __restrict__ q, const uint32_t* __restrict__ starts,
                                                     const float2* __restrict__ bstat, hml_model* __restrict__ mdl,
-                                                    double* __restrict__ partial /*[GROUPS][K][2]*/,
+                                                    double* __restrict__ partial /*[K][2][GROUPS]: plane (state, sum | sum of squares), one double per group*/,
                                                     const unsigned long long* __restrict__ smap,
                                                     const uint8_t* __restrict__ entry) {
     __shared__ unsigned long long h_trans[K * K];
@@ -478,8 +478,8 @@ __global__ __launch_bounds__(256) void hml_k_counts(int16_t* __restrict__ q, con
             double cs = 0.0, cq = 0.0;
 #pragma unroll
             for (int wv = 0; wv < 4; ++wv) { cs = cs + wsum[wv][s][0]; cq = cq + wsum[wv][s][1]; }
-            partial[((uint64_t)g * K + s) * 2 + 0] = cs;
-            partial[((uint64_t)g * K + s) * 2 + 1] = cq;
+            partial[(uint64_t)(s * 2 + 0) * HML_REDUCE_GROUPS + g] = cs;
+            partial[(uint64_t)(s * 2 + 1) * HML_REDUCE_GROUPS + g] = cq;
         }
     }
     // fold the per-lane counters: wavefront sums, then one LDS update per wavefront and state
@@ -516,7 +516,7 @@ __global__ __launch_bounds__(256) void hml_k_counts(int16_t* __restrict__ q, con
 template <int K, bool FB>
 __global__ __launch_bounds__(256) void hml_k_counts_dense(int16_t* __restrict__ q, const uint32_t* __restrict__ starts,
                                                           const float2* __restrict__ bstat, hml_model* __restrict__ mdl,
-                                                          double* __restrict__ partial /*[GROUPS][K][2]*/,
+                                                          double* __restrict__ partial /*[K][2][GROUPS]: plane (state, sum | sum of squares), one double per group*/,
                                                           const unsigned long long* __restrict__ smap,
                                                           const uint8_t* __restrict__ entry) {
     __shared__ unsigned long long h_trans[K * K];
@@ -596,8 +596,8 @@ __global__ __launch_bounds__(256) void hml_k_counts_dense(int16_t* __restrict__ 
             double cs = 0.0, cq = 0.0;
 #pragma unroll
             for (int wv = 0; wv < 4; ++wv) { cs = cs + wsum[wv][s][0]; cq = cq + wsum[wv][s][1]; }
-            partial[((uint64_t)g * K + s) * 2 + 0] = cs;
-            partial[((uint64_t)g * K + s) * 2 + 1] = cq;
+            partial[(uint64_t)(s * 2 + 0) * HML_REDUCE_GROUPS + g] = cs;
+            partial[(uint64_t)(s * 2 + 1) * HML_REDUCE_GROUPS + g] = cq;
         }
     }
     // fold the per-lane counters: wavefront sums, then one LDS update per wavefront and state

@@ -72,6 +72,7 @@ __global__ __launch_bounds__(1024) void hml_k_params(hml_model* __restrict__ mdl
     __shared__ unsigned long long s_trans[K * K];
     __shared__ unsigned long long s_occ[K];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) mdl->dbg_t[0] = wall_clock64();
     __shared__ float s_var[K], s_logN[K];
     const int P = mdl->P, D = mdl->D;
     const unsigned long long epoch = mdl->epoch;
@@ -81,7 +82,6 @@ __global__ __launch_bounds__(1024) void hml_k_params(hml_model* __restrict__ mdl
     if (wave == 0 && lane < P) { hyp0 = mdl->nig_post[lane][0]; hyp1 = mdl->nig_post[lane][1]; hyp2 = mdl->nig_post[lane][2]; hyp3 = mdl->nig_post[lane][3]; }
     if (wave == 1 && lane < K) hyp0 = mdl->dirPi[lane];
     if (tid >= 128 && tid < 128 + K * K) hyp0 = mdl->dirA[tid - 128];
-
     // gather the split integer accumulators
     if (tid >= 128 && tid < 128 + K * K) {
         const int e = tid - 128;
@@ -105,87 +105,46 @@ __global__ __launch_bounds__(1024) void hml_k_params(hml_model* __restrict__ mdl
         s_occ[k] = t;
         mdl->last_occ[k] = t;
     }
-    if (mode != 0) __syncthreads();
-    if (mode == 0) {
-        // finish the fixed tree over the 1024 group partials: butterfly inside each wavefront ...
+    // this thread's group partials of the count pass (the tree below), requested behind the counts - which the first draws
+    // wait for - and travelling while those draws run
+    // The wavefronts that draw variates (0: theta, 1: pi, 2..: the K * K entries of A) leave their 64 groups of the tree to
+    // the last wavefronts, which take a second set: drawing and summing then run side by side.
+    constexpr int NDRAW = 2 + (K * K + 63) / 64;
+    static_assert(2 * NDRAW <= 16, "wavefronts of the parameter kernel");
+    const bool draws = wave < NDRAW;                       // this wavefront draws; its tree groups are taken by wavefront wave + 16 - NDRAW
+    const int mirror = wave - (16 - NDRAW);                // >= 0: this wavefront also sums the groups of wavefront `mirror`
+    double part_s[K], part_q[K], part2_s[K], part2_q[K];
 #pragma unroll
-        for (int s = 0; s < K; ++s) {
-            double a = partial[((uint64_t)tid * K + s) * 2 + 0], d = partial[((uint64_t)tid * K + s) * 2 + 1];
-#pragma unroll
-            for (int m = 1; m < 64; m <<= 1) {
-                a = a + hml_shfl_xor_f64(a, m);
-                d = d + hml_shfl_xor_f64(d, m);
-            }
-            if (lane == 0) { wp[wave][s][0] = a; wp[wave][s][1] = d; }
-        }
-        __syncthreads();
-        // ... then a pairwise tree over the 16 wavefront sums
-        if (tid < 2 * K) {
-            const int s = tid >> 1, c = tid & 1;
-            double v[16];
-#pragma unroll
-            for (int i = 0; i < 16; ++i) v[i] = wp[i][s][c];
-#pragma unroll
-            for (int st = 1; st < 16; st <<= 1)
-#pragma unroll
-                for (int i = 0; i < 16; i += 2 * st) v[i] = v[i] + v[i + st];
-            fin[s][c] = (float)v[0];
-        }
-        __syncthreads();
+    for (int s = 0; s < K; ++s) {
+        part_s[s] = (mode == 0 && !draws) ? partial[(uint64_t)(s * 2 + 0) * HML_REDUCE_GROUPS + tid] : 0.0;
+        part_q[s] = (mode == 0 && !draws) ? partial[(uint64_t)(s * 2 + 1) * HML_REDUCE_GROUPS + tid] : 0.0;
+        part2_s[s] = (mode == 0 && mirror >= 0) ? partial[(uint64_t)(s * 2 + 0) * HML_REDUCE_GROUPS + (mirror * 64 + lane)] : 0.0;
+        part2_q[s] = (mode == 0 && mirror >= 0) ? partial[(uint64_t)(s * 2 + 1) * HML_REDUCE_GROUPS + (mirror * 64 + lane)] : 0.0;
     }
 
+    // s_occ / s_trans (LDS) must be visible to the drawing lanes; the group partials requested above may keep travelling:
+    // a barrier that waits for LDS traffic only (__syncthreads would also wait for every outstanding global load)
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if (tid == 0) mdl->dbg_t[1] = wall_clock64();
+
+    // ---- the draws that need the COUNTS only, ahead of the sums: the gamma rejection loop depends on its shape parameter
+    // alone (hml_gamma_core_f32), the normal variate on nothing; scale and location follow behind the tree.  Same
+    // operations on the same Philox sub-streams as drawing everything afterwards.
+    unsigned long long cnt = 0ull;       // number of terms of parameter k (theta lanes)
+    float th_alpha = hyp0, th_gcore = 0.0f, th_z = 0.0f;
     if (wave == 0 && lane < P) {
         const int k = lane;
-        float alpha = hyp0, beta = hyp1, mu0 = hyp2, nu = hyp3;
-        // number of terms of parameter k: the positions of every (state, dimension) mapped to it - the occupancy of
-        // state k when D = 1 (exact integers)
-        unsigned long long cnt = 0ull;
+        // the positions of every (state, dimension) mapped to parameter k - the occupancy of state k when D = 1
         if (mode == 0) {
             if (D == 1) cnt = s_occ[k];
             else for (int st = 0; st < K; ++st) for (int d = 0; d < D; ++d) if (mdl->map[st][d] == k) cnt += s_occ[st];
         }
-        if (mode == 0) { mdl->last_sum[k] = fin[k][0]; mdl->last_sumsq[k] = fin[k][1]; }
-        if (cnt > 0ull) {
-            // Conjugate<NormalInverseGammaParam>::addObservation (Conjugate.hpp:121-168)
-            const float sum = fin[k][0], sumSq = fin[k][1];
-            if (sumSq < 0.0f) hml_raise(mdl, HML_DEVERR_NEG_SUMSQ, sumSq);
-            const double N = (double)cnt;
-            const float xbar = (float)((double)sum / N);
-            float ssN = (float)((double)(sum * sum) / N);
-            if (ssN > sumSq) ssN = sumSq;
-            const float na = (float)((double)alpha + N / 2.0);
-            const float dxm = (xbar - mu0) * (xbar - mu0);
-            const float nb = (float)((double)beta +
-                                     (((double)sumSq + (N * (double)nu / (N + (double)nu)) * (double)dxm) - (double)ssN) / 2.0);
-            const float nm = (float)((double)(nu * mu0 + sum) / ((double)nu + N));
-            const float nn = (float)((double)nu + N);
-            if (na <= 0.0f) hml_raise(mdl, HML_DEVERR_NIG_ALPHA, na);
-            if (nb <= 0.0f) hml_raise(mdl, HML_DEVERR_NIG_BETA, nb);
-            if (nn <= 0.0f) hml_raise(mdl, HML_DEVERR_NIG_NU, nn);
-            if (!hml_isfinite(nm)) hml_raise(mdl, HML_DEVERR_NIG_MU0, nm);
-            alpha = na; beta = nb; mu0 = nm; nu = nn;
-        }
-        // Distribution<NormalInverseGamma>::resample (Distribution.hpp:77-87)
+        if (cnt > 0ull) th_alpha = (float)((double)hyp0 + (double)cnt / 2.0);   // Conjugate.hpp:141-146: alpha + N / 2
         hml_dev_src src;
         src.s = hml_stream_open(key, HML_KIND_THETA, epoch, (uint32_t)k);
-        const float g = hml_gamma_f32<hml_devmath>(src, alpha, (float)(1.0 / (double)beta));
-        const float v = (float)(1.0 / (double)g);
+        th_gcore = hml_gamma_core_f32<hml_devmath>(src, th_alpha);
         hml_normal_f32<hml_devmath> nd;
-        const float m = nd.draw(src, mu0, HML_SQRTF(v / nu));
-        if (!hml_isfinite(m)) hml_raise(mdl, HML_DEVERR_MEAN_NOT_FINITE, m);
-        if (!hml_isfinite(v)) hml_raise(mdl, HML_DEVERR_VAR_NOT_FINITE, v);
-        else if (v <= 0.0f) hml_raise(mdl, HML_DEVERR_VAR_NOT_POSITIVE, v);
-        const float sd = HML_SQRTF(v);
-        mdl->mu[k] = m; mdl->var[k] = v; mdl->sd[k] = sd;
-        mdl->rvar2[k] = 1.0 / (2.0 * (double)v);
-        if (mode == 0) {   // hml_derive's logNormalizer, from the registers instead of a round trip through memory
-            const float ln = hml_logf(sd) + m * m / (2 * v);
-            mdl->logN[k] = ln;
-            s_logN[k] = ln;
-            s_var[k] = v;
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) mdl->nig_post[k][i] = mdl->nig_prior[i];
+        th_z = nd.draw_std(src);
     }
     if (mode != 2) {
         if (wave == 1 && lane < K) {
@@ -203,7 +162,88 @@ __global__ __launch_bounds__(1024) void hml_k_params(hml_model* __restrict__ mdl
             graw[e] = hml_gamma_f32<hml_devmath>(src, al, 1.0f);
         }
     }
+    if (tid == 128) mdl->dbg_t[4] = wall_clock64();
+
+    if (mode == 0) {
+        // finish the fixed tree over the 1024 group partials: pairwise inside each wavefront ...
+        if (!draws) {   // wave-uniform
+#pragma unroll
+            for (int s = 0; s < K; ++s) {
+                const double a = hml_wave_tree_f64(part_s[s]), d = hml_wave_tree_f64(part_q[s]);
+                if (lane == 0) { wp[wave][s][0] = a; wp[wave][s][1] = d; }
+            }
+        }
+        if (mirror >= 0) {
+#pragma unroll
+            for (int s = 0; s < K; ++s) {
+                const double a = hml_wave_tree_f64(part2_s[s]), d = hml_wave_tree_f64(part2_q[s]);
+                if (lane == 0) { wp[mirror][s][0] = a; wp[mirror][s][1] = d; }
+            }
+        }
+        __syncthreads();
+        // ... then a pairwise tree over the 16 wavefront sums
+        if (tid < 2 * K) {
+            const int s = tid >> 1, c = tid & 1;
+            double v[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) v[i] = wp[i][s][c];
+#pragma unroll
+            for (int st = 1; st < 16; st <<= 1)
+#pragma unroll
+                for (int i = 0; i < 16; i += 2 * st) v[i] = v[i] + v[i + st];
+            fin[s][c] = (float)v[0];
+        }
+        __syncthreads();
+        if (tid == 0) mdl->dbg_t[2] = wall_clock64();
+    }
+
+    if (wave == 0 && lane < P) {
+        const int k = lane;
+        float alpha = hyp0, beta = hyp1, mu0 = hyp2, nu = hyp3;
+        if (mode == 0) { mdl->last_sum[k] = fin[k][0]; mdl->last_sumsq[k] = fin[k][1]; }
+        if (cnt > 0ull) {
+            // Conjugate<NormalInverseGammaParam>::addObservation (Conjugate.hpp:121-168)
+            const float sum = fin[k][0], sumSq = fin[k][1];
+            if (sumSq < 0.0f) hml_raise(mdl, HML_DEVERR_NEG_SUMSQ, sumSq);
+            const double N = (double)cnt;
+            const float xbar = (float)((double)sum / N);
+            float ssN = (float)((double)(sum * sum) / N);
+            if (ssN > sumSq) ssN = sumSq;
+            const float na = th_alpha;   // (float)((double)alpha + N / 2.0), computed ahead of the sums
+            const float dxm = (xbar - mu0) * (xbar - mu0);
+            const float nb = (float)((double)beta +
+                                     (((double)sumSq + (N * (double)nu / (N + (double)nu)) * (double)dxm) - (double)ssN) / 2.0);
+            const float nm = (float)((double)(nu * mu0 + sum) / ((double)nu + N));
+            const float nn = (float)((double)nu + N);
+            if (na <= 0.0f) hml_raise(mdl, HML_DEVERR_NIG_ALPHA, na);
+            if (nb <= 0.0f) hml_raise(mdl, HML_DEVERR_NIG_BETA, nb);
+            if (nn <= 0.0f) hml_raise(mdl, HML_DEVERR_NIG_NU, nn);
+            if (!hml_isfinite(nm)) hml_raise(mdl, HML_DEVERR_NIG_MU0, nm);
+            alpha = na; beta = nb; mu0 = nm; nu = nn;
+        }
+        (void)alpha;
+        // Distribution<NormalInverseGamma>::resample (Distribution.hpp:77-87): gamma(alpha, 1 / beta), then the mean
+        const float g = th_gcore * (float)(1.0 / (double)beta);
+        const float v = (float)(1.0 / (double)g);
+        const float m = th_z * HML_SQRTF(v / nu) + mu0;
+        if (!hml_isfinite(m)) hml_raise(mdl, HML_DEVERR_MEAN_NOT_FINITE, m);
+        if (!hml_isfinite(v)) hml_raise(mdl, HML_DEVERR_VAR_NOT_FINITE, v);
+        else if (v <= 0.0f) hml_raise(mdl, HML_DEVERR_VAR_NOT_POSITIVE, v);
+        const float sd = HML_SQRTF(v);
+        mdl->mu[k] = m; mdl->var[k] = v; mdl->sd[k] = sd;
+        mdl->rvar2[k] = 1.0 / (2.0 * (double)v);
+        if (mode == 0) {   // hml_derive's logNormalizer, from the registers instead of a round trip through memory
+            const float ln = hml_logf(sd) + m * m / (2 * v);
+            mdl->logN[k] = ln;
+            s_logN[k] = ln;
+            s_var[k] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) mdl->nig_post[k][i] = mdl->nig_prior[i];
+        if (tid == 0) mdl->dbg_t[3] = wall_clock64();
+    }
     __syncthreads();
+    if (tid == 0) mdl->dbg_t[5] = wall_clock64();
     if (mode != 2) {
         // dirichlet_sample's normalisation (Distribution.hpp:116-139): float sum in index order
         if (tid < K) {
@@ -284,6 +324,7 @@ __global__ __launch_bounds__(1024) void hml_k_params(hml_model* __restrict__ mdl
             mdl->fwd_serial_seen = mdl->forward_serial;
             mdl->fwd_serial_ran = 0u;
         }
+        mdl->dbg_t[6] = wall_clock64();
         mdl->fwd_mismatch = 0u;
         mdl->fwd_mismatch2 = 0u;
         mdl->epoch = epoch + 1ull;

@@ -31,6 +31,14 @@ __global__ __launch_bounds__(1024) void k_lds(uint32_t* sink) {
     if (buf[(threadIdx.x * 7) & 1023] == 0xdeadbeefu) sink[0] = 1;
 }
 
+template <int NT, int WORDS>
+__global__ __launch_bounds__(NT) void k_shape(uint32_t* sink) {
+    __shared__ uint32_t buf[WORDS > 0 ? WORDS : 1];
+    buf[threadIdx.x % (WORDS > 0 ? WORDS : 1)] = threadIdx.x;
+    __syncthreads();
+    if (buf[(threadIdx.x * 7) % (WORDS > 0 ? WORDS : 1)] == 0xdeadbeefu) sink[0] = 1;
+}
+
 static float per_launch_us(hipStream_t s, const std::function<void()>& seq, int launches_per_seq, int reps) {
     hipEvent_t e0, e1;
     (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
@@ -84,6 +92,12 @@ int main() {
     printf("empty, 15 arguments               : %6.2f us/launch\n", per_launch_us(st, [&] { hipLaunchKernelGGL(k_empty_args, dim3(1), dim3(64), 0, st, buf, buf, buf, buf, buf, buf, buf, buf, buf, buf, buf, buf, 1, 2, 3); }, 1, 4000));
     printf("empty, grid 1024 x 256            : %6.2f us/launch\n", per_launch_us(st, [&] { hipLaunchKernelGGL(k_empty, dim3(1024), dim3(256), 0, st); }, 1, 4000));
     printf("one workgroup 1024 thr, 40 KB LDS : %6.2f us/launch\n", per_launch_us(st, [&] { hipLaunchKernelGGL(k_lds, dim3(1), dim3(1024), 0, st, sink); }, 1, 4000));
+    printf("one workgroup, by shape: 1024 thr no LDS %5.2f | 1024 thr 40 KB %5.2f | 256 thr no LDS %5.2f | 256 thr 40 KB %5.2f | 64 thr 40 KB %5.2f us/launch\n",
+           per_launch_us(st, [&] { hipLaunchKernelGGL(HIP_KERNEL_NAME(k_shape<1024, 16>), dim3(1), dim3(1024), 0, st, sink); }, 1, 4000),
+           per_launch_us(st, [&] { hipLaunchKernelGGL(HIP_KERNEL_NAME(k_shape<1024, 10240>), dim3(1), dim3(1024), 0, st, sink); }, 1, 4000),
+           per_launch_us(st, [&] { hipLaunchKernelGGL(HIP_KERNEL_NAME(k_shape<256, 16>), dim3(1), dim3(256), 0, st, sink); }, 1, 4000),
+           per_launch_us(st, [&] { hipLaunchKernelGGL(HIP_KERNEL_NAME(k_shape<256, 10240>), dim3(1), dim3(256), 0, st, sink); }, 1, 4000),
+           per_launch_us(st, [&] { hipLaunchKernelGGL(HIP_KERNEL_NAME(k_shape<64, 10240>), dim3(1), dim3(64), 0, st, sink); }, 1, 4000));
     for (uint32_t mb : {1u, 4u, 16u, 64u}) {
         const uint32_t n = mb << 18;   // mb MB of u32
         const float w = per_launch_us(st, [&] { hipLaunchKernelGGL(k_write, dim3(n / 256), dim3(256), 0, st, buf, n); }, 1, 1000);
