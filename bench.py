@@ -35,6 +35,8 @@ WORKLOADS = {
 
 
 PMC_FILE = "profiles/round2_pmc_hbm_traffic.json"
+# "c3u" = the uncompressed leg (same trace, every position its own block), collected with tools/time_dense.py
+PMC_FILES = {"c3_1e8_k5_dynamic": PMC_FILE, "c3u": "profiles/round2_pmc_hbm_traffic_c3u.json"}
 
 # kernel families timed by the library's event brackets (hml_profile_enable) -> the kernel each one launches in the
 # default dynamic sweep (names as rocprofv3 prints them, without template arguments)
@@ -54,9 +56,9 @@ def pmc_table(workload):
     MI355X_MICROARCH.md for FETCH_SIZE).  Counters cannot be collected from inside the timed run, so the JSON line
     quotes the profile; Infinity-Cache hits are counted in FETCH_SIZE, so the figure is an upper bound on HBM bytes."""
     try:
-        if workload != "c3_1e8_k5_dynamic":
+        if workload not in PMC_FILES:
             return {}
-        with open(os.path.join(REPO, PMC_FILE)) as f:
+        with open(os.path.join(REPO, PMC_FILES[workload])) as f:
             return json.load(f)["kernels"]
     except Exception:
         return {}
@@ -420,8 +422,10 @@ def main():
         ch.set_model(K, ch.autoprior(0.2, 0.9))
         ch.sample_prior()
         ch.set_recording(marginals=False)
-        n_u = max(5, min(20, args.steps))
-        ch.iterate("F", 6, 0)
+        # burn-in: a fresh chain starts the dense path with the longest filter warm-up (64 rows) and the parameter
+        # kernel steps it down while the verification finds (almost) no stale chunk - about 40 sweeps to settle
+        n_u = max(20, min(100, args.steps))
+        ch.iterate("F", 40, 0)
         ch.sync()
         u0 = ch.stats()
         barrier()
@@ -433,10 +437,33 @@ def main():
         u1 = ch.stats()
         bu = u1["block_updates"] - u0["block_updates"]
         Bu = bu / n_u
+        fams = {"blocks_compact": "hml_k_blocks_fused", "trellis": "hml_k_trellis_tile", "trellis_repair": "hml_k_trellis_verify + refit + serial",
+                "backward_chain": "hml_k_trellis_super + chain + states", "counts": "hml_k_counts_dense", "params": "hml_k_params"}
+        ch.profile_enable(2)
+        ch.iterate("F", 10, 0)
+        ch.sync()
+        ch.profile_enable(0)
+        nb_ms, nb_n = ch.profile_get("event_null")
+        nb_us = 1e3 * nb_ms / max(1, nb_n)
+        dense_tab = {}
+        for nm, kern in fams.items():
+            ms, n = ch.profile_get(nm)
+            if n:
+                us = max(1e3 * ms / n - nb_us, 0.5)
+                row = {"kernels": kern, "us_per_sweep": round(us, 1)}
+                tr = pmc_traffic("c3u", kern)
+                if tr:
+                    row["traffic"] = tr
+                    row["frac"] = round(tr / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)
+                    assert row["frac"] <= 1.0
+                dense_tab[nm] = row
         out["uncompressed_c3u"] = {"value": bu / (t1 - t0), "unit": "block-updates/s", "steps": n_u, "ms_per_step": 1e3 * (t1 - t0) / n_u,
                                    "blocks_per_sweep": Bu, "forward_refits": u1["forward_refits"] - u0["forward_refits"],
+                                   "forward_warmup_rows": u1["forward_warmup"],
                                    "sweep_frac": (4.0 * T + Bu * (36 + 8 * K)) / ((t1 - t0) / n_u) / 1e9 / HBM_PEAK_GBS,
-                                   "note": "B = T: instruction-bound (about 1000 VALU instructions per block), DESIGN.md 3a"}
+                                   "kernels": dense_tab,
+                                   "note": "B = T: the fused trellis path (hml_k_trellis.h) - instruction-bound, about 450 VALU "
+                                           "instructions per block in hml_k_trellis_tile; DESIGN.md 3a"}
         ch.close()
         chain = None
 
