@@ -423,9 +423,10 @@ def main():
         ch.sample_prior()
         ch.set_recording(marginals=False)
         # burn-in: a fresh chain starts the dense path with the longest filter warm-up (64 rows) and the parameter
-        # kernel steps it down while the verification finds (almost) no stale chunk - about 40 sweeps to settle
+        # kernel steps it down while the verification finds (almost) no stale chunk - about 40 sweeps to settle; sweeps
+        # 48 .. 57 then measure the candidate chunk lengths of the trellis kernels (include/hml.h "trellis_L")
         n_u = max(20, min(100, args.steps))
-        ch.iterate("F", 40, 0)
+        ch.iterate("F", 64, 0)
         ch.sync()
         u0 = ch.stats()
         barrier()

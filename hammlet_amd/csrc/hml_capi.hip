@@ -289,7 +289,8 @@ int hml_create(hml_ctx** out, int device, uint64_t seed, uint32_t chain_id, void
     if (const char* e = getenv("HML_WEIGHT_KEYS")) c->use_keys = atoi(e) != 0;
     if (const char* e = getenv("HML_FUSED_BLOCKS")) { c->fused_blocks = atoi(e) != 0; c->fused_keep = atoi(e) == 2; }   // 0: a GPU shared with other processes
     if (const char* e = getenv("HML_TRELLIS_FUSED")) c->tre_fused = atoi(e) != 0;
-    if (const char* e = getenv("HML_TRELLIS_L")) { const int l = atoi(e); c->tre_L = (l >= 256) ? 256u : (l >= 128) ? 128u : (l >= 64) ? 64u : (l > 0 ? 32u : 0u); }
+    if (const char* e = getenv("HML_TRELLIS_L")) { const int l = atoi(e); c->tre_L = (l <= 0) ? 0u : (l >= 256) ? 256u : (l < 32) ? 32u : (uint32_t)l / 32u * 32u; }   // a multiple of 32
+    if (const char* e = getenv("HML_TRELLIS_TUNE")) c->tre_autotune = atoi(e) != 0;
     if (const char* e = getenv("HML_FUSED_SPIN_LIMIT")) c->fused_spin_limit = (uint32_t)strtoul(e, nullptr, 10);
     if (device < 64) g_live_ctx[device].fetch_add(1);
     *out = c;
@@ -841,6 +842,56 @@ static bool fused_geometry(hml_ctx* c, uint32_t* n_sub, uint32_t* n_wg) {
     return true;
 }
 
+// ---- chunk length of the fused trellis path (hml_ctx.hpp: tre_autotune)
+#define HML_TRE_TUNE_AFTER 48u   // sweeps before the measurement: the filter's warm-up length has settled by then
+static uint32_t tre_default_L(uint32_t hint) { return hint >= (1u << 26) ? 128u : hint >= (1u << 24) ? 64u : (uint32_t)HML_TRE_MIN_L; }
+static int tre_candidates(uint32_t hint, uint32_t* out) {
+    const uint32_t L0 = tre_default_L(hint);
+    int n = 0;
+    for (uint32_t q = 4; q <= 8; ++q) {   // L0 * {1, 1.25, 1.5, 1.75, 2}, multiples of 32
+        const uint32_t l = L0 * q / 4u;
+        if (l % 32u == 0u && l <= 256u) out[n++] = l;
+    }
+    return n;
+}
+static bool tre_tuned_for(const hml_ctx* c, uint32_t hint) {
+    return c->tre_tuned_L && hint <= c->tre_tuned_hint + c->tre_tuned_hint / 8u && hint + hint / 8u >= c->tre_tuned_hint;
+}
+// does the next fused-trellis sweep measure a candidate?  (it then runs outside any graph and waits for its own events)
+static bool tre_wants_measurement(const hml_ctx* c, uint32_t hint) {
+    return !c->tre_L && c->tre_autotune && !tre_tuned_for(c, hint) && c->tre_dense_sweeps >= HML_TRE_TUNE_AFTER;
+}
+// the chunk length of the next sweep; *measure: bracket the trellis kernels with events and report (tre_tune_report)
+static uint32_t tre_pick_L(hml_ctx* c, uint32_t hint, bool capturing, bool* measure) {
+    *measure = false;
+    if (c->tre_L) return c->tre_L;
+    if (tre_tuned_for(c, hint)) return c->tre_tuned_L;
+    if (capturing || !tre_wants_measurement(c, hint)) return c->tre_tuned_L ? c->tre_tuned_L : tre_default_L(hint);
+    uint32_t cand[8];
+    const int n = tre_candidates(hint, cand);
+    if (n < 2) { c->tre_tuned_L = cand[0]; c->tre_tuned_hint = hint; return cand[0]; }
+    if (c->tre_tune_step < 0) { c->tre_tune_step = 0; for (float& v : c->tre_tune_ms) v = 3.4e38f; }
+    *measure = true;
+    return cand[c->tre_tune_step % n];
+}
+static void tre_tune_report(hml_ctx* c, uint32_t hint, float ms) {
+    uint32_t cand[8];
+    const int n = tre_candidates(hint, cand);
+    const int i = c->tre_tune_step % n;
+    c->tre_tune_ms[i] = std::min(c->tre_tune_ms[i], ms);
+    if (++c->tre_tune_step < 2 * n) return;
+    int best = 0;
+    for (int k = 1; k < n; ++k) if (c->tre_tune_ms[k] < c->tre_tune_ms[best]) best = k;
+    c->tre_tuned_L = cand[best];
+    c->tre_tuned_hint = hint;
+    c->tre_tune_step = -1;
+    if (getenv("HML_TRELLIS_TUNE_DEBUG")) {
+        fprintf(stderr, "[trellis tune] %u blocks:", hint);
+        for (int k = 0; k < n; ++k) fprintf(stderr, " L=%u %.3f ms", cand[k], c->tre_tune_ms[k]);
+        fprintf(stderr, " -> L=%u\n", cand[best]);
+    }
+}
+
 template <int KK>
 static int sweep_k(hml_ctx* c, char method, bool record) {
     hipStream_t s = c->stream;
@@ -925,7 +976,13 @@ static int sweep_k(hml_ctx* c, char method, bool record) {
     if (trellis) {
         // chunk length by the number of blocks: the warm-up (emission terms included) is paid once per chunk, and a
         // wavefront takes 64 chunks - long chunks where there are enough blocks to fill the machine with wavefronts anyway
-        uint32_t TL = c->tre_L ? c->tre_L : (hint >= (1u << 26) ? 128u : hint >= (1u << 24) ? 64u : (uint32_t)HML_TRE_MIN_L);
+        hipStreamCaptureStatus capst = hipStreamCaptureStatusNone;
+        (void)hipStreamIsCapturing(s, &capst);
+        bool measure = false;
+        const uint32_t TL = tre_pick_L(c, hint, capst != hipStreamCaptureStatusNone, &measure);
+        hipEvent_t tev0 = nullptr, tev1 = nullptr;
+        if (measure) { tev0 = ev_get(c); tev1 = ev_get(c); hipEventRecord(tev0, s); }
+        c->graph_tre_L = TL;
         const uint64_t tchunks = ((uint64_t)hint + TL - 1) / TL;
         const uint64_t tgroups = (tchunks + HML_TRE_NCH - 1) / HML_TRE_NCH;
         float* ep = c->probes ? c->d_eprobe : nullptr;
@@ -962,6 +1019,16 @@ static int sweep_k(hml_ctx* c, char method, bool record) {
             hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_trellis_states<KK>), dim3(grid_for(tgroups, 1, 16, 1 << 20)), dim3(64), 0, s, c->d_smap,
                                c->d_scmap, c->d_bentry2, c->d_mdl, c->d_q, TL);
         }
+        if (measure) {
+            // a measuring sweep (a few per chain): wait for the trellis kernels and note what this chunk length cost
+            hipEventRecord(tev1, s);
+            float ms = 0.0f;
+            const bool ok = hipEventSynchronize(tev1) == hipSuccess && hipEventElapsedTime(&ms, tev0, tev1) == hipSuccess;
+            c->ev_pool.push_back(tev0);
+            c->ev_pool.push_back(tev1);
+            if (ok) tre_tune_report(c, hint, ms); else { (void)hipGetLastError(); c->tre_autotune = false; }
+        }
+        c->tre_dense_sweeps++;
         {
             ProfScope ps(c, "counts");
             hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_counts_dense<KK, false>), dim3(HML_REDUCE_GROUPS), dim3(256), 0, s, c->d_q,
@@ -1063,13 +1130,17 @@ int hml_iterate(hml_ctx* c, char method, uint64_t iterations, uint64_t thinning)
     if (int r = ctx_bind(c)) return r;
     for (uint64_t i = 0; i < iterations; ++i) {
         const bool record = thinning > 0 && ((i + 1) % thinning == 0);
-        if (c->use_graph && !record && !c->profiling && !c->probes && (c->dynamic || c->blocks_valid)) {
-            // replay a captured sweep; capture again when the launch geometry (grid hint / mode) changed
-            refresh_hint(c);
+        refresh_hint(c);
+        const bool tre_path = c->tre_fused && c->D == 1 && method == HML_METHOD_FB && c->B_hint >= c->dense_min_blocks;
+        if (c->use_graph && !record && !c->profiling && !c->probes && (c->dynamic || c->blocks_valid) &&
+            !(tre_path && tre_wants_measurement(c, c->B_hint))) {
+            // replay a captured sweep; capture again when the launch geometry (grid hint / mode / chunk length) changed
             const uint32_t hint = c->B_hint;
+            bool unused = false;
             const bool stale = !c->graph_exec || c->graph_method != method || c->graph_dynamic != c->dynamic ||
                                hint > c->graph_hint || hint * 2u < c->graph_hint ||
-                               c->graph_dense != (hint >= c->dense_min_blocks);
+                               c->graph_dense != (hint >= c->dense_min_blocks) ||
+                               (tre_path && c->graph_tre_L != tre_pick_L(c, hint, true, &unused));
             if (stale && hint) {
                 if (c->graph_exec) { hipGraphExecDestroy(c->graph_exec); c->graph_exec = nullptr; }
                 hipGraph_t g = nullptr;
@@ -1091,6 +1162,7 @@ int hml_iterate(hml_ctx* c, char method, uint64_t iterations, uint64_t thinning)
             }
             if (c->graph_exec) {
                 HIPCHK(hipGraphLaunch(c->graph_exec, c->stream));
+                if (tre_path) c->tre_dense_sweeps++;
                 continue;
             }
         }
@@ -1116,6 +1188,11 @@ int hml_set_option(hml_ctx* c, const char* name, int value) {
         c->fused_blocks = value != 0;
         c->fused_keep = value == 2;
         if (c->graph_exec) { hipGraphExecDestroy(c->graph_exec); c->graph_exec = nullptr; }
+        return 0;
+    }
+    if (std::string(name) == "trellis_L") {   // chunk length of the fused trellis path: 0 = measured, else a multiple of 32 up to 256
+        if (value < 0 || value > 256 || value % 32) return set_err(HML_ERR_ARG, "trellis_L: 0 or a multiple of 32 up to 256");
+        c->tre_L = (uint32_t)value;
         return 0;
     }
     return set_err(HML_ERR_ARG, std::string("unknown option ") + name);

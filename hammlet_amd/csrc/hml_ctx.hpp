@@ -63,7 +63,17 @@ struct hml_ctx {
     uint32_t* d_redo = nullptr;    // backward chunks that failed the forward verification (list for the repair step)
     uint32_t* d_redo2 = nullptr;   // second list of stale chunks and the bitmap of the sequential finisher (fused trellis path)
     uint32_t* d_tre_bitmap = nullptr;
-    uint32_t tre_L = 0;            // its chunk length (0: chosen from the number of blocks; HML_TRELLIS_L)
+    uint32_t tre_L = 0;            // its chunk length (0: chosen from the number of blocks, then by measurement; HML_TRELLIS_L, option "trellis_L")
+    // The best chunk length depends on how the wavefronts of hml_k_trellis_tile (64 chunks each, resident for the whole
+    // launch) divide among the CUs' slots - a rounding effect no formula of ours predicted - so it is MEASURED: once the
+    // warm-up policy has settled, every candidate length runs two sweeps between a pair of events and the fastest
+    // stays.  The chain's results do not depend on the chunk length (rows, maps and draws are addressed by block).
+    bool tre_autotune = true;      // HML_TRELLIS_TUNE=0: keep the length chosen from the number of blocks
+    uint32_t tre_tuned_L = 0, tre_tuned_hint = 0;
+    int tre_tune_step = -1;        // >= 0 while measuring: candidate step % n, pass step / n
+    float tre_tune_ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    uint64_t tre_dense_sweeps = 0; // fused-trellis sweeps of this chain so far
+    uint32_t graph_tre_L = 0;      // chunk length of the captured sweep
     bool tre_fused = true;         // weakly compressed FB sweeps take the fused trellis kernels (HML_TRELLIS_FUSED=0: the separate ones)
     uint32_t* d_touched = nullptr; // backward chunks whose rows the repair recomputed, tagged with the sweep
     uint32_t* d_fb = nullptr;

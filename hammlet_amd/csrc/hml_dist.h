@@ -16,6 +16,7 @@
 
 #include "hml_common.h"
 #include "hml_math.h"
+#include "hml_philox.h"
 
 struct hml_devmath {
     static HML_HDM float logf_(float x) { return hml_logf(x); }
@@ -38,6 +39,20 @@ HML_HD double hml_canonical_f64(uint32_t r0, uint32_t r1) {
     double ret = sum / 18446744073709551616.0;
     if (ret >= 1.0) ret = 0.99999999999999989;  // nextafter(1.0, 0.0)
     return ret;
+}
+
+// The uniforms of the backward draws (sub-stream kind CAT).  Row t (1-based; block b = t - 1) is addressed by b: blocks
+// 2m and 2m + 1 share Philox block m of the sweep - words (0, 1) make the uniform of the even block, words (2, 3) that of
+// the odd one - so a lane that owns two consecutive rows pays for one block of ten rounds instead of two.
+HML_HD void hml_cat_uniform_pair(hml_key key, uint64_t epoch, uint32_t pair, double& u_even, double& u_odd) {
+    const hml_u32x4 o = hml_stream4(key, HML_KIND_CAT, epoch, pair, 0);
+    u_even = hml_canonical_f64(o.v[0], o.v[1]);
+    u_odd = hml_canonical_f64(o.v[2], o.v[3]);
+}
+HML_HD double hml_cat_uniform(hml_key key, uint64_t epoch, uint32_t t) {
+    const uint32_t b = t - 1u;
+    const hml_u32x4 o = hml_stream4(key, HML_KIND_CAT, epoch, b >> 1, 0);
+    return (b & 1u) ? hml_canonical_f64(o.v[2], o.v[3]) : hml_canonical_f64(o.v[0], o.v[1]);
 }
 
 // std::discrete_distribution over K float weights: normalise in double, cumulative sums with the

@@ -76,17 +76,52 @@ __device__ __forceinline__ int hml_categorical_k_fast(const float (&w)[K], doubl
     return res;
 }
 
+// The float screen in front of both: the same comparisons with float running sums and a float copy of u.  The float
+// sums carry a relative error of at most (K-1) 2^-24, the product fl(u) * sum one of (K+1) 2^-24 and the difference one
+// more rounding, so for K <= 16 the computed s_i - u sum lies within 2^-18.9 sum of the real one: whenever it is
+// farther than 2^-17 sum from zero for every i the real comparison - and with it the literal form, which agrees with
+// the real numbers outside 2^-44 sum - comes out the same way.  About 3 in 10^5 draws (measured on the dense regime of
+// config 3; and sums that are tiny, not finite or not positive) go on to the double forms; the rest never touch a double.
+template <int K>
+__device__ __forceinline__ int hml_categorical_k_screen(const float (&w)[K], float uf, bool& unsure_out) {
+    static_assert(K <= 16, "error bound of the float screen");
+    float s[K];
+    float acc = 0.0f;
+#pragma unroll
+    for (int i = 0; i < K; ++i) { acc += w[i]; s[i] = acc; }
+    const float t = uf * acc;
+    const float margin = acc * 7.62939453125e-06f;   // 2^-17
+    bool unsure = !(acc > 7.888609052210118e-31f) || !(acc < 3.4028234663852886e38f);   // 2^-100 < sum < inf
+    int res = K - 1;
+    bool done = false;
+#pragma unroll
+    for (int i = 0; i < K - 1; ++i) {
+        const float d = s[i] - t;
+        unsure = unsure || !(__builtin_fabsf(d) > margin);
+        if (!done && d >= 0.0f) { res = i; done = true; }
+    }
+    unsure_out = unsure;
+    return res;
+}
+
 template <int K>
 __device__ __forceinline__ int hml_categorical_k(const float (&w)[K], double u) {
     bool unsure = false;
-    const int res = hml_categorical_k_fast<K>(w, u, unsure);
-    return unsure ? hml_categorical_k_literal<K>(w, u) : res;
+    int res = hml_categorical_k_screen<K>(w, (float)u, unsure);
+    if (unsure) {
+        // (the empty statement keeps the compiler from evaluating the double forms ahead of the branch for every draw)
+        asm volatile("" ::: "memory");
+        unsure = false;
+        res = hml_categorical_k_fast<K>(w, u, unsure);
+        if (unsure) res = hml_categorical_k_literal<K>(w, u);
+    }
+    return res;
 }
 
 // ------------------------------------------------------------------------------------------
 // K7a backward_maps - backward sampling (reference src/StateSequence/ForwardBackward.hpp:133-162,
 // Trellis::sample src/Trellis.hpp:61-66):  q_B ~ Cat(r_B),  q_t ~ Cat(r_t[i] * A(i, q_{t+1})).
-// Row t's uniform u_t comes from Philox sub-stream (CAT, epoch, t), so for every possible
+// Row t's uniform u_t is addressed by the row alone (hml_cat_uniform, hml_dist.h), so for every possible
 // successor state x the draw cand_t(x) is known in advance: row t is a MAP [K]->[K].  The state
 // sequence is the composition of those maps applied from the last row down - associative, hence a
 // scan.  One wavefront owns 64 consecutive rows: lane l evaluates row t = 64c + l + 1, then a
@@ -110,8 +145,7 @@ __device__ __forceinline__ void hml_bwd_chunk_maps(const float (&r)[K], hml_mode
     const uint32_t t = c * HML_BWD_CHUNK + (uint32_t)lane + 1u;
     unsigned long long map = HML_MAP_IDENTITY;
     if (t <= B) {
-        const hml_u32x4 o = hml_stream4(key, HML_KIND_CAT, epoch, t, 0);
-        const double u = hml_canonical_f64(o.v[0], o.v[1]);
+        const double u = hml_cat_uniform(key, epoch, t);
         map = 0ull;
         if (t == B) {
             const unsigned long long st = (unsigned long long)hml_categorical_k<K>(r, u);

@@ -75,12 +75,11 @@ __device__ __forceinline__ void hml_tre_emit(const hml_emit_params<K>& p, hml_mo
     for (int s = 0; s < K; ++s) ev[s] = hml_expf(E[s] - maxE);
 }
 
-// candidate map of row t from its (rescaled) row r: cand(x) = draw of Cat(r_i A(i, x)); the last row's map is constant
+// candidate map of row t from its (rescaled) row r and the row's uniform u (hml_cat_uniform): cand(x) = draw of
+// Cat(r_i A(i, x)); the last row's map is constant
 template <int K>
-__device__ __forceinline__ unsigned long long hml_tre_cand(const float (&r)[K], const float* __restrict__ A, hml_model* mdl, uint32_t t,
-                                                           uint32_t B, unsigned long long epoch, const hml_key key) {
-    const hml_u32x4 o = hml_stream4(key, HML_KIND_CAT, epoch, t, 0);
-    const double u = hml_canonical_f64(o.v[0], o.v[1]);
+__device__ __forceinline__ unsigned long long hml_tre_cand_u(const float (&r)[K], const float* __restrict__ A, hml_model* mdl, uint32_t t,
+                                                             uint32_t B, const double u) {
     unsigned long long map = 0ull;
     // "Negative backward variable!" (ForwardBackward.hpp:147-149): the products r_i A(i, x) below are negative exactly
     // when r_i is (A holds probabilities), so the row is checked once instead of K times
@@ -102,12 +101,17 @@ __device__ __forceinline__ unsigned long long hml_tre_cand(const float (&r)[K], 
     }
     return map;
 }
+template <int K>
+__device__ __forceinline__ unsigned long long hml_tre_cand(const float (&r)[K], const float* __restrict__ A, hml_model* mdl, uint32_t t,
+                                                           uint32_t B, unsigned long long epoch, const hml_key key) {
+    return hml_tre_cand_u<K>(r, A, mdl, t, B, hml_cat_uniform(key, epoch, t));
+}
 
 // ------------------------------------------------------------------------------------------
 // the first pass: one wavefront (= one workgroup of 64 threads) per 64 chunks
 // ------------------------------------------------------------------------------------------
 template <int K>
-__global__ __launch_bounds__(64) void hml_k_trellis_tile(const float2* __restrict__ ia, const uint32_t* __restrict__ starts,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void hml_k_trellis_tile(const float2* __restrict__ ia, const uint32_t* __restrict__ starts,
                                                          hml_model* __restrict__ mdl, const hml_model* __restrict__ mdl_ro,
                                                          float2* __restrict__ bstat, unsigned long long* __restrict__ cand,
                                                          unsigned long long* __restrict__ fmap, float* __restrict__ entry,
@@ -216,26 +220,36 @@ __global__ __launch_bounds__(64) void hml_k_trellis_tile(const float2* __restric
             }
             __syncthreads();
             if (rel0 >= 0) {
-                // ---------------- P3: candidate maps of the batch's rows, lane = (chunk, row) as in P1
+                // ---------------- P3: candidate maps of the batch's rows, lane = (chunk, pair of rows): the two rows of a
+                // pair (blocks 2m, 2m + 1: chunks and batches start at even blocks) share one Philox block
+                static_assert(HML_TRE_R % 2 == 0 && HML_TRE_MIN_L % 2 == 0, "row pairs");
 #pragma unroll 1
-                for (int k = 0; k < R; ++k) {
+                for (int k = 0; k < R / 2; ++k) {
                     const int slot = k * 64 + lane;
-                    const int c = slot / R, r = slot % R;
-                    const uint32_t n = sm_n[c * PITCH + r];
-                    if (n != 0u) {   // (a block of the batch, see P1)
-                        const long long b = (long long)(f0 + (uint32_t)c) * L + rel0 + r;
-                        const uint32_t t = (uint32_t)b + 1u;
-                        float row[K];
+                    const int c = slot / (R / 2), r0 = 2 * (slot % (R / 2));
+                    const uint32_t n0 = sm_n[c * PITCH + r0];
+                    if (n0 != 0u) {   // (a block of the batch, see P1; the pair's second row exists only behind its first)
+                        const uint32_t b0 = (f0 + (uint32_t)c) * L + (uint32_t)rel0 + (uint32_t)r0;
+                        double u2[2];
+                        hml_cat_uniform_pair(key, epoch, b0 >> 1, u2[0], u2[1]);
 #pragma unroll
-                        for (int s = 0; s < K; ++s) row[s] = sm_v[s * PLANE + c * PITCH + r];
-                        if (cx.self && t < B) {   // the reference rescales row t after step t + 1 has consumed it (ForwardBackward.hpp:115-119)
+                        for (int h = 0; h < 2; ++h) {
+                            const uint32_t n = h ? sm_n[c * PITCH + r0 + 1] : n0;
+                            if (n != 0u) {
+                                const uint32_t t = b0 + (uint32_t)h + 1u;
+                                float row[K];
 #pragma unroll
-                            for (int s = 0; s < K; ++s)
-                                row[s] = row[s] * ((n <= (uint32_t)HML_TRE_GTAB) ? gtab[(n - 1u) * K + s] : hml_expf(((float)n - 1.0f) * p.logA[s]));
+                                for (int s = 0; s < K; ++s) row[s] = sm_v[s * PLANE + c * PITCH + r0 + h];
+                                if (cx.self && t < B) {   // the reference rescales row t after step t + 1 has consumed it (ForwardBackward.hpp:115-119)
+#pragma unroll
+                                    for (int s = 0; s < K; ++s)
+                                        row[s] = row[s] * ((n <= (uint32_t)HML_TRE_GTAB) ? gtab[(n - 1u) * K + s] : hml_expf(((float)n - 1.0f) * p.logA[s]));
+                                }
+                                const unsigned long long cm = hml_tre_cand_u<K>(row, cx.A, mdl, t, B, u2[h]);
+                                hml_tre_store_cand<K>(cand, t, cm);
+                                sm_c[c * PITCH + r0 + h] = cm;
+                            }
                         }
-                        const unsigned long long cm = hml_tre_cand<K>(row, cx.A, mdl, t, B, epoch, key);
-                        hml_tre_store_cand<K>(cand, t, cm);
-                        sm_c[c * PITCH + r] = cm;
                     }
                 }
                 __syncthreads();

@@ -149,7 +149,12 @@ int hml_set_option(hml_ctx* ctx, const char* name, int value);
  * wait: when the GPU is shared and a wait expires the waiting workgroup computes the missing word itself, and the chain
  * takes the other path from the next sweep on); 0: always the scan + scatter + statistics launches, which share
  * nothing inside a launch - the setting for a GPU that several processes use; 2: like 1, but keep the kernel after an
- * expired wait (tests).  Same results every way.  Environment: HML_FUSED_BLOCKS. */
+ * expired wait (tests).  Same results every way.  Environment: HML_FUSED_BLOCKS.
+ * "trellis_L" (any time): chunk length of the fused trellis kernels that weakly compressed univariate FB sweeps take
+ * (millions of blocks; hml_k_trellis.h).  0 (default): chosen from the number of blocks and then, after 48 such sweeps,
+ * by measurement - every candidate length runs two sweeps between a pair of events and the fastest stays; a multiple of
+ * 32 up to 256: that length.  A launch geometry only: rows, maps and draws are addressed by block, so the chain's
+ * results are the same for every length.  Environment: HML_TRELLIS_L, HML_TRELLIS_TUNE=0 (no measurement). */
 
 /* wait for all enqueued work; surfaces model errors raised on the device */
 int hml_sync(hml_ctx* ctx);

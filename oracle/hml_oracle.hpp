@@ -547,6 +547,8 @@ public:
         return hml_categorical(wts, K, hml_canonical_f64(r0, r1));
     }
     int categorical_ctr(uint32_t kind, uint32_t index, const float* wts, int K) const {
+        // backward rows: two consecutive blocks share one Philox block (hml_cat_uniform, hml_dist.h)
+        if (kind == HML_KIND_CAT) return hml_categorical(wts, K, hml_cat_uniform(hml_make_key(cfg.seed, cfg.chain), epoch, index));
         hml_u32x4 o = hml_stream4(hml_make_key(cfg.seed, cfg.chain), kind, epoch, index, 0);
         return hml_categorical(wts, K, hml_canonical_f64(o.v[0], o.v[1]));
     }

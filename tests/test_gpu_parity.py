@@ -645,7 +645,7 @@ def test_fused_block_kernel_retires_itself_after_an_expired_wait(hml, monkeypatc
     assert g.profile_get("blocks_scatter")[1] >= 10
 
 
-@pytest.mark.parametrize("chunk,fused", [(32, 1), (128, 1), (256, 1), (32, 0)])
+@pytest.mark.parametrize("chunk,fused", [(32, 1), (96, 1), (128, 1), (256, 1), (32, 0)])
 def test_fused_trellis_repair_paths_on_twin_states(hml, monkeypatch, chunk, fused):
     """The fused trellis kernels of weakly compressed sweeps (hml_k_trellis.h; HML_TRELLIS_FUSED=0 runs the separate
     kernels for comparison) on the adversarial twin-state parameters: an uncompressed trace on which the filter hardly
@@ -687,3 +687,33 @@ def test_fused_trellis_repair_paths_on_twin_states(hml, monkeypatch, chunk, fuse
     compare_state(o, g)
     seg, cnt = g.marginals_rle()
     assert hml.marginals_text(seg, cnt) == o.text("marginals")
+
+
+def test_trellis_chunk_length_is_measured_and_changes_nothing(hml, monkeypatch, capfd):
+    """The fused trellis path picks its chunk length by measurement once the chain has run 48 such sweeps (hml_ctx.hpp:
+    tre_autotune): the sweeps that measure, and the ones after them with whatever length won, must leave the chain in the
+    checker's state bit for bit - the chunk length is a launch geometry, not part of the chain's definition."""
+    monkeypatch.setenv("HML_DENSE_MIN_BLOCKS", "1")
+    monkeypatch.setenv("HML_TRELLIS_TUNE_DEBUG", "1")
+    T, K = 200_000, 3
+    xx, o, g = make_pair(hml, T, K, 0, 7, weight_mult=1e9)
+    setup_model(o, g, K)
+    o.token("F")
+    g.sample_prior()
+    o.iterate("F", 47, 0)
+    g.iterate("F", 47, 0)
+    g.sync()
+    compare_state(o, g)
+    o.iterate("F", 8, 0)          # sweeps 48 .. 51 measure the candidates 32 and 64 twice each
+    g.iterate("F", 8, 0)
+    g.sync()
+    compare_state(o, g)
+    assert np.array_equal(o.states(), g.states())
+    assert "[trellis tune]" in capfd.readouterr().err
+    with pytest.raises(hml.HmlError):
+        g.set_option("trellis_L", 48)
+    g.set_option("trellis_L", 96)
+    o.iterate("F", 2, 0)
+    g.iterate("F", 2, 0)
+    g.sync()
+    compare_state(o, g)
