@@ -283,6 +283,8 @@ int hml_create(hml_ctx** out, int device, uint64_t seed, uint32_t chain_id, void
     }
     if (const char* e = getenv("HML_FWD_CHUNK")) { int l = std::max(1, atoi(e)); int sh = 0; while ((1 << (sh + 1)) <= l && sh < 10) ++sh; c->fwdL = 1 << sh; }
     if (const char* e = getenv("HML_FWD_WARMUP")) c->fwdW = c->fwdW_init = std::max(0, atoi(e));
+    if (const char* e = getenv("HML_FWD_BURNIN_SWEEPS")) c->fwd_burnin_sweeps = (uint32_t)std::max(0, atoi(e));
+    if (const char* e = getenv("HML_FWD_QUIET")) c->fwd_quiet_need = (uint32_t)std::max(1, atoi(e));
     if (const char* e = getenv("HML_FWD_CHUNK_DENSE")) { int l = std::max(1, atoi(e)); int sh = 0; while ((1 << (sh + 1)) <= l && sh < 10) ++sh; c->fwdL_dense = 1 << sh; }
     if (const char* e = getenv("HML_DENSE_MIN_BLOCKS")) c->dense_min_blocks = (uint32_t)strtoul(e, nullptr, 10);
     if (const char* e = getenv("HML_USE_GRAPH")) c->use_graph = atoi(e) != 0;
@@ -726,6 +728,8 @@ int hml_set_model(hml_ctx* c, int K, const float nig4[4], float a_off, float a_d
     m.tre_fused = (c->tre_fused && c->D == 1) ? 1u : 0u;
     m.fwd_W0 = (uint32_t)c->fwdW;
     m.fwd_W = m.fwd_W_burnin = (uint32_t)std::max(c->fwdW, c->fwdW_init);
+    m.fwd_burnin_sweeps = c->fwd_burnin_sweeps;
+    m.fwd_quiet_need = c->fwd_quiet_need;
     m.n_spans = c->n_spans;
     // keep the block count of an earlier enumeration (autoprior) out of the model: B = 0
     HIPCHK(hipMemcpyAsync(c->d_mdl, &m, sizeof m, hipMemcpyHostToDevice, c->stream));

@@ -92,7 +92,12 @@ struct hml_ctx {
     bool hint_stale = true;         // the hint predates the current parameters (new model, prior draw, mode switch)
     // forward geometry
     int fwdL = 4, fwdW = 12;   // W is the floor of the adaptive warm-up (measured: 12 beats 16 and 24 on C1-C4; 8 does not)
-    int fwdW_init = 24;        // where a chain starts and the floor of its first 256 sweeps: while the parameters are
+    // the warm-up policy of hml_k_params (HML_FWD_BURNIN_SWEEPS, HML_FWD_QUIET): the floor of a young chain holds for 64
+    // sweeps and the warm-up shrinks by a quarter after 16 sweeps without a refit.  Measured over the first 400 sweeps
+    // of configs 2 / 3 / 4 (tools/burnin_sweep.sh): 19.9 / 25.4 / 50.4 ms against 21.0 / 26.1 / 52.2 ms with (256, 32);
+    // (32, 8) and faster let the warm-up fall while the parameters still move - bursts of 150+ refits, 26.6 ms on config 3
+    uint32_t fwd_burnin_sweeps = 64, fwd_quiet_need = 16;
+    int fwdW_init = 24;        // where a chain starts and the floor of its first fwd_burnin_sweeps sweeps: while the parameters are
                                // still far from settled the filter forgets slowly (131 refits in sweeps 20-220 of C3 with a floor of 12)
     hml_layout lay = {2, 0};
     // weakly compressed sweeps (B_hint >= dense_min_blocks): longer forward chunks - the warm-up is a smaller share

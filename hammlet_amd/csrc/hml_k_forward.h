@@ -318,7 +318,10 @@ __global__ __launch_bounds__(256) void hml_k_emission_tiled(const float2* __rest
 // Geometry: ONE LANE per chunk - the lane carries the whole K-vector in registers, A comes from scalar
 // registers (it is the same for every lane), and nothing crosses lanes.  (A 16-lanes-per-chunk layout
 // with one state per lane was measured first: its 2K ds_bpermute round trips per step made a step cost
-// ~530 cycles and used 9x more wavefront-instructions per block.)
+// ~530 cycles and used 9x more wavefront-instructions per block.  The same layout with DPP row broadcasts instead
+// (row_newbcast folded into the multiplies and adds: 45 instructions a step, no LDS) was measured in round 2: 26.9 us
+// against 12.5 us for the 44 000 chunks of config 3 at W = 24 - with 4 chunks per wavefront instead of 64 the pass
+// issues 4x the wavefront-instructions, and 11 000 wavefronts are throughput-bound where 700 are latency-bound.)
 template <int K>
 struct hml_fwd_ctx {
     float A[K * K];

@@ -295,7 +295,7 @@ __global__ __launch_bounds__(1024) void hml_k_params(hml_model* __restrict__ mdl
     if (tid == 1023) {
         // adapt the forward warm-up (speed only - the rows are bit-exact for every W): double it when the repair step
         // had real work - its serial pass ran, or it recomputed more than a handful of chunks - and shrink it slowly
-        // after 32 sweeps without a single refit (shrinking while a few chunks still fail was measured: the failure
+        // after fwd_quiet_need (16) sweeps without a single refit (shrinking while a few chunks still fail was measured: the failure
         // count has a cliff, sweeps with 10^5 refits follow)
         if (mode == 0) {
             uint32_t W = mdl->fwd_W;
@@ -316,8 +316,8 @@ __global__ __launch_bounds__(1024) void hml_k_params(hml_model* __restrict__ mdl
             } else
             if (serial != 0ull || refits > handful) { W = (2u * W < 1024u) ? 2u * W : 1024u; mdl->fwd_quiet = 0u; }
             else if (refits == 0ull) {
-                const uint32_t floorW = (mdl->sweeps < 256ull) ? mdl->fwd_W_burnin : mdl->fwd_W0;
-                if (++mdl->fwd_quiet >= 32u) { const uint32_t w2 = W - W / 4u; W = (w2 > floorW) ? ((w2 & ~7u) > floorW ? (w2 & ~7u) : floorW) : floorW; mdl->fwd_quiet = 0u; }
+                const uint32_t floorW = (mdl->sweeps < (unsigned long long)mdl->fwd_burnin_sweeps) ? mdl->fwd_W_burnin : mdl->fwd_W0;
+                if (++mdl->fwd_quiet >= mdl->fwd_quiet_need) { const uint32_t w2 = W - W / 4u; W = (w2 > floorW) ? ((w2 & ~7u) > floorW ? (w2 & ~7u) : floorW) : floorW; mdl->fwd_quiet = 0u; }
             } else mdl->fwd_quiet = 0u;
             mdl->fwd_W = W;
             mdl->fwd_refits_seen = mdl->forward_refits;

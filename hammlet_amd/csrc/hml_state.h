@@ -98,7 +98,9 @@ struct hml_model {
     uint32_t fwd_mismatch2;      // the fused trellis path alternates between two lists of stale chunks (refit rounds)
     // adaptive warm-up length of the speculative forward pass (results never depend on it)
     uint32_t fwd_W, fwd_W0, fwd_serial_ran, fwd_quiet;
-    uint32_t fwd_W_burnin;       // floor during the first 256 sweeps of a chain (parameters still far from settled)
+    uint32_t fwd_W_burnin;       // floor during the first fwd_burnin_sweeps sweeps of a chain (parameters still far from settled)
+    uint32_t fwd_burnin_sweeps;  // (HML_FWD_BURNIN_SWEEPS)
+    uint32_t fwd_quiet_need;     // sweeps without a single refit before the warm-up shrinks by a quarter (HML_FWD_QUIET)
     uint32_t tre_fused;          // weakly compressed FB sweeps take the fused trellis kernels (hml_k_trellis.h): stale chunks are
                                  // refitted in parallel there, so the warm-up follows a different rule (hml_k_params)
     unsigned long long fwd_refits_seen, fwd_serial_seen;

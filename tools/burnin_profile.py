@@ -17,7 +17,7 @@ for g in range(groups):
     n = int(os.environ.get("PER", "10"))
     t0 = time.perf_counter(); ch.iterate("F", n, 0); ch.sync(); t1 = time.perf_counter()
     s = ch.stats()
-    print("sweeps %3d-%3d: %8.2f ms/sweep  B %10d  refits %8d  serial %6d  warm-up %d" % (
-        10 * g, 10 * g + 9, 1e3 * (t1 - t0) / n, (s["block_updates"] - prev["block_updates"]) // n,
+    print("sweeps %3d-%3d: %8.4f ms/sweep  B %10d  refits %8d  serial %6d  warm-up %d" % (
+        n * g, n * g + n - 1, 1e3 * (t1 - t0) / n, (s["block_updates"] - prev["block_updates"]) // n,
         s["forward_refits"] - prev["forward_refits"], s["forward_serial"] - prev["forward_serial"], s["forward_warmup"]))
     prev = s
