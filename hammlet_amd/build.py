@@ -11,6 +11,7 @@ CLI_PATH = os.path.join(PKG_DIR, "hammlet")
 TOOL_PATH = os.path.join(PKG_DIR, "maxSegmentation")
 SORT_TOOL_PATH = os.path.join(PKG_DIR, "sortStates")
 AVG_TOOL_PATH = os.path.join(PKG_DIR, "avg")
+GENOME_TOOLS = ("mapLinesToGenome", "combineCounts")   # host tools over zlib (csrc/host/*_main.cpp)
 
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC"]
 
@@ -106,6 +107,14 @@ def build_cli(force=False, verbose=False):
         if verbose:
             print(" ".join(cmd))
         subprocess.run(cmd, check=True)
+    for tool in GENOME_TOOLS:
+        gsrc = os.path.join(CSRC, "host", tool + "_main.cpp")
+        gout = os.path.join(PKG_DIR, tool)
+        if force or _newer(gout, [gsrc, os.path.join(CSRC, "host", "gz_lines.hpp"), os.path.join(REPO_DIR, "include", "hammlet", "Parser.hpp")]):
+            cmd = ["g++", "-O2", "-std=c++17", "-o", gout, gsrc, "-I", os.path.join(REPO_DIR, "include"), "-lz"]
+            if verbose:
+                print(" ".join(cmd))
+            subprocess.run(cmd, check=True)
     ssrc = os.path.join(CSRC, "host", "sortStates_main.cpp")
     if force or _newer(SORT_TOOL_PATH, [ssrc]):
         cmd = ["g++", "-O2", "-std=c++17", "-o", SORT_TOOL_PATH, ssrc]
