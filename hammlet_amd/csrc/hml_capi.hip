@@ -292,6 +292,7 @@ int hml_create(hml_ctx** out, int device, uint64_t seed, uint32_t chain_id, void
     if (const char* e = getenv("HML_FUSED_BLOCKS")) { c->fused_blocks = atoi(e) != 0; c->fused_keep = atoi(e) == 2; }   // 0: a GPU shared with other processes
     if (const char* e = getenv("HML_TRELLIS_FUSED")) c->tre_fused = atoi(e) != 0;
     if (const char* e = getenv("HML_TRELLIS_L")) { const int l = atoi(e); c->tre_L = (l <= 0) ? 0u : (l >= 256) ? 256u : (l < 32) ? 32u : (uint32_t)l / 32u * 32u; }   // a multiple of 32
+    if (const char* e = getenv("HML_LATE_RESCALE")) c->late_rescale = atoi(e) != 0;
     if (const char* e = getenv("HML_TRELLIS_TUNE")) c->tre_autotune = atoi(e) != 0;
     if (const char* e = getenv("HML_FUSED_SPIN_LIMIT")) c->fused_spin_limit = (uint32_t)strtoul(e, nullptr, 10);
     if (device < 64) g_live_ctx[device].fetch_add(1);
@@ -923,6 +924,11 @@ static int sweep_k(hml_ctx* c, char method, bool record) {
     const bool trellis = dense_geo && !mix && c->D == 1 && c->tre_fused;
     const int L = dense_geo ? c->fwdL_dense : c->fwdL;
     const hml_layout lay = dense_geo ? c->lay_dense : c->lay;
+    // strongly compressed univariate sweeps keep no plane of rescale factors: the forward rows stay unscaled and the
+    // backward maps apply the factor where they read a row (hml_bwd_row_load) - 3.5 of the block kernel's 11 MB of
+    // stores at 10^8 positions, and what a dependent launch waits for is the write-back of its predecessor's stores
+    float* const gsc_plane = (!dense_geo && c->D == 1 && c->late_rescale) ? nullptr : c->d_gsc;
+    const uint32_t* const starts_for_maps = gsc_plane ? nullptr : c->d_starts;
     if (c->dynamic || !c->blocks_valid) {
         // the fused block kernel: univariate chains that have the GPU to themselves, unless compression is weak (the
         // float stream is the better access pattern then), the kernel reported a bounded wait that expired (someone
@@ -935,7 +941,7 @@ static int sweep_k(hml_ctx* c, char method, bool record) {
             ProfScope ps(c, "blocks_compact", 1);
             hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_blocks_fused<KK>), dim3(n_wg), dim3(HML_FUSED_WAVES * 64), 0, s, c->d_summary, c->d_w, c->d_ia,
                                T, c->d_mdl, c->key_base, c->d_group_word, c->d_stage, c->d_starts, c->d_bstat, c->d_em,
-                               c->d_gsc, c->probes ? c->d_eprobe : nullptr, mix ? 1 : 0, lay, c->d_hB, n_sub, c->fused_spin_limit, c->d_dbg, c->d_mdl);
+                               gsc_plane, c->probes ? c->d_eprobe : nullptr, mix ? 1 : 0, lay, c->d_hB, n_sub, c->fused_spin_limit, c->d_dbg, c->d_mdl);
             fused = true;
         } else {
             launch_compact_pair(c, 0, 0.0f);
@@ -946,15 +952,15 @@ static int sweep_k(hml_ctx* c, char method, bool record) {
             ProfScope ps(c, "stats_emission");
             if (c->D > 1)
                 hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_emission_mv<KK, true>), dim3(grid_for(h0, 256, 64, 16384)), dim3(256), 0, s,
-                                   c->d_ia, c->d_starts, c->d_mdl, c->d_bstat, c->d_em, c->d_gsc, c->probes ? c->d_eprobe : nullptr,
+                                   c->d_ia, c->d_starts, c->d_mdl, c->d_bstat, c->d_em, gsc_plane, c->probes ? c->d_eprobe : nullptr,
                                    mix ? 1 : 0, lay);
             else if (dense_geo && L <= hml_emit_tile<KK>::MAXL)
                 hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_emission_tiled<KK, true>), dim3(grid_for(h0, hml_emit_tile<KK>::BLOCKS, 64, 65536)),
-                                   dim3(256), 0, s, c->d_ia, c->d_starts, c->d_mdl, c->d_bstat, c->d_em, c->d_gsc,
+                                   dim3(256), 0, s, c->d_ia, c->d_starts, c->d_mdl, c->d_bstat, c->d_em, gsc_plane,
                                    c->probes ? c->d_eprobe : nullptr, mix ? 1 : 0, lay);
             else
             hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_stats_emission<KK>), dim3(grid_for(h0, 256, 64, 16384)), dim3(256), 0, s,
-                               c->d_ia, c->d_starts, c->d_mdl, c->d_bstat, c->d_em, c->d_gsc, c->probes ? c->d_eprobe : nullptr,
+                               c->d_ia, c->d_starts, c->d_mdl, c->d_bstat, c->d_em, gsc_plane, c->probes ? c->d_eprobe : nullptr,
                                mix ? 1 : 0, lay);
         }
         KLAUNCH_CHECK();
@@ -968,14 +974,14 @@ static int sweep_k(hml_ctx* c, char method, bool record) {
         ProfScope ps(c, "emission");
         if (c->D > 1)
             hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_emission_mv<KK, false>), dim3(gB), dim3(256), 0, s, c->d_ia, c->d_starts, c->d_mdl,
-                               c->d_bstat, c->d_em, c->d_gsc, c->probes ? c->d_eprobe : nullptr, mix ? 1 : 0, lay);
+                               c->d_bstat, c->d_em, gsc_plane, c->probes ? c->d_eprobe : nullptr, mix ? 1 : 0, lay);
         else if (dense_geo && L <= hml_emit_tile<KK>::MAXL)
             hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_emission_tiled<KK, false>), dim3(grid_for(hint, hml_emit_tile<KK>::BLOCKS, 64, 65536)),
-                               dim3(256), 0, s, c->d_ia, c->d_starts, c->d_mdl, c->d_bstat, c->d_em, c->d_gsc,
+                               dim3(256), 0, s, c->d_ia, c->d_starts, c->d_mdl, c->d_bstat, c->d_em, gsc_plane,
                                c->probes ? c->d_eprobe : nullptr, mix ? 1 : 0, lay);
         else
         hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_emission<KK>), dim3(gB), dim3(256), 0, s, c->d_bstat, c->d_starts, c->d_mdl,
-                           c->d_em, c->d_gsc, c->probes ? c->d_eprobe : nullptr, mix ? 1 : 0, lay);
+                           c->d_em, gsc_plane, c->probes ? c->d_eprobe : nullptr, mix ? 1 : 0, lay);
     }
     if (trellis) {
         // chunk length by the number of blocks: the warm-up (emission terms included) is paid once per chunk, and a
@@ -1043,7 +1049,7 @@ static int sweep_k(hml_ctx* c, char method, bool record) {
         const int gF = grid_for(chunks, 256, 16, 1 << 20);
         {
             ProfScope ps(c, "forward");
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_forward<KK>), dim3(gF), dim3(256), 0, s, c->d_em, c->d_gsc, c->d_mdl, c->d_rows,
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_forward<KK>), dim3(gF), dim3(256), 0, s, c->d_em, gsc_plane, c->d_mdl, c->d_rows,
                                c->probes ? c->d_aprobe : nullptr, c->d_entry, c->d_exitA, c->d_fb, L, lay);
         }
         {
@@ -1053,23 +1059,23 @@ static int sweep_k(hml_ctx* c, char method, bool record) {
             {
                 ProfScope ps(c, "backward_maps");
                 hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_backward_maps<KK>), dim3(grid_for(bch * 64, 256, 16, 1 << 18)), dim3(256), 0,
-                                   s, c->d_rows, c->d_mdl, c->d_smap, c->d_cmap, lay, c->d_entry, c->d_exitA, c->d_redo, L);
+                                   s, c->d_rows, c->d_mdl, c->d_smap, c->d_cmap, lay, c->d_entry, c->d_exitA, c->d_redo, L, starts_for_maps);
             }
             ProfScope ps(c, "backward_chain");
             if (!dense_geo) {
                 hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_backward_chain<KK>), dim3(1), dim3(1024), 0, s, c->d_cmap, c->d_mdl,
-                                   c->d_bentry, c->d_em, c->d_gsc, c->d_rows, c->probes ? c->d_aprobe : nullptr, c->d_entry,
-                                   c->d_exitA, c->d_fb, c->d_redo, c->d_touched, c->d_smap, L, lay, 3, 0);
+                                   c->d_bentry, c->d_em, gsc_plane, c->d_rows, c->probes ? c->d_aprobe : nullptr, c->d_entry,
+                                   c->d_exitA, c->d_fb, c->d_redo, c->d_touched, c->d_smap, L, lay, 3, 0, starts_for_maps);
             } else {
                 // millions of backward chunks: repair step alone, then the two-level chain
                 hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_backward_chain<KK>), dim3(1), dim3(1024), 0, s, c->d_cmap, c->d_mdl,
-                                   c->d_bentry, c->d_em, c->d_gsc, c->d_rows, c->probes ? c->d_aprobe : nullptr, c->d_entry,
-                                   c->d_exitA, c->d_fb, c->d_redo, c->d_touched, c->d_smap, L, lay, 1, 0);
+                                   c->d_bentry, c->d_em, gsc_plane, c->d_rows, c->probes ? c->d_aprobe : nullptr, c->d_entry,
+                                   c->d_exitA, c->d_fb, c->d_redo, c->d_touched, c->d_smap, L, lay, 1, 0, starts_for_maps);
                 hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_backward_super<KK>), dim3(grid_for(bch, 256, 16, 1 << 16)), dim3(256), 0, s,
                                    c->d_cmap, c->d_mdl, c->d_scmap, c->d_super);
                 hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_backward_chain<KK>), dim3(1), dim3(1024), 0, s, c->d_super, c->d_mdl,
-                                   c->d_bentry2, c->d_em, c->d_gsc, c->d_rows, c->probes ? c->d_aprobe : nullptr, c->d_entry,
-                                   c->d_exitA, c->d_fb, c->d_redo, c->d_touched, c->d_smap, L, lay, 2, 1);
+                                   c->d_bentry2, c->d_em, gsc_plane, c->d_rows, c->probes ? c->d_aprobe : nullptr, c->d_entry,
+                                   c->d_exitA, c->d_fb, c->d_redo, c->d_touched, c->d_smap, L, lay, 2, 1, starts_for_maps);
                 hipLaunchKernelGGL(hml_k_backward_entries, dim3(grid_for(bch, 256, 16, 1 << 16)), dim3(256), 0, s, c->d_scmap,
                                    c->d_bentry2, c->d_mdl, c->d_bentry);
             }

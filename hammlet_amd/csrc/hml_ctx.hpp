@@ -63,6 +63,7 @@ struct hml_ctx {
     uint32_t* d_redo = nullptr;    // backward chunks that failed the forward verification (list for the repair step)
     uint32_t* d_redo2 = nullptr;   // second list of stale chunks and the bitmap of the sequential finisher (fused trellis path)
     uint32_t* d_tre_bitmap = nullptr;
+    bool late_rescale = true;      // strongly compressed univariate sweeps: no plane of rescale factors (HML_LATE_RESCALE=0: keep it)
     uint32_t tre_L = 0;            // its chunk length (0: chosen from the number of blocks, then by measurement; HML_TRELLIS_L, option "trellis_L")
     // The best chunk length depends on how the wavefronts of hml_k_trellis_tile (64 chunks each, resident for the whole
     // launch) divide among the CUs' slots - a rounding effect no formula of ours predicted - so it is MEASURED: once the

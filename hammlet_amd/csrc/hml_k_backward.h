@@ -128,13 +128,23 @@ __device__ __forceinline__ int hml_categorical_k(const float (&w)[K], double u) 
 // suffix scan over the wavefront yields S_t = cand_t o ... o cand_{64c+64} for each row and the
 // chunk's map S_{64c+1}.
 // ------------------------------------------------------------------------------------------
-// row t = 64c + lane + 1 of backward chunk c (rows are stored by block b = t-1)
+// row t = 64c + lane + 1 of backward chunk c (rows are stored by block b = t-1).  `starts` != nullptr: the forward pass
+// stored the rows unscaled (it was given no plane of rescale factors) and the factor of row t < B - expf((N - 1) logA_s)
+// with N the size of block t - 1, the very expression of hml_emit_compute - is applied here (ForwardBackward.hpp:115-119).
 template <int K>
 __device__ __forceinline__ void hml_bwd_row_load(const float* __restrict__ rows, const hml_layout lay, uint32_t c, int lane,
-                                                 uint32_t B, float (&r)[K]) {
+                                                 uint32_t B, float (&r)[K], const uint32_t* __restrict__ starts = nullptr,
+                                                 const hml_model* __restrict__ mdl = nullptr) {
     const uint32_t t = c * HML_BWD_CHUNK + (uint32_t)lane + 1u;
+    uint32_t st = 0u, en = 1u;
+    if (starts && t < B) { st = starts[t - 1u]; en = starts[t]; }
 #pragma unroll
     for (int i = 0; i < K; ++i) r[i] = (t <= B) ? rows[hml_bk(lay, t - 1u, K, i)] : 0.0f;
+    if (starts && t < B && mdl->self_trans != 0) {
+        const float N = (float)(en - st);
+#pragma unroll
+        for (int i = 0; i < K; ++i) r[i] = r[i] * hml_expf((N - 1.0f) * mdl->logA[i]);
+    }
 }
 
 // the maps of backward chunk c (rows 64c+1 .. 64c+64), by one wavefront
@@ -183,7 +193,8 @@ __global__ __launch_bounds__(256) void hml_k_backward_maps(const float* __restri
                                                            unsigned long long* __restrict__ smap,
                                                            unsigned long long* __restrict__ cmap, const hml_layout lay,
                                                            const float* __restrict__ entry, const float* __restrict__ exitv,
-                                                           uint32_t* __restrict__ fail_list, int L) {
+                                                           uint32_t* __restrict__ fail_list, int L,
+                                                           const uint32_t* __restrict__ starts) {
     const uint32_t B = mdl->B;
     const uint32_t nchunks = (B + HML_BWD_CHUNK - 1u) / HML_BWD_CHUNK;
     const int lane = threadIdx.x & 63;
@@ -195,7 +206,7 @@ __global__ __launch_bounds__(256) void hml_k_backward_maps(const float* __restri
     const uint32_t C = (B + (uint32_t)L - 1u) / (uint32_t)L;
     for (uint32_t c = wave_global; c < nchunks; c += nwaves) {
         float r[K];
-        hml_bwd_row_load<K>(rows, lay, c, lane, B, r);   // in flight together with the verification's loads
+        hml_bwd_row_load<K>(rows, lay, c, lane, B, r, starts, mdl);   // in flight together with the verification's loads
         // forward chunks that overlap blocks [64c, 64c+64): at most 64 of them, one per lane
         bool ok = true;
         {
@@ -226,7 +237,7 @@ __global__ __launch_bounds__(1024) void hml_k_backward_chain(unsigned long long*
                                                              float* __restrict__ exitv, uint32_t* __restrict__ fb_count,
                                                              const uint32_t* __restrict__ fail_list, uint32_t* __restrict__ touched,
                                                              unsigned long long* __restrict__ smap, int L, const hml_layout lay,
-                                                             int mode, int super_level) {
+                                                             int mode, int super_level, const uint32_t* __restrict__ starts) {
     // mode: bit 0 = repair step, bit 1 = chain.  super_level: the chain runs over the maps of super-chunks (64 backward
     // chunks each, hml_k_backward_super) - `cmap` and `entry_state` are then the super-level arrays.
     __shared__ unsigned long long P[1024];
@@ -245,7 +256,7 @@ __global__ __launch_bounds__(1024) void hml_k_backward_chain(unsigned long long*
         const int lane = tid & 63, wave = tid >> 6;
         auto redo = [&](uint32_t c) {
             float r[K];
-            hml_bwd_row_load<K>(rows, lay, c, lane, B, r);
+            hml_bwd_row_load<K>(rows, lay, c, lane, B, r, starts, mdl);
             hml_bwd_chunk_maps<K>(r, mdl, smap, cmap, c, lane, B, epoch, key);
         };
         for (uint32_t i = (uint32_t)wave; i < n_fail; i += 16u) redo(fail_list[i]);

@@ -58,7 +58,7 @@ __device__ __forceinline__ void hml_emit_load(hml_emit_params<K>& p, const hml_m
 // the terms of one block in registers: E_s, e_s = expf(E_s - max E), g_s = expf((N-1) logA_s) (1 without self-transitions)
 template <int K>
 __device__ __forceinline__ void hml_emit_compute(const hml_emit_params<K>& p, hml_model* mdl, float sx, float sq, float N, int mixture,
-                                                 float (&E)[K], float (&ev)[K], float (&gv)[K]) {
+                                                 float (&E)[K], float (&ev)[K], float (&gv)[K], bool want_g = true) {
     float maxE = -3.40282346638528859812e+38f;   // numeric_limits<float>::lowest()
 #pragma unroll
     for (int s = 0; s < K; ++s) {
@@ -73,7 +73,7 @@ __device__ __forceinline__ void hml_emit_compute(const hml_emit_params<K>& p, hm
 #pragma unroll
     for (int s = 0; s < K; ++s) {
         ev[s] = hml_expf(E[s] - maxE);
-        gv[s] = (!mixture && p.self) ? hml_expf((N - 1.0f) * p.logA[s]) : 1.0f;
+        gv[s] = (want_g && !mixture && p.self) ? hml_expf((N - 1.0f) * p.logA[s]) : 1.0f;
     }
 }
 
@@ -85,7 +85,7 @@ __device__ __forceinline__ void hml_emit_store(uint32_t b, const float (&E)[K], 
     for (int s = 0; s < K; ++s) {
         if (eprobe) eprobe[(uint64_t)b * K + s] = E[s];
         em[hml_bk(lay, b, K, s)] = ev[s];
-        if (!mixture) gsc[hml_bk(lay, b, K, s)] = gv[s];
+        if (!mixture && gsc) gsc[hml_bk(lay, b, K, s)] = gv[s];
     }
 }
 
@@ -93,8 +93,10 @@ template <int K>
 __device__ __forceinline__ void hml_emit_block(const hml_emit_params<K>& p, hml_model* mdl, uint32_t b, float sx, float sq,
                                                float N, float* __restrict__ em, float* __restrict__ gsc,
                                                float* __restrict__ eprobe, int mixture, const hml_layout lay) {
+    // gsc == nullptr: the rescale factors are not stored - the backward maps compute them where they apply them
+    // (hml_bwd_row_load; strongly compressed univariate sweeps, where the plane was a third of this kernel's stores)
     float E[K], ev[K], gv[K];
-    hml_emit_compute<K>(p, mdl, sx, sq, N, mixture, E, ev, gv);
+    hml_emit_compute<K>(p, mdl, sx, sq, N, mixture, E, ev, gv, gsc != nullptr);
     hml_emit_store<K>(b, E, ev, gv, em, gsc, eprobe, mixture, lay);
 }
 
@@ -376,7 +378,7 @@ __device__ __forceinline__ void hml_fwd_run(const hml_fwd_ctx<K>& cx, float (&al
 #pragma unroll
             for (int s = 0; s < K; ++s) {
                 e[i][s] = ok ? em[hml_bk(lay, bi, K, s)] : 0.0f;
-                g[i][s] = (STORE && ok && cx.self) ? gsc[hml_bk(lay, bi, K, s)] : 1.0f;
+                g[i][s] = (STORE && ok && cx.self && gsc) ? gsc[hml_bk(lay, bi, K, s)] : 1.0f;   // (no plane: the rows stay unscaled)
             }
         }
 #pragma unroll
