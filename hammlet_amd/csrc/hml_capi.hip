@@ -1059,7 +1059,7 @@ static int sweep_k(hml_ctx* c, char method, bool record) {
             {
                 ProfScope ps(c, "backward_maps");
                 hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_backward_maps<KK>), dim3(grid_for(bch * 64, 256, 16, 1 << 18)), dim3(256), 0,
-                                   s, c->d_rows, c->d_mdl, c->d_smap, c->d_cmap, lay, c->d_entry, c->d_exitA, c->d_redo, L, starts_for_maps);
+                                   s, c->d_rows, c->d_mdl, c->d_smap, c->d_cmap, lay, c->d_entry, c->d_exitA, c->d_redo, L, starts_for_maps, c->d_mdl);
             }
             ProfScope ps(c, "backward_chain");
             if (!dense_geo) {

@@ -131,25 +131,43 @@ __device__ __forceinline__ int hml_categorical_k(const float (&w)[K], double u) 
 // row t = 64c + lane + 1 of backward chunk c (rows are stored by block b = t-1).  `starts` != nullptr: the forward pass
 // stored the rows unscaled (it was given no plane of rescale factors) and the factor of row t < B - expf((N - 1) logA_s)
 // with N the size of block t - 1, the very expression of hml_emit_compute - is applied here (ForwardBackward.hpp:115-119).
+// The model's read-only values the backward maps need, fetched once per wavefront through a pointer the compiler may
+// treat as constant (scalar loads, one wait): read through the kernels' writable hml_model* every element of A was a
+// separate vector load with its own wait - 25 cache round trips in a row per chunk at K = 5.
+template <int K>
+struct hml_bwd_ctx {
+    float A[K * K];
+    float logA[K];
+    bool self;
+};
+template <int K>
+__device__ __forceinline__ void hml_bwd_ctx_load(hml_bwd_ctx<K>& bx, const hml_model* __restrict__ mdl_ro) {
+#pragma unroll
+    for (int i = 0; i < K * K; ++i) bx.A[i] = mdl_ro->A[i];
+#pragma unroll
+    for (int i = 0; i < K; ++i) bx.logA[i] = mdl_ro->logA[i];
+    bx.self = mdl_ro->self_trans != 0;
+}
+
 template <int K>
 __device__ __forceinline__ void hml_bwd_row_load(const float* __restrict__ rows, const hml_layout lay, uint32_t c, int lane,
-                                                 uint32_t B, float (&r)[K], const uint32_t* __restrict__ starts = nullptr,
-                                                 const hml_model* __restrict__ mdl = nullptr) {
+                                                 uint32_t B, float (&r)[K], const uint32_t* __restrict__ starts,
+                                                 const hml_bwd_ctx<K>& bx) {
     const uint32_t t = c * HML_BWD_CHUNK + (uint32_t)lane + 1u;
     uint32_t st = 0u, en = 1u;
     if (starts && t < B) { st = starts[t - 1u]; en = starts[t]; }
 #pragma unroll
     for (int i = 0; i < K; ++i) r[i] = (t <= B) ? rows[hml_bk(lay, t - 1u, K, i)] : 0.0f;
-    if (starts && t < B && mdl->self_trans != 0) {
+    if (starts && t < B && bx.self) {
         const float N = (float)(en - st);
 #pragma unroll
-        for (int i = 0; i < K; ++i) r[i] = r[i] * hml_expf((N - 1.0f) * mdl->logA[i]);
+        for (int i = 0; i < K; ++i) r[i] = r[i] * hml_expf((N - 1.0f) * bx.logA[i]);
     }
 }
 
 // the maps of backward chunk c (rows 64c+1 .. 64c+64), by one wavefront
 template <int K>
-__device__ __forceinline__ void hml_bwd_chunk_maps(const float (&r)[K], hml_model* __restrict__ mdl,
+__device__ __forceinline__ void hml_bwd_chunk_maps(const float (&r)[K], hml_model* __restrict__ mdl, const hml_bwd_ctx<K>& bx,
                                                    unsigned long long* __restrict__ smap, unsigned long long* __restrict__ cmap,
                                                    uint32_t c, int lane, uint32_t B, unsigned long long epoch, const hml_key key) {
     const uint32_t t = c * HML_BWD_CHUNK + (uint32_t)lane + 1u;
@@ -167,7 +185,7 @@ __device__ __forceinline__ void hml_bwd_chunk_maps(const float (&r)[K], hml_mode
                 float w[K];
 #pragma unroll
                 for (int i = 0; i < K; ++i) {
-                    w[i] = r[i] * mdl->A[i * K + x];
+                    w[i] = r[i] * bx.A[i * K + x];
                     if (w[i] < 0.0f) hml_raise(mdl, HML_DEVERR_NEG_BACKWARD, w[i]);
                 }
                 map |= (unsigned long long)hml_categorical_k<K>(w, u) << (4 * x);
@@ -194,19 +212,22 @@ __global__ __launch_bounds__(256) void hml_k_backward_maps(const float* __restri
                                                            unsigned long long* __restrict__ cmap, const hml_layout lay,
                                                            const float* __restrict__ entry, const float* __restrict__ exitv,
                                                            uint32_t* __restrict__ fail_list, int L,
-                                                           const uint32_t* __restrict__ starts) {
-    const uint32_t B = mdl->B;
+                                                           const uint32_t* __restrict__ starts,
+                                                           const hml_model* __restrict__ mdl_ro) {
+    const uint32_t B = mdl_ro->B;
     const uint32_t nchunks = (B + HML_BWD_CHUNK - 1u) / HML_BWD_CHUNK;
     const int lane = threadIdx.x & 63;
     const uint32_t wave_global = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
-    const unsigned long long epoch = mdl->epoch;
-    const hml_key key = mdl->key;
-    const int W = (int)mdl->fwd_W;
+    const unsigned long long epoch = mdl_ro->epoch;
+    const hml_key key = mdl_ro->key;
+    const int W = (int)mdl_ro->fwd_W;
+    hml_bwd_ctx<K> bx;
+    hml_bwd_ctx_load<K>(bx, mdl_ro);
     const uint32_t C = (B + (uint32_t)L - 1u) / (uint32_t)L;
     for (uint32_t c = wave_global; c < nchunks; c += nwaves) {
         float r[K];
-        hml_bwd_row_load<K>(rows, lay, c, lane, B, r, starts, mdl);   // in flight together with the verification's loads
+        hml_bwd_row_load<K>(rows, lay, c, lane, B, r, starts, bx);   // in flight together with the verification's loads
         // forward chunks that overlap blocks [64c, 64c+64): at most 64 of them, one per lane
         bool ok = true;
         {
@@ -214,15 +235,17 @@ __global__ __launch_bounds__(256) void hml_k_backward_maps(const float* __restri
             const uint32_t f1 = (c * HML_BWD_CHUNK + HML_BWD_CHUNK - 1u) / (uint32_t)L;
             const uint32_t f = f0 + (uint32_t)lane;
             if (f <= f1 && f < C && !hml_fwd_chunk_exact(f, L, W)) {
+                uint32_t differ = 0u;   // (no short circuit: the 2 K loads travel together)
 #pragma unroll
-                for (int s = 0; s < K; ++s) ok = ok && (hml_f2u(entry[(uint64_t)f * K + s]) == hml_f2u(exitv[(uint64_t)(f - 1) * K + s]));
+                for (int s = 0; s < K; ++s) differ |= hml_f2u(entry[(uint64_t)f * K + s]) ^ hml_f2u(exitv[(uint64_t)(f - 1) * K + s]);
+                ok = differ == 0u;
             }
         }
         if (__ballot(!ok) != 0ull) {   // wave-uniform
             if (lane == 0) fail_list[atomicAdd(&mdl->fwd_mismatch, 1u)] = c;   // at most one entry per backward chunk
             continue;
         }
-        hml_bwd_chunk_maps<K>(r, mdl, smap, cmap, c, lane, B, epoch, key);
+        hml_bwd_chunk_maps<K>(r, mdl, bx, smap, cmap, c, lane, B, epoch, key);
     }
 }
 
@@ -254,10 +277,12 @@ __global__ __launch_bounds__(1024) void hml_k_backward_chain(unsigned long long*
         hml_fwd_repair<K>(em, gsc, mdl, rows, aprobe, entry, exitv, fb_count, fail_list, n_fail, touched, gen, L, lay, sh);
         // maps of the chunks that failed verification and of those whose rows were recomputed
         const int lane = tid & 63, wave = tid >> 6;
+        hml_bwd_ctx<K> bx;
+        hml_bwd_ctx_load<K>(bx, mdl);
         auto redo = [&](uint32_t c) {
             float r[K];
-            hml_bwd_row_load<K>(rows, lay, c, lane, B, r, starts, mdl);
-            hml_bwd_chunk_maps<K>(r, mdl, smap, cmap, c, lane, B, epoch, key);
+            hml_bwd_row_load<K>(rows, lay, c, lane, B, r, starts, bx);
+            hml_bwd_chunk_maps<K>(r, mdl, bx, smap, cmap, c, lane, B, epoch, key);
         };
         for (uint32_t i = (uint32_t)wave; i < n_fail; i += 16u) redo(fail_list[i]);
         const uint32_t n_touched = sh.tcount;
@@ -283,25 +308,63 @@ __global__ __launch_bounds__(1024) void hml_k_backward_chain(unsigned long long*
     const uint32_t per = (NC + 1023u) / 1024u;
     const uint32_t a = (uint32_t)tid * per < NC ? (uint32_t)tid * per : NC;
     const uint32_t b = (a + per < NC) ? a + per : NC;
-    // product of this thread's maps: cmap[a] o cmap[a+1] o ... o cmap[b-1]
+    const int lane = tid & 63, wave = tid >> 6;
+    // product of this thread's maps: cmap[a] o cmap[a+1] o ... o cmap[b-1].  Up to four maps per thread (NC <= 4096: every
+    // strongly compressed sweep) are fetched together and kept for the walk at the end - read one by one through the
+    // writable pointer each was a cache round trip of its own, twice.
+    constexpr int CACHED = 4;
+    unsigned long long mine[CACHED];
     unsigned long long prod = HML_MAP_IDENTITY;
-    for (uint32_t c = b; c > a; --c) prod = hml_map_compose<K>(cmap[c - 1], prod);
-    P[tid] = prod;
-    __syncthreads();
-    // suffix scan: Q[tid] = P[tid] o P[tid+1] o ... o P[1023]
-    for (int d = 1; d < 1024; d <<= 1) {
-        const unsigned long long o = (tid + d < 1024) ? P[tid + d] : HML_MAP_IDENTITY;
-        __syncthreads();
-        P[tid] = hml_map_compose<K>(P[tid], o);
-        __syncthreads();
+    if (per <= (uint32_t)CACHED) {   // workgroup-uniform
+#pragma unroll
+        for (int j = 0; j < CACHED; ++j) mine[j] = (a + (uint32_t)j < b) ? cmap[a + (uint32_t)j] : HML_MAP_IDENTITY;
+#pragma unroll
+        for (int j = CACHED - 1; j >= 0; --j) prod = hml_map_compose<K>(mine[j], prod);
+    } else {
+        for (uint32_t c = b; c > a; --c) prod = hml_map_compose<K>(cmap[c - 1], prod);
     }
+    // suffix products over the 1024 threads, Q[tid] = P[tid] o P[tid+1] o ... o P[1023]: inside a wavefront by shuffles
+    // (S), the sixteen wavefront products by the first sixteen lanes (LDS, two barriers instead of twenty)
+    unsigned long long S = prod;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        unsigned long long o = hml_shfl_down_u64(S, d);
+        if (lane + d >= 64) o = HML_MAP_IDENTITY;
+        S = hml_map_compose<K>(S, o);
+    }
+    if (lane == 0) P[wave] = S;
+    __syncthreads();
+    if (tid < 64) {
+        unsigned long long w = (tid < 16) ? P[tid] : HML_MAP_IDENTITY;
+#pragma unroll
+        for (int d = 1; d < 16; d <<= 1) {
+            unsigned long long o = hml_shfl_down_u64(w, d);
+            if (tid + d >= 16) o = HML_MAP_IDENTITY;
+            w = hml_map_compose<K>(w, o);
+        }
+        if (tid < 16) P[16 + tid] = w;   // P[16 + w] = product of the wavefronts w .. 15
+    }
+    __syncthreads();
+    const unsigned long long after_wave = (wave < 15) ? P[16 + wave + 1] : HML_MAP_IDENTITY;
+    // the composition of everything behind this thread: Q[tid + 1]
+    unsigned long long next_S = hml_shfl_down_u64(S, 1);
+    const unsigned long long later = (lane < 63) ? hml_map_compose<K>(next_S, after_wave) : after_wave;
     if (a >= b) return;
     // state entering this thread's last chunk = (composition of all later chunks)(dummy 0)
-    const unsigned long long later = (tid + 1 < 1024) ? P[tid + 1] : HML_MAP_IDENTITY;
     unsigned x = (unsigned)(later & 15ull);
-    for (uint32_t c = b; c > a; --c) {
-        entry_state[c - 1] = (uint8_t)x;
-        x = (unsigned)(cmap[c - 1] >> (4 * x)) & 15u;
+    if (per <= (uint32_t)CACHED) {
+#pragma unroll
+        for (int j = CACHED - 1; j >= 0; --j) {
+            if (a + (uint32_t)j < b) {
+                entry_state[a + (uint32_t)j] = (uint8_t)x;
+                x = (unsigned)(mine[j] >> (4 * x)) & 15u;
+            }
+        }
+    } else {
+        for (uint32_t c = b; c > a; --c) {
+            entry_state[c - 1] = (uint8_t)x;
+            x = (unsigned)(cmap[c - 1] >> (4 * x)) & 15u;
+        }
     }
 }
 

@@ -103,6 +103,8 @@ __global__ __launch_bounds__(HML_FUSED_WAVES * 64, (K <= 6 ? 6 : 4)) void hml_k_
     __shared__ uint16_t wave_list[NW][HML_FUSED_WAVE_LIST];    // per wavefront: its first starts (offsets into its eighth)
     __shared__ uint32_t wave_total[NW], wave_last[NW];         // block starts per wavefront; 1 + tile-relative position of the last
     __shared__ unsigned long long red_sum[NW], red_near[NW];
+    __shared__ uint64_t sm_exp_tab[32];   // hml_expf's table: phase B looks it up at the end of the launch's critical path
+    if (threadIdx.x < 32u) sm_exp_tab[threadIdx.x] = HML_EXP2F_TAB[threadIdx.x];   // (visible behind the barriers of phase A)
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t g = blockIdx.x;
@@ -327,7 +329,7 @@ __global__ __launch_bounds__(HML_FUSED_WAVES * 64, (K <= 6 ? 6 : 4)) void hml_k_
             starts[b] = t;   // (item wg_total of the last workgroup: starts[B] = T)
             if (t == 0u) continue;   // no block ends at position 0
             bstat[b - 1u] = make_float2(sx, sq);
-            hml_emit_block<K>(p, mdl, b - 1u, sx, sq, (float)n, em, gsc, eprobe, mixture, lay);
+            hml_emit_block<K, true>(p, mdl, b - 1u, sx, sq, (float)n, em, gsc, eprobe, mixture, lay, sm_exp_tab);
         }
     }
     if (dbg) { __syncthreads(); if (threadIdx.x == 0) dbg[blockIdx.x * 4 + 3] = wall_clock64(); }

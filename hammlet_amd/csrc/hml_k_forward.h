@@ -56,9 +56,11 @@ __device__ __forceinline__ void hml_emit_load(hml_emit_params<K>& p, const hml_m
 }
 
 // the terms of one block in registers: E_s, e_s = expf(E_s - max E), g_s = expf((N-1) logA_s) (1 without self-transitions)
-template <int K>
+template <int K, bool LEAN = false>
 __device__ __forceinline__ void hml_emit_compute(const hml_emit_params<K>& p, hml_model* mdl, float sx, float sq, float N, int mixture,
-                                                 float (&E)[K], float (&ev)[K], float (&gv)[K], bool want_g = true) {
+                                                 float (&E)[K], float (&ev)[K], float (&gv)[K], bool want_g = true,
+                                                 const uint64_t* exp_tab = nullptr) {
+    const uint64_t* const tab = exp_tab ? exp_tab : HML_EXP2F_TAB;
     float maxE = -3.40282346638528859812e+38f;   // numeric_limits<float>::lowest()
 #pragma unroll
     for (int s = 0; s < K; ++s) {
@@ -72,8 +74,8 @@ __device__ __forceinline__ void hml_emit_compute(const hml_emit_params<K>& p, hm
     }
 #pragma unroll
     for (int s = 0; s < K; ++s) {
-        ev[s] = hml_expf(E[s] - maxE);
-        gv[s] = (want_g && !mixture && p.self) ? hml_expf((N - 1.0f) * p.logA[s]) : 1.0f;
+        ev[s] = LEAN ? hml_expf_lean(E[s] - maxE, tab) : hml_expf_tab(E[s] - maxE, tab);
+        gv[s] = (want_g && !mixture && p.self) ? hml_expf_tab((N - 1.0f) * p.logA[s], tab) : 1.0f;
     }
 }
 
@@ -89,14 +91,15 @@ __device__ __forceinline__ void hml_emit_store(uint32_t b, const float (&E)[K], 
     }
 }
 
-template <int K>
+template <int K, bool LEAN = false>
 __device__ __forceinline__ void hml_emit_block(const hml_emit_params<K>& p, hml_model* mdl, uint32_t b, float sx, float sq,
                                                float N, float* __restrict__ em, float* __restrict__ gsc,
-                                               float* __restrict__ eprobe, int mixture, const hml_layout lay) {
+                                               float* __restrict__ eprobe, int mixture, const hml_layout lay,
+                                               const uint64_t* exp_tab = nullptr) {
     // gsc == nullptr: the rescale factors are not stored - the backward maps compute them where they apply them
     // (hml_bwd_row_load; strongly compressed univariate sweeps, where the plane was a third of this kernel's stores)
     float E[K], ev[K], gv[K];
-    hml_emit_compute<K>(p, mdl, sx, sq, N, mixture, E, ev, gv, gsc != nullptr);
+    hml_emit_compute<K, LEAN>(p, mdl, sx, sq, N, mixture, E, ev, gv, gsc != nullptr, exp_tab);
     hml_emit_store<K>(b, E, ev, gv, em, gsc, eprobe, mixture, lay);
 }
 
