@@ -1230,6 +1230,7 @@ int hml_sync(hml_ctx* c) {
             fprintf(stderr, "[params dbg] us since the kernel's start: accumulators read %.2f | tree %.2f | theta drawn %.2f | A gammas %.2f | barrier %.2f | end %.2f\n",
                     (m.dbg_t[1] - m.dbg_t[0]) * 0.01, (m.dbg_t[2] - m.dbg_t[0]) * 0.01, (m.dbg_t[3] - m.dbg_t[0]) * 0.01, (m.dbg_t[4] - m.dbg_t[0]) * 0.01,
                     (m.dbg_t[5] - m.dbg_t[0]) * 0.01, (m.dbg_t[6] - m.dbg_t[0]) * 0.01);
+            fprintf(stderr, "[params dbg]   theta's gamma core + normal drawn %.2f | last wavefront's tree %.2f\n", (m.dbg_t[7] - m.dbg_t[0]) * 0.01, (m.dbg_t[8] - m.dbg_t[0]) * 0.01);
         }
     }
     if (c->model_set) return check_device_error(c);

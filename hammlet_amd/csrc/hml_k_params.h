@@ -145,6 +145,7 @@ __global__ __launch_bounds__(1024) void hml_k_params(hml_model* __restrict__ mdl
         th_gcore = hml_gamma_core_f32<hml_devmath>(src, th_alpha);
         hml_normal_f32<hml_devmath> nd;
         th_z = nd.draw_std(src);
+        if (tid == 0) mdl->dbg_t[7] = wall_clock64();
     }
     if (mode != 2) {
         if (wave == 1 && lane < K) {
@@ -180,6 +181,7 @@ __global__ __launch_bounds__(1024) void hml_k_params(hml_model* __restrict__ mdl
                 if (lane == 0) { wp[mirror][s][0] = a; wp[mirror][s][1] = d; }
             }
         }
+        if (tid == 1023) mdl->dbg_t[8] = wall_clock64();
         __syncthreads();
         // ... then a pairwise tree over the 16 wavefront sums
         if (tid < 2 * K) {

@@ -104,7 +104,7 @@ struct hml_model {
     uint32_t tre_fused;          // weakly compressed FB sweeps take the fused trellis kernels (hml_k_trellis.h): stale chunks are
                                  // refitted in parallel there, so the warm-up follows a different rule (hml_k_params)
     unsigned long long fwd_refits_seen, fwd_serial_seen;
-    unsigned long long dbg_t[8];   // wall_clock64 stamps of the parameter kernel's stages (printed by hml_sync with HML_PARAMS_DEBUG)
+    unsigned long long dbg_t[12];   // wall_clock64 stamps of the parameter kernel's stages (printed by hml_sync with HML_PARAMS_DEBUG)
 };
 
 #if defined(__HIPCC__)
