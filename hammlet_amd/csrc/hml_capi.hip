@@ -1563,6 +1563,12 @@ int hml_get_stats(hml_ctx* c, hml_stats* out) {
 
 int hml_profile_enable(hml_ctx* c, int on) {
     if (!c) return set_err(HML_ERR_ARG, "null context");
+    if (on && c->ev_pool.size() < 64) {
+        // events for the first brackets are created here, not inside the region the caller is about to time
+        // (hipEventCreate costs tens of microseconds; a 20-sweep timed region saw four of them in its first sweep)
+        if (int r = ctx_bind(c)) return r;
+        while (c->ev_pool.size() < 64) { hipEvent_t e; HIPCHK(hipEventCreate(&e)); c->ev_pool.push_back(e); }
+    }
     c->profiling = on;
     return 0;
 }

@@ -29,6 +29,11 @@ for it in range(n_cfg):
               e_var=float(rng.choice([0.2, 0.1])), e_p=float(rng.choice([0.9, 0.8])), self_trans=self_trans, weight_mult=mult)
     os.environ["HML_DENSE_MIN_BLOCKS"] = "500" if dense else str(1 << 22)
     os.environ["HML_FWD_CHUNK_DENSE"] = str(int(rng.choice([8, 16, 32])))
+    # round 2's switches: fused trellis path and its chunk length, late rescale, forward chunk length
+    os.environ["HML_TRELLIS_FUSED"] = str(int(rng.choice([1, 1, 1, 0])))
+    os.environ["HML_TRELLIS_L"] = str(int(rng.choice([0, 32, 64, 96, 160, 256])))
+    os.environ["HML_LATE_RESCALE"] = str(int(rng.choice([1, 1, 0])))
+    os.environ["HML_FWD_CHUNK"] = str(int(rng.choice([4, 4, 1, 2, 8])))
     seed = int(rng.integers(0, 1 << 30))
     levels = min(K if D == 1 else P, 5)
     if rng.random() < 0.2 and D == 1:
