@@ -136,14 +136,13 @@ __device__ __forceinline__ int hml_categorical_k(const float (&w)[K], double u) 
 // separate vector load with its own wait - 25 cache round trips in a row per chunk at K = 5.
 template <int K>
 struct hml_bwd_ctx {
-    float A[K * K];
+    hml_amat<K> A;   // registers up to 7 states, the workgroup's LDS copy beyond (hml_k_forward.h)
     float logA[K];
     bool self;
 };
 template <int K>
-__device__ __forceinline__ void hml_bwd_ctx_load(hml_bwd_ctx<K>& bx, const hml_model* __restrict__ mdl_ro) {
-#pragma unroll
-    for (int i = 0; i < K * K; ++i) bx.A[i] = mdl_ro->A[i];
+__device__ __forceinline__ void hml_bwd_ctx_load(hml_bwd_ctx<K>& bx, const hml_model* __restrict__ mdl_ro, const float* lds_A) {
+    bx.A.attach(mdl_ro, lds_A);
 #pragma unroll
     for (int i = 0; i < K; ++i) bx.logA[i] = mdl_ro->logA[i];
     bx.self = mdl_ro->self_trans != 0;
@@ -175,6 +174,11 @@ __device__ __forceinline__ void hml_bwd_chunk_maps(const float (&r)[K], hml_mode
     if (t <= B) {
         const double u = hml_cat_uniform(key, epoch, t);
         map = 0ull;
+        // "Negative backward variable!" (ForwardBackward.hpp:147-149): the products r_i A(i, x) below are negative exactly
+        // when r_i is (A holds probabilities), so the row is checked once instead of K * K times with a branch each
+#pragma unroll
+        for (int i = 0; i < K; ++i)
+            if (r[i] < 0.0f) hml_raise(mdl, HML_DEVERR_NEG_BACKWARD, r[i]);
         if (t == B) {
             const unsigned long long st = (unsigned long long)hml_categorical_k<K>(r, u);
 #pragma unroll
@@ -184,10 +188,7 @@ __device__ __forceinline__ void hml_bwd_chunk_maps(const float (&r)[K], hml_mode
             for (int x = 0; x < K; ++x) {
                 float w[K];
 #pragma unroll
-                for (int i = 0; i < K; ++i) {
-                    w[i] = r[i] * bx.A[i * K + x];
-                    if (w[i] < 0.0f) hml_raise(mdl, HML_DEVERR_NEG_BACKWARD, w[i]);
-                }
+                for (int i = 0; i < K; ++i) w[i] = r[i] * bx.A[i * K + x];
                 map |= (unsigned long long)hml_categorical_k<K>(w, u) << (4 * x);
             }
         }
@@ -222,8 +223,10 @@ __global__ __launch_bounds__(256) void hml_k_backward_maps(const float* __restri
     const unsigned long long epoch = mdl_ro->epoch;
     const hml_key key = mdl_ro->key;
     const int W = (int)mdl_ro->fwd_W;
+    __shared__ float sm_A[hml_amat<K>::LDS_FLOATS];
+    hml_amat_fill<K>(sm_A, mdl_ro, (int)threadIdx.x, (int)blockDim.x);
     hml_bwd_ctx<K> bx;
-    hml_bwd_ctx_load<K>(bx, mdl_ro);
+    hml_bwd_ctx_load<K>(bx, mdl_ro, sm_A);
     const uint32_t C = (B + (uint32_t)L - 1u) / (uint32_t)L;
     for (uint32_t c = wave_global; c < nchunks; c += nwaves) {
         float r[K];
@@ -274,11 +277,13 @@ __global__ __launch_bounds__(1024) void hml_k_backward_chain(unsigned long long*
         const unsigned long long epoch = mdl->epoch;
         const uint32_t gen = (uint32_t)epoch + 1u;
         const hml_key key = mdl->key;
-        hml_fwd_repair<K>(em, gsc, mdl, rows, aprobe, entry, exitv, fb_count, fail_list, n_fail, touched, gen, L, lay, sh);
+        __shared__ float sm_A[hml_amat<K>::LDS_FLOATS];
+        hml_amat_fill<K>(sm_A, mdl, tid, 1024);
+        hml_fwd_repair<K>(em, gsc, mdl, rows, aprobe, entry, exitv, fb_count, fail_list, n_fail, touched, gen, L, lay, sh, sm_A);
         // maps of the chunks that failed verification and of those whose rows were recomputed
         const int lane = tid & 63, wave = tid >> 6;
         hml_bwd_ctx<K> bx;
-        hml_bwd_ctx_load<K>(bx, mdl);
+        hml_bwd_ctx_load<K>(bx, mdl, sm_A);
         auto redo = [&](uint32_t c) {
             float r[K];
             hml_bwd_row_load<K>(rows, lay, c, lane, B, r, starts, bx);

@@ -80,7 +80,7 @@ __device__ __forceinline__ unsigned long long hml_fused_tile_word(const uint8_t*
 }
 
 template <int K>
-__global__ __launch_bounds__(HML_FUSED_WAVES * 64, (K <= 6 ? 6 : 4)) void hml_k_blocks_fused(const uint8_t* __restrict__ summary, const float* __restrict__ w,
+__global__ __launch_bounds__(HML_FUSED_WAVES * 64, 6) void hml_k_blocks_fused(const uint8_t* __restrict__ summary, const float* __restrict__ w,
                                                           const float2* __restrict__ ia, uint32_t T,
                                                           hml_model* __restrict__ mdl, int32_t base,
                                                           unsigned long long* __restrict__ group_word,
@@ -105,6 +105,9 @@ __global__ __launch_bounds__(HML_FUSED_WAVES * 64, (K <= 6 ? 6 : 4)) void hml_k_
     __shared__ unsigned long long red_sum[NW], red_near[NW];
     __shared__ uint64_t sm_exp_tab[32];   // hml_expf's table: phase B looks it up at the end of the launch's critical path
     if (threadIdx.x < 32u) sm_exp_tab[threadIdx.x] = HML_EXP2F_TAB[threadIdx.x];   // (visible behind the barriers of phase A)
+    constexpr bool LOOPED = K > 6;        // many states: emission parameters from LDS, states walked in a loop (hml_emit_block_looped)
+    __shared__ hml_emit_lds<LOOPED ? K : 1> sm_emit;
+    if (LOOPED) hml_emit_lds_fill<LOOPED ? K : 1>(sm_emit, mdl_ro, (int)threadIdx.x);
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t g = blockIdx.x;
@@ -309,8 +312,9 @@ __global__ __launch_bounds__(HML_FUSED_WAVES * 64, (K <= 6 ? 6 : 4)) void hml_k_
         nr ? (uint32_t)(((nr >> HML_FUSED_POS_BITS) - 1ull) * tile_positions + (nr & ((1ull << HML_FUSED_POS_BITS) - 1ull))) : 0u;
 
     // ---------------- phase B: emission terms and the writes
-    hml_emit_params<K> p;
-    hml_emit_load<K>(p, mdl_ro, mixture);
+    hml_emit_params<LOOPED ? 1 : K> p;
+    if (!LOOPED) hml_emit_load<LOOPED ? 1 : K>(p, mdl_ro, mixture);
+    const bool self_trans = mdl_ro->self_trans != 0;
     {
         uint32_t t = first_t, n = first_n;
         float sx = first_sx, sq = first_sq;
@@ -329,7 +333,10 @@ __global__ __launch_bounds__(HML_FUSED_WAVES * 64, (K <= 6 ? 6 : 4)) void hml_k_
             starts[b] = t;   // (item wg_total of the last workgroup: starts[B] = T)
             if (t == 0u) continue;   // no block ends at position 0
             bstat[b - 1u] = make_float2(sx, sq);
-            hml_emit_block<K, true>(p, mdl, b - 1u, sx, sq, (float)n, em, gsc, eprobe, mixture, lay, sm_exp_tab);
+            if constexpr (LOOPED)
+                hml_emit_block_looped<K>(reinterpret_cast<const hml_emit_lds<K>&>(sm_emit), mdl, self_trans, b - 1u, sx, sq, (float)n, em, gsc, eprobe, mixture, lay, sm_exp_tab);
+            else
+                hml_emit_block<LOOPED ? 1 : K, true>(p, mdl, b - 1u, sx, sq, (float)n, em, gsc, eprobe, mixture, lay, sm_exp_tab);
         }
     }
     if (dbg) { __syncthreads(); if (threadIdx.x == 0) dbg[blockIdx.x * 4 + 3] = wall_clock64(); }

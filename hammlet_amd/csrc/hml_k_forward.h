@@ -103,6 +103,49 @@ __device__ __forceinline__ void hml_emit_block(const hml_emit_params<K>& p, hml_
     hml_emit_store<K>(b, E, ev, gv, em, gsc, eprobe, mixture, lay);
 }
 
+// The same terms for MANY STATES with few registers (the fused block kernel beyond 6 states: its register budget is
+// fixed by the number of workgroups it needs resident): the parameters come from LDS (hml_emit_lds, filled once per
+// workgroup), the states are walked twice - first for max E, then again for E_s and e_s = expf(E_s - max E), which are
+// stored at once - so no per-state array lives in registers.  Every E_s is computed by the same operations as in
+// hml_emit_compute (twice), hence the same bits.
+template <int K>
+struct hml_emit_lds {
+    float mu[K], var[K], logN[K], logA[K];
+    double rvar[K];
+};
+template <int K>
+__device__ __forceinline__ void hml_emit_lds_fill(hml_emit_lds<K>& l, const hml_model* mdl, int tid) {
+    if (tid < K) { l.mu[tid] = mdl->mu[tid]; l.var[tid] = mdl->var[tid]; l.logN[tid] = mdl->logN[tid]; l.logA[tid] = mdl->logA[tid]; l.rvar[tid] = mdl->rvar2[tid]; }
+}
+template <int K>
+__device__ __forceinline__ float hml_emit_E(const hml_emit_lds<K>& l, hml_model* mdl, int s, bool self, float sx, float sq, float N) {
+    const float ip = hml_inner_product(l.mu[s], l.var[s], l.rvar[s], sx, sq);
+    if (!hml_isfinite(ip)) hml_raise(mdl, HML_DEVERR_IP_NOT_FINITE, ip);
+    float e = (0.0f + ip) - N * l.logN[s];
+    if (self) e += (N - 1.0f) * l.logA[s];
+    return e;
+}
+template <int K>
+__device__ __forceinline__ void hml_emit_block_looped(const hml_emit_lds<K>& l, hml_model* mdl, bool self_trans, uint32_t b, float sx, float sq,
+                                                      float N, float* __restrict__ em, float* __restrict__ gsc,
+                                                      float* __restrict__ eprobe, int mixture, const hml_layout lay,
+                                                      const uint64_t* exp_tab) {
+    const bool self = self_trans && !mixture;
+    float maxE = -3.40282346638528859812e+38f;   // numeric_limits<float>::lowest()
+#pragma unroll 1
+    for (int s = 0; s < K; ++s) {
+        const float e = hml_emit_E<K>(l, mdl, s, self, sx, sq, N);
+        maxE = (e < maxE) ? maxE : e;
+    }
+#pragma unroll 1
+    for (int s = 0; s < K; ++s) {
+        const float e = hml_emit_E<K>(l, mdl, s, self, sx, sq, N);
+        if (eprobe) eprobe[(uint64_t)b * K + s] = e;
+        em[hml_bk(lay, b, K, s)] = hml_expf_lean(e - maxE, exp_tab);
+        if (!mixture && gsc) gsc[hml_bk(lay, b, K, s)] = self ? hml_expf_lean((N - 1.0f) * l.logA[s], exp_tab) : 1.0f;
+    }
+}
+
 template <int K>
 __global__ __launch_bounds__(256) void hml_k_emission(const float2* __restrict__ bstat,
                                                       const uint32_t* __restrict__ starts, hml_model* __restrict__ mdl,
@@ -327,18 +370,50 @@ __global__ __launch_bounds__(256) void hml_k_emission_tiled(const float2* __rest
 // (row_newbcast folded into the multiplies and adds: 45 instructions a step, no LDS) was measured in round 2: 26.9 us
 // against 12.5 us for the 44 000 chunks of config 3 at W = 24 - with 4 chunks per wavefront instead of 64 the pass
 // issues 4x the wavefront-instructions, and 11 000 wavefronts are throughput-bound where 700 are latency-bound.)
+// The transition matrix as the kernels see it.  Up to 7 states its K * K floats live in (scalar) registers; beyond that
+// they do not fit (at K = 10 a third of the forward kernel's vector instructions were v_readlane / v_writelane moves of
+// spilled scalar registers, and the backward maps took 28 us against 5 us at K = 5): the workgroup keeps A in LDS and
+// every use is a broadcast read.  hml_amat_fill must be called by all threads of the workgroup (it ends in a barrier).
+#define HML_A_REGISTERS_MAX_K 7
+template <int K, bool REG = (K <= HML_A_REGISTERS_MAX_K)>
+struct hml_amat;
+template <int K>
+struct hml_amat<K, true> {
+    static constexpr int LDS_FLOATS = 1;
+    float v[K * K];
+    __device__ __forceinline__ void attach(const hml_model* mdl, const float*) {
+#pragma unroll
+        for (int i = 0; i < K * K; ++i) v[i] = mdl->A[i];
+    }
+    __device__ __forceinline__ float operator[](int i) const { return v[i]; }
+};
+template <int K>
+struct hml_amat<K, false> {
+    static constexpr int LDS_FLOATS = K * K;
+    const float* p;
+    __device__ __forceinline__ void attach(const hml_model*, const float* lds) { p = lds; }
+    __device__ __forceinline__ float operator[](int i) const { return p[i]; }
+};
+template <int K>
+__device__ __forceinline__ void hml_amat_fill(float* lds, const hml_model* mdl, int tid, int nthreads) {
+    if (K > HML_A_REGISTERS_MAX_K) {
+        for (int i = tid; i < K * K; i += nthreads) lds[i] = mdl->A[i];
+        __syncthreads();
+    }
+}
+
 template <int K>
 struct hml_fwd_ctx {
-    float A[K * K];
+    hml_amat<K> A;
     float invK;
     bool self;
     uint32_t B;
 };
 
+// lds_A: the workgroup's copy of A behind hml_amat_fill (unused up to HML_A_REGISTERS_MAX_K states)
 template <int K>
-__device__ __forceinline__ void hml_fwd_ctx_load(hml_fwd_ctx<K>& cx, const hml_model* mdl) {
-#pragma unroll
-    for (int i = 0; i < K * K; ++i) cx.A[i] = mdl->A[i];
+__device__ __forceinline__ void hml_fwd_ctx_load(hml_fwd_ctx<K>& cx, const hml_model* mdl, const float* lds_A) {
+    cx.A.attach(mdl, lds_A);
     cx.invK = (float)(1.0 / (double)(float)K);
     cx.self = mdl->self_trans != 0;
     cx.B = mdl->B;
@@ -412,8 +487,10 @@ __global__ __launch_bounds__(256) void hml_k_forward(const float* __restrict__ e
                                                      float* __restrict__ aprobe, float* __restrict__ entry,
                                                      float* __restrict__ exitv, uint32_t* __restrict__ fb_count, int L,
                                                      const hml_layout lay) {
+    __shared__ float sm_A[hml_amat<K>::LDS_FLOATS];
+    hml_amat_fill<K>(sm_A, mdl, (int)threadIdx.x, (int)blockDim.x);
     hml_fwd_ctx<K> cx;
-    hml_fwd_ctx_load<K>(cx, mdl);
+    hml_fwd_ctx_load<K>(cx, mdl, sm_A);
     const uint32_t B = cx.B;
     const int W = (int)mdl->fwd_W;   // adaptive, device-resident
     const uint32_t C = (B + (uint32_t)L - 1u) / (uint32_t)L;
@@ -495,9 +572,9 @@ __device__ void hml_fwd_repair(const float* __restrict__ em, const float* __rest
                                float* __restrict__ rows, float* __restrict__ aprobe, float* __restrict__ entry,
                                float* __restrict__ exitv, uint32_t* __restrict__ fb_count,
                                const uint32_t* __restrict__ fail_list, uint32_t n_fail, uint32_t* __restrict__ touched,
-                               uint32_t gen, int L, const hml_layout lay, hml_repair_lds& sh) {
+                               uint32_t gen, int L, const hml_layout lay, hml_repair_lds& sh, const float* lds_A) {
     hml_fwd_ctx<K> cx;
-    hml_fwd_ctx_load<K>(cx, mdl);
+    hml_fwd_ctx_load<K>(cx, mdl, lds_A);
     const uint32_t B = cx.B;
     const int W = (int)mdl->fwd_W;
     const uint32_t C = (B + (uint32_t)L - 1u) / (uint32_t)L;

@@ -78,7 +78,7 @@ __device__ __forceinline__ void hml_tre_emit(const hml_emit_params<K>& p, hml_mo
 // candidate map of row t from its (rescaled) row r and the row's uniform u (hml_cat_uniform): cand(x) = draw of
 // Cat(r_i A(i, x)); the last row's map is constant
 template <int K>
-__device__ __forceinline__ unsigned long long hml_tre_cand_u(const float (&r)[K], const float* __restrict__ A, hml_model* mdl, uint32_t t,
+__device__ __forceinline__ unsigned long long hml_tre_cand_u(const float (&r)[K], const hml_amat<K>& A, hml_model* mdl, uint32_t t,
                                                              uint32_t B, const double u) {
     unsigned long long map = 0ull;
     // "Negative backward variable!" (ForwardBackward.hpp:147-149): the products r_i A(i, x) below are negative exactly
@@ -102,7 +102,7 @@ __device__ __forceinline__ unsigned long long hml_tre_cand_u(const float (&r)[K]
     return map;
 }
 template <int K>
-__device__ __forceinline__ unsigned long long hml_tre_cand(const float (&r)[K], const float* __restrict__ A, hml_model* mdl, uint32_t t,
+__device__ __forceinline__ unsigned long long hml_tre_cand(const float (&r)[K], const hml_amat<K>& A, hml_model* mdl, uint32_t t,
                                                            uint32_t B, unsigned long long epoch, const hml_key key) {
     return hml_tre_cand_u<K>(r, A, mdl, t, B, hml_cat_uniform(key, epoch, t));
 }
@@ -111,7 +111,7 @@ __device__ __forceinline__ unsigned long long hml_tre_cand(const float (&r)[K], 
 // the first pass: one wavefront (= one workgroup of 64 threads) per 64 chunks
 // ------------------------------------------------------------------------------------------
 template <int K>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void hml_k_trellis_tile(const float2* __restrict__ ia, const uint32_t* __restrict__ starts,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(K <= 6 ? 4 : 1, K <= 6 ? 4 : 8))) void hml_k_trellis_tile(const float2* __restrict__ ia, const uint32_t* __restrict__ starts,
                                                          hml_model* __restrict__ mdl, const hml_model* __restrict__ mdl_ro,
                                                          float2* __restrict__ bstat, unsigned long long* __restrict__ cand,
                                                          unsigned long long* __restrict__ fmap, float* __restrict__ entry,
@@ -130,8 +130,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     const unsigned long long epoch = mdl_ro->epoch;
     const hml_key key = mdl_ro->key;
     for (int i = lane; i < HML_TRE_GTAB * K; i += 64) gtab[i] = hml_expf(((float)(i / K + 1) - 1.0f) * mdl_ro->logA[i % K]);   // N = i / K + 1
+    __shared__ float sm_A[hml_amat<K>::LDS_FLOATS];
+    hml_amat_fill<K>(sm_A, mdl_ro, lane, 64);
     hml_fwd_ctx<K> cx;
-    hml_fwd_ctx_load<K>(cx, mdl_ro);
+    hml_fwd_ctx_load<K>(cx, mdl_ro, sm_A);
     if (blockIdx.x == 0 && lane < K && aprobe) aprobe[lane] = mdl_ro->pi[lane];
     const uint32_t C = (B + L - 1u) / L;
     const uint32_t n_groups = (C + (uint32_t)HML_TRE_NCH - 1u) / (uint32_t)HML_TRE_NCH;
@@ -410,8 +412,10 @@ __global__ __launch_bounds__(64) void hml_k_trellis_refit(const float2* __restri
     const int lane = threadIdx.x;
     hml_emit_params<K> p;
     hml_emit_load<K>(p, mdl, 0);
+    __shared__ float sm_A[hml_amat<K>::LDS_FLOATS];
+    hml_amat_fill<K>(sm_A, mdl, lane, (int)blockDim.x);
     hml_fwd_ctx<K> cx;
-    hml_fwd_ctx_load<K>(cx, mdl);
+    hml_fwd_ctx_load<K>(cx, mdl, sm_A);
     const uint32_t B = cx.B;
     const uint32_t Wt = hml_tre_warmup(mdl);
     const unsigned long long epoch = mdl->epoch;
@@ -509,11 +513,13 @@ __global__ __launch_bounds__(256) void hml_k_trellis_serial(const float2* __rest
     __syncthreads();
     for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) atomicOr(&bitmap[list[i] >> 5], 1u << (list[i] & 31u));
     __syncthreads();
+    __shared__ float sm_A[hml_amat<K>::LDS_FLOATS];
+    hml_amat_fill<K>(sm_A, mdl, (int)threadIdx.x, (int)blockDim.x);
     if (threadIdx.x != 0) return;
     hml_emit_params<K> p;
     hml_emit_load<K>(p, mdl, 0);
     hml_fwd_ctx<K> cx;
-    hml_fwd_ctx_load<K>(cx, mdl);
+    hml_fwd_ctx_load<K>(cx, mdl, sm_A);
     const unsigned long long epoch = mdl->epoch;
     const hml_key key = mdl->key;
     for (uint32_t wi = 0; wi < words; ++wi) {
