@@ -120,7 +120,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(K <= 6 ? 4 :
     constexpr int R = HML_TRE_R, PITCH = HML_TRE_R + 1, PLANE = HML_TRE_NCH * PITCH;
     __shared__ float sm_v[K * PLANE];                          // e_s, then alpha_s in place: [s][chunk][row of the batch], chunk pitch R + 1
     __shared__ unsigned long long sm_c[HML_TRE_NCH * PITCH];   // the batch's candidate maps
-    __shared__ uint32_t sm_n[HML_TRE_NCH * PITCH];             // the batch's block sizes (0: no block in this slot)
+    // the batch's block sizes (0: no block in this slot).  Up to 8 states they need no array of their own: between P1a and
+    // P1b a size waits in plane 0 of sm_v (free until P1b writes the terms), from P1b to P3 in the upper half of the slot's
+    // sm_c word (the statistics are consumed by then, a map of <= 8 states takes the lower half) - 10 KB of LDS per
+    // wavefront instead of 11.5, i.e. 16 wavefronts per CU instead of 13
+    constexpr bool PACKN = (K <= 8);
+    __shared__ uint32_t sm_n[PACKN ? 1 : HML_TRE_NCH * PITCH];
     __shared__ float gtab[HML_TRE_GTAB * K];
     const uint32_t B = mdl_ro->B;
     const int lane = threadIdx.x;
@@ -169,7 +174,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(K <= 6 ? 4 :
                     hml_block_stats_one(ia, st, en, sx, sq);
                     nb = en - st;
                 }
-                sm_n[c * PITCH + r] = nb;
+                if (PACKN) sm_v[c * PITCH + r] = hml_u2f(nb); else sm_n[c * PITCH + r] = nb;
                 sm_c[c * PITCH + r] = ((unsigned long long)hml_f2u(sq) << 32) | hml_f2u(sx);
             }
             // P1b, one copy of the arithmetic (eight unrolled copies here and in P3 made 100 KB of code)
@@ -177,9 +182,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(K <= 6 ? 4 :
             for (int k = 0; k < R; ++k) {
                 const int slot = k * 64 + lane;
                 const int c = slot / R, r = slot % R;
-                const uint32_t nb = sm_n[c * PITCH + r];
+                const uint32_t nb = PACKN ? hml_f2u(sm_v[c * PITCH + r]) : sm_n[c * PITCH + r];
+                const unsigned long long pk = sm_c[c * PITCH + r];
+                if (PACKN) sm_c[c * PITCH + r] = (unsigned long long)nb << 32;
                 if (nb != 0u) {
-                    const unsigned long long pk = sm_c[c * PITCH + r];
                     const float sx = hml_u2f((uint32_t)pk), sq = hml_u2f((uint32_t)(pk >> 32));
                     float E[K], ev[K];
                     hml_tre_emit<K>(p, mdl, sx, sq, (float)nb, E, ev);
@@ -229,14 +235,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(K <= 6 ? 4 :
                 for (int k = 0; k < R / 2; ++k) {
                     const int slot = k * 64 + lane;
                     const int c = slot / (R / 2), r0 = 2 * (slot % (R / 2));
-                    const uint32_t n0 = sm_n[c * PITCH + r0];
+                    const uint32_t n1 = PACKN ? (uint32_t)(sm_c[c * PITCH + r0 + 1] >> 32) : sm_n[c * PITCH + r0 + 1];   // (before row r0's map lands next to it)
+                    const uint32_t n0 = PACKN ? (uint32_t)(sm_c[c * PITCH + r0] >> 32) : sm_n[c * PITCH + r0];
                     if (n0 != 0u) {   // (a block of the batch, see P1; the pair's second row exists only behind its first)
                         const uint32_t b0 = (f0 + (uint32_t)c) * L + (uint32_t)rel0 + (uint32_t)r0;
                         double u2[2];
                         hml_cat_uniform_pair(key, epoch, b0 >> 1, u2[0], u2[1]);
 #pragma unroll
                         for (int h = 0; h < 2; ++h) {
-                            const uint32_t n = h ? sm_n[c * PITCH + r0 + 1] : n0;
+                            const uint32_t n = h ? n1 : n0;
                             if (n != 0u) {
                                 const uint32_t t = b0 + (uint32_t)h + 1u;
                                 float row[K];
