@@ -284,6 +284,8 @@ def main():
                          "kernel_avg_us": 1e6 * scan_avg_s, "kernel_bracket_us": 1e6 * scan_raw_s,
                          "empty_bracket_us": 1e6 * null_s, "launches": scan_n,
                          "limiter": "latency: three dependent memory round trips + one inter-workgroup hand-off per launch",
+                         "profile_pair": "rocprofv3 adds 1.5-2 us to every dispatch of this kernel: the line that pairs with "
+                                         "profiles/round2_kernel_stats_c3_bench.csv is profiles/round2_bench_c3_under_rocprof.json",
                          "algorithmic_bytes_per_launch": algo_bytes,
                          "algorithmic_equivalent_gbs": algo_bytes / scan_avg_s / 1e9,
                          "algorithmic_speedup_vs_peak_float_stream": algo_bytes / scan_avg_s / 1e9 / HBM_PEAK_GBS,
