@@ -36,7 +36,8 @@ WORKLOADS = {
 
 PMC_FILE = "profiles/round2_pmc_hbm_traffic.json"
 # "c3u" = the uncompressed leg (same trace, every position its own block), collected with tools/time_dense.py
-PMC_FILES = {"c3_1e8_k5_dynamic": PMC_FILE, "c3u": "profiles/round2_pmc_hbm_traffic_c3u.json"}
+PMC_FILES = {"c3_1e8_k5_dynamic": PMC_FILE, "c3u": "profiles/round2_pmc_hbm_traffic_c3u.json",
+             "c5_2.5e8_depth_k5": "profiles/round2_pmc_hbm_traffic_c5.json"}
 
 # kernel families timed by the library's event brackets (hml_profile_enable) -> the kernel each one launches in the
 # default dynamic sweep (names as rocprofv3 prints them, without template arguments)
@@ -222,8 +223,11 @@ def main():
         return ch, t1 - t0, s1["block_updates"] - s0["block_updates"], s0, s1
 
     # headline leg: the library's default path - the block structure is recomputed in every sweep (dynamic blocks)
-    chain, elapsed, blocks, st0, st1 = run_leg(weight_summary=True, profile_level=1)
-    scan_ms, scan_n = chain.profile_get("blocks_compact")      # HIP events around every 32nd launch of the kernel
+    # weakly compressed workloads (config 5: millions of blocks per sweep) spend their time in the trellis tile kernel:
+    # every launch is bracketed there (15 pairs of events per 7 ms sweep)
+    dense_workload = levels is None
+    chain, elapsed, blocks, st0, st1 = run_leg(weight_summary=True, profile_level=2 if dense_workload else 1)
+    scan_ms, scan_n = chain.profile_get("trellis" if dense_workload else "blocks_compact")   # HIP events around the kernel's launches
     null_ms, null_n = chain.profile_get("event_null")          # empty brackets recorded right behind them
 
     if dist is not None:
@@ -255,6 +259,15 @@ def main():
         algo_bytes = 4.0 * T + 20.0 * B_avg
         phys_bytes = T / 16.0 + B_avg * (64.0 + 128.0 + 12.0 + 8.0 * K)     # estimate, used when no profile is committed
         traffic = pmc_traffic(args.workload, FAMILY_KERNEL["blocks_compact"])
+        if dense_workload:
+            # hml_k_trellis_tile: per block a start and two integral-array gathers read, statistics and a 4-byte map written
+            # (DESIGN.md 3a); the estimate used without a committed profile is what the counters showed on C3u (125 B/block)
+            algo_bytes = B_avg * (4.0 + 16.0 + 8.0 + 4.0)
+            phys_bytes = 125.0 * B_avg
+            traffic = pmc_traffic(args.workload, "hml_k_trellis_tile")
+            if null_n == 0:               # (profile level 2 records no empty brackets: the usual 5.3 us)
+                null_s = 5.3e-6
+                scan_avg_s = max(scan_raw_s - null_s, 1e-9)
         moved = traffic if traffic else phys_bytes
         achieved = moved / scan_avg_s / 1e9
         sweep_bytes = 4.0 * T + B_avg * (36 + 8 * K)   # SURVEY.md 8d bytes_iter
@@ -277,14 +290,17 @@ def main():
                        "compression": T / max(B_avg, 1.0), "block_structure": "dynamic", "chains": world,
                        "parallelism": "chain-parallel x%d" % world,
                        "cpu_baseline_sample": "port: the same 10^8 trace; reference binary: its first 10^7 positions"},
-            "roofline": {"bound": "hbm", "kernel": "hml_k_blocks_fused (block scan + block statistics + emission terms)",
+            "roofline": {"bound": "hbm", "kernel": "hml_k_trellis_tile (emission terms + forward filter + backward candidate maps)" if dense_workload
+                         else "hml_k_blocks_fused (block scan + block statistics + emission terms)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": frac,
-                         "traffic": traffic, "traffic_source": PMC_FILE if traffic else None,
+                         "traffic": traffic, "traffic_source": PMC_FILES.get(args.workload) if traffic else None,
                          "bytes_priced": "pmc: 2*FETCH_SIZE + WRITE_SIZE per launch" if traffic else "estimate (no committed profile)",
                          "kernel_avg_us": 1e6 * scan_avg_s, "kernel_bracket_us": 1e6 * scan_raw_s,
                          "empty_bracket_us": 1e6 * null_s, "launches": scan_n,
-                         "limiter": "latency: three dependent memory round trips + one inter-workgroup hand-off per launch",
-                         "profile_pair": "rocprofv3 adds 1.5-2 us to every dispatch of this kernel: the line that pairs with "
+                         "limiter": "waits between the phases of a batch at 4 wavefronts per SIMD (DESIGN.md 3a)" if dense_workload else
+                                    "latency: three dependent memory round trips + one inter-workgroup hand-off per launch",
+                         "profile_pair": None if dense_workload else
+                                         "rocprofv3 adds 1.5-2 us to every dispatch of this kernel: the line that pairs with "
                                          "profiles/round2_kernel_stats_c3_bench.csv is profiles/round2_bench_c3_under_rocprof.json",
                          "algorithmic_bytes_per_launch": algo_bytes,
                          "algorithmic_equivalent_gbs": algo_bytes / scan_avg_s / 1e9,
@@ -299,10 +315,16 @@ def main():
     # per-kernel table (not part of the timed region): every launch of 200 further sweeps bracketed by HIP events on the
     # chain's stream, next to the PMC traffic of the committed profile
     if rank == 0 and world == 1:
-        names = list(FAMILY_KERNEL)
+        fam_kernel = dict(FAMILY_KERNEL)
+        n_extra = 200
+        if dense_workload:
+            fam_kernel = {"blocks_compact": "hml_k_compact_scan", "blocks_scatter": "hml_k_compact_scatter", "trellis": "hml_k_trellis_tile",
+                          "trellis_repair": "hml_k_trellis_verify + refit + serial", "backward_chain": "hml_k_trellis_super + chain + states",
+                          "counts": "hml_k_counts_dense", "params": "hml_k_params"}
+            n_extra = 10
+        names = list(fam_kernel)
         before = {nm: chain.profile_get(nm) for nm in names + ["event_null"]}
         chain.profile_enable(2)
-        n_extra = 200
         chain.iterate("F", n_extra, 0)
         chain.sync()
         chain.profile_enable(0)
@@ -313,14 +335,14 @@ def main():
             if dn <= 0:
                 continue
             us = 1e3 * (ms - before[nm][0]) / dn
-            tr = pmc_traffic(args.workload, FAMILY_KERNEL[nm])
+            tr = pmc_traffic(args.workload, fam_kernel[nm])
             row = {"bracket_us": round(us, 2), "launches_per_sweep": round(dn / n_extra, 2), "traffic": tr}
             net = max(us - 1e6 * null_s, 0.5)
             row["kernel_us"] = round(net, 2)
             if tr:
                 row["frac"] = round(tr / (net * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)
                 assert row["frac"] <= 1.0
-            table[FAMILY_KERNEL[nm]] = row
+            table[fam_kernel[nm]] = row
         out["kernels"] = table
 
     if args.breakdown and rank == 0:

@@ -20,16 +20,19 @@ echo "== pmc write";     rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pm
 echo "== dense stats";   rocprofv3 --kernel-trace --stats --output-format csv -d $O/dense_stats -o run -- python3 $R/tools/time_dense.py c3u 20 > $O/dense_c3u.txt 2> $O/dense_stats.err
 echo "== dense pmc fetch"; rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/dense_fetch -o run -- python3 $R/tools/time_dense.py c3u 20 > /dev/null 2> $O/dense_fetch.err
 echo "== dense pmc write"; rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/dense_write -o run -- python3 $R/tools/time_dense.py c3u 20 > /dev/null 2> $O/dense_write.err
+echo "== c5 pmc fetch"; rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/c5_fetch -o run -- python3 $R/tools/time_dense.py c5 10 > /dev/null 2> $O/c5_fetch.err
+echo "== c5 pmc write"; rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/c5_write -o run -- python3 $R/tools/time_dense.py c5 10 > /dev/null 2> $O/c5_write.err
 echo "== c5 stats";      rocprofv3 --kernel-trace --stats --output-format csv -d $O/c5_stats -o run -- python3 $R/tools/time_dense.py c5 20 > $O/dense_c5.txt 2> $O/c5_stats.err
 
 cd $R
 python3 tools/pmc_summary.py $O/pmc_fetch $O/pmc_write $O/pmc_hbm_traffic.json "rocprofv3 --pmc <COUNTER> --output-format csv -- python3 bench.py --steps 200 --warmup 50 --no-cpu-baseline --no-uncompressed-leg" > /dev/null
 python3 tools/pmc_summary.py $O/dense_fetch $O/dense_write $O/pmc_hbm_traffic_c3u.json "rocprofv3 --pmc <COUNTER> --output-format csv -- python3 tools/time_dense.py c3u 20" > /dev/null
+python3 tools/pmc_summary.py $O/c5_fetch $O/c5_write $O/pmc_hbm_traffic_c5.json "rocprofv3 --pmc <COUNTER> --output-format csv -- python3 tools/time_dense.py c5 10" > /dev/null
 python3 tools/kstats.py $O/stats > $O/kernel_stats_c3_bench.txt
 python3 tools/kstats.py $O/dense_stats > $O/kernel_stats_c3u.txt
 python3 tools/kstats.py $O/c5_stats > $O/kernel_stats_c5.txt
 for d in stats dense_stats c5_stats; do find $O/$d -name '*kernel_stats.csv' -exec cp {} $O/${d}_kernel_stats.csv \; ; done
 # the raw traces are large: keep the summaries only
 rm -rf $O/stats $O/dense_stats $O/c5_stats
-find $O/pmc_fetch $O/pmc_write $O/dense_fetch $O/dense_write -name '*.csv' -size +8M -delete
+find $O/pmc_fetch $O/pmc_write $O/dense_fetch $O/dense_write $O/c5_fetch $O/c5_write -name '*.csv' -size +8M -delete
 cat $O/bench_driver.json; cat $O/dense_c3u.txt $O/dense_c5.txt; head -14 $O/kernel_stats_c3_bench.txt
