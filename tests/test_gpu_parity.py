@@ -717,3 +717,21 @@ def test_trellis_chunk_length_is_measured_and_changes_nothing(hml, monkeypatch, 
     g.iterate("F", 2, 0)
     g.sync()
     compare_state(o, g)
+
+
+def test_trellis_chunk_length_measurement_under_graph_replay(hml, monkeypatch):
+    """hipGraph replay (HML_USE_GRAPH=1) of fused-trellis sweeps: the sweeps that measure a chunk length run outside the
+    graph, and the graph is captured again with the length that won - the chain stays the checker's bit for bit."""
+    monkeypatch.setenv("HML_DENSE_MIN_BLOCKS", "1")
+    monkeypatch.setenv("HML_USE_GRAPH", "1")
+    T, K = 150_000, 4
+    xx, o, g = make_pair(hml, T, K, 2, 11, weight_mult=1e9)
+    setup_model(o, g, K)
+    o.token("F")
+    g.sample_prior()
+    for n in (40, 12, 20):          # 40: replayed graph; 12: crosses sweeps 48..51 (measurement); 20: graph with the new length
+        o.iterate("F", n, 0)
+        g.iterate("F", n, 0)
+        g.sync()
+        compare_state(o, g)
+        assert np.array_equal(o.states(), g.states())
