@@ -735,3 +735,36 @@ def test_trellis_chunk_length_measurement_under_graph_replay(hml, monkeypatch):
         g.sync()
         compare_state(o, g)
         assert np.array_equal(o.states(), g.states())
+
+
+@pytest.mark.parametrize("K", [6, 7, 8, 12, 16])
+def test_many_states_in_the_strongly_compressed_sweep(hml, K):
+    """Round 2's forms for more than 6 / 7 states on the default path: the block kernel walks the states in a loop with
+    its emission parameters in LDS (beyond 6: hml_emit_block_looped), the forward filter and the backward maps keep the
+    transition matrix in LDS (beyond 7: hml_amat) - emission terms, forward rows, states, parameters and marginals must
+    be the checker's bit for bit on both sides of either switch; the probes show that the fused block kernel ran."""
+    T = 150_000
+    x, o, g = make_pair(hml, T, K, 31, 77, weight_keys=2, x=ol.trace(T, 5, 31))   # five levels under K states
+    g.set_option("fused_blocks", 2)
+    setup_model(o, g, K)
+    o.token("F")
+    g.sample_prior()
+    o.set_probes(True)
+    g.enable_probes(True)
+    o.iterate("F", 1, 0)
+    g.iterate("F", 1, 0)
+    g.sync()
+    assert np.array_equal(bits(o.loglik()), bits(g.block_loglik()))
+    assert np.array_equal(bits(o.forward_rows()), bits(g.forward_rows()))
+    compare_state(o, g)
+    o.set_probes(False)
+    g.enable_probes(False)
+    o.set_record(marginals=True)
+    g._pending_prior = False
+    g.profile_enable(2)
+    run_both(o, g, [("F", 9, 3), ("M", 2, 1), ("F", 4, 2)])
+    g.profile_enable(0)
+    compare_state(o, g)
+    seg, cnt = g.marginals_rle()
+    assert hml.marginals_text(seg, cnt) == o.text("marginals")
+    assert g.profile_get("blocks_compact")[1] >= 14 and g.profile_get("blocks_scatter")[1] <= 1
