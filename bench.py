@@ -167,7 +167,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--breakdown", action="store_true", help="extra profiled pass: per-kernel-family times")
     ap.add_argument("--no-stream-leg", action="store_true", help="skip the second leg (float weight stream instead of the summary)")
-    ap.add_argument("--no-two-chain-leg", action="store_true", help="skip the third leg (two chains sharing one GPU)")
+    ap.add_argument("--no-two-chain-leg", action="store_true", help="skip the third leg (two and three chains sharing one GPU)")
     ap.add_argument("--no-uncompressed-leg", action="store_true", help="skip the fourth leg (same trace, weights x 1e9: every position its own block)")
     args = ap.parse_args()
 
@@ -397,43 +397,49 @@ def main():
                                                 "bytes_per_launch": f_bytes, "launches": f_n},
                                    "note": "same chain, same results; the default path above replaces this stream by the group summary"}
 
-    # third leg: two independent chains of the same workload on ONE GPU, each on its own stream and host thread
+    # third leg: two and three independent chains of the same workload on ONE GPU, each on its own stream and host thread
     # (chain-parallel inside the GPU: a single chain is latency-bound and leaves most of the machine idle)
     if not args.no_two_chain_leg and world == 1:
         import threading
         chain.close()
-        pair = []
-        for r in range(2):
-            ch = hammlet_amd.Chain(device=local_rank, seed=args.seed, chain_id=r)
-            ch.load(x)
-            ch.set_model(K, ch.autoprior(0.2, 0.9))
-            ch.sample_prior()
-            ch.set_recording(marginals=False)
-            ch.iterate("F", args.warmup, 0)
-            pair.append(ch)
-        for ch in pair:
-            ch.sync()
-        b0 = [ch.stats()["block_updates"] for ch in pair]
-
-        def run(ch):
-            ch.iterate("F", args.steps, 0)
-            ch.sync()
-        ths = [threading.Thread(target=run, args=(ch,)) for ch in pair]
-        barrier()
-        t0 = time.perf_counter()
-        for t in ths:
-            t.start()
-        for t in ths:
-            t.join()
-        barrier()
-        t1 = time.perf_counter()
-        b2 = sum(ch.stats()["block_updates"] - b for ch, b in zip(pair, b0))
-        out["two_chains_one_gpu"] = {"value": b2 / (t1 - t0), "unit": "block-updates/s", "chains": 2,
-                                     "ms_per_sweep_round": 1e3 * (t1 - t0) / args.steps,
-                                     "note": "aggregate of two independent chains on one GPU; the headline value is one chain per GPU"}
-        for ch in pair:
-            ch.close()
         chain = None
+
+        def several(n_chains):
+            group = []
+            for r in range(n_chains):
+                ch = hammlet_amd.Chain(device=local_rank, seed=args.seed, chain_id=r)
+                ch.load(x)
+                ch.set_model(K, ch.autoprior(0.2, 0.9))
+                ch.sample_prior()
+                ch.set_recording(marginals=False)
+                ch.iterate("F", args.warmup, 0)
+                group.append(ch)
+            for ch in group:
+                ch.sync()
+            b0 = [ch.stats()["block_updates"] for ch in group]
+
+            def run(ch):
+                ch.iterate("F", args.steps, 0)
+                ch.sync()
+            ths = [threading.Thread(target=run, args=(ch,)) for ch in group]
+            barrier()
+            t0 = time.perf_counter()
+            for t in ths:
+                t.start()
+            for t in ths:
+                t.join()
+            barrier()
+            t1 = time.perf_counter()
+            b2 = sum(ch.stats()["block_updates"] - b for ch, b in zip(group, b0))
+            for ch in group:
+                ch.close()
+            return b2 / (t1 - t0), 1e3 * (t1 - t0) / args.steps
+        v2, ms2 = several(2)
+        out["two_chains_one_gpu"] = {"value": v2, "unit": "block-updates/s", "chains": 2, "ms_per_sweep_round": ms2,
+                                     "note": "aggregate of two independent chains on one GPU; the headline value is one chain per GPU"}
+        v3, ms3 = several(3)
+        out["three_chains_one_gpu"] = {"value": v3, "unit": "block-updates/s", "chains": 3, "ms_per_sweep_round": ms3,
+                                       "note": "profiles/round2_chains_per_gpu.txt: the aggregate peaks at three chains per GPU"}
 
     # fourth leg: SURVEY 8d's stress case C3u - the same trace with the breakpoint weights multiplied by 1e9, so that
     # every position is its own block (B = T): the regime in which the trellis itself, not the block scan, is the load
