@@ -20,6 +20,7 @@
 #include "hml_k_marginals.h"
 #include "hml_k_segment.h"
 #include "hml_k_trellis.h"
+#include "hml_k_trellis_rows.h"
 #include "hml_k_params.h"
 #include "hml_state.h"
 #include "hml_synth_host.hpp"
@@ -291,7 +292,8 @@ int hml_create(hml_ctx** out, int device, uint64_t seed, uint32_t chain_id, void
     if (const char* e = getenv("HML_WEIGHT_KEYS")) c->use_keys = atoi(e) != 0;
     if (const char* e = getenv("HML_FUSED_BLOCKS")) { c->fused_blocks = atoi(e) != 0; c->fused_keep = atoi(e) == 2; }   // 0: a GPU shared with other processes
     if (const char* e = getenv("HML_TRELLIS_FUSED")) c->tre_fused = atoi(e) != 0;
-    if (const char* e = getenv("HML_TRELLIS_L")) { const int l = atoi(e); c->tre_L = (l <= 0) ? 0u : (l >= 256) ? 256u : (l < 32) ? 32u : (uint32_t)l / 32u * 32u; }   // a multiple of 32
+    if (const char* e = getenv("HML_TRELLIS_L")) { const int l = atoi(e); c->tre_L = (l <= 0) ? 0u : (l >= HML_TRE_MAX_L) ? (uint32_t)HML_TRE_MAX_L : (l < 32) ? 32u : (uint32_t)l / 32u * 32u; }   // a multiple of 32
+    if (const char* e = getenv("HML_TRELLIS_ROWS")) c->tre_rows = atoi(e) != 0;   // 0: round 2's first pass (hml_k_trellis_tile) for comparison
     if (const char* e = getenv("HML_LATE_RESCALE")) c->late_rescale = atoi(e) != 0;
     if (const char* e = getenv("HML_TRELLIS_TUNE")) c->tre_autotune = atoi(e) != 0;
     if (const char* e = getenv("HML_FUSED_SPIN_LIMIT")) c->fused_spin_limit = (uint32_t)strtoul(e, nullptr, 10);
@@ -999,6 +1001,10 @@ static int sweep_k(hml_ctx* c, char method, bool record) {
         float* ap = c->probes ? c->d_aprobe : nullptr;
         {
             ProfScope ps(c, "trellis");
+            if (c->tre_rows)
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_trellis_rows<KK>), dim3(grid_for(tgroups, HML_TR2_WAVES, 4, 1 << 20)), dim3(64 * HML_TR2_WAVES), 0, s,
+                                   c->d_ia, c->d_starts, c->d_mdl, c->d_mdl, c->d_bstat, c->d_smap, c->d_cmap, c->d_entry, c->d_exitA, c->d_fb, ep, ap, TL);
+            else
             hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_trellis_tile<KK>), dim3(grid_for(tgroups, 1, 16, 1 << 20)), dim3(64), 0, s,
                                c->d_ia, c->d_starts, c->d_mdl, c->d_mdl, c->d_bstat, c->d_smap, c->d_cmap, c->d_entry, c->d_exitA, c->d_fb, ep, ap, TL);
         }
@@ -1200,8 +1206,8 @@ int hml_set_option(hml_ctx* c, const char* name, int value) {
         if (c->graph_exec) { hipGraphExecDestroy(c->graph_exec); c->graph_exec = nullptr; }
         return 0;
     }
-    if (std::string(name) == "trellis_L") {   // chunk length of the fused trellis path: 0 = measured, else a multiple of 32 up to 256
-        if (value < 0 || value > 256 || value % 32) return set_err(HML_ERR_ARG, "trellis_L: 0 or a multiple of 32 up to 256");
+    if (std::string(name) == "trellis_L") {   // chunk length of the fused trellis path: 0 = measured, else a multiple of 32 up to HML_TRE_MAX_L
+        if (value < 0 || value > HML_TRE_MAX_L || value % 32) return set_err(HML_ERR_ARG, "trellis_L: 0 or a multiple of 32 up to 1024");
         c->tre_L = (uint32_t)value;
         return 0;
     }

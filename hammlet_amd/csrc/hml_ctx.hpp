@@ -75,6 +75,7 @@ struct hml_ctx {
     float tre_tune_ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     uint64_t tre_dense_sweeps = 0; // fused-trellis sweeps of this chain so far
     uint32_t graph_tre_L = 0;      // chunk length of the captured sweep
+    bool tre_rows = true;          // its first pass is hml_k_trellis_rows (round 3); HML_TRELLIS_ROWS=0: hml_k_trellis_tile (round 2)
     bool tre_fused = true;         // weakly compressed FB sweeps take the fused trellis kernels (HML_TRELLIS_FUSED=0: the separate ones)
     uint32_t* d_touched = nullptr; // backward chunks whose rows the repair recomputed, tagged with the sweep
     uint32_t* d_fb = nullptr;

@@ -36,6 +36,7 @@
 #define HML_TRE_HALO 64     // longest warm-up of the first pass (a multiple of HML_TRE_R)
 #define HML_TRE_GTAB 64     // block sizes whose rescale factors expf((N-1) logA_s) come from a table
 #define HML_TRE_MIN_L 32    // shortest chunk (a multiple of 32; per-chunk arrays are sized for it)
+#define HML_TRE_MAX_L 1024  // longest chunk
 
 // warm-up of the first pass: the chain's adaptive warm-up, capped and rounded up to whole batches
 __device__ __forceinline__ uint32_t hml_tre_warmup(const hml_model* mdl) {
@@ -60,7 +61,8 @@ __device__ __forceinline__ unsigned long long hml_tre_load_cand(const unsigned l
 
 // E_s and e_s = expf(E_s - max E) of one block (hml_emit_compute without the rescale factors)
 template <int K>
-__device__ __forceinline__ void hml_tre_emit(const hml_emit_params<K>& p, hml_model* mdl, float sx, float sq, float N, float (&E)[K], float (&ev)[K]) {
+__device__ __forceinline__ void hml_tre_emit(const hml_emit_params<K>& p, hml_model* mdl, float sx, float sq, float N, float (&E)[K], float (&ev)[K],
+                                             const uint64_t* exp_tab = HML_EXP2F_TAB) {
     float maxE = -3.40282346638528859812e+38f;   // numeric_limits<float>::lowest()
 #pragma unroll
     for (int s = 0; s < K; ++s) {
@@ -72,7 +74,7 @@ __device__ __forceinline__ void hml_tre_emit(const hml_emit_params<K>& p, hml_mo
         maxE = (e < maxE) ? maxE : e;
     }
 #pragma unroll
-    for (int s = 0; s < K; ++s) ev[s] = hml_expf(E[s] - maxE);
+    for (int s = 0; s < K; ++s) ev[s] = hml_expf_tab(E[s] - maxE, exp_tab);
 }
 
 // candidate map of row t from its (rescaled) row r and the row's uniform u (hml_cat_uniform): cand(x) = draw of
