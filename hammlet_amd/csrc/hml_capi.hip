@@ -1008,6 +1008,9 @@ static int sweep_k(hml_ctx* c, char method, bool record) {
             hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_trellis_tile<KK>), dim3(grid_for(tgroups, 1, 16, 1 << 20)), dim3(64), 0, s,
                                c->d_ia, c->d_starts, c->d_mdl, c->d_mdl, c->d_bstat, c->d_smap, c->d_cmap, c->d_entry, c->d_exitA, c->d_fb, ep, ap, TL);
         }
+#if HML_TR2_SKIP
+        if (!getenv("HML_DEV_KEEP_REPAIR")) { /* development builds with row stages disabled: the rows are wrong anyway, and repairing them would take for ever */ } else
+#endif
         {
             // verification, four rounds of parallel refits from the predecessors' end vectors (the lists of stale chunks
             // alternate between d_redo and d_redo2), then the sequential finisher: each exits at once when its list is empty

@@ -32,8 +32,16 @@
 
 #include "hml_k_trellis.h"
 
+#ifndef HML_TR2_R
 #define HML_TR2_R 16        // rows per batch
+#endif
+#ifndef HML_TR2_WPE
+#define HML_TR2_WPE 3       // wavefronts per SIMD the register allocation aims at (up to 8 states)
+#endif
 #define HML_TR2_WAVES 4     // wavefronts per workgroup
+#ifndef HML_TR2_SKIP
+#define HML_TR2_SKIP 0      // development only: bit mask of row stages replaced by a trivial stand-in (timing experiments; results are then wrong)
+#endif
 template <int K>
 struct hml_tr2 {
     static constexpr int SLOTW = (K <= 8) ? 3 : 4;              // words per block in the tile: {N, then the map} {high half of a 64-bit map} Sx Sxx
@@ -89,10 +97,10 @@ __device__ __forceinline__ void hml_tr2_params_fill(hml_tr2_params<K>& p, const 
     }
 }
 
-// e^x for x <= 0 or NaN - all the rows ever ask for (x = E_s - max E): hml_expf_tab with its case analysis folded.
-// Below -0x1.9fe368p6 (and for -inf) hml_expf_tab answers 0; clamped to -104 the arithmetic gives e^-104 = 6.8e-46, less
-// than half the smallest float, which rounds to the same 0.  A NaN takes the clamp's other operand and is put back at the
-// end (x + x, as there).
+// e^x for x <= 0 - all the rows ever ask for (x = E_s - max E): hml_expf_tab with its case analysis folded.  Below
+// -0x1.9fe368p6 (and for -inf) hml_expf_tab answers 0; clamped to -104 the arithmetic gives e^-104 = 6.8e-46, less than half
+// the smallest float, which rounds to the same 0.  NOT for a NaN (the clamp would swallow it): the caller looks for one
+// among the arguments of a block and takes hml_expf_tab then.
 __device__ __forceinline__ float hml_tr2_expf_nonpos(float x, const uint64_t* tab) {
     const float xc = __builtin_fmaxf(x, -104.0f);
     const double xd = (double)xc;
@@ -103,19 +111,19 @@ __device__ __forceinline__ float hml_tr2_expf_nonpos(float x, const uint64_t* ta
     const double C2 = 0x1.62e42ff0c52d6p-1 / 32.0;
     double z = InvLn2N * xd;
     double kd = z + Shift;
-    const uint64_t ki = hml_d2u(kd);
+    const uint32_t ki = (uint32_t)hml_d2u(kd);   // (the table index and the exponent adjustment only take its low 17 bits)
     kd = kd - Shift;
     const double r = z - kd;
-    uint64_t t = tab[ki & 31u];
-    t += ki << 47;
-    const double s = hml_u2d(t);
+    const uint64_t tw = tab[ki & 31u];
+    // t = tab + (ki << 47): the shifted word has nothing below bit 47, so only the high half moves
+    const uint32_t thi = (uint32_t)(tw >> 32) + (ki << 15);
+    const double s = hml_u2d(((uint64_t)thi << 32) | (uint32_t)tw);
     z = C0 * r + C1;
     const double r2 = r * r;
     double y = C2 * r + 1.0;
     y = z * r2 + y;
     y = y * s;
-    const float res = (float)y;
-    return (x != x) ? x + x : res;
+    return (float)y;
 }
 
 // E_s of one block through the double reciprocal (hml_inner_product's common case).  Returns true when some state's
@@ -207,8 +215,55 @@ __device__ __forceinline__ typename hml_tre_map<K>::stored hml_tr2_compose(typen
     return r;
 }
 
+// f / Z, correctly rounded to float like the IEEE division it stands for, from a double reciprocal r of Z (relative error
+// below 2^-27 is enough): q1 = f r, then one correction step q2 = q1 + (f - q1 Z) r with the residual from a fused
+// multiply-add, which leaves q2 within 2^-53 q of the quotient q - and EQUAL to q whenever q is a double (r's error enters
+// squared).  (float)q2 is the division's result: if q is a double nothing was rounded before the conversion; otherwise q is
+// not a float midpoint, and no quotient of two floats lies closer to one than 2^-49 q (numerator minus midpoint times
+// denominator is a non-zero multiple of the unit both are multiples of; holds for the sub-normal grid as well), so q2 is on
+// q's side of it.  Five divisions of the filter step were 55 of its 101 instructions; tools/div_check.hip and
+// test_quotient_by_reciprocal compare with the division itself, exact ties on the sub-normal grid included.
+__device__ __forceinline__ double hml_tr2_reciprocal(double Zd) {
+    double r = __builtin_amdgcn_rcp(Zd);
+    const double e = __builtin_fma(-Zd, r, 1.0);
+    return __builtin_fma(r, e, r);
+}
+__device__ __forceinline__ float hml_tr2_quotient(float f, double Zd, double r) {
+    const double fd = (double)f;
+    const double q1 = fd * r;
+    const double rho = __builtin_fma(-q1, Zd, fd);
+    return (float)__builtin_fma(rho, r, q1);
+}
+
+// one step of the recursion (hml_fwd_step) with the five quotients taken through one reciprocal
 template <int K>
-__global__ __launch_bounds__(64 * HML_TR2_WAVES) __attribute__((amdgpu_waves_per_eu(K <= 8 ? 3 : 1, K <= 8 ? 3 : 8)))
+__device__ __forceinline__ bool hml_tr2_step(const hml_fwd_ctx<K>& cx, float (&alpha)[K], const float (&e)[K]) {
+    float f[K];
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+        float tt = 0.0f;
+#pragma unroll
+        for (int i = 0; i < K; ++i) tt += alpha[i] * cx.A[i * K + j];
+        f[j] = e[j] * tt;
+    }
+    float Z = 0.0f;
+#pragma unroll
+    for (int j = 0; j < K; ++j) Z += f[j];
+    if (__builtin_expect(!(Z > 0.0f) || !(Z < 3.4028234663852886e38f), 0)) {   // 0: the uniform vector; negative, infinite or NaN: whatever the division says
+        const bool ok = (Z != 0.0f);
+#pragma unroll
+        for (int j = 0; j < K; ++j) alpha[j] = ok ? f[j] / Z : cx.invK;
+        return !ok;
+    }
+    const double Zd = (double)Z;
+    const double r = hml_tr2_reciprocal(Zd);
+#pragma unroll
+    for (int j = 0; j < K; ++j) alpha[j] = hml_tr2_quotient(f[j], Zd, r);
+    return false;
+}
+
+template <int K>
+__global__ __launch_bounds__(64 * HML_TR2_WAVES) __attribute__((amdgpu_waves_per_eu(K <= 8 ? HML_TR2_WPE : 1, K <= 8 ? HML_TR2_WPE : 8)))
 void hml_k_trellis_rows(const float2* __restrict__ ia, const uint32_t* __restrict__ starts, hml_model* __restrict__ mdl,
                         const hml_model* __restrict__ mdl_ro, float2* __restrict__ bstat, unsigned long long* __restrict__ cand,
                         unsigned long long* __restrict__ fmap, float* __restrict__ entry, float* __restrict__ exitv,
@@ -238,10 +293,13 @@ void hml_k_trellis_rows(const float2* __restrict__ ia, const uint32_t* __restric
     if (blockIdx.x == 0 && threadIdx.x < K && aprobe) aprobe[threadIdx.x] = mdl_ro->pi[threadIdx.x];
     const uint32_t C = (B + L - 1u) / L;
     const uint32_t n_groups = (C + (uint32_t)HML_TRE_NCH - 1u) / (uint32_t)HML_TRE_NCH;
+    const bool probes = eprobe != nullptr || aprobe != nullptr;
     __syncthreads();
-    // the (chunk, row) a lane serves while the wavefront moves a batch between memory and the tile: slot k takes chunks
-    // 4k .. 4k+3, sixteen consecutive lanes per chunk
-    const int sr = lane & (R - 1), sc = lane >> 4;
+    // the (chunk, row) a lane serves while the wavefront moves a batch between memory and the tile: R consecutive lanes per
+    // chunk, slot k takes chunks CPS k .. CPS k + CPS - 1
+    constexpr int CPS = 64 / R;
+    static_assert(CPS * R == 64, "a slot is whole chunks");
+    const int sr = lane % R, sc = lane / R;
     for (uint32_t grp = blockIdx.x * (uint32_t)HML_TR2_WAVES + (uint32_t)wave; grp < n_groups; grp += gridDim.x * (uint32_t)HML_TR2_WAVES) {   // wave-uniform
         const uint32_t f0 = grp * (uint32_t)HML_TRE_NCH;
         const uint32_t f = f0 + (uint32_t)lane;   // this lane's own chunk
@@ -264,21 +322,25 @@ void hml_k_trellis_rows(const float2* __restrict__ ia, const uint32_t* __restric
                 bool have[R / 2];
 #pragma unroll
                 for (int k = 0; k < R / 2; ++k) {
-                    const int c = (half * (R / 2) + k) * 4 + sc;
+                    const int c = (half * (R / 2) + k) * CPS + sc;
                     const long long cf = (long long)(f0 + (uint32_t)c) * L;
                     const long long b = cf + rel0 + sr;
                     const long long cl = (cf + L < (long long)B) ? cf + L : (long long)B;
                     have[k] = f0 + (uint32_t)c < C && b >= 0ll && b < cl && rel0 + sr >= -(int)Wt;
                     const uint32_t bb = have[k] ? (uint32_t)b : 0u;
+                    if (HML_TR2_SKIP & 64) { st[k] = bb; en[k] = bb + 1u; } else {
                     st[k] = starts[bb];
-                    en[k] = starts[bb + 1u];
+                    en[k] = starts[bb + 1u]; }
                 }
                 float2 a[R / 2], z[R / 2];
 #pragma unroll
-                for (int k = 0; k < R / 2; ++k) { a[k] = ia[st[k]]; z[k] = ia[en[k]]; }
+                for (int k = 0; k < R / 2; ++k) {
+                    if (HML_TR2_SKIP & 64) { a[k] = make_float2(1.0f + 0.001f * (float)(st[k] & 255u), 2.0f); z[k] = make_float2(0.5f, 0.25f); } else {
+                    a[k] = ia[st[k]]; z[k] = ia[en[k]]; }
+                }
 #pragma unroll
                 for (int k = 0; k < R / 2; ++k) {
-                    const int c = (half * (R / 2) + k) * 4 + sc;
+                    const int c = (half * (R / 2) + k) * CPS + sc;
                     float sx, sq;
                     bool inside;
                     hml_tr2_stats(st[k], en[k], a[k], z[k], sx, sq, inside);
@@ -297,52 +359,89 @@ void hml_k_trellis_rows(const float2* __restrict__ ia, const uint32_t* __restric
             }
             if (active) {
                 const uint32_t* const mine = tile + lane * PITCH;
+                // rows [r_lo, r_hi) of the batch are blocks of this lane's chunk (its warm-up included); 32-bit from here on
+                const long long base = first + rel0;
+                const int r_lo = (ws > base) ? (int)((ws - base < (long long)R) ? ws - base : (long long)R) : 0;
+                const int r_hi = (last > base) ? (int)((last - base < (long long)R) ? last - base : (long long)R) : 0;
+                const uint32_t b0 = (uint32_t)base;   // (block numbers below 2^32; only used where the row is a block)
+                const int r_first = (rel0 < -(int)Wt) ? -(int)Wt - rel0 : 0;   // (wave-uniform: the first batch of a warm-up that is no multiple of 16)
                 double u_odd = 0.0;
 #pragma unroll 1
-                for (int r = 0; r < R; ++r) {
-                    if (rel0 + r < -(int)Wt) continue;   // (wave-uniform: the first batch of a warm-up that is no multiple of 16)
-                    const long long b = first + rel0 + r;
+                for (int r = r_first; r < R; ++r) {
+                    const uint32_t b = b0 + (uint32_t)r;
                     double u = u_odd;
-                    if (rel0 >= 0 && (r & 1) == 0) {   // blocks 2m, 2m + 1 share Philox block m (D1)
+                    if (HML_TR2_SKIP & 16) { u = 0.37 + 1e-9 * (double)(b & 1023); }
+                    else if (rel0 >= 0 && (r & 1) == 0) {   // blocks 2m, 2m + 1 share Philox block m (D1)
                         // (the key words pass through an empty statement: left alone the compiler keeps the ten round keys of
                         // the schedule - two adds each - in twenty scalar registers across the loop, which it does not have)
                         hml_key kk = key;
                         asm volatile("" : "+s"(kk.k0), "+s"(kk.k1));
-                        hml_cat_uniform_pair(kk, epoch, (uint32_t)(b >> 1), u, u_odd);
+                        hml_cat_uniform_pair(kk, epoch, b >> 1, u, u_odd);
                     }
-                    if (b < ws || b >= last) continue;
+                    if (r < r_lo || r >= r_hi) continue;
                     const uint32_t nb = mine[r * SLOTW];
                     const float sx = hml_u2f(mine[r * SLOTW + SX]), sq = hml_u2f(mine[r * SLOTW + SX + 1]);
                     const float N = (float)nb;
                     float E[K], e[K];
+                    if (HML_TR2_SKIP & 1) {
+#pragma unroll
+                        for (int s = 0; s < K; ++s) E[s] = sx * (0.001f * (float)(s + 1)) - sq;
+                    } else
                     if (__builtin_expect(hml_tr2_energies<K>(p, self, sx, sq, N, E), 0)) hml_tr2_energies_literal<K>(mdl_ro, mdl, self, sx, sq, N, E);
                     float maxE = -3.40282346638528859812e+38f;   // numeric_limits<float>::lowest()
 #pragma unroll
                     for (int s = 0; s < K; ++s) maxE = (E[s] < maxE) ? maxE : E[s];
+                    float xs[K], xsum = 0.0f;
 #pragma unroll
-                    for (int s = 0; s < K; ++s) e[s] = hml_tr2_expf_nonpos(E[s] - maxE, etab);
-                    const bool fb = hml_fwd_step<K>(cx, alpha, e);
+                    for (int s = 0; s < K; ++s) { xs[s] = E[s] - maxE; xsum += xs[s]; }   // every term <= 0 or NaN: the sum is a NaN only if a term is
+                    if (HML_TR2_SKIP & 2) {
+#pragma unroll
+                        for (int s = 0; s < K; ++s) e[s] = 1.0f + 0.01f * xs[s];
+                    } else
+                    if (__builtin_expect(xsum != xsum, 0)) {
+#pragma unroll
+                        for (int s = 0; s < K; ++s) e[s] = hml_expf_tab(xs[s], etab);
+                    } else {
+#pragma unroll
+                        for (int s = 0; s < K; ++s) e[s] = hml_tr2_expf_nonpos(xs[s], etab);
+                    }
+                    bool fb = false;
+                    if (HML_TR2_SKIP & 4) {
+#pragma unroll
+                        for (int s = 0; s < K; ++s) alpha[s] = 0.5f * alpha[s] + 0.1f * e[s];
+                    } else
+                    fb = hml_tr2_step<K>(cx, alpha, e);
                     if (rel0 >= 0) {
                         if (fb) nfb++;
-                        const uint32_t t = (uint32_t)b + 1u;
+                        const uint32_t t = b + 1u;
+                        if (__builtin_expect(probes, 0)) {   // (tests: E_s and the unscaled rows)
+#pragma unroll
+                            for (int s = 0; s < K; ++s) {
+                                if (eprobe) eprobe[(uint64_t)b * K + s] = E[s];
+                                if (aprobe) aprobe[(uint64_t)t * K + s] = alpha[s];
+                            }
+                        }
                         float row[K];
 #pragma unroll
-                        for (int s = 0; s < K; ++s) {
-                            if (eprobe) eprobe[(uint64_t)b * K + s] = E[s];
-                            if (aprobe) aprobe[(uint64_t)t * K + s] = alpha[s];
-                            row[s] = alpha[s];
-                        }
-                        if (self && t < B) {   // the reference rescales row t after step t + 1 has consumed it (ForwardBackward.hpp:115-119)
+                        for (int s = 0; s < K; ++s) row[s] = alpha[s];
+                        // the reference rescales row t < B after step t + 1 has consumed it (ForwardBackward.hpp:115-119); blocks of
+                        // one position have the factor expf(0) = 1, and a wavefront that holds nothing else skips the step
+                        if (self && __ballot(nb != 1u && t < B) != 0ull) {
+                            if (t < B) {
 #pragma unroll
-                            for (int s = 0; s < K; ++s)
-                                row[s] = row[s] * ((nb <= (uint32_t)HML_TRE_GTAB) ? gtab[(nb - 1u) * K + s] : hml_expf_tab(((float)nb - 1.0f) * p.logA[s], etab));
+                                for (int s = 0; s < K; ++s)
+                                    row[s] = row[s] * ((nb <= (uint32_t)HML_TRE_GTAB) ? gtab[(nb - 1u) * K + s] : hml_expf_tab(((float)nb - 1.0f) * p.logA[s], etab));
+                            }
                         }
-                        bool unsure;
-                        map_t cm = hml_tr2_maps<K>(row, cx.A, (float)u, unsure);
+                        bool unsure = false;
+                        map_t cm;
+                        if (HML_TR2_SKIP & 8) cm = (map_t)(hml_f2u(row[0]) ^ hml_f2u(row[1]) ^ hml_f2u((float)u)) & (map_t)0x11111u;
+                        else cm = hml_tr2_maps<K>(row, cx.A, (float)u, unsure);
                         if (__builtin_expect(unsure || t >= B, 0)) cm = (map_t)hml_tre_cand_u<K>(row, cx.A, mdl, t, B, u);   // (also the last row's constant map)
                         uint32_t* const w = tile + lane * PITCH + r * SLOTW;
                         w[0] = (uint32_t)cm;
                         if (SLOTW == 4) w[1] = (uint32_t)(cm >> 32);
+                        if (HML_TR2_SKIP & 32) cmap ^= cm; else
                         cmap = hml_tr2_compose<K>(cmap, cm);
                     }
                 }
@@ -352,7 +451,7 @@ void hml_k_trellis_rows(const float2* __restrict__ ia, const uint32_t* __restric
             if (rel0 >= 0) {
 #pragma unroll
                 for (int k = 0; k < R; ++k) {
-                    const int c = k * 4 + sc;
+                    const int c = k * CPS + sc;
                     const long long cf = (long long)(f0 + (uint32_t)c) * L;
                     const long long b = cf + rel0 + sr;
                     const long long cl = (cf + L < (long long)B) ? cf + L : (long long)B;
@@ -360,8 +459,9 @@ void hml_k_trellis_rows(const float2* __restrict__ ia, const uint32_t* __restric
                         const uint32_t* const w = tile + c * PITCH + sr * SLOTW;
                         unsigned long long cm = w[0];
                         if (SLOTW == 4) cm |= (unsigned long long)w[1] << 32;
+                        if (HML_TR2_SKIP & 128) { if (cm == 0x12345678u && w[SX] == 77u) bstat[b] = make_float2(0.0f, 0.0f); } else {
                         bstat[b] = make_float2(hml_u2f(w[SX]), hml_u2f(w[SX + 1]));
-                        hml_tre_store_cand<K>(cand, (uint32_t)b + 1u, cm);
+                        hml_tre_store_cand<K>(cand, (uint32_t)b + 1u, cm); }
                     }
                 }
                 hml_wave_lds_fence();

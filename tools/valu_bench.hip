@@ -21,6 +21,8 @@ __global__ __launch_bounds__(256) void k(unsigned long long* out, const float* i
     f2 p[8]; for (int i = 0; i < 8; ++i) { p[i].x = f[i]; p[i].y = g[i]; }
     const float c = in[16]; const double cd = (double)in[17]; const uint32_t cu = (uint32_t)in[18] | 1u;
     const f2 cp = {c, c};
+    unsigned long long msk = __ballot(threadIdx.x & 1); unsigned long long m2[8] = {0,0,0,0,0,0,0,0}; uint32_t sr[8] = {0,0,0,0,0,0,0,0};
+    __shared__ double lds[64]; lds[threadIdx.x & 63] = cd; const uint32_t ldsaddr = (uint32_t)(uintptr_t)&lds[3];
     __syncthreads();
     const unsigned long long t0 = __builtin_amdgcn_s_memtime();
     for (int it = 0; it < ITERS; ++it) {
@@ -100,6 +102,106 @@ __global__ __launch_bounds__(256) void k(unsigned long long* out, const float* i
 #define X(i) asm volatile("v_div_fixup_f32 %0, %0, %1, %1" : "+v"(f[i]) : "v"(c));
             BODY4(X)
 #undef X
+        } else if (OP == 20) {
+#define X(i) asm volatile("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(f[i]) : "v"(c), "s"(msk));
+            BODY4(X)
+#undef X
+        } else if (OP == 21) {
+#define X(i) asm volatile("v_cmp_lt_f32_e64 %0, %1, %2" : "=s"(m2[i]) : "v"(f[i]), "v"(c));
+            BODY4(X)
+#undef X
+        } else if (OP == 22) {
+#define X(i) asm volatile("v_bfe_u32 %0, %0, 3, 11" : "+v"(u[i]));
+            BODY4(X)
+#undef X
+        } else if (OP == 23) {
+#define X(i) asm volatile("v_lshl_or_b32 %0, %0, 4, %1" : "+v"(u[i]) : "v"(cu));
+            BODY4(X)
+#undef X
+        } else if (OP == 24) {
+#define X(i) asm volatile("v_or3_b32 %0, %0, %1, %1" : "+v"(u[i]) : "v"(cu));
+            BODY4(X)
+#undef X
+        } else if (OP == 25) {
+#define X(i) asm volatile("v_add3_u32 %0, %0, %1, %1" : "+v"(u[i]) : "v"(cu));
+            BODY4(X)
+#undef X
+        } else if (OP == 26) {
+#define X(i) asm volatile("v_mul_f32_e64 %0, |%0|, %1" : "+v"(f[i]) : "v"(c));
+            BODY4(X)
+#undef X
+        } else if (OP == 27) {
+#define X(i) asm volatile("v_mul_f32_e32 %0, %1, %0" : "+v"(f[i]) : "s"(c));
+            BODY4(X)
+#undef X
+        } else if (OP == 28) {
+#define X(i) asm volatile("v_max_f32_e32 %0, %0, %1" : "+v"(f[i]) : "v"(c));
+            BODY4(X)
+#undef X
+        } else if (OP == 29) {
+#define X(i) asm volatile("v_fract_f64 %0, %0" : "+v"(d[i]));
+            BODY4(X)
+#undef X
+        } else if (OP == 30) {
+#define X(i) asm volatile("v_ldexp_f64 %0, %0, 1" : "+v"(d[i]));
+            BODY4(X)
+#undef X
+        } else if (OP == 31) {
+#define X(i) asm volatile("v_cvt_f32_u32_e32 %0, %1" : "=v"(f[i]) : "v"(u[i]));
+            BODY4(X)
+#undef X
+        } else if (OP == 32) {
+#define X(i) asm volatile("v_alignbit_b32 %0, %0, %1, 1" : "+v"(u[i]) : "v"(cu));
+            BODY4(X)
+#undef X
+        } else if (OP == 33) {
+#define X(i) asm volatile("v_mov_b32_e32 %0, %1" : "=v"(u[i]) : "v"(cu));
+            BODY4(X)
+#undef X
+        } else if (OP == 34) {
+#define X(i) asm volatile("v_readlane_b32 %0, %1, 3" : "=s"(sr[i]) : "v"(u[i]));
+            BODY4(X)
+#undef X
+        } else if (OP == 35) {
+#define X(i) asm volatile("v_cmp_lt_f32_e32 vcc, %0, %1" : : "v"(f[i]), "v"(c) : "vcc");
+            BODY4(X)
+#undef X
+        } else if (OP == 36) {
+#define X(i) asm volatile("v_cndmask_b32_e32 %0, %0, %1, vcc" : "+v"(f[i]) : "v"(c) : "vcc");
+            BODY4(X)
+#undef X
+        } else if (OP == 37) {
+#define X(i) asm volatile("v_addc_co_u32_e32 %0, vcc, 0, %0, vcc" : "+v"(u[i]) : : "vcc");
+            BODY4(X)
+#undef X
+        } else if (OP == 38) {
+#define X(i) asm volatile("v_cmp_neq_f64_e64 %0, 0, %1" : "=s"(m2[i]) : "v"(d[i]));
+            BODY4(X)
+#undef X
+        } else if (OP == 39) {
+#define X(i) asm volatile("v_lshl_add_u64 %0, %0, 0, %1" : "+v"(d[i]) : "v"(cd));
+            BODY4(X)
+#undef X
+        } else if (OP == 40) {
+#define X(i) asm volatile("v_and_b32_e32 %0, %1, %0" : "+v"(u[i]) : "v"(cu));
+            BODY4(X)
+#undef X
+        } else if (OP == 41) {
+#define X(i) asm volatile("v_sub_f32_e32 %0, %0, %1" : "+v"(f[i]) : "v"(c));
+            BODY4(X)
+#undef X
+        } else if (OP == 42) {
+#define X(i) asm volatile("v_lshlrev_b32_e32 %0, 1, %0" : "+v"(u[i]));
+            BODY4(X)
+#undef X
+        } else if (OP == 43) {
+#define X(i) asm volatile("s_and_b64 %0, %0, %1" : "+s"(m2[i]) : "s"(msk) : "scc");
+            BODY4(X)
+#undef X
+        } else if (OP == 44) {
+#define X(i) asm volatile("ds_read_b64 %0, %1" : "=v"(d[i]) : "v"(ldsaddr)); asm volatile("s_waitcnt lgkmcnt(8)");
+            BODY4(X)
+#undef X
         } else if (OP == 19) {
 #define X(i) asm volatile("v_mul_u32_u24 %0, %0, %1" : "+v"(u[i]) : "v"(cu));
             BODY4(X)
@@ -109,6 +211,7 @@ __global__ __launch_bounds__(256) void k(unsigned long long* out, const float* i
     const unsigned long long t1 = __builtin_amdgcn_s_memtime();
     float s = 0; double sd = 0; uint32_t su = 0;
     for (int i = 0; i < 8; ++i) { s += f[i] + p[i].x + p[i].y; sd += d[i]; su += u[i]; }
+    for (int i = 0; i < 8; ++i) { su += (uint32_t)m2[i] + sr[i]; }
     if (s == 1.2345f && sd == 3.0 && su == 7u) out[1 << 20] = 1;
     if ((threadIdx.x & 63) == 0) out[(blockIdx.x * blockDim.x + threadIdx.x) >> 6] = t1 - t0;
 }
@@ -163,5 +266,30 @@ int main() {
     run<17>("v_min3_f32", 1, d_out, d_in);
     run<18>("v_div_fixup_f32", 1, d_out, d_in);
     run<19>("v_mul_u32_u24", 1, d_out, d_in);
+    run<20>("v_cndmask_b32_e64 (sgpr mask)", 1, d_out, d_in);
+    run<21>("v_cmp_lt_f32_e64 -> sgpr", 1, d_out, d_in);
+    run<22>("v_bfe_u32", 1, d_out, d_in);
+    run<23>("v_lshl_or_b32", 1, d_out, d_in);
+    run<24>("v_or3_b32", 1, d_out, d_in);
+    run<25>("v_add3_u32", 1, d_out, d_in);
+    run<26>("v_mul_f32_e64 |abs|", 1, d_out, d_in);
+    run<27>("v_mul_f32_e32 sgpr src0", 1, d_out, d_in);
+    run<28>("v_max_f32_e32", 1, d_out, d_in);
+    run<29>("v_fract_f64", 1, d_out, d_in);
+    run<30>("v_ldexp_f64", 1, d_out, d_in);
+    run<31>("v_cvt_f32_u32", 1, d_out, d_in);
+    run<32>("v_alignbit_b32", 1, d_out, d_in);
+    run<33>("v_mov_b32", 1, d_out, d_in);
+    run<34>("v_readlane_b32", 1, d_out, d_in);
+    run<35>("v_cmp_lt_f32_e32 (vcc) alone", 1, d_out, d_in);
+    run<36>("v_cndmask_b32_e32 (vcc) alone", 1, d_out, d_in);
+    run<37>("v_addc_co_u32 (vcc)", 1, d_out, d_in);
+    run<38>("v_cmp_neq_f64_e64", 1, d_out, d_in);
+    run<39>("v_lshl_add_u64", 1, d_out, d_in);
+    run<40>("v_and_b32 e32", 1, d_out, d_in);
+    run<41>("v_sub_f32 e32", 1, d_out, d_in);
+    run<42>("v_lshlrev_b32 e32", 1, d_out, d_in);
+    run<43>("s_and_b64 (salu)", 1, d_out, d_in);
+    run<44>("ds_read_b64 broadcast", 1, d_out, d_in);
     return 0;
 }
