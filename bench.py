@@ -34,10 +34,12 @@ WORKLOADS = {
 }
 
 
-PMC_FILE = "profiles/round2_pmc_hbm_traffic.json"
+PMC_FILE = "profiles/round3_pmc_hbm_traffic.json"
 # "c3u" = the uncompressed leg (same trace, every position its own block), collected with tools/time_dense.py
-PMC_FILES = {"c3_1e8_k5_dynamic": PMC_FILE, "c3u": "profiles/round2_pmc_hbm_traffic_c3u.json",
-             "c5_2.5e8_depth_k5": "profiles/round2_pmc_hbm_traffic_c5.json"}
+PMC_FILES = {"c3_1e8_k5_dynamic": PMC_FILE, "c3u": "profiles/round3_pmc_hbm_traffic_c3u.json",
+             "c5_2.5e8_depth_k5": "profiles/round3_pmc_hbm_traffic_c5.json"}
+DENSE_KERNEL = "hml_k_trellis_rows"   # first pass over the trellis of a weakly compressed sweep (hml_k_trellis_rows.h)
+MIN_BRACKETS = 32                     # launches of the roofline kernel that are bracketed by events, whatever --steps is
 
 # kernel families timed by the library's event brackets (hml_profile_enable) -> the kernel each one launches in the
 # default dynamic sweep (names as rocprofv3 prints them, without template arguments)
@@ -65,11 +67,12 @@ def pmc_table(workload):
         return {}
 
 
-def pmc_traffic(workload, kernel):
-    """bytes per launch of `kernel` (name without template arguments)"""
+def pmc_traffic(workload, kernel, key="bytes_fetch_doubled"):
+    """bytes per launch of `kernel` (name without template arguments): 2 x FETCH_SIZE + WRITE_SIZE, or with key = "bytes_raw"
+    FETCH_SIZE + WRITE_SIZE as counted"""
     for name, k in pmc_table(workload).items():
         if name.split("<")[0] == kernel:
-            return k["bytes_fetch_doubled"]
+            return k[key]
     return None
 
 
@@ -86,7 +89,7 @@ def host_cpu():
     return model, n
 
 
-def cpu_baseline(x, K, seed, budget_s=20.0):
+def cpu_baseline(x, K, seed, budget_s=16.0, ref_sweeps=24):
     """The CPU restatement in reference mode (sequential mt19937, glibc math, pointer-jumping block
     enumeration), timed on this box's host cores; one thread like the reference."""
     from tests import oracle_lib as ol
@@ -98,9 +101,13 @@ def cpu_baseline(x, K, seed, budget_s=20.0):
     # burn in a few sweeps so the timed ones see the compression level of a running chain
     t = o.time_sweeps("F", 3)
     per = max(t / 3, 1e-6)
-    n = int(max(3, min(200, budget_s / per)))
+    n = int(max(ref_sweeps, min(200, budget_s / per)))
     b0 = o.total_blocks()
-    t = o.time_sweeps("F", n)
+    # (the first ref_sweeps sweeps of the chain are what the reference binary is asked for below: same seed, same chain)
+    t_a = o.time_sweeps("F", ref_sweeps - 3)
+    blocks_ref = o.total_blocks()
+    t_b = o.time_sweeps("F", n - (ref_sweeps - 3)) if n > ref_sweeps - 3 else 0.0
+    t = t_a + t_b
     blocks = o.total_blocks() - b0
     o.close()
     model, total = host_cpu()
@@ -108,7 +115,7 @@ def cpu_baseline(x, K, seed, budget_s=20.0):
            "sample": "%d sweeps of the same %d-position trace (reference-mode CPU restatement, %.1f ms/sweep); one thread, "
                      "like the reference (src/main.cpp:108)" % (n, x.size, 1e3 * t / n)}
     try:
-        ref = reference_binary_baseline(x, K, seed)
+        ref = reference_binary_baseline(x, K, seed, ref_sweeps, blocks_ref)
         if ref:
             out["reference_binary"] = ref
     except Exception as e:   # the prebuilt binary is optional on the GPU box
@@ -116,25 +123,26 @@ def cpu_baseline(x, K, seed, budget_s=20.0):
     return out
 
 
-def reference_binary_baseline(x, K, seed, prefix=10_000_000, sweeps=300):
+def reference_binary_baseline(x, K, seed, sweeps, blocks):
     """The UNMODIFIED reference binary (oracle/_ref/hammlet, prebuilt in the build container from the reference's own
-    main.cpp; absent -> None) on a bounded sample: the first 10^7 positions of the same trace as text, sweep time =
-    wall(-i F n 0) - wall(-i F 0 0) (start-up and text parsing cancel), block count from the restatement run with the
-    same seed on the same prefix (it reproduces the reference's files byte for byte, hence its block structures)."""
+    main.cpp; absent -> None) on the WHOLE trace as text, a bounded number of sweeps: sweep time = wall(-i F n 0) -
+    wall(-i F 0 0) (start-up and the reference's text parsing, reported separately, cancel); `blocks` = the block updates of
+    those sweeps, from the restatement's run of the same chain (it reproduces the reference's files byte for byte, hence its
+    block structures)."""
     import subprocess
     import tempfile
     exe = os.path.join(REPO, "oracle", "_ref", "hammlet")
     if not os.path.exists(exe):
         return None
     from tests import oracle_lib as ol
-    xp = np.ascontiguousarray(x[:prefix])
-    with tempfile.TemporaryDirectory() as tmp:
-        txt = os.path.join(tmp, "prefix.txt")
-        try:
-            import pandas as pd
-            pd.Series(xp).to_csv(txt, index=False, header=False, float_format="%.9g")
-        except Exception:
-            np.savetxt(txt, xp, fmt="%.9g")
+    lib = ol.load()
+    with tempfile.TemporaryDirectory(dir=os.environ.get("HML_BENCH_TMP") or None) as tmp:
+        txt = os.path.join(tmp, "trace.txt")
+        import ctypes as C
+        lib.orc_write_text.argtypes = [C.c_void_p, C.c_uint64, C.c_char_p, C.c_int]
+        xc = np.ascontiguousarray(x, dtype=np.float32)
+        if lib.orc_write_text(xc.ctypes.data, xc.size, txt.encode(), max(1, min(16, os.cpu_count() or 1))) != 0:
+            raise RuntimeError("could not write the trace as text")
 
         def run(n):
             t0 = time.perf_counter()
@@ -143,18 +151,10 @@ def reference_binary_baseline(x, K, seed, prefix=10_000_000, sweeps=300):
             return time.perf_counter() - t0
         t_zero = run(0)
         t_n = run(sweeps)
-    o = ol.OracleChain(K=K, seed=seed, rng=ol.RNG_MT, math=ol.MATH_LIBM, reduce=ol.REDUCE_REF)
-    o.load(xp)
-    o.autoprior()
-    o.init_model()
-    o.set_record(marginals=False)
-    o.time_sweeps("F", sweeps)
-    blocks = o.total_blocks()
-    o.close()
     dt = max(t_n - t_zero, 1e-9)
-    return {"value": blocks / dt, "unit": "block-updates/s", "cores": 1, "kind": "reference", "sample_positions": int(xp.size),
-            "sample": "unmodified reference binary, first %d positions of the trace as text (a bounded sample: not the 10^8 trace), %d sweeps: %.2f ms/sweep, "
-                      "%.0f blocks/sweep (start-up + text parsing %.1f s, subtracted)" % (xp.size, sweeps, 1e3 * dt / sweeps, blocks / sweeps, t_zero)}
+    return {"value": blocks / dt, "unit": "block-updates/s", "cores": 1, "kind": "reference", "sample_positions": int(x.size),
+            "sample": "unmodified reference binary on the whole %d-position trace as text, %d sweeps: %.1f ms/sweep, "
+                      "%.0f blocks/sweep (start-up + text parsing %.1f s, subtracted)" % (x.size, sweeps, 1e3 * dt / sweeps, blocks / sweeps, t_zero)}
 
 
 def main():
@@ -168,6 +168,7 @@ def main():
     ap.add_argument("--breakdown", action="store_true", help="extra profiled pass: per-kernel-family times")
     ap.add_argument("--no-stream-leg", action="store_true", help="skip the second leg (float weight stream instead of the summary)")
     ap.add_argument("--no-two-chain-leg", action="store_true", help="skip the third leg (two and three chains sharing one GPU)")
+    ap.add_argument("--no-scheme-legs", action="store_true", help="skip the recorded / config-2 mixture / config-2 static legs")
     ap.add_argument("--no-uncompressed-leg", action="store_true", help="skip the fourth leg (same trace, weights x 1e9: every position its own block)")
     args = ap.parse_args()
 
@@ -177,9 +178,12 @@ def main():
     if world != args.gpus and world > 1:
         raise SystemExit("WORLD_SIZE (%d) != --gpus (%d)" % (world, args.gpus))
 
+    # HML_BENCH_FORCE_DIST=1: take the multi-rank branches (process group over RCCL, communicator id by broadcast, pooling
+    # through hml_pool_marginals) whatever the world size - what tests/test_gpu_bench_dist.py runs on a one-GPU box
+    dist_mode = world > 1 or os.environ.get("HML_BENCH_FORCE_DIST") == "1"
     import torch
     dist = None
-    if world > 1:
+    if dist_mode:
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
@@ -227,8 +231,21 @@ def main():
     # every launch is bracketed there (15 pairs of events per 7 ms sweep)
     dense_workload = levels is None
     chain, elapsed, blocks, st0, st1 = run_leg(weight_summary=True, profile_level=2 if dense_workload else 1)
-    scan_ms, scan_n = chain.profile_get("trellis" if dense_workload else "blocks_compact")   # HIP events around the kernel's launches
+    roof_family = "trellis" if dense_workload else "blocks_compact"
+    scan_ms, scan_n = chain.profile_get(roof_family)           # HIP events around the kernel's launches
     null_ms, null_n = chain.profile_get("event_null")          # empty brackets recorded right behind them
+    brackets_timed = scan_n
+    if scan_n < MIN_BRACKETS:
+        # the timed region brackets every 32nd launch of the roofline kernel (a bracket costs ~5 us of stream time): with few
+        # steps that is one sample or none.  A short pass OUTSIDE the timed region, same chain, same level, tops the sample
+        # up to MIN_BRACKETS launches; kernel_avg_us is the average over all of them.
+        per = 1 if dense_workload else 32
+        chain.profile_enable(2 if dense_workload else 1)
+        chain.iterate("F", (MIN_BRACKETS - scan_n) * per, 0)
+        chain.sync()
+        chain.profile_enable(0)
+        scan_ms, scan_n = chain.profile_get(roof_family)
+        null_ms, null_n = chain.profile_get("event_null")
 
     if dist is not None:
         tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
@@ -263,12 +280,13 @@ def main():
             # hml_k_trellis_tile: per block a start and two integral-array gathers read, statistics and a 4-byte map written
             # (DESIGN.md 3a); the estimate used without a committed profile is what the counters showed on C3u (125 B/block)
             algo_bytes = B_avg * (4.0 + 16.0 + 8.0 + 4.0)
-            phys_bytes = 125.0 * B_avg
-            traffic = pmc_traffic(args.workload, "hml_k_trellis_tile")
+            phys_bytes = 50.0 * B_avg
+            traffic = pmc_traffic(args.workload, DENSE_KERNEL)
             if null_n == 0:               # (profile level 2 records no empty brackets: the usual 5.3 us)
                 null_s = 5.3e-6
                 scan_avg_s = max(scan_raw_s - null_s, 1e-9)
         moved = traffic if traffic else phys_bytes
+        traffic_raw = pmc_traffic(args.workload, DENSE_KERNEL if dense_workload else FAMILY_KERNEL["blocks_compact"], "bytes_raw")
         achieved = moved / scan_avg_s / 1e9
         sweep_bytes = 4.0 * T + B_avg * (36 + 8 * K)   # SURVEY.md 8d bytes_iter
         frac = achieved / HBM_PEAK_GBS
@@ -290,14 +308,19 @@ def main():
                        "compression": T / max(B_avg, 1.0), "block_structure": "dynamic", "chains": world,
                        "parallelism": "chain-parallel x%d" % world,
                        "cpu_baseline_sample": "port: the same 10^8 trace; reference binary: its first 10^7 positions"},
-            "roofline": {"bound": "hbm", "kernel": "hml_k_trellis_tile (emission terms + forward filter + backward candidate maps)" if dense_workload
+            "roofline": {"bound": "hbm", "kernel": DENSE_KERNEL + " (emission terms + forward filter + backward candidate maps)" if dense_workload
                          else "hml_k_blocks_fused (block scan + block statistics + emission terms)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": frac,
                          "traffic": traffic, "traffic_source": PMC_FILES.get(args.workload) if traffic else None,
                          "bytes_priced": "pmc: 2*FETCH_SIZE + WRITE_SIZE per launch" if traffic else "estimate (no committed profile)",
+                         "traffic_raw": traffic_raw,
+                         "frac_raw": (traffic_raw / scan_avg_s / 1e9 / HBM_PEAK_GBS) if traffic_raw else None,
+                         "frac_raw_note": "FETCH_SIZE + WRITE_SIZE as counted (no gfx950 doubling of the fetches): the lower bound of the bytes moved",
                          "kernel_avg_us": 1e6 * scan_avg_s, "kernel_bracket_us": 1e6 * scan_raw_s,
-                         "empty_bracket_us": 1e6 * null_s, "launches": scan_n,
-                         "limiter": "waits between the phases of a batch at 4 wavefronts per SIMD (DESIGN.md 3a)" if dense_workload else
+                         "empty_bracket_us": 1e6 * null_s, "launches": scan_n, "launches_in_timed_region": brackets_timed,
+                         "launches_note": "HIP events on the chain's stream; launches beyond those of the timed region come from a "
+                                          "short extra pass of the same chain outside it (at least %d in all)" % MIN_BRACKETS,
+                         "limiter": "vector issue: about 600 VALU instructions per block-row, 40 %% of them double precision (DESIGN.md 3a)" if dense_workload else
                                     "latency: three dependent memory round trips + one inter-workgroup hand-off per launch",
                          "profile_pair": None if dense_workload else
                                          "rocprofv3 adds 1.5-2 us to every dispatch of this kernel: the line that pairs with "
@@ -318,7 +341,7 @@ def main():
         fam_kernel = dict(FAMILY_KERNEL)
         n_extra = 200
         if dense_workload:
-            fam_kernel = {"blocks_compact": "hml_k_compact_scan", "blocks_scatter": "hml_k_compact_scatter", "trellis": "hml_k_trellis_tile",
+            fam_kernel = {"blocks_compact": "hml_k_compact_scan", "blocks_scatter": "hml_k_compact_scatter", "trellis": DENSE_KERNEL,
                           "trellis_repair": "hml_k_trellis_verify + refit + serial", "backward_chain": "hml_k_trellis_super + chain + states",
                           "counts": "hml_k_counts_dense", "params": "hml_k_params"}
             n_extra = 10
@@ -360,9 +383,9 @@ def main():
 
     # chain-parallel pooling (not timed): a few recorded sweeps, then the library's own collective - every rank joins
     # an RCCL communicator (hml_pool_create) and hml_pool_marginals relabels, all-reduces and installs the pooled marginals
-    if world > 1:
+    if dist_mode:
         from hammlet_amd import chains
-        pool = chains.make_pool(local_rank)
+        pool = chains.make_pool(local_rank, always_broadcast=True)
         chain.set_recording(marginals=True)
         chain.iterate("F", 10, 5)
         chain.sync()
@@ -376,7 +399,7 @@ def main():
                               "rccl_version": info["rccl_version"], "all_reduce_bytes": info["last_bytes"],
                               "all_reduce_ms": info["last_allreduce_ms"],
                               "seconds_incl_export_and_install": time.perf_counter() - tp0,
-                              "pooled_segments": int(len(seg)), "counts_per_position": int(cnt[0].sum())}
+                              "pooled_segments": int(len(seg)), "counts_per_position": int(cnt[0].sum()), "ranks": world}
         pool.close()
 
     # second leg: the same chain with the float weight stream (option weight_keys = 0): every sweep reads all T
@@ -397,11 +420,76 @@ def main():
                                                 "bytes_per_launch": f_bytes, "launches": f_n},
                                    "note": "same chain, same results; the default path above replaces this stream by the group summary"}
 
+    # scheme legs: what the headline's plain sweeps leave out.  (a) C3's own scheme records every 10th sweep
+    # (-i F n 10, marginals on): hml_k_record inside the timed region.  (b) BASELINE config 2: 10^7 positions, scheme
+    # M 100 0 S P F n 10 - mixture sweeps on dynamic blocks, then FB sweeps on a FIXED block structure (static blocks).
+    if not args.no_scheme_legs and world == 1 and args.workload == "c3_1e8_k5_dynamic":
+        chain.close()
+        ch = hammlet_amd.Chain(device=local_rank, seed=args.seed, chain_id=rank)
+        ch.load(x)
+        ch.set_model(K, ch.autoprior(0.2, 0.9))
+        ch.sample_prior()
+        ch.set_recording(marginals=True)
+        ch.iterate("F", args.warmup, 0)
+        ch.sync()
+        r0 = ch.stats()
+        barrier()
+        t0 = time.perf_counter()
+        ch.iterate("F", args.steps, 10)
+        ch.sync()
+        barrier()
+        t1 = time.perf_counter()
+        r1 = ch.stats()
+        out["recorded"] = {"value": (r1["block_updates"] - r0["block_updates"]) / (t1 - t0), "unit": "block-updates/s",
+                           "ms_per_step": 1e3 * (t1 - t0) / args.steps, "scheme": "F %d 10, marginals recorded" % args.steps,
+                           "recorded_sweeps": ch.recorded_sweeps(),
+                           "note": "the headline's chain with every 10th sweep recorded into the marginals (hml_k_record)"}
+        ch.close()
+        T2, K2, lv2, sg2, dw2, ds2 = WORKLOADS["c2_1e7_k5"]
+        x2 = hammlet_amd.synth_gauss(T2, K2, lv2, sg2, dw2, ds2, nthreads=nthr)
+        ch = hammlet_amd.Chain(device=local_rank, seed=args.seed, chain_id=rank)
+        ch.load(x2)
+        ch.set_model(K2, ch.autoprior(0.2, 0.9))
+        ch.sample_prior()
+        ch.set_recording(marginals=True)
+        ch.iterate("M", 20, 0)                      # (clocks and caches)
+        ch.sync()
+        m0 = ch.stats()
+        barrier()
+        t0 = time.perf_counter()
+        ch.iterate("M", 100, 0)
+        ch.sync()
+        barrier()
+        t1 = time.perf_counter()
+        m1 = ch.stats()
+        ch.set_static_blocks()                      # S: createBlocks(theta) once
+        ch.sample_prior()                           # P
+        ch.iterate("F", args.warmup, 0)
+        ch.sync()
+        f0 = ch.stats()
+        barrier()
+        t2 = time.perf_counter()
+        ch.iterate("F", args.steps, 10)
+        ch.sync()
+        barrier()
+        t3 = time.perf_counter()
+        f1 = ch.stats()
+        out["c2_mixture"] = {"value": (m1["block_updates"] - m0["block_updates"]) / (t1 - t0), "unit": "block-updates/s",
+                             "ms_per_step": 1e3 * (t1 - t0) / 100, "scheme": "M 100 0 on the 10^7-position trace of config 2 (dynamic blocks)"}
+        out["c2_static"] = {"value": (f1["block_updates"] - f0["block_updates"]) / (t3 - t2), "unit": "block-updates/s",
+                            "ms_per_step": 1e3 * (t3 - t2) / args.steps, "blocks_per_sweep": (f1["block_updates"] - f0["block_updates"]) / args.steps,
+                            "scheme": "M 120 0 S P F %d 10 (BASELINE config 2: fixed wavelet block structure), marginals recorded" % args.steps,
+                            "note": "latency-bound: 2 MB of block data per sweep (SURVEY.md 8d) - a launch-overhead-limited rate, not a bandwidth fraction"}
+        ch.close()
+        del x2
+        chain = None
+
     # third leg: two and three independent chains of the same workload on ONE GPU, each on its own stream and host thread
     # (chain-parallel inside the GPU: a single chain is latency-bound and leaves most of the machine idle)
     if not args.no_two_chain_leg and world == 1:
         import threading
-        chain.close()
+        if chain is not None:
+            chain.close()
         chain = None
 
         def several(n_chains):
@@ -468,7 +556,7 @@ def main():
         u1 = ch.stats()
         bu = u1["block_updates"] - u0["block_updates"]
         Bu = bu / n_u
-        fams = {"blocks_compact": "hml_k_blocks_fused", "trellis": "hml_k_trellis_tile", "trellis_repair": "hml_k_trellis_verify + refit + serial",
+        fams = {"blocks_compact": "hml_k_compact_scan", "blocks_scatter": "hml_k_compact_scatter", "trellis": DENSE_KERNEL, "trellis_repair": "hml_k_trellis_verify + refit + serial",
                 "backward_chain": "hml_k_trellis_super + chain + states", "counts": "hml_k_counts_dense", "params": "hml_k_params"}
         ch.profile_enable(2)
         ch.iterate("F", 10, 0)
@@ -493,8 +581,8 @@ def main():
                                    "forward_warmup_rows": u1["forward_warmup"],
                                    "sweep_frac": (4.0 * T + Bu * (36 + 8 * K)) / ((t1 - t0) / n_u) / 1e9 / HBM_PEAK_GBS,
                                    "kernels": dense_tab,
-                                   "note": "B = T: the fused trellis path (hml_k_trellis.h) - instruction-bound, about 450 VALU "
-                                           "instructions per block in hml_k_trellis_tile; DESIGN.md 3a"}
+                                   "note": "B = T: the fused trellis path (hml_k_trellis_rows.h) - bound by vector issue: SQ_INSTS_VALU of the "
+                                           "first pass = about 700 wavefront instructions per 64 blocks and warm-up row (profiles/round3_sq_counters_c3u.txt); DESIGN.md 3a"}
         ch.close()
         chain = None
 

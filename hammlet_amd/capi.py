@@ -93,6 +93,8 @@ SIGNATURES = {
     "hml_pool_marginals": (C.c_int, [_P, _P, _P]),
     "hml_pool_info": (C.c_int, [_P, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.POINTER(C.c_int)]),
     "hml_allreduce_marginals": (C.c_int, [_P, C.c_int]),
+    "hml_allreduce_marginals_perm": (C.c_int, [_P, C.c_int, _P]),
+    "hml_pool_permutation": (C.c_int, [_P, _P]),
     "hml_get_stats": (C.c_int, [_P, C.POINTER(HmlStats)]),
     "hml_profile_enable": (C.c_int, [_P, C.c_int]),
     "hml_profile_get": (C.c_int, [_P, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
@@ -100,6 +102,9 @@ SIGNATURES = {
     "hml_synth_depth": (C.c_int, [_P, _P, C.c_uint64, C.c_double, C.c_double, C.c_uint64, C.c_int]),
     "hml_synth_gauss": (C.c_int, [_P, _P, C.c_uint64, C.c_int, _P, C.c_float, C.c_double, C.c_uint64, C.c_int]),
 }
+
+
+ABI_VERSION = 2   # hml_abi_version() of include/hml.h this mirror was written against
 
 
 def load_library(path=None):
@@ -116,6 +121,8 @@ def load_library(path=None):
         fn = getattr(lib, name)  # AttributeError if the library does not export a declared symbol
         fn.restype = res
         fn.argtypes = args
+    if lib.hml_abi_version() != ABI_VERSION:
+        raise HmlError(-1, "%s has ABI version %d, this package expects %d: rebuild the library" % (path, lib.hml_abi_version(), ABI_VERSION))
     _lib = lib
     return lib
 
@@ -422,6 +429,12 @@ class Chain:
         _check(self.lib.hml_pool_export(self.h, payload_ptr, perm.ctypes.data))
         return perm
 
+    def pool_permutation(self):
+        """perm[j] = this chain's label of pooled state j (identity before any pooling)"""
+        perm = np.zeros(self.K, np.int32)
+        _check(self.lib.hml_pool_permutation(self.h, perm.ctypes.data))
+        return perm
+
     def pool_install(self, payload_ptr):
         _check(self.lib.hml_pool_install(self.h, payload_ptr))
 
@@ -487,11 +500,17 @@ class Pool:
             pass
 
 
-def allreduce_marginals(chains):
-    """hml_allreduce_marginals: one process driving several chains (possibly on several GPUs)"""
+def allreduce_marginals(chains, with_perms=False):
+    """hml_allreduce_marginals(_perm): one process driving several chains (possibly on several GPUs).  with_perms: returns
+    perms[i][j] = chain i's own label of pooled state j."""
     lib = load_library()
     arr = (_P * len(chains))(*[c.h for c in chains])
-    _check(lib.hml_allreduce_marginals(C.cast(arr, _P), len(chains)))
+    if not with_perms:
+        _check(lib.hml_allreduce_marginals(C.cast(arr, _P), len(chains)))
+        return None
+    perms = np.zeros((len(chains), chains[0].K), np.int32)
+    _check(lib.hml_allreduce_marginals_perm(C.cast(arr, _P), len(chains), perms.ctypes.data))
+    return perms
 
 
 def marginals_text(seg, cnt):

@@ -87,13 +87,14 @@ def max_segmentation(seg, cnt):
     return csum[ends] - csum[starts], state[starts]
 
 
-def make_pool(device, group=None):
+def make_pool(device, group=None, always_broadcast=False):
     """The RCCL communicator of this rank inside a torch.distributed job (one process per GPU): rank 0 creates the id,
     the job's own backend broadcasts its 128 bytes, every rank joins (ncclCommInitRank).  Without an initialised
-    process group: a one-rank communicator."""
+    process group: a one-rank communicator.  always_broadcast: take the broadcast path in a one-rank group as well
+    (rehearsal of the multi-rank path on one GPU)."""
     import torch.distributed as dist
     from .capi import Pool
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+    if dist.is_available() and dist.is_initialized() and (dist.get_world_size(group) > 1 or always_broadcast):
         rank, world = dist.get_rank(group), dist.get_world_size(group)
         box = [Pool.unique_id() if rank == 0 else None]
         dist.broadcast_object_list(box, src=0, group=group)

@@ -245,7 +245,7 @@ __global__ void hml_k_debug_eval(int fn, const float* __restrict__ a, const floa
 extern "C" {
 
 const char* hml_last_error(void) { return g_err.c_str(); }
-uint32_t hml_abi_version(void) { return 1; }
+uint32_t hml_abi_version(void) { return 2; }   // 2: hml_stats.fused_fallbacks, hml_allreduce_marginals_perm, hml_pool_permutation, option "compat"
 const char* hml_device_arch(void) { return "gfx950"; }
 int hml_device_count(int* n) {
     if (!n) return set_err(HML_ERR_ARG, "null argument");
@@ -851,15 +851,40 @@ static bool fused_geometry(hml_ctx* c, uint32_t* n_sub, uint32_t* n_wg) {
 
 // ---- chunk length of the fused trellis path (hml_ctx.hpp: tre_autotune)
 #define HML_TRE_TUNE_AFTER 48u   // sweeps before the measurement: the filter's warm-up length has settled by then
-static uint32_t tre_default_L(uint32_t hint) { return hint >= (1u << 26) ? 128u : hint >= (1u << 24) ? 64u : (uint32_t)HML_TRE_MIN_L; }
-static int tre_candidates(uint32_t hint, uint32_t* out) {
-    const uint32_t L0 = tre_default_L(hint);
+// Candidates.  The wavefronts of the first pass (64 chunks each) all do the same work and stay resident from launch to
+// exit, so the pass takes a whole number of ROUNDS over the machine's wavefront slots: the chunk lengths worth measuring
+// are those that fill 1, 2, 3 ... rounds almost completely (longer chunks = a smaller warm-up share, but longer refits of
+// the chunks that fail verification).  hml_k_trellis_tile (HML_TRELLIS_ROWS=0) keeps round 2's list.
+static uint32_t tre_default_L_old(uint32_t hint) { return hint >= (1u << 26) ? 128u : hint >= (1u << 24) ? 64u : (uint32_t)HML_TRE_MIN_L; }
+static int tre_candidates(const hml_ctx* c, uint32_t hint, uint32_t* out) {
     int n = 0;
-    for (uint32_t q = 4; q <= 8; ++q) {   // L0 * {1, 1.25, 1.5, 1.75, 2}, multiples of 32
-        const uint32_t l = L0 * q / 4u;
-        if (l % 32u == 0u && l <= 256u) out[n++] = l;
+    if (!c->tre_rows || c->tre_slots <= 0) {
+        const uint32_t L0 = tre_default_L_old(hint);
+        for (uint32_t q = 4; q <= 8; ++q) {   // L0 * {1, 1.25, 1.5, 1.75, 2}, multiples of 32
+            const uint32_t l = L0 * q / 4u;
+            if (l % 32u == 0u && l <= 256u) out[n++] = l;
+        }
+        return n;
     }
+    for (uint32_t rounds = 1; rounds <= 8u && n < 6; ++rounds) {
+        const double waves = 0.985 * (double)c->tre_slots * rounds;              // (a little air: one wavefront too many costs a round)
+        uint32_t l = (uint32_t)((double)hint / (64.0 * waves)) + 1u;
+        l = (l + 31u) / 32u * 32u;
+        if (l < (uint32_t)HML_TRE_MIN_L) l = HML_TRE_MIN_L;
+        if (l > 512u) continue;                                                    // (refits of longer chunks cost more than their warm-up saves)
+        bool seen = false;
+        for (int i = 0; i < n; ++i) seen = seen || out[i] == l;
+        if (!seen) out[n++] = l;
+        if (l == (uint32_t)HML_TRE_MIN_L) break;
+    }
+    if (n == 0) out[n++] = 512u;
     return n;
+}
+static uint32_t tre_default_L(const hml_ctx* c, uint32_t hint) {   // until the measurement: two rounds where there are blocks for them
+    if (!c->tre_rows || c->tre_slots <= 0) return tre_default_L_old(hint);
+    uint32_t cand[8];
+    const int n = tre_candidates(c, hint, cand);
+    return cand[n > 1 ? 1 : 0];
 }
 static bool tre_tuned_for(const hml_ctx* c, uint32_t hint) {
     return c->tre_tuned_L && hint <= c->tre_tuned_hint + c->tre_tuned_hint / 8u && hint + hint / 8u >= c->tre_tuned_hint;
@@ -873,9 +898,9 @@ static uint32_t tre_pick_L(hml_ctx* c, uint32_t hint, bool capturing, bool* meas
     *measure = false;
     if (c->tre_L) return c->tre_L;
     if (tre_tuned_for(c, hint)) return c->tre_tuned_L;
-    if (capturing || !tre_wants_measurement(c, hint)) return c->tre_tuned_L ? c->tre_tuned_L : tre_default_L(hint);
+    if (capturing || !tre_wants_measurement(c, hint)) return c->tre_tuned_L ? c->tre_tuned_L : tre_default_L(c, hint);
     uint32_t cand[8];
-    const int n = tre_candidates(hint, cand);
+    const int n = tre_candidates(c, hint, cand);
     if (n < 2) { c->tre_tuned_L = cand[0]; c->tre_tuned_hint = hint; return cand[0]; }
     if (c->tre_tune_step < 0) { c->tre_tune_step = 0; for (float& v : c->tre_tune_ms) v = 3.4e38f; }
     *measure = true;
@@ -883,7 +908,7 @@ static uint32_t tre_pick_L(hml_ctx* c, uint32_t hint, bool capturing, bool* meas
 }
 static void tre_tune_report(hml_ctx* c, uint32_t hint, float ms) {
     uint32_t cand[8];
-    const int n = tre_candidates(hint, cand);
+    const int n = tre_candidates(c, hint, cand);
     const int i = c->tre_tune_step % n;
     c->tre_tune_ms[i] = std::min(c->tre_tune_ms[i], ms);
     if (++c->tre_tune_step < 2 * n) return;
@@ -991,6 +1016,14 @@ static int sweep_k(hml_ctx* c, char method, bool record) {
         hipStreamCaptureStatus capst = hipStreamCaptureStatusNone;
         (void)hipStreamIsCapturing(s, &capst);
         bool measure = false;
+        if (c->tre_rows && c->tre_slots == 0) {   // wavefront slots of the first pass on this device (asked once)
+            int per_cu = 0, cus = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, hml_k_trellis_rows<KK>, 64 * HML_TR2_WAVES, 0) == hipSuccess &&
+                hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device) == hipSuccess && per_cu > 0 && cus > 0)
+                c->tre_slots = per_cu * cus * HML_TR2_WAVES;
+            else { (void)hipGetLastError(); c->tre_slots = -1; }
+            if (const char* e = getenv("HML_TRELLIS_SLOTS")) c->tre_slots = atoi(e);
+        }
         const uint32_t TL = tre_pick_L(c, hint, capst != hipStreamCaptureStatusNone, &measure);
         hipEvent_t tev0 = nullptr, tev1 = nullptr;
         if (measure) { tev0 = ev_get(c); tev1 = ev_get(c); hipEventRecord(tev0, s); }
@@ -1123,6 +1156,7 @@ static int sweep_k(hml_ctx* c, char method, bool record) {
         }
     }
     if (record && c->rec_marginals) {
+        if (c->pooled) return set_err(HML_ERR_ARG, "the marginals of this context are pooled (common labels, several chains): further sweeps cannot be recorded into them");
         if (int r = ensure_marginal_buffers(c)) return r;
         ProfScope ps(c, "marginals");
         hipLaunchKernelGGL(hml_k_record, dim3(gB), dim3(256), 0, s, c->d_q, c->d_starts, c->d_mdl, c->d_diff, c->d_boundary);
@@ -1156,8 +1190,11 @@ int hml_iterate(hml_ctx* c, char method, uint64_t iterations, uint64_t thinning)
             // replay a captured sweep; capture again when the launch geometry (grid hint / mode / chunk length) changed
             const uint32_t hint = c->B_hint;
             bool unused = false;
+            // (a captured sweep holds the fused block kernel or the scan + scatter pair: capture again when a second
+            // context appeared on the device, a bounded wait expired or the option changed)
+            const bool wants_fused = c->fused_blocks && !(c->h_B[1] && !c->fused_keep) && !shares_device(c);
             const bool stale = !c->graph_exec || c->graph_method != method || c->graph_dynamic != c->dynamic ||
-                               hint > c->graph_hint || hint * 2u < c->graph_hint ||
+                               hint > c->graph_hint || hint * 2u < c->graph_hint || c->graph_fused != wants_fused ||
                                c->graph_dense != (hint >= c->dense_min_blocks) ||
                                (tre_path && c->graph_tre_L != tre_pick_L(c, hint, true, &unused));
             if (stale && hint) {
@@ -1176,7 +1213,7 @@ int hml_iterate(hml_ctx* c, char method, uint64_t iterations, uint64_t thinning)
                 const hipError_t ei = hipGraphInstantiate(&c->graph_exec, g, nullptr, nullptr, 0);
                 hipGraphDestroy(g);
                 if (ei != hipSuccess) { c->graph_exec = nullptr; return set_err(HML_ERR_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(ei)); }
-                c->graph_method = method; c->graph_dynamic = c->dynamic; c->graph_hint = c->B_hint;
+                c->graph_method = method; c->graph_dynamic = c->dynamic; c->graph_hint = c->B_hint; c->graph_fused = wants_fused;
                 c->graph_dense = c->B_hint >= c->dense_min_blocks;
             }
             if (c->graph_exec) {

@@ -57,6 +57,7 @@ struct hml_ctx {
     char graph_method = 0;
     uint32_t graph_hint = 0;
     bool graph_dynamic = false, graph_valid_blocks = false;
+    bool graph_fused = false;       // the captured sweep was free to take the fused block kernel
     // sweep buffers (allocated by set_model)
     float *d_em = nullptr, *d_gsc = nullptr, *d_rows = nullptr, *d_eprobe = nullptr, *d_aprobe = nullptr;
     float *d_entry = nullptr, *d_exitA = nullptr;
@@ -75,6 +76,7 @@ struct hml_ctx {
     float tre_tune_ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     uint64_t tre_dense_sweeps = 0; // fused-trellis sweeps of this chain so far
     uint32_t graph_tre_L = 0;      // chunk length of the captured sweep
+    int tre_slots = 0;             // wavefronts of hml_k_trellis_rows the device holds at once (0: not asked yet, -1: unknown)
     bool tre_rows = true;          // its first pass is hml_k_trellis_rows (round 3); HML_TRELLIS_ROWS=0: hml_k_trellis_tile (round 2)
     bool tre_fused = true;         // weakly compressed FB sweeps take the fused trellis kernels (HML_TRELLIS_FUSED=0: the separate ones)
     uint32_t* d_touched = nullptr; // backward chunks whose rows the repair recomputed, tagged with the sweep
@@ -112,6 +114,8 @@ struct hml_ctx {
     bool rec_marginals = true;
     hml_record_cb cb = nullptr;
     void* cb_user = nullptr;
+    bool pooled = false;           // the marginals are a pooled payload (hml_pool_install): common labels, counts of several chains
+    std::vector<int32_t> pool_perm;   // perm[pooled label] = this chain's label, from the export that preceded the pooling
     int profiling = 0;             // 0 off, 1 dominant kernel only (blocks_compact, every 32nd launch), 2 every kernel family
     uint32_t prof_tick = 0;
     std::map<std::string, ProfAcc> prof;

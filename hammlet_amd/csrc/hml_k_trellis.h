@@ -131,6 +131,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(K <= 6 ? 4 :
     __shared__ float gtab[HML_TRE_GTAB * K];
     const uint32_t B = mdl_ro->B;
     const int lane = threadIdx.x;
+    if (blockDim.x != 64u) __builtin_trap();   // one wavefront per workgroup: the phases below rely on its in-order LDS traffic
     hml_emit_params<K> p;
     hml_emit_load<K>(p, mdl_ro, 0);
     const uint32_t Wt = hml_tre_warmup(mdl_ro);
@@ -273,7 +274,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(K <= 6 ? 4 :
                         cmap = hml_map_compose<K>(cmap, sm_c[lane * PITCH + r]);
                     }
                 }
-                // (the next batch's P3 writes sm_c only behind two more barriers)
+                // (no barrier here: the next batch's P1a writes sm_c - and plane 0 of sm_v - straight behind these reads, and the
+                // warm-up batches go from P2's barrier straight into P1a.  That is sound because the workgroup IS one
+                // wavefront - launch_bounds(64), asserted by the host's launch - whose LDS instructions execute in order.)
             }
         }
         if (active) {

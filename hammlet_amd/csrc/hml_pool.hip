@@ -88,23 +88,37 @@ int grid_for(uint64_t items, int per_block, int hi) {
     return (int)std::max<uint64_t>(1, std::min<uint64_t>(g, (uint64_t)hi));
 }
 
-// relabelled difference arrays + boundary row + tail of one chain -> payload (device, payload_count(c) int32)
+// device memory and events that are released on every way out of a function
+struct DevBuf {
+    void* p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    template <class T> T* as() const { return static_cast<T*>(p); }
+};
+struct EventPair {
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    ~EventPair() { if (e0) (void)hipEventDestroy(e0); if (e1) (void)hipEventDestroy(e1); }
+};
+
+// relabelled difference arrays + boundary row + tail of one chain -> payload (device, payload_count(c) int32).
+// A context whose marginals ARE a pooled payload (hml_pool_install) is refused: exporting them again would apply the
+// relabelling a second time and count every chain once more.
 int export_payload(hml_ctx* c, int32_t* payload, int32_t* perm_out) {
+    if (c->pooled) return set_err(HML_ERR_ARG, "the marginals of this context are pooled already: they cannot be pooled again");
     if (int r = hml_ctx_bind(c)) return r;
     if (int r = hml_ctx_ensure_marginal_buffers(c)) return r;
     std::vector<int32_t> perm(c->K);
     if (int r = hml_relabel_permutation(c, perm.data())) return r;
     if (perm_out) memcpy(perm_out, perm.data(), sizeof(int32_t) * c->K);
-    int32_t* d_perm = nullptr;
-    HIPCHK(hipMalloc(&d_perm, sizeof(int32_t) * c->K));
-    HIPCHK(hipMemcpyAsync(d_perm, perm.data(), sizeof(int32_t) * c->K, hipMemcpyHostToDevice, c->stream));
+    DevBuf d_perm;
+    HIPCHK(hipMalloc(&d_perm.p, sizeof(int32_t) * c->K));
+    HIPCHK(hipMemcpyAsync(d_perm.p, perm.data(), sizeof(int32_t) * c->K, hipMemcpyHostToDevice, c->stream));
     const uint64_t n = payload_count(c);
     HIPCHK(hipMemsetAsync(payload + (n - 1u - (uint64_t)c->K), 0, sizeof(int32_t) * (1u + (uint64_t)c->K), c->stream));
     hipLaunchKernelGGL(hml_k_pool_export, dim3(grid_for(n, 256, 1 << 16)), dim3(256), 0, c->stream, c->d_diff, c->d_boundary, c->d_mdl,
-                       d_perm, (uint32_t)c->T, c->K, payload);
+                       d_perm.as<int32_t>(), (uint32_t)c->T, c->K, payload);
     KLAUNCH_CHECK();
     HIPCHK(hipStreamSynchronize(c->stream));
-    HIPCHK(hipFree(d_perm));
+    c->pool_perm = perm;   // the label space the chain's marginals are in once a payload is installed
     return 0;
 }
 
@@ -118,6 +132,24 @@ int install_payload(hml_ctx* c, const int32_t* payload) {
                        (uint32_t)c->T, c->K, c->d_boundary, c->d_mdl);
     KLAUNCH_CHECK();
     HIPCHK(hipStreamSynchronize(c->stream));
+    c->pooled = true;
+    return 0;
+}
+
+// Before a collective over the payload every rank learns whether all ranks got this far and agree on the shape: a rank
+// that left early (a failed export, a chain of another K or T) would otherwise leave the others waiting in
+// ncclAllReduce.  ncclMax over {status, K, -K, T's halves and their negatives}.
+int handshake(ncclComm_t comm, hipStream_t stream, int32_t* d_hs, int local_rc, const hml_ctx* c) {
+    const int32_t tl = (int32_t)(c->T & 0x7fffffffu), th = (int32_t)(c->T >> 31);
+    const int32_t h[8] = {local_rc ? 1 : 0, c->K, -c->K, tl, -tl, th, -th, 0};
+    HIPCHK(hipMemcpyAsync(d_hs, h, sizeof h, hipMemcpyHostToDevice, stream));
+    NCCLCHK(rccl().AllReduce(d_hs, d_hs, 8, ncclInt32, ncclMax, comm, stream));
+    int32_t g[8];
+    HIPCHK(hipMemcpyAsync(g, d_hs, sizeof g, hipMemcpyDeviceToHost, stream));
+    HIPCHK(hipStreamSynchronize(stream));
+    if (local_rc) return local_rc;
+    if (g[0] != 0) return set_err(HML_ERR_ARG, "pooling abandoned: another rank failed before the collective");
+    if (g[1] != -g[2] || g[3] != -g[4] || g[5] != -g[6]) return set_err(HML_ERR_ARG, "pooling abandoned: the ranks' chains differ in the number of states or positions");
     return 0;
 }
 
@@ -128,6 +160,7 @@ struct hml_pool {
     int device = 0, rank = 0, n_ranks = 1;
     hipStream_t stream = nullptr;
     int32_t* d_payload = nullptr;
+    int32_t* d_handshake = nullptr;
     uint64_t capacity = 0;       // int32 elements
     double last_ms = 0;
     uint64_t last_bytes = 0;
@@ -171,6 +204,7 @@ void hml_pool_destroy(hml_pool* p) {
     if (p->stream) hipStreamSynchronize(p->stream);
     if (p->comm) rccl().CommDestroy(p->comm);
     if (p->d_payload) hipFree(p->d_payload);
+    if (p->d_handshake) hipFree(p->d_handshake);
     if (p->stream) hipStreamDestroy(p->stream);
     delete p;
 }
@@ -205,40 +239,57 @@ int hml_pool_marginals(hml_pool* p, hml_ctx* c, int32_t* perm_out) {
     if (!p || !c || !c->model_set) return set_err(HML_ERR_ARG, "model not set");
     if (c->device != p->device) return set_err(HML_ERR_ARG, "the chain lives on another device than the communicator's rank");
     HIPCHK(hipSetDevice(p->device));
+    if (!p->d_handshake) HIPCHK(hipMalloc(&p->d_handshake, 8 * sizeof(int32_t)));
     const uint64_t n = payload_count(c);
+    // from here on every rank reaches the handshake, whatever happens to it before
+    int rc = 0;
     if (p->capacity < n) {
-        if (p->d_payload) HIPCHK(hipFree(p->d_payload));
+        if (p->d_payload) (void)hipFree(p->d_payload);
         p->d_payload = nullptr; p->capacity = 0;
-        HIPCHK(hipMalloc(&p->d_payload, n * sizeof(int32_t)));
-        p->capacity = n;
+        if (hipMalloc(&p->d_payload, n * sizeof(int32_t)) != hipSuccess) { (void)hipGetLastError(); rc = set_err(HML_ERR_HIP, "out of device memory for the pooling payload"); }
+        else p->capacity = n;
     }
-    if (int r = export_payload(c, p->d_payload, perm_out)) return r;
-    hipEvent_t e0, e1;
-    HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
-    HIPCHK(hipEventRecord(e0, p->stream));
+    if (!rc) rc = export_payload(c, p->d_payload, perm_out);
+    if (int r = handshake(p->comm, p->stream, p->d_handshake, rc, c)) return r;
+    EventPair ev;
+    HIPCHK(hipEventCreate(&ev.e0)); HIPCHK(hipEventCreate(&ev.e1));
+    HIPCHK(hipEventRecord(ev.e0, p->stream));
     NCCLCHK(rccl().AllReduce(p->d_payload, p->d_payload, (size_t)n, ncclInt32, ncclSum, p->comm, p->stream));
-    HIPCHK(hipEventRecord(e1, p->stream));
+    HIPCHK(hipEventRecord(ev.e1, p->stream));
     HIPCHK(hipStreamSynchronize(p->stream));
     float ms = 0;
-    hipEventElapsedTime(&ms, e0, e1);
-    hipEventDestroy(e0); hipEventDestroy(e1);
+    (void)hipEventElapsedTime(&ms, ev.e0, ev.e1);
     p->last_ms = ms; p->last_bytes = n * sizeof(int32_t);
     return install_payload(c, p->d_payload);
+}
+
+int hml_pool_permutation(hml_ctx* c, int32_t* perm) {
+    if (!c || !c->model_set || !perm) return set_err(HML_ERR_ARG, "model not set");
+    for (int k = 0; k < c->K; ++k) perm[k] = (c->pooled && (int)c->pool_perm.size() == c->K) ? c->pool_perm[k] : k;
+    return 0;
 }
 
 // One process driving n chains (hammlet -chains N): contexts that share a device are summed on that device first, the
 // per-device sums go through one grouped ncclAllReduce over a communicator of the distinct devices (ncclCommInitAll;
 // a single device still forms a one-rank communicator), and every context receives the pooled marginals.
-int hml_allreduce_marginals(hml_ctx* const* ctxs, int n) {
+int hml_allreduce_marginals(hml_ctx* const* ctxs, int n) { return hml_allreduce_marginals_perm(ctxs, n, nullptr); }
+
+int hml_allreduce_marginals_perm(hml_ctx* const* ctxs, int n, int32_t* perms) {
     if (!ctxs || n < 1) return set_err(HML_ERR_ARG, "no contexts");
     for (int i = 0; i < n; ++i) {
         if (!ctxs[i] || !ctxs[i]->model_set) return set_err(HML_ERR_ARG, "model not set");
         if (ctxs[i]->K != ctxs[0]->K || ctxs[i]->T != ctxs[0]->T) return set_err(HML_ERR_ARG, "chains of different shape cannot be pooled");
     }
-    if (int r = need_rccl()) return r;
+    for (int i = 0; i < n; ++i)
+        if (ctxs[i]->pooled) return set_err(HML_ERR_ARG, "the marginals of a context are pooled already: they cannot be pooled again");
     const uint64_t cnt = payload_count(ctxs[0]);
+    const int K = ctxs[0]->K;
     std::map<int, std::vector<int>> by_dev;
     for (int i = 0; i < n; ++i) by_dev[ctxs[i]->device].push_back(i);
+    // chains that all share one device are summed there and that is the result: RCCL (570 MB to map, a communicator to
+    // build) is not touched
+    const bool one_device = by_dev.size() == 1;
+    if (!one_device) { if (int r = need_rccl()) return r; }
     std::vector<int> devs;
     std::vector<int32_t*> bufs;
     int rc = 0;
@@ -250,9 +301,10 @@ int hml_allreduce_marginals(hml_ctx* const* ctxs, int n) {
         devs.push_back(kv.first); bufs.push_back(acc);
         for (size_t j = 0; j < kv.second.size() && !rc; ++j) {
             hml_ctx* c = ctxs[kv.second[j]];
-            if (j == 0) { rc = export_payload(c, acc, nullptr); continue; }
+            int32_t* const perm_j = perms ? perms + (size_t)kv.second[j] * K : nullptr;
+            if (j == 0) { rc = export_payload(c, acc, perm_j); continue; }
             if (!tmp && hipMalloc(&tmp, cnt * sizeof(int32_t)) != hipSuccess) { rc = set_err(HML_ERR_HIP, "out of device memory for the pooling payload"); break; }
-            rc = export_payload(c, tmp, nullptr);
+            rc = export_payload(c, tmp, perm_j);
             if (!rc) {
                 hipLaunchKernelGGL(hml_k_pool_add, dim3(grid_for(cnt, 256, 1 << 16)), dim3(256), 0, c->stream, acc, tmp, cnt);
                 if (hipStreamSynchronize(c->stream) != hipSuccess) rc = set_err(HML_ERR_HIP, "pooling kernel failed");
@@ -262,6 +314,11 @@ int hml_allreduce_marginals(hml_ctx* const* ctxs, int n) {
         if (rc) { cleanup(); return rc; }
     }
     const int nd = (int)devs.size();
+    if (one_device) {
+        for (int i : by_dev[devs[0]]) { rc = install_payload(ctxs[i], bufs[0]); if (rc) break; }
+        cleanup();
+        return rc;
+    }
     std::vector<ncclComm_t> comms(nd);
     {
         ncclResult_t r = rccl().CommInitAll(comms.data(), nd, devs.data());

@@ -49,7 +49,10 @@ static const char* kHelp =
     "  -i, -iterations SCHEME         tokens: M n t | F n t | S | D | P (default M 500 0 S P F 200 0 F 300 3)\n"
     "  -m, -weight-multiplier F       multiply breakpoint weights (default 1)\n"
     "  -device N  -chain N            GPU and Philox sub-key of the chain (extensions)\n"
-    "  -chains N                      N independent chains, one per GPU, marginals pooled over RCCL (extension)\n"
+    "  -chains N                      N independent chains, one per GPU, marginals pooled over RCCL (extension).\n"
+    "                                 The pooled marginals / maxsegmentation files use common labels (states by\n"
+    "                                 ascending mean); PREFIX[chainK.]relabelSUFFIX lists each chain's own label of\n"
+    "                                 pooled state 0, 1, ... (its parameters / sequences files keep its own labels)\n"
     "  -v, -verbose   -g, -arguments   -h, -help\n";
 
 // one entry of the sampling scheme (-i)
@@ -395,9 +398,25 @@ int main(int argc, const char* argv[]) {
             // all chains have sampled (or one has failed): pool, then let them write their files
             vector<hml_ctx*> ctxs = rv.waitForAll();
             std::exception_ptr poolError;
-            if ((int)ctxs.size() == nrChains) {
+            // (nothing to pool when neither the marginals nor their arg-max segmentation were asked for)
+            const bool wantsPool = job.outputs.at("marginals") || job.outputs.at("maxsegmentation");
+            if ((int)ctxs.size() == nrChains && wantsPool) {
                 if (verbose) cout << "Pooling the marginals of " << nrChains << " chains" << endl << flush;
-                try { hml_check(hml_allreduce_marginals(ctxs.data(), nrChains)); } catch (...) { poolError = std::current_exception(); }
+                try {
+                    // The pooled files (PREFIXmarginalsSUFFIX, PREFIXmaxsegmentationSUFFIX) use COMMON labels - states by
+                    // ascending mean - while every chain's parameters / sequences / segments files keep the chain's own
+                    // labels: PREFIX[chainK.]relabelSUFFIX holds, tab-separated, the chain's label of pooled state 0, 1, ...
+                    vector<int32_t> perms((size_t)nrChains * job.nrStates);
+                    hml_check(hml_allreduce_marginals_perm(ctxs.data(), nrChains, perms.data()));
+                    for (int k = 0; k < nrChains; ++k) {
+                        const string fn = (k == 0 ? job.opref : job.opref + "chain" + std::to_string(k) + ".") + "relabel" + job.osuff;
+                        if (!job.overwrite) { std::ifstream probe(fn); if (probe.good()) throw std::runtime_error("File " + fn + " already exists!"); }
+                        std::ofstream out(fn);
+                        if (!out) throw std::runtime_error("Cannot open file " + fn + " for writing!");
+                        for (size_t j = 0; j < job.nrStates; ++j) out << (j ? "\t" : "") << perms[(size_t)k * job.nrStates + j];
+                        out << "\n";
+                    }
+                } catch (...) { poolError = std::current_exception(); }
             }
             rv.release(poolError == nullptr && (int)ctxs.size() == nrChains);
             for (auto& t : threads) t.join();

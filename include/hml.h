@@ -233,6 +233,14 @@ int hml_pool_info(hml_pool* pool, int* rank, int* n_ranks, double* last_allreduc
  * the per-device sums go through one grouped ncclAllReduce (ncclCommInitAll over the distinct devices), every context
  * receives the pooled marginals. */
 int hml_allreduce_marginals(hml_ctx* const* ctxs, int n);
+/* The same with the relabelling it applied: perms[i * K + j] = chain i's own label of pooled state j (may be null).  Chains
+ * that all share one device are summed on it without RCCL. */
+int hml_allreduce_marginals_perm(hml_ctx* const* ctxs, int n, int32_t* perms /* n * K */);
+/* LABEL SPACES.  Pooling puts the context's MARGINALS (hml_marginals_rle, hml_max_segmentation, hml_marginals_dense_device)
+ * into the common labels - states by ascending mean - while its parameters, state sequences and transition counts keep the
+ * chain's own labels: perm[j] = the chain's label of pooled state j (the identity before any pooling).  A pooled context
+ * refuses a second pooling (it would relabel and count twice) and refuses to record further sweeps into its marginals. */
+int hml_pool_permutation(hml_ctx* ctx, int32_t* perm /*K*/);
 
 /* ---- counters for measurement ---- */
 typedef struct {

@@ -3,7 +3,10 @@
 // the math/RNG/distribution building blocks.
 #include <chrono>
 #include <cmath>
+#include <algorithm>
+#include <cstdio>
 #include <cstring>
+#include <thread>
 #include <random>
 #include <sstream>
 #include <vector>
@@ -299,6 +302,37 @@ void orc_parse_tokens(const char* toks, uint64_t n, uint32_t stride, float* out,
         out[i] = v;
         strtof_out[i] = strtof(t, nullptr);
     }
+}
+
+// n floats as decimal text, one per line, "%.9g" (round-trips a float): what bench.py feeds the unmodified reference binary
+// with on the full trace (numpy.savetxt needs minutes for 10^8 values).  Formatting on `nthreads` threads, one sequential write.
+int orc_write_text(const float* x, uint64_t n, const char* path, int nthreads) {
+    if (nthreads < 1) nthreads = 1;
+    FILE* f = fopen(path, "wb");
+    if (!f) return 1;
+    const uint64_t piece = 1u << 22;
+    std::vector<std::vector<char>> bufs(nthreads);
+    int rc = 0;
+    for (uint64_t base = 0; base < n && !rc; base += piece * (uint64_t)nthreads) {
+        std::vector<std::thread> ths;
+        std::vector<size_t> used(nthreads, 0);
+        for (int t = 0; t < nthreads; ++t) {
+            const uint64_t a = base + piece * (uint64_t)t, b = std::min<uint64_t>(n, a + piece);
+            if (a >= n) break;
+            ths.emplace_back([&, t, a, b] {
+                std::vector<char>& buf = bufs[t];
+                buf.resize((size_t)(b - a) * 17);
+                size_t o = 0;
+                for (uint64_t i = a; i < b; ++i) o += (size_t)snprintf(buf.data() + o, 17, "%.9g\n", (double)x[i]);
+                used[t] = o;
+            });
+        }
+        for (auto& th : ths) th.join();
+        for (size_t t = 0; t < ths.size(); ++t)
+            if (fwrite(bufs[t].data(), 1, used[t], f) != used[t]) { rc = 2; break; }
+    }
+    if (fclose(f) != 0 && !rc) rc = 3;
+    return rc;
 }
 
 double orc_time_sweeps(void* h, char method, uint64_t iters) {

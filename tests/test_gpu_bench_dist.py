@@ -1,0 +1,40 @@
+"""bench.py's multi-rank branches rehearsed on ONE GPU: `python -m torch.distributed.run --nproc-per-node 1 bench.py --gpus 1`
+with HML_BENCH_FORCE_DIST=1 takes the world > 1 code at world size 1 - torch.distributed over the "nccl" backend (RCCL), the
+communicator id created on rank 0 and handed round by broadcast_object_list (hammlet_amd.chains.make_pool), the library's own
+collective hml_pool_marginals (dlopen of librccl next to torch's copy in one process), the `pooling` record of the JSON line.
+The scaling runs on 2 / 4 / 8 GPUs are the driver's; this is their dry run."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+@pytest.mark.gpu
+def test_bench_multi_rank_branches_on_one_gpu():
+    env = dict(os.environ, HML_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(REPO, "bench.py"), "--gpus", "1", "--steps", "20", "--warmup", "5",
+           "--workload", "c2_1e7_k5", "--no-stream-leg", "--no-two-chain-leg", "--no-uncompressed-leg", "--no-scheme-legs",
+           "--no-cpu-baseline"]
+    r = subprocess.run(cmd, cwd=REPO, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-1500:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 1 and line["value"] > 0
+    p = line["pooling"]
+    assert p["rccl_version"] > 0
+    assert p["all_reduce_bytes"] == 4 * ((5 + 1) * (10_000_000 + 1) + 1 + 5)      # int32 [K+1][T+1] + recorded sweeps + used states
+    assert p["counts_per_position"] == 2                                           # two recorded sweeps (F 10 5) of one chain
+    assert line["roofline"]["launches"] >= 32

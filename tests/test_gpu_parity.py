@@ -645,7 +645,7 @@ def test_fused_block_kernel_retires_itself_after_an_expired_wait(hml, monkeypatc
     assert g.profile_get("blocks_scatter")[1] >= 10
 
 
-@pytest.mark.parametrize("chunk,fused", [(32, 1), (96, 1), (128, 1), (256, 1), (32, 0)])
+@pytest.mark.parametrize("chunk,fused", [(32, 1), (96, 1), (128, 1), (256, 1), (512, 1), (32, 0), (96, 2)])
 def test_fused_trellis_repair_paths_on_twin_states(hml, monkeypatch, chunk, fused):
     """The fused trellis kernels of weakly compressed sweeps (hml_k_trellis.h; HML_TRELLIS_FUSED=0 runs the separate
     kernels for comparison) on the adversarial twin-state parameters: an uncompressed trace on which the filter hardly
@@ -654,7 +654,9 @@ def test_fused_trellis_repair_paths_on_twin_states(hml, monkeypatch, chunk, fuse
     every chunk length."""
     monkeypatch.setenv("HML_DENSE_MIN_BLOCKS", "1")
     monkeypatch.setenv("HML_TRELLIS_L", str(chunk))
-    monkeypatch.setenv("HML_TRELLIS_FUSED", str(fused))
+    monkeypatch.setenv("HML_TRELLIS_FUSED", "1" if fused else "0")
+    if fused == 2:
+        monkeypatch.setenv("HML_TRELLIS_ROWS", "0")     # round 2's first pass (hml_k_trellis_tile), kept for comparison
     T, K = 300_000, 3
     x = ol.trace(T, 3, 1)
     xx, o, g = make_pair(hml, T, K, 0, 1, x=x, weight_mult=1e9)
@@ -695,6 +697,7 @@ def test_trellis_chunk_length_is_measured_and_changes_nothing(hml, monkeypatch, 
     checker's state bit for bit - the chunk length is a launch geometry, not part of the chain's definition."""
     monkeypatch.setenv("HML_DENSE_MIN_BLOCKS", "1")
     monkeypatch.setenv("HML_TRELLIS_TUNE_DEBUG", "1")
+    monkeypatch.setenv("HML_TRELLIS_SLOTS", "16")   # a machine of 16 wavefront slots: chunk lengths 224, 128, 96, ... fill 1, 2, 3 ... rounds
     T, K = 200_000, 3
     xx, o, g = make_pair(hml, T, K, 0, 7, weight_mult=1e9)
     setup_model(o, g, K)
@@ -704,8 +707,8 @@ def test_trellis_chunk_length_is_measured_and_changes_nothing(hml, monkeypatch, 
     g.iterate("F", 47, 0)
     g.sync()
     compare_state(o, g)
-    o.iterate("F", 8, 0)          # sweeps 48 .. 51 measure the candidates 32 and 64 twice each
-    g.iterate("F", 8, 0)
+    o.iterate("F", 16, 0)         # from sweep 48 on every candidate runs two sweeps between a pair of events
+    g.iterate("F", 16, 0)
     g.sync()
     compare_state(o, g)
     assert np.array_equal(o.states(), g.states())
@@ -724,12 +727,13 @@ def test_trellis_chunk_length_measurement_under_graph_replay(hml, monkeypatch):
     graph, and the graph is captured again with the length that won - the chain stays the checker's bit for bit."""
     monkeypatch.setenv("HML_DENSE_MIN_BLOCKS", "1")
     monkeypatch.setenv("HML_USE_GRAPH", "1")
+    monkeypatch.setenv("HML_TRELLIS_SLOTS", "16")
     T, K = 150_000, 4
     xx, o, g = make_pair(hml, T, K, 2, 11, weight_mult=1e9)
     setup_model(o, g, K)
     o.token("F")
     g.sample_prior()
-    for n in (40, 12, 20):          # 40: replayed graph; 12: crosses sweeps 48..51 (measurement); 20: graph with the new length
+    for n in (40, 20, 20):          # 40: replayed graph; 20: crosses the measuring sweeps (48 ...); 20: graph with the new length
         o.iterate("F", n, 0)
         g.iterate("F", n, 0)
         g.sync()
