@@ -459,10 +459,30 @@ class Chain:
         return ms.value, n.value
 
 
+def _prefer_torch_rccl():
+    """A Python process that also runs PyTorch must not hold two RCCL libraries (torch bundles one; the second copy ends the
+    process in `double free or corruption` at exit): point the library's dlopen at torch's copy before its first pooling
+    call, without importing torch.  No torch, or HML_RCCL_LIBRARY set by the user: nothing happens."""
+    if os.environ.get("HML_RCCL_LIBRARY"):
+        return
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        cand = os.path.join(os.path.dirname(spec.origin), "lib", "librccl.so") if spec and spec.origin else None
+        if cand and os.path.exists(cand):
+            os.environ["HML_RCCL_LIBRARY"] = cand
+            # ... and let torch bring up its runtime FIRST: an RCCL communicator created before `import torch` has been seen
+            # to end the process in the same way when it exits (the order of the two libraries' exit handlers)
+            import torch  # noqa: F401
+    except Exception:
+        pass
+
+
 class Pool:
     """RCCL communicator of the chain-parallel pooling (hml_pool_* of include/hml.h): one rank per process and GPU."""
 
     def __init__(self, device, rank, n_ranks, unique_id):
+        _prefer_torch_rccl()
         self.lib = load_library()
         h = _P()
         buf = C.create_string_buffer(bytes(unique_id), 128)
@@ -472,6 +492,7 @@ class Pool:
     @staticmethod
     def unique_id():
         """ncclGetUniqueId: made by rank 0, handed to every rank by the launcher"""
+        _prefer_torch_rccl()
         lib = load_library()
         buf = C.create_string_buffer(128)
         _check(lib.hml_pool_unique_id(C.cast(buf, _P)))
@@ -503,6 +524,7 @@ class Pool:
 def allreduce_marginals(chains, with_perms=False):
     """hml_allreduce_marginals(_perm): one process driving several chains (possibly on several GPUs).  with_perms: returns
     perms[i][j] = chain i's own label of pooled state j."""
+    _prefer_torch_rccl()
     lib = load_library()
     arr = (_P * len(chains))(*[c.h for c in chains])
     if not with_perms:

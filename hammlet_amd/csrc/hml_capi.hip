@@ -21,6 +21,7 @@
 #include "hml_k_segment.h"
 #include "hml_k_trellis.h"
 #include "hml_k_trellis_rows.h"
+#include "hml_k_compat.h"
 #include "hml_k_params.h"
 #include "hml_state.h"
 #include "hml_synth_host.hpp"
@@ -199,6 +200,10 @@ __global__ void hml_k_debug_eval(int fn, const float* __restrict__ a, const floa
             case 7: r = (float)hml_log((double)x); break;
             case 8: r = (float)hml_exp_nonpos((double)x); break;
             case 9: r = (float)((double)x / (double)y); break;
+            case 40: r = hml_glibc_expf(x); break;            // hml_math_glibc.h: the reference-compatible mode's arithmetic
+            case 41: r = hml_glibc_logf(x); break;
+            case 42: r = hml_glibc_powf_unit(x, y); break;
+            case 43: { const double Zd = (double)y; r = hml_tr2_quotient(x, Zd, hml_tr2_reciprocal(Zd)); } break;   // x / y through the double reciprocal (hml_k_trellis_rows.h)
             case 10: r = (float)(1.0 / (double)x); break;
             case 12: case 13: case 14: case 15: case 16: case 17: case 18: case 19: case 20: case 21: case 22: case 23: {
                 hml_dev_src src; src.s = hml_stream_open(hml_make_key(seed, 0), HML_KIND_THETA, seed, (uint32_t)i);
@@ -295,6 +300,7 @@ int hml_create(hml_ctx** out, int device, uint64_t seed, uint32_t chain_id, void
     if (const char* e = getenv("HML_TRELLIS_L")) { const int l = atoi(e); c->tre_L = (l <= 0) ? 0u : (l >= HML_TRE_MAX_L) ? (uint32_t)HML_TRE_MAX_L : (l < 32) ? 32u : (uint32_t)l / 32u * 32u; }   // a multiple of 32
     if (const char* e = getenv("HML_TRELLIS_ROWS")) c->tre_rows = atoi(e) != 0;   // 0: round 2's first pass (hml_k_trellis_tile) for comparison
     if (const char* e = getenv("HML_LATE_RESCALE")) c->late_rescale = atoi(e) != 0;
+    if (const char* e = getenv("HML_COMPAT")) c->compat = atoi(e) != 0;   // option "compat" for unmodified callers (`hammlet -compat`)
     if (const char* e = getenv("HML_TRELLIS_TUNE")) c->tre_autotune = atoi(e) != 0;
     if (const char* e = getenv("HML_FUSED_SPIN_LIMIT")) c->fused_spin_limit = (uint32_t)strtoul(e, nullptr, 10);
     if (device < 64) g_live_ctx[device].fetch_add(1);
@@ -308,7 +314,7 @@ static void free_all(hml_ctx* c) {
     void* ptrs[] = {c->d_group_word, c->d_summary, c->d_w, c->d_coeff, c->d_ia, c->d_stage, c->d_span_count, c->d_starts, c->d_bstat,
                     c->d_em, c->d_gsc, c->d_rows, c->d_eprobe, c->d_aprobe, c->d_entry, c->d_exitA, c->d_redo, c->d_touched, c->d_fb, c->d_coarse1,
                     c->d_smap, c->d_cmap, c->d_scmap, c->d_super, c->d_bentry2, c->d_bentry, c->d_q, c->d_partial, c->d_diff, c->d_boundary, c->d_mdl,
-                    c->d_redo2, c->d_tre_bitmap};
+                    c->d_redo2, c->d_tre_bitmap, c->d_mt, c->d_crows};
     for (void* p : ptrs) if (p) hipFree(p);
     if (c->h_B) hipHostFree(c->h_B);
     c->h_B = nullptr;
@@ -741,6 +747,20 @@ int hml_set_model(hml_ctx* c, int K, const float nig4[4], float a_off, float a_d
     c->dynamic = true;
     c->hint_stale = true;
     // Theta's constructor samples once from the prior (src/Theta.hpp:126-127)
+    if (c->compat) {
+        // reference-compatible mode (hml_k_compat.h): the reference's engine, seeded like `rng_t RNG(seed)` (main.cpp:107-108),
+        // and a plain (B + 1) x K trellis
+        if (c->D != 1) return set_err(HML_ERR_ARG, "the reference-compatible mode (option compat) is for univariate models");
+        hml_mt_state h;
+        hml_mt_seed(&h, c->seed);
+        HIPCHK(hipMalloc(&c->d_mt, sizeof(hml_mt_state)));
+        HIPCHK(hipMemcpyAsync(c->d_mt, &h, sizeof h, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(hipMalloc(&c->d_crows, (T + 1) * K * sizeof(float)));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        HML_DISPATCH_K(K, hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_compat_draw<KK>), dim3(1), dim3(64), 0, c->stream, c->d_mdl, (hml_mt_state*)c->d_mt, 2));
+        KLAUNCH_CHECK();
+        return 0;
+    }
     HML_DISPATCH_K(K, hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_params<KK>), dim3(1), dim3(1024), 0, c->stream, c->d_mdl, c->d_partial, 2));
     KLAUNCH_CHECK();
     return 0;
@@ -749,6 +769,9 @@ int hml_set_model(hml_ctx* c, int K, const float nig4[4], float a_off, float a_d
 int hml_sample_prior(hml_ctx* c) {
     if (!c || !c->model_set) return set_err(HML_ERR_ARG, "model not set");
     if (int r = ctx_bind(c)) return r;
+    if (c->compat) {
+        HML_DISPATCH_K(c->K, hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_compat_draw<KK>), dim3(1), dim3(64), 0, c->stream, c->d_mdl, (hml_mt_state*)c->d_mt, 1));
+    } else
     HML_DISPATCH_K(c->K, hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_params<KK>), dim3(1), dim3(1024), 0, c->stream, c->d_mdl, c->d_partial, 1));
     KLAUNCH_CHECK();
     if (c->dynamic) c->blocks_valid = false;
@@ -924,8 +947,31 @@ static void tre_tune_report(hml_ctx* c, uint32_t hint, float ms) {
     }
 }
 
+// A sweep of the reference-compatible mode (hml_k_compat.h): block starts and block statistics by the default path's
+// kernels, everything order-dependent by one lane in the reference's order, the marginals by hml_k_record.
+template <int KK>
+static int sweep_compat(hml_ctx* c, char method, bool record) {
+    hipStream_t s = c->stream;
+    if (c->dynamic || !c->blocks_valid) {
+        if (int r = launch_compact(c, false, 0.0f)) return r;   // starts, block count, block statistics at the model's threshold
+        if (!c->dynamic) c->blocks_valid = true;
+    }
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_compat_sweep<KK>), dim3(1), dim3(64), 0, s, c->d_mdl, (hml_mt_state*)c->d_mt, c->d_starts, c->d_bstat,
+                       c->d_crows, c->d_q, method == HML_METHOD_MIXTURE ? 1 : 0, c->probes ? c->d_eprobe : nullptr, c->probes ? c->d_aprobe : nullptr);
+    if (record && c->rec_marginals) {
+        if (c->pooled) return set_err(HML_ERR_ARG, "the marginals of this context are pooled (common labels, several chains): further sweeps cannot be recorded into them");
+        if (int r = ensure_marginal_buffers(c)) return r;
+        refresh_hint(c);
+        const uint32_t hint = c->B_hint ? c->B_hint : (uint32_t)std::min<uint64_t>(c->T, 1u << 20);
+        hipLaunchKernelGGL(hml_k_record, dim3(grid_for(hint, 256, 64, 16384)), dim3(256), 0, s, c->d_q, c->d_starts, c->d_mdl, c->d_diff, c->d_boundary);
+    }
+    KLAUNCH_CHECK();
+    return 0;
+}
+
 template <int KK>
 static int sweep_k(hml_ctx* c, char method, bool record) {
+    if (c->compat) return sweep_compat<KK>(c, method, record);
     hipStream_t s = c->stream;
     const bool mix = (method == HML_METHOD_MIXTURE);
     const uint32_t T = (uint32_t)c->T;
@@ -1181,11 +1227,13 @@ int hml_iterate(hml_ctx* c, char method, uint64_t iterations, uint64_t thinning)
     if (method != HML_METHOD_FB && method != HML_METHOD_MIXTURE)
         return set_err(HML_ERR_ARG, std::string("Unknown sampling type ") + method + "!");
     if (int r = ctx_bind(c)) return r;
+    if (thinning > 0 && thinning <= iterations && c->rec_marginals && c->pooled)   // (before anything is enqueued: a sweep is not abandoned half-way)
+        return set_err(HML_ERR_ARG, "the marginals of this context are pooled (common labels, several chains): further sweeps cannot be recorded into them");
     for (uint64_t i = 0; i < iterations; ++i) {
         const bool record = thinning > 0 && ((i + 1) % thinning == 0);
         refresh_hint(c);
         const bool tre_path = c->tre_fused && c->D == 1 && method == HML_METHOD_FB && c->B_hint >= c->dense_min_blocks;
-        if (c->use_graph && !record && !c->profiling && !c->probes && (c->dynamic || c->blocks_valid) &&
+        if (c->use_graph && !c->compat && !record && !c->profiling && !c->probes && (c->dynamic || c->blocks_valid) &&
             !(tre_path && tre_wants_measurement(c, c->B_hint))) {
             // replay a captured sweep; capture again when the launch geometry (grid hint / mode / chunk length) changed
             const uint32_t hint = c->B_hint;
@@ -1244,6 +1292,11 @@ int hml_set_option(hml_ctx* c, const char* name, int value) {
         c->fused_blocks = value != 0;
         c->fused_keep = value == 2;
         if (c->graph_exec) { hipGraphExecDestroy(c->graph_exec); c->graph_exec = nullptr; }
+        return 0;
+    }
+    if (std::string(name) == "compat") {   // the reference-compatible mode (hml_k_compat.h): before hml_set_model
+        if (c->model_set) return set_err(HML_ERR_ARG, "compat must be set before the model");
+        c->compat = value != 0;
         return 0;
     }
     if (std::string(name) == "trellis_L") {   // chunk length of the fused trellis path: 0 = measured, else a multiple of 32 up to HML_TRE_MAX_L

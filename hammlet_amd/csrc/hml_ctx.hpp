@@ -114,6 +114,9 @@ struct hml_ctx {
     bool rec_marginals = true;
     hml_record_cb cb = nullptr;
     void* cb_user = nullptr;
+    bool compat = false;           // option "compat": sweeps exactly as the reference computes them (hml_k_compat.h)
+    void* d_mt = nullptr;          // its engine (hml_mt_state)
+    float* d_crows = nullptr;      // its trellis, (T + 1) x K
     bool pooled = false;           // the marginals are a pooled payload (hml_pool_install): common labels, counts of several chains
     std::vector<int32_t> pool_perm;   // perm[pooled label] = this chain's label, from the export that preceded the pooling
     int profiling = 0;             // 0 off, 1 dominant kernel only (blocks_compact, every 32nd launch), 2 every kernel family

@@ -42,12 +42,19 @@ RcclApi& rccl() {
     static RcclApi api;
     static std::once_flag once;
     std::call_once(once, [] {
+        // An RCCL that the process has loaded already wins (a PyTorch process: torch bundles its own copy - two copies in
+        // one process end in "double free or corruption" when the process exits, whichever is used), then
+        // HML_RCCL_LIBRARY, then the system's.
         const char* names[] = {getenv("HML_RCCL_LIBRARY"), "librccl.so.1", "librccl.so"};
+        for (const char* n : {"librccl.so.1", "librccl.so"}) {
+            api.handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL | RTLD_NOLOAD);
+            if (api.handle) break;
+        }
         for (const char* n : names) {
+            if (api.handle) break;
             if (!n || !*n) continue;
             api.handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
-            if (api.handle) break;
-            api.error = dlerror();
+            if (!api.handle) api.error = dlerror();
         }
         if (!api.handle) return;
         bool ok = true;

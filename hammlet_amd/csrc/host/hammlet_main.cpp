@@ -9,6 +9,7 @@
 // with one all-reduce over RCCL before PREFIXmarginalsSUFFIX is written (hml_allreduce_marginals); the per-sweep side
 // files of chain k >= 1 are PREFIXchainK.{sequences,...}SUFFIX.
 #include <condition_variable>
+#include <cstdlib>
 #include <ctime>
 #include <exception>
 #include <fstream>
@@ -49,6 +50,9 @@ static const char* kHelp =
     "  -i, -iterations SCHEME         tokens: M n t | F n t | S | D | P (default M 500 0 S P F 200 0 F 300 3)\n"
     "  -m, -weight-multiplier F       multiply breakpoint weights (default 1)\n"
     "  -device N  -chain N            GPU and Philox sub-key of the chain (extensions)\n"
+    "  -compat                        reference-compatible mode: the reference's mt19937 stream, libm arithmetic and\n"
+    "                                 summation orders on the GPU - the same files as the reference for the same -R\n"
+    "                                 (univariate models; one lane walks the blocks: for traces up to ~10^6 positions)\n"
     "  -chains N                      N independent chains, one per GPU, marginals pooled over RCCL (extension).\n"
     "                                 The pooled marginals / maxsegmentation files use common labels (states by\n"
     "                                 ascending mean); PREFIX[chainK.]relabelSUFFIX lists each chain's own label of\n"
@@ -224,6 +228,7 @@ int main(int argc, const char* argv[]) {
         args.registerFlags({"-device"}, "0");
         args.registerFlags({"-chain"}, "0");
         args.registerFlags({"-chains"}, "1");
+        args.registerFlags({"-compat"});
         args.parseArgs();
 
         if (args.isSet("-g")) args.print();
@@ -247,6 +252,9 @@ int main(int argc, const char* argv[]) {
         }
 
         const size_t rng_seed = args.parse<size_t>("-R", 0);
+        // -compat: the reference-compatible mode of the library (include/hml.h, option "compat"): the reference's own
+        // std::mt19937 stream, libm arithmetic and summation orders, so that -R SEED writes the reference's files
+        if (args.isSet("-compat")) setenv("HML_COMPAT", "1", 1);
         const int device = args.parse<int>("-device");
         const uint32_t chain = args.parse<uint32_t>("-chain");
         const int nrChains = args.parse<int>("-chains");

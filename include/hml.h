@@ -153,8 +153,16 @@ int hml_set_option(hml_ctx* ctx, const char* name, int value);
  * "trellis_L" (any time): chunk length of the fused trellis kernels that weakly compressed univariate FB sweeps take
  * (millions of blocks; hml_k_trellis.h).  0 (default): chosen from the number of blocks and then, after 48 such sweeps,
  * by measurement - every candidate length runs two sweeps between a pair of events and the fastest stays; a multiple of
- * 32 up to 256: that length.  A launch geometry only: rows, maps and draws are addressed by block, so the chain's
- * results are the same for every length.  Environment: HML_TRELLIS_L, HML_TRELLIS_TUNE=0 (no measurement). */
+ * 32 up to 1024: that length.  A launch geometry only: rows, maps and draws are addressed by block, so the chain's
+ * results are the same for every length.  Environment: HML_TRELLIS_L, HML_TRELLIS_TUNE=0 (no measurement).
+ * "compat" (before hml_set_model), 0 (default) / 1: the REFERENCE-COMPATIBLE mode.  The default path addresses every
+ * random decision by a Philox counter, uses its own logf / powf, sums block statistics over a fixed tree and counts in
+ * exact integers: same posterior, but a chain of its own for every seed.  With compat = 1 a
+ * sweep is computed exactly as the reference's single thread computes it - one std::mt19937 seeded like
+ * `rng_t RNG(seed)` (src/main.cpp:107-108) and consumed in its order, glibc's expf / logf / powf bit for bit
+ * (hml_math_glibc.h), float Kahan sums in block order, `size_t += float` counts - so that a run with the reference's
+ * seed leaves the reference's states, parameters and marginals.  Univariate models; the order-dependent part of a sweep
+ * runs on one lane (meant for traces up to ~10^6 positions - the default path is the fast one).  Environment: HML_COMPAT. */
 
 /* wait for all enqueued work; surfaces model errors raised on the device */
 int hml_sync(hml_ctx* ctx);

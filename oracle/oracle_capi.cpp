@@ -14,6 +14,7 @@
 #include "../hammlet_amd/csrc/hml_synth_host.hpp"
 #include "../hammlet_amd/csrc/hml_text.h"
 #include "hml_oracle.hpp"
+#include "../hammlet_amd/csrc/hml_math_glibc.h"
 
 using namespace hml_oracle;
 
@@ -333,6 +334,37 @@ int orc_write_text(const float* x, uint64_t n, const char* path, int nthreads) {
     }
     if (fclose(f) != 0 && !rc) rc = 3;
     return rc;
+}
+
+// hml_math_glibc.h (the reference-compatible mode's expf / logf / powf) against this host's libm: mismatches among the
+// float bit patterns [lo, hi) (fn 0: expf, 1: logf) or among n pseudo-random pairs x in [0, 1], y > 0 (fn 2: powf; `lo` seeds).
+// -1: this CPU has no fused multiply-add (the functions are built for it; glibc itself would then run its other variant).
+static __attribute__((target("fma"))) int64_t glibc_mismatches_fma(int fn, uint64_t lo, uint64_t hi, uint32_t* first_bad) {
+    int64_t bad = 0;
+    if (fn == 0 || fn == 1) {
+        for (uint64_t i = lo; i < hi; ++i) {
+            const float x = hml_u2f((uint32_t)i);
+            const float a = fn == 0 ? hml_glibc_expf(x) : hml_glibc_logf(x);
+            const float b = fn == 0 ? std::exp(x) : std::log(x);
+            if (hml_f2u(a) != hml_f2u(b) && !(a != a && b != b)) { if (!bad && first_bad) *first_bad = (uint32_t)i; ++bad; }
+        }
+    } else {
+        uint64_t st = lo * 0x9e3779b97f4a7c15ull + 12345u;
+        auto next = [&]() { st ^= st << 13; st ^= st >> 7; st ^= st << 17; return st; };
+        for (uint64_t i = 0; i < hi; ++i) {
+            const uint64_t r = next();
+            // x: a canonical uniform (24 bits) or an arbitrary pattern in [0, 1]; y: 1 / alpha for alpha in (0, 1), or arbitrary positive
+            float x = (i & 1) ? (float)(r >> 40) * 5.9604645e-08f : hml_u2f((uint32_t)(r % 0x3f800001u));
+            float y = (i & 2) ? 1.0f / (0.001f + 0.999f * (float)((r >> 8) & 0xffffffu) * 5.9604645e-08f) : hml_u2f(0x00800000u + (uint32_t)((r >> 20) % 0x7f000000u));
+            const float a = hml_glibc_powf_unit(x, y), b = std::pow(x, y);
+            if (hml_f2u(a) != hml_f2u(b) && !(a != a && b != b)) { if (!bad && first_bad) { first_bad[0] = hml_f2u(x); first_bad[1] = hml_f2u(y); } ++bad; }
+        }
+    }
+    return bad;
+}
+int64_t orc_glibc_mismatches(int fn, uint64_t lo, uint64_t hi, uint32_t* first_bad) {
+    if (!__builtin_cpu_supports("fma")) return -1;
+    return glibc_mismatches_fma(fn, lo, hi, first_bad);
 }
 
 double orc_time_sweeps(void* h, char method, uint64_t iters) {

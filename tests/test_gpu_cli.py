@@ -110,6 +110,9 @@ def test_cli_chains_pools_marginals_over_rccl(tmp_path):
         rows = [list(map(int, l.split("\t"))) for l in open(pre + "marginals.csv").read().strip().split("\n")]
         last = [float(v) for v in open(pre + "parameters.csv").read().strip().split("\n")[-1].split("\t")]
         perm = chains.relabel_permutation(np.array(last[0::2], np.float32))
+        # the pooled files use common labels; PREFIX[chainK.]relabelSUFFIX holds the chain's own label of pooled state 0, 1, ...
+        rel = "pool-relabel.csv" if k == 0 else "pool-chain%d.relabel.csv" % k
+        assert open(str(tmp_path / rel)).read() == "\t".join(str(int(v)) for v in perm) + "\n"
         seg = np.array([r_[0] for r_ in rows])
         cnt = np.array([r_[1:] + [0] * (K + 1 - len(r_)) for r_ in rows])
         starts = np.concatenate([[0], np.cumsum(seg)[:-1]])
@@ -123,3 +126,7 @@ def test_cli_chains_pools_marginals_over_rccl(tmp_path):
     assert got == want
     assert all(sum(map(int, l.split("\t")[1:])) == 30 for l in got.strip().split("\n"))
     assert open(str(tmp_path / "pool-maxsegmentation.csv")).read() == ol.max_segmentation_text(got)
+    # nothing to pool when neither marginals nor their segmentation are asked for: no relabel files, no RCCL
+    r = subprocess.run([CLI] + common + ["-chains", "2", "-o", str(tmp_path / "np-"), ".csv", "-O", "parameters"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert not (tmp_path / "np-relabel.csv").exists() and (tmp_path / "np-chain1.parameters.csv").exists()

@@ -89,6 +89,39 @@ def test_allreduce_marginals_of_three_chains_on_one_device(hml):
         g.close()
 
 
+def test_pooled_contexts_keep_their_permutation_and_refuse_a_second_pooling(hml):
+    """hml_allreduce_marginals_perm hands out every chain's relabelling (chain i's own label of pooled state
+    j), hml_pool_permutation keeps it with the context, and a context whose marginals are a pooled payload refuses to be
+    exported or pooled again (the relabelling would be applied twice and the counts multiplied) and to record further
+    sweeps into them (own labels into common labels)."""
+    x = ol.trace(T, K, 3)
+    cs = [gpu_chain(hml, x, c) for c in (0, 1)]
+    assert all(np.array_equal(g.pool_permutation(), np.arange(K)) for g in cs)          # identity before any pooling
+    perms = hml.allreduce_marginals(cs, with_perms=True)
+    _, _, perms_e = expected_pooled(x, [0, 1])
+    for i, g in enumerate(cs):
+        assert np.array_equal(perms[i], perms_e[i])
+        assert np.array_equal(g.pool_permutation(), perms_e[i])
+    seg0, cnt0 = cs[0].marginals_rle()
+    with pytest.raises(hml.HmlError, match="pooled already"):
+        hml.allreduce_marginals(cs)
+    with pytest.raises(hml.HmlError, match="pooled already"):
+        pool = hml.Pool(0, 0, 1, hml.Pool.unique_id())
+        try:
+            pool.marginals(cs[0])
+        finally:
+            pool.close()
+    with pytest.raises(hml.HmlError, match="cannot be recorded"):
+        cs[0].iterate("F", 3, 1)
+    cs[0].set_recording(marginals=False)
+    cs[0].iterate("F", 3, 1)                     # sampling goes on; the pooled marginals stay as they are
+    cs[0].sync()
+    seg1, cnt1 = cs[0].marginals_rle()
+    assert np.array_equal(seg0, seg1) and np.array_equal(cnt0, cnt1)
+    for g in cs:
+        g.close()
+
+
 def test_export_external_sum_install_equals_the_library_path(hml):
     """hml_pool_export / hml_pool_install with the sum done by the caller (any transport may stand in between)"""
     import torch
