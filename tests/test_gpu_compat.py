@@ -132,3 +132,36 @@ def test_cli_compat_writes_the_reference_binarys_files(case):
             got = open(os.path.join(tmp, "g-%s.csv" % o)).read()
             want = open(os.path.join(GOLD, case, o + ".csv")).read()
             assert got == want, (case, o)
+
+
+def test_compat_counts_above_2_24_round_like_the_reference(hml):
+    """where the reference's `size_t += float` counts (ForwardBackward.hpp:183-187) exceed 2^24 they
+    ROUND - the default path counts exactly (D4), so only the reference-compatible mode can be compared with the reference
+    there.  4 10^7 positions, two states: occupancies of 2 10^7 each; the compat chain's counts, Kahan sums, parameters and
+    states equal the checker's reference mode bit for bit, and the counts do differ from the exact ones."""
+    T, K, seed = 40_000_000, 2, 4
+    x = ol.synth_gauss(T, K, ol.LEVELS[K], ol.SIGMA[K], ol.DWELL[K], seed, nthreads=16)
+    o = ol.OracleChain(K=K, seed=seed, rng=ol.RNG_MT, math=ol.MATH_LIBM, reduce=ol.REDUCE_REF)
+    o.load(x)
+    o.autoprior()
+    o.init_model()
+    o.token("F")
+    g = hml.Chain(device=0, seed=seed)
+    g.set_option("compat", 1)
+    g.load(x)
+    g.set_model(K, g.autoprior(0.2, 0.9))
+    g.sample_prior()
+    o.iterate("F", 4, 0)
+    g.iterate("F", 4, 0)
+    g.sync()
+    assert np.array_equal(o.blocks(), g.blocks())
+    assert np.array_equal(o.states(), g.states())
+    assert np.array_equal(bits(o.theta()), bits(g.theta()))
+    to, oo, so, qo, _ = o.counts()
+    tg, og, sg, qg, _ = g.counts()
+    assert np.array_equal(to, tg) and np.array_equal(oo, og)
+    assert np.array_equal(bits(so), bits(sg)) and np.array_equal(bits(qo), bits(qg))
+    st, bl = g.states(), g.blocks()
+    exact = np.bincount(st, weights=np.diff(bl).astype(np.float64), minlength=K).astype(np.uint64)
+    assert exact.max() > (1 << 24) and not np.array_equal(exact, og)        # the rounding is really there
+    assert int(exact.sum()) == T
