@@ -307,7 +307,7 @@ def main():
             "config": {"workload": args.workload, "positions": T, "states": K, "blocks_per_sweep": B_avg,
                        "compression": T / max(B_avg, 1.0), "block_structure": "dynamic", "chains": world,
                        "parallelism": "chain-parallel x%d" % world,
-                       "cpu_baseline_sample": "port: the same 10^8 trace; reference binary: its first 10^7 positions"},
+                       "cpu_baseline_sample": "port and reference binary: the same 10^8-position trace, a bounded number of sweeps"},
             "roofline": {"bound": "hbm", "kernel": DENSE_KERNEL + " (emission terms + forward filter + backward candidate maps)" if dense_workload
                          else "hml_k_blocks_fused (block scan + block statistics + emission terms)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": frac,
@@ -528,6 +528,32 @@ def main():
         v3, ms3 = several(3)
         out["three_chains_one_gpu"] = {"value": v3, "unit": "block-updates/s", "chains": 3, "ms_per_sweep_round": ms3,
                                        "note": "profiles/round2_chains_per_gpu.txt: the aggregate peaks at three chains per GPU"}
+        # eight chains in ONE set of launches by one host thread (hml_iterate_many: the chain is the grid's second dimension)
+        group = []
+        for r in range(8):
+            ch = hammlet_amd.Chain(device=local_rank, seed=args.seed, chain_id=r)
+            ch.load(x)
+            ch.set_model(K, ch.autoprior(0.2, 0.9))
+            ch.sample_prior()
+            ch.set_recording(marginals=False)
+            group.append(ch)
+        hammlet_amd.iterate_many(group, "F", args.warmup, 0)
+        for ch in group:
+            ch.sync()
+        b0 = [ch.stats()["block_updates"] for ch in group]
+        barrier()
+        t0 = time.perf_counter()
+        hammlet_amd.iterate_many(group, "F", args.steps, 0)
+        for ch in group:
+            ch.sync()
+        barrier()
+        t1 = time.perf_counter()
+        b8 = sum(ch.stats()["block_updates"] - b for ch, b in zip(group, b0))
+        for ch in group:
+            ch.close()
+        out["eight_chains_one_gpu_batched"] = {"value": b8 / (t1 - t0), "unit": "block-updates/s", "chains": 8, "ms_per_sweep_round": 1e3 * (t1 - t0) / args.steps,
+                                               "note": "hml_iterate_many: one launch per kernel for all eight chains, one host thread.  The aggregate is bounded by the "
+                                                       "GPU, not by the host's launch rate: eight chains take 4-5 times one chain's kernel times (profiles/round3_chains_batched.txt)"}
 
     # fourth leg: SURVEY 8d's stress case C3u - the same trace with the breakpoint weights multiplied by 1e9, so that
     # every position is its own block (B = T): the regime in which the trellis itself, not the block scan, is the load

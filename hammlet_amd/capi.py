@@ -60,6 +60,7 @@ SIGNATURES = {
     "hml_set_dynamic": (C.c_int, [_P, C.c_int]),
     "hml_create_blocks": (C.c_int, [_P, C.c_float]),
     "hml_iterate": (C.c_int, [_P, C.c_char, C.c_uint64, C.c_uint64]),
+    "hml_iterate_many": (C.c_int, [_P, C.c_int, C.c_char, C.c_uint64, C.c_uint64]),
     "hml_set_recording": (C.c_int, [_P, C.c_int, RECORD_CB, _P]),
     "hml_set_option": (C.c_int, [_P, C.c_char_p, C.c_int]),
     "hml_sync": (C.c_int, [_P]),
@@ -533,6 +534,13 @@ def allreduce_marginals(chains, with_perms=False):
     perms = np.zeros((len(chains), chains[0].K), np.int32)
     _check(lib.hml_allreduce_marginals_perm(C.cast(arr, _P), len(chains), perms.ctypes.data))
     return perms
+
+
+def iterate_many(chains, method, iterations, thinning=0):
+    """hml_iterate_many: `iterations` sweeps of every chain; chains of one GPU and one shape share their launches"""
+    lib = load_library()
+    arr = (_P * len(chains))(*[c.h for c in chains])
+    _check(lib.hml_iterate_many(C.cast(arr, _P), len(chains), method.encode(), iterations, thinning))
 
 
 def marginals_text(seg, cnt):

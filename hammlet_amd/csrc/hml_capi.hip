@@ -22,6 +22,7 @@
 #include "hml_k_trellis.h"
 #include "hml_k_trellis_rows.h"
 #include "hml_k_compat.h"
+#include "hml_k_many.h"
 #include "hml_k_params.h"
 #include "hml_state.h"
 #include "hml_synth_host.hpp"
@@ -314,7 +315,7 @@ static void free_all(hml_ctx* c) {
     void* ptrs[] = {c->d_group_word, c->d_summary, c->d_w, c->d_coeff, c->d_ia, c->d_stage, c->d_span_count, c->d_starts, c->d_bstat,
                     c->d_em, c->d_gsc, c->d_rows, c->d_eprobe, c->d_aprobe, c->d_entry, c->d_exitA, c->d_redo, c->d_touched, c->d_fb, c->d_coarse1,
                     c->d_smap, c->d_cmap, c->d_scmap, c->d_super, c->d_bentry2, c->d_bentry, c->d_q, c->d_partial, c->d_diff, c->d_boundary, c->d_mdl,
-                    c->d_redo2, c->d_tre_bitmap, c->d_mt, c->d_crows};
+                    c->d_redo2, c->d_tre_bitmap, c->d_mt, c->d_crows, c->d_many};
     for (void* p : ptrs) if (p) hipFree(p);
     if (c->h_B) hipHostFree(c->h_B);
     c->h_B = nullptr;
@@ -1279,6 +1280,148 @@ int hml_iterate(hml_ctx* c, char method, uint64_t iterations, uint64_t thinning)
     }
     return 0;
 }
+
+}  // extern "C"
+
+// ---- several chains of one device in one set of launches (hml_k_many.h) ----
+static bool many_eligible(hml_ctx* const* cs, int n, char method) {
+    if (n < 2 || n > 64 || method != HML_METHOD_FB) return false;
+    const hml_ctx* a = cs[0];
+    for (int i = 0; i < n; ++i) {
+        const hml_ctx* c = cs[i];
+        if (!c->model_set || c->device != a->device || c->K != a->K || c->T != a->T || c->D != 1 || c->compat || !c->dynamic || !c->use_keys ||
+            c->probes || c->profiling || c->fwdL != a->fwdL || c->late_rescale != a->late_rescale || c->n_spans != a->n_spans)
+            return false;
+        for (int j = 0; j < i; ++j) if (cs[j] == c) return false;
+    }
+    return true;
+}
+// weakly compressed sweeps (either criterion of sweep_k / launch_compact_pair) keep their own kernels: not batched
+static bool many_sparse(hml_ctx* c) {
+    refresh_hint(c);
+    return !(c->B_hint >= c->dense_min_blocks) && !(!c->summary_always && c->B_hint && (uint64_t)c->B_hint * 24u > c->T);
+}
+
+template <int KK>
+static int iterate_many_k(hml_ctx* const* cs, int n, uint64_t first, uint64_t iterations, uint64_t thinning, uint64_t* done) {
+    hml_ctx* c0 = cs[0];
+    hipStream_t s = c0->stream;
+    const uint32_t T = (uint32_t)c0->T;
+    const int L = c0->fwdL;
+    const hml_layout lay = c0->lay;
+    const int with_gsc = c0->late_rescale ? 0 : 1;
+    const uint32_t n_groups = (c0->n_spans + HML_GROUP_SPANS - 1) / HML_GROUP_SPANS;
+    const bool records = thinning > 0 && thinning <= iterations;
+    unsigned long long rec_mask = 0ull;
+    for (int i = 0; i < n; ++i) {
+        if (records && cs[i]->rec_marginals) {
+            if (cs[i]->pooled) return set_err(HML_ERR_ARG, "the marginals of a context are pooled (common labels, several chains): further sweeps cannot be recorded into them");
+            if (int r = ensure_marginal_buffers(cs[i])) return r;
+            rec_mask |= 1ull << i;
+        }
+    }
+    // the chains' pointers, in device memory of chain 0 (kept for the next call)
+    std::vector<hml_chain_dev> h(n);
+    for (int i = 0; i < n; ++i) {
+        hml_ctx* c = cs[i];
+        hml_chain_dev& d = h[i];
+        d.summary = c->d_summary; d.w = c->d_w; d.ia = c->d_ia; d.key_base = c->key_base; d.n_spans = c->n_spans;
+        d.stage = c->d_stage; d.span_count = c->d_span_count; d.coarse1 = c->d_coarse1; d.starts = c->d_starts; d.host_B = c->d_hB;
+        d.bstat = c->d_bstat; d.mdl = c->d_mdl; d.em = c->d_em; d.gsc = c->d_gsc; d.rows = c->d_rows; d.entry = c->d_entry; d.exitv = c->d_exitA;
+        d.fb = c->d_fb; d.redo = c->d_redo; d.touched = c->d_touched; d.smap = c->d_smap; d.cmap = c->d_cmap; d.bentry = c->d_bentry;
+        d.q = c->d_q; d.partial = c->d_partial; d.diff = c->d_diff; d.boundary = c->d_boundary;
+    }
+    if (c0->many_cap < n) {
+        if (c0->d_many) HIPCHK(hipFree(c0->d_many));
+        c0->d_many = nullptr; c0->many_cap = 0;
+        HIPCHK(hipMalloc(&c0->d_many, n * sizeof(hml_chain_dev)));
+        c0->many_cap = n;
+    }
+    HIPCHK(hipMemcpyAsync(c0->d_many, h.data(), n * sizeof(hml_chain_dev), hipMemcpyHostToDevice, s));
+    HIPCHK(hipStreamSynchronize(s));   // (the staging vector goes out of scope below)
+    const hml_chain_dev* d_cs = (const hml_chain_dev*)c0->d_many;
+    for (uint64_t i = first; i < iterations; ++i) {
+        for (int k = 0; k < n; ++k) if (!many_sparse(cs[k])) { *done = i; return 0; }   // a chain left the strongly compressed regime: the caller goes on one by one
+        const bool record = thinning > 0 && ((i + 1) % thinning == 0);
+        uint32_t hint = 0;
+        for (int k = 0; k < n; ++k) hint = std::max(hint, cs[k]->B_hint ? cs[k]->B_hint : (uint32_t)std::min<uint64_t>(T, 1u << 20));
+        const unsigned ny = (unsigned)n;
+        hipLaunchKernelGGL(hml_m_compact_scan_summary, dim3(n_groups, ny), dim3(256), 0, s, d_cs, T);
+        hipLaunchKernelGGL(hml_m_compact_scatter, dim3(n_groups, ny), dim3(256), 0, s, d_cs, T);
+        const unsigned gB = (unsigned)grid_for(hint, 256, 64, 16384);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_m_stats_emission<KK>), dim3(gB, ny), dim3(256), 0, s, d_cs, with_gsc, lay);
+        const uint64_t chunks = ((uint64_t)hint + L - 1) / L;
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_m_forward<KK>), dim3((unsigned)grid_for(chunks, 256, 16, 1 << 20), ny), dim3(256), 0, s, d_cs, with_gsc, L, lay);
+        const uint64_t bch = ((uint64_t)hint + HML_BWD_CHUNK - 1) / HML_BWD_CHUNK;
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_m_backward_maps<KK>), dim3((unsigned)grid_for(bch * 64, 256, 16, 1 << 18), ny), dim3(256), 0, s, d_cs, with_gsc, L, lay);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_m_backward_chain<KK>), dim3(1, ny), dim3(1024), 0, s, d_cs, with_gsc, L, lay);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_m_counts<KK>), dim3(HML_REDUCE_GROUPS, ny), dim3(256), 0, s, d_cs);
+        if (record && rec_mask) hipLaunchKernelGGL(hml_m_record, dim3(gB, ny), dim3(256), 0, s, d_cs, rec_mask);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_m_params<KK>), dim3(1, ny), dim3(1024), 0, s, d_cs);
+        KLAUNCH_CHECK();
+        if (record) {
+            bool any_cb = false;
+            for (int k = 0; k < n; ++k) any_cb = any_cb || cs[k]->cb;
+            if (any_cb) {
+                HIPCHK(hipStreamSynchronize(s));
+                for (int k = 0; k < n; ++k) {
+                    if (int r = check_device_error(cs[k])) return r;
+                    if (cs[k]->cb) cs[k]->cb(cs[k], i, cs[k]->cb_user);
+                }
+            }
+        }
+    }
+    *done = iterations;
+    return 0;
+}
+
+extern "C" int hml_iterate_many(hml_ctx* const* cs, int n, char method, uint64_t iterations, uint64_t thinning) {
+    if (!cs || n < 1) return set_err(HML_ERR_ARG, "no contexts");
+    for (int i = 0; i < n; ++i) if (!cs[i] || !cs[i]->model_set) return set_err(HML_ERR_ARG, "model not set");
+    if (method != HML_METHOD_FB && method != HML_METHOD_MIXTURE) return set_err(HML_ERR_ARG, std::string("Unknown sampling type ") + method + "!");
+    uint64_t done = 0;
+    if (many_eligible(cs, n, method)) {
+        if (int r = ctx_bind(cs[0])) return r;
+        // everything the chains have enqueued on their own streams comes first; a block count that predates the current
+        // parameters is refreshed chain by chain (sweep_k's first-sweep rule)
+        for (int i = 0; i < n; ++i) {
+            hml_ctx* c = cs[i];
+            if (c->hint_stale) { launch_compact_pair(c, 0, 0.0f); KLAUNCH_CHECK(); }
+            HIPCHK(hipStreamSynchronize(c->stream));
+            c->hint_stale = false;
+            if (c->graph_exec) { hipGraphExecDestroy(c->graph_exec); c->graph_exec = nullptr; }
+        }
+        int r = 0;
+        HML_DISPATCH_K(cs[0]->K, r = iterate_many_k<KK>(cs, n, 0, iterations, thinning, &done));
+        if (r) return r;
+        // the other chains' streams continue behind the batch
+        hipEvent_t ev = ev_get(cs[0]);
+        HIPCHK(hipEventRecord(ev, cs[0]->stream));
+        for (int i = 1; i < n; ++i) HIPCHK(hipStreamWaitEvent(cs[i]->stream, ev, 0));
+        cs[0]->ev_pool.push_back(ev);
+        if (done == iterations) return 0;
+        HIPCHK(hipStreamSynchronize(cs[0]->stream));
+    }
+    // not batched (different shapes or devices, mixture sweeps, weakly compressed or reference-compatible chains): sweep by
+    // sweep in turn, so that recorded sweeps stay aligned across the chains
+    for (uint64_t i = done; i < iterations; ++i) {
+        const bool record = thinning > 0 && ((i + 1) % thinning == 0);
+        for (int k = 0; k < n; ++k) {
+            hml_ctx* c = cs[k];
+            if (int r = ctx_bind(c)) return r;
+            if (record && c->rec_marginals && c->pooled) return set_err(HML_ERR_ARG, "the marginals of a context are pooled (common labels, several chains): further sweeps cannot be recorded into them");
+            if (int r = sweep_dispatch(c, method, record)) return r;
+            if (record && c->cb) {
+                HIPCHK(hipStreamSynchronize(c->stream));
+                if (int r = check_device_error(c)) return r;
+                c->cb(c, i, c->cb_user);
+            }
+        }
+    }
+    return 0;
+}
+
+extern "C" {
 
 int hml_set_option(hml_ctx* c, const char* name, int value) {
     if (!c || !name) return set_err(HML_ERR_ARG, "null argument");

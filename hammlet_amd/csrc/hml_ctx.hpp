@@ -114,6 +114,8 @@ struct hml_ctx {
     bool rec_marginals = true;
     hml_record_cb cb = nullptr;
     void* cb_user = nullptr;
+    void* d_many = nullptr;        // hml_iterate_many: the chains' pointers (hml_chain_dev), kept by the first chain of a batch
+    int many_cap = 0;
     bool compat = false;           // option "compat": sweeps exactly as the reference computes them (hml_k_compat.h)
     void* d_mt = nullptr;          // its engine (hml_mt_state)
     float* d_crows = nullptr;      // its trellis, (T + 1) x K

@@ -208,7 +208,7 @@ __device__ __forceinline__ void hml_bwd_chunk_maps(const float (&r)[K], hml_mode
 // (start vector == predecessor's end vector, bit for bit; see hml_k_forward): after a failed check the chunk
 // goes on the list of the repair step (fail_list, counted by mdl->fwd_mismatch), which also computes its maps.
 template <int K>
-__global__ __launch_bounds__(256) void hml_k_backward_maps(const float* __restrict__ rows, hml_model* __restrict__ mdl,
+__device__ __forceinline__ void hml_b_backward_maps(const float* __restrict__ rows, hml_model* __restrict__ mdl,
                                                            unsigned long long* __restrict__ smap,
                                                            unsigned long long* __restrict__ cmap, const hml_layout lay,
                                                            const float* __restrict__ entry, const float* __restrict__ exitv,
@@ -251,12 +251,24 @@ __global__ __launch_bounds__(256) void hml_k_backward_maps(const float* __restri
         hml_bwd_chunk_maps<K>(r, mdl, bx, smap, cmap, c, lane, B, epoch, key);
     }
 }
+// the kernel: hml_b_backward_maps over one chain (hml_k_many.h runs it over several chains in one launch)
+template <int K>
+__global__ __launch_bounds__(256) void hml_k_backward_maps(const float* __restrict__ rows, hml_model* __restrict__ mdl,
+                                                           unsigned long long* __restrict__ smap,
+                                                           unsigned long long* __restrict__ cmap, const hml_layout lay,
+                                                           const float* __restrict__ entry, const float* __restrict__ exitv,
+                                                           uint32_t* __restrict__ fail_list, int L,
+                                                           const uint32_t* __restrict__ starts,
+                                                           const hml_model* __restrict__ mdl_ro) {
+    hml_b_backward_maps<K>(rows, mdl, smap, cmap, lay, entry, exitv, fail_list, L, starts, mdl_ro);
+}
+
 
 // K7b repair + chain, one workgroup.  Normally only the chain: compose the chunk maps from the last chunk down,
 // entry[c] = state of the first row of chunk c+1 (entry of the last chunk is a dummy 0: its map is constant).
 // When a verification failed, the forward repair (hml_fwd_repair) and the maps of the affected chunks come first.
 template <int K>
-__global__ __launch_bounds__(1024) void hml_k_backward_chain(unsigned long long* __restrict__ cmap, hml_model* __restrict__ mdl,
+__device__ __forceinline__ void hml_b_backward_chain(unsigned long long* __restrict__ cmap, hml_model* __restrict__ mdl,
                                                              uint8_t* __restrict__ entry_state, const float* __restrict__ em,
                                                              const float* __restrict__ gsc, float* __restrict__ rows,
                                                              float* __restrict__ aprobe, float* __restrict__ entry,
@@ -372,6 +384,19 @@ __global__ __launch_bounds__(1024) void hml_k_backward_chain(unsigned long long*
         }
     }
 }
+// the kernel: hml_b_backward_chain over one chain (hml_k_many.h runs it over several chains in one launch)
+template <int K>
+__global__ __launch_bounds__(1024) void hml_k_backward_chain(unsigned long long* __restrict__ cmap, hml_model* __restrict__ mdl,
+                                                             uint8_t* __restrict__ entry_state, const float* __restrict__ em,
+                                                             const float* __restrict__ gsc, float* __restrict__ rows,
+                                                             float* __restrict__ aprobe, float* __restrict__ entry,
+                                                             float* __restrict__ exitv, uint32_t* __restrict__ fb_count,
+                                                             const uint32_t* __restrict__ fail_list, uint32_t* __restrict__ touched,
+                                                             unsigned long long* __restrict__ smap, int L, const hml_layout lay,
+                                                             int mode, int super_level, const uint32_t* __restrict__ starts) {
+    hml_b_backward_chain<K>(cmap, mdl, entry_state, em, gsc, rows, aprobe, entry, exitv, fb_count, fail_list, touched, smap, L, lay, mode, super_level, starts);
+}
+
 
 // Two-level chain for sweeps with millions of backward chunks (one workgroup walking all chunk maps would take
 // milliseconds): a wavefront composes the maps of 64 consecutive chunks - scmap[c] = cmap[c] o .. o cmap[last chunk of
@@ -482,7 +507,7 @@ __device__ __forceinline__ double hml_wave_tree_f64(double a) {
 // MV = true ("-s C P D"): the floating-point sums are per emission PARAMETER; a lane's term for parameter p is the sum,
 // in dimension order, of its block's statistics of the dimensions that the block's state maps to p.
 template <int K, bool FB, bool MV = false>
-__global__ __launch_bounds__(256) void hml_k_counts(int16_t* __restrict__ q, const uint32_t* __restrict__ starts,
+__device__ __forceinline__ void hml_b_counts(int16_t* __restrict__ q, const uint32_t* __restrict__ starts,
                                                     const float2* __restrict__ bstat, hml_model* __restrict__ mdl,
                                                     double* __restrict__ partial /*[K][2][GROUPS]: plane (state, sum | sum of squares), one double per group*/,
                                                     const unsigned long long* __restrict__ smap,
@@ -620,6 +645,16 @@ __global__ __launch_bounds__(256) void hml_k_counts(int16_t* __restrict__ q, con
         if (h_trans[i]) atomicAdd(&mdl->trans[slot][i], h_trans[i]);
     if (tid < K && h_occ[tid]) atomicAdd(&mdl->occ[slot][tid], h_occ[tid]);
 }
+// the kernel: hml_b_counts over one chain (hml_k_many.h runs it over several chains in one launch)
+template <int K, bool FB, bool MV = false>
+__global__ __launch_bounds__(256) void hml_k_counts(int16_t* __restrict__ q, const uint32_t* __restrict__ starts,
+                                                    const float2* __restrict__ bstat, hml_model* __restrict__ mdl,
+                                                    double* __restrict__ partial ,
+                                                    const unsigned long long* __restrict__ smap,
+                                                    const uint8_t* __restrict__ entry) {
+    hml_b_counts<K, FB, MV>(q, starts, bstat, mdl, partial, smap, entry);
+}
+
 
 // ------------------------------------------------------------------------------------------
 // K8 for sweeps with many blocks (weakly compressed input: hundreds of 256-block chunks per workgroup), univariate: the
@@ -744,7 +779,7 @@ __global__ __launch_bounds__(256) void hml_k_counts_dense(int16_t* __restrict__ 
 // marginals file is cut wherever any recorded sweep had a segment boundary.  Device form: +1/-1
 // into a per-state difference array at segment starts and a boundary bit; one thread per block.
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void hml_k_record(const int16_t* __restrict__ q, const uint32_t* __restrict__ starts,
+__device__ __forceinline__ void hml_b_record(const int16_t* __restrict__ q, const uint32_t* __restrict__ starts,
                                                     hml_model* __restrict__ mdl, int32_t* __restrict__ diff,
                                                     uint32_t* __restrict__ boundary) {
     const uint32_t B = mdl->B;
@@ -768,5 +803,12 @@ __global__ __launch_bounds__(256) void hml_k_record(const int16_t* __restrict__ 
         if (n >= 0x7fffffffull) hml_raise(mdl, HML_DEVERR_TOO_MANY_RECORDS, 0.0f);
     }
 }
+// the kernel: hml_b_record over one chain (hml_k_many.h runs it over several chains in one launch)
+__global__ __launch_bounds__(256) void hml_k_record(const int16_t* __restrict__ q, const uint32_t* __restrict__ starts,
+                                                    hml_model* __restrict__ mdl, int32_t* __restrict__ diff,
+                                                    uint32_t* __restrict__ boundary) {
+    hml_b_record(q, starts, mdl, diff, boundary);
+}
+
 
 #endif

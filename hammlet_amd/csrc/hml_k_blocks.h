@@ -185,7 +185,7 @@ __device__ __forceinline__ uint32_t hml_group_mask16(const float* __restrict__ w
     }
     return m16;
 }
-__global__ __launch_bounds__(256) void hml_k_compact_scan_summary(const uint8_t* __restrict__ summary, const float* __restrict__ w,
+__device__ __forceinline__ void hml_b_compact_scan_summary(const uint8_t* __restrict__ summary, const float* __restrict__ w,
                                                                   uint32_t T, const hml_model* __restrict__ mdl,
                                                                   float thr_override, int use_override, int32_t base,
                                                                   uint16_t* __restrict__ stage,
@@ -280,6 +280,16 @@ __global__ __launch_bounds__(256) void hml_k_compact_scan_summary(const uint8_t*
     __syncthreads();
     if (threadIdx.x == 0) group_total[blockIdx.x] = wave_total[0] + wave_total[1] + wave_total[2] + wave_total[3];
 }
+// the kernel: hml_b_compact_scan_summary over one chain (hml_k_many.h runs it over several chains in one launch)
+__global__ __launch_bounds__(256) void hml_k_compact_scan_summary(const uint8_t* __restrict__ summary, const float* __restrict__ w,
+                                                                  uint32_t T, const hml_model* __restrict__ mdl,
+                                                                  float thr_override, int use_override, int32_t base,
+                                                                  uint16_t* __restrict__ stage,
+                                                                  uint32_t* __restrict__ span_count,
+                                                                  uint32_t* __restrict__ group_total) {
+    hml_b_compact_scan_summary(summary, w, T, mdl, thr_override, use_override, base, stage, span_count, group_total);
+}
+
 
 __device__ __forceinline__ uint32_t hml_wave_sum_u32(uint32_t v) {
 #pragma unroll
@@ -302,7 +312,7 @@ __global__ __launch_bounds__(256) void hml_k_group_totals(const uint32_t* __rest
 // One workgroup per span group, HML_SUM_SPANS spans per wavefront.  The exclusive offset of a span is the sum
 // of the totals of the groups before its group (summed once per workgroup: T = 10^8 has 1526 groups, six
 // loads per thread) plus the counts of the spans before it inside the group.
-__global__ __launch_bounds__(256) void hml_k_compact_scatter(const uint16_t* __restrict__ stage,
+__device__ __forceinline__ void hml_b_compact_scatter(const uint16_t* __restrict__ stage,
                                                              const uint32_t* __restrict__ span_count,
                                                              const uint32_t* __restrict__ group_total, uint32_t n_spans,
                                                              uint32_t T, hml_model* __restrict__ mdl,
@@ -349,6 +359,15 @@ __global__ __launch_bounds__(256) void hml_k_compact_scatter(const uint16_t* __r
         }
     }
 }
+// the kernel: hml_b_compact_scatter over one chain (hml_k_many.h runs it over several chains in one launch)
+__global__ __launch_bounds__(256) void hml_k_compact_scatter(const uint16_t* __restrict__ stage,
+                                                             const uint32_t* __restrict__ span_count,
+                                                             const uint32_t* __restrict__ group_total, uint32_t n_spans,
+                                                             uint32_t T, hml_model* __restrict__ mdl,
+                                                             uint32_t* __restrict__ starts, uint32_t* __restrict__ host_B) {
+    hml_b_compact_scatter(stage, span_count, group_total, n_spans, T, mdl, starts, host_B);
+}
+
 
 // ------------------------------------------------------------------------------------------
 // K5 block_stats - Statistics<IntegralArray,Normal>::addBlockStats / setStats (reference

@@ -165,7 +165,7 @@ __global__ __launch_bounds__(256) void hml_k_emission(const float2* __restrict__
 // K5+K6a fused for the sweeps that rebuild the block structure: one thread per block gathers the block
 // statistics from the integral array and emits the per-state terms - one dense launch instead of two.
 template <int K>
-__global__ __launch_bounds__(256) void hml_k_stats_emission(const float2* __restrict__ ia, const uint32_t* __restrict__ starts,
+__device__ __forceinline__ void hml_b_stats_emission(const float2* __restrict__ ia, const uint32_t* __restrict__ starts,
                                                             hml_model* __restrict__ mdl, float2* __restrict__ bstat,
                                                             float* __restrict__ em, float* __restrict__ gsc,
                                                             float* __restrict__ eprobe, int mixture, const hml_layout lay) {
@@ -181,6 +181,15 @@ __global__ __launch_bounds__(256) void hml_k_stats_emission(const float2* __rest
         hml_emit_block<K>(p, mdl, b, sx, sq, (float)(e - s), em, gsc, eprobe, mixture, lay);
     }
 }
+// the kernel: hml_b_stats_emission over one chain (hml_k_many.h runs it over several chains in one launch)
+template <int K>
+__global__ __launch_bounds__(256) void hml_k_stats_emission(const float2* __restrict__ ia, const uint32_t* __restrict__ starts,
+                                                            hml_model* __restrict__ mdl, float2* __restrict__ bstat,
+                                                            float* __restrict__ em, float* __restrict__ gsc,
+                                                            float* __restrict__ eprobe, int mixture, const hml_layout lay) {
+    hml_b_stats_emission<K>(ia, starts, mdl, bstat, em, gsc, eprobe, mixture, lay);
+}
+
 
 // ------------------------------------------------------------------------------------------
 // Multivariate / shared-parameter form ("-s C P D", reference src/Mapping.hpp, src/EFD.hpp:83-93, src/Theta.hpp:148-158):
@@ -482,7 +491,7 @@ __device__ __forceinline__ void hml_fwd_run(const hml_fwd_ctx<K>& cx, float (&al
 // (entry) and the one it ends in (exit).  Verification (entry[c] == exit[c-1], bit for bit) happens in the
 // backward-map kernel, which reads the rows anyway; repairs in hml_fwd_repair.
 template <int K>
-__global__ __launch_bounds__(256) void hml_k_forward(const float* __restrict__ em, const float* __restrict__ gsc,
+__device__ __forceinline__ void hml_b_forward(const float* __restrict__ em, const float* __restrict__ gsc,
                                                      hml_model* __restrict__ mdl, float* __restrict__ rows,
                                                      float* __restrict__ aprobe, float* __restrict__ entry,
                                                      float* __restrict__ exitv, uint32_t* __restrict__ fb_count, int L,
@@ -519,6 +528,16 @@ __global__ __launch_bounds__(256) void hml_k_forward(const float* __restrict__ e
         if (nfb) atomicAdd(&mdl->uniform_fallbacks, (unsigned long long)nfb);
     }
 }
+// the kernel: hml_b_forward over one chain (hml_k_many.h runs it over several chains in one launch)
+template <int K>
+__global__ __launch_bounds__(256) void hml_k_forward(const float* __restrict__ em, const float* __restrict__ gsc,
+                                                     hml_model* __restrict__ mdl, float* __restrict__ rows,
+                                                     float* __restrict__ aprobe, float* __restrict__ entry,
+                                                     float* __restrict__ exitv, uint32_t* __restrict__ fb_count, int L,
+                                                     const hml_layout lay) {
+    hml_b_forward<K>(em, gsc, mdl, rows, aprobe, entry, exitv, fb_count, L, lay);
+}
+
 
 // a chunk started from pi itself (its warm-up window reaches block 0): exact by construction
 __device__ __forceinline__ bool hml_fwd_chunk_exact(uint32_t c, int L, int W) { return c == 0u || c * (uint32_t)L <= (uint32_t)W; }

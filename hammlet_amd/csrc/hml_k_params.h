@@ -63,7 +63,7 @@ __global__ __launch_bounds__(64) void hml_k_set_dynamic(hml_model* mdl, int on, 
 // of A, every variate from its own Philox sub-stream.
 // ------------------------------------------------------------------------------------------
 template <int K>
-__global__ __launch_bounds__(1024) void hml_k_params(hml_model* __restrict__ mdl, const double* __restrict__ partial,
+__device__ __forceinline__ void hml_b_params(hml_model* __restrict__ mdl, const double* __restrict__ partial,
                                                      int mode) {
     __shared__ double wp[16][K][2];
     __shared__ float fin[K][2];
@@ -333,5 +333,12 @@ __global__ __launch_bounds__(1024) void hml_k_params(hml_model* __restrict__ mdl
         if (mode == 0) { mdl->sweeps += 1ull; mdl->block_updates += (unsigned long long)mdl->B; }
     }
 }
+// the kernel: hml_b_params over one chain (hml_k_many.h runs it over several chains in one launch)
+template <int K>
+__global__ __launch_bounds__(1024) void hml_k_params(hml_model* __restrict__ mdl, const double* __restrict__ partial,
+                                                     int mode) {
+    hml_b_params<K>(mdl, partial, mode);
+}
+
 
 #endif

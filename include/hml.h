@@ -164,6 +164,15 @@ int hml_set_option(hml_ctx* ctx, const char* name, int value);
  * seed leaves the reference's states, parameters and marginals.  Univariate models; the order-dependent part of a sweep
  * runs on one lane (meant for traces up to ~10^6 positions - the default path is the fast one).  Environment: HML_COMPAT. */
 
+/* hml_iterate for SEVERAL chains at once: `iterations` sweeps of every chain, sweep i of all chains before sweep i + 1.
+ * Chains that live on one device, have the same shape (positions, states) and are in the strongly compressed regime of a
+ * univariate Forward-Backward sweep are BATCHED: every kernel of the sweep is launched once for all of them (the chain
+ * is the grid's second dimension), so the host pays for one chain's launches - a single such chain is bound by latency
+ * and leaves most of the GPU idle.  Everything else (other shapes or devices, mixture sweeps, weakly compressed,
+ * multivariate or reference-compatible chains) is run chain by chain inside the same call.  A chain's results are the
+ * same bit for bit as under hml_iterate; recorded sweeps call each chain's callback in chain order. */
+int hml_iterate_many(hml_ctx* const* ctxs, int n, char method, uint64_t iterations, uint64_t thinning);
+
 /* wait for all enqueued work; surfaces model errors raised on the device */
 int hml_sync(hml_ctx* ctx);
 

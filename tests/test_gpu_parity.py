@@ -416,6 +416,48 @@ def test_independent_chains_and_device_input(hml):
     assert not np.array_equal(res[1][1], res[7][1])
 
 
+@pytest.mark.parametrize("K,n_chains", [(5, 4), (3, 2), (10, 3)])
+def test_batched_chains_are_the_chains_run_alone(hml, K, n_chains):
+    """hml_iterate_many (hml_k_many.h): chains of one GPU share every launch of the sweep - the chain is the grid's second
+    dimension - and each must stay, bit for bit, the chain the checker runs alone: plain and recorded sweeps, a prior
+    re-draw in between, then mixture sweeps (not batched: the call runs them chain by chain) and batched sweeps again."""
+    T = 300_000
+    x = ol.trace(T, K, 12)
+    pairs = []
+    for chain in range(n_chains):
+        o = ol.OracleChain(K=K, seed=9, chain=chain, rng=ol.RNG_CTR, math=ol.MATH_DEV, reduce=ol.REDUCE_DEV)
+        o.load(x)
+        g = hml.Chain(device=0, seed=9, chain_id=chain)
+        g.load(x)
+        setup_model(o, g, K)
+        o.token("F")
+        g.sample_prior()
+        o.set_record(marginals=True)
+        pairs.append((o, g))
+    gs = [g for _, g in pairs]
+    s0 = [g.stats()["sweeps"] for g in gs]
+    for method, iters, thin in (("F", 25, 0), ("F", 12, 4), ("P", 0, 0), ("F", 9, 3), ("M", 4, 2), ("F", 6, 1)):
+        if method == "P":
+            for o, g in pairs:
+                o.token("P")
+                o.token("F")
+                g.sample_prior()
+            continue
+        for o, _ in pairs:
+            o.iterate(method, iters, thin)
+        hml.iterate_many(gs, method, iters, thin)
+        for chain, (o, g) in enumerate(pairs):
+            g.sync()
+            compare_state(o, g, what="batched chain %d" % chain)
+    for (o, g), s in zip(pairs, s0):
+        assert g.stats()["sweeps"] - s == 25 + 12 + 9 + 4 + 6
+        seg, cnt = g.marginals_rle()
+        assert hml.marginals_text(seg, cnt) == o.text("marginals")
+    assert not np.array_equal(gs[0].theta(), gs[1].theta())
+    for g in gs:
+        g.close()
+
+
 @pytest.mark.parametrize("dense_L,min_blocks", [(16, 1000), (32, 1000), (64, 50000), (8, 1)])
 def test_dense_forward_geometry_is_invisible_in_the_results(hml, monkeypatch, dense_L, min_blocks):
     """Sweeps with many blocks run the forward pass with longer chunks in their own layout (HML_FWD_CHUNK_DENSE,

@@ -1,11 +1,13 @@
-"""Several independent chains on ONE GPU, each on its own stream and host thread: aggregate block-updates/s.
-    python tools/multi_chain.py [chains] [sweeps] [workload]"""
+"""Several independent chains on ONE GPU: aggregate block-updates/s - each chain on its own stream and host thread, or (mode
+"many") all chains in one set of launches by one host thread (hml_iterate_many).
+    python tools/multi_chain.py [chains] [sweeps] [workload] [threads|many]"""
 import os, sys, threading, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench, hammlet_amd
 R = int(sys.argv[1]) if len(sys.argv) > 1 else 4
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 500
 wl = sys.argv[3] if len(sys.argv) > 3 else "c3_1e8_k5_dynamic"
+mode = sys.argv[4] if len(sys.argv) > 4 else "threads"
 T, K, levels, sigma, dwell, data_seed = bench.WORKLOADS[wl]
 x = hammlet_amd.synth_gauss(T, K, levels, sigma, dwell, data_seed, nthreads=8)
 chains = []
@@ -25,9 +27,13 @@ def run(ch):
     ch.sync()
 ths = [threading.Thread(target=run, args=(ch,)) for ch in chains]
 t0 = time.perf_counter()
-for t in ths: t.start()
-for t in ths: t.join()
+if mode == "many":
+    hammlet_amd.iterate_many(chains, "F", n, 0)
+    for ch in chains: ch.sync()
+else:
+    for t in ths: t.start()
+    for t in ths: t.join()
 t1 = time.perf_counter()
 blocks = sum(ch.stats()["block_updates"] - s["block_updates"] for ch, s in zip(chains, s0))
-print("%d chains x %d sweeps on one GPU: %.4f ms per sweep-round, %.3e block-updates/s aggregate (%.3e per chain)" % (
+print("[%s] " % mode + "%d chains x %d sweeps on one GPU: %.4f ms per sweep-round, %.3e block-updates/s aggregate (%.3e per chain)" % (
     R, n, 1e3 * (t1 - t0) / n, blocks / (t1 - t0), blocks / (t1 - t0) / R))
