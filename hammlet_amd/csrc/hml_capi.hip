@@ -1001,7 +1001,7 @@ static int sweep_k(hml_ctx* c, char method, bool record) {
     // strongly compressed univariate sweeps keep no plane of rescale factors: the forward rows stay unscaled and the
     // backward maps apply the factor where they read a row (hml_bwd_row_load) - 3.5 of the block kernel's 11 MB of
     // stores at 10^8 positions, and what a dependent launch waits for is the write-back of its predecessor's stores
-    float* const gsc_plane = (!dense_geo && c->D == 1 && c->late_rescale) ? nullptr : c->d_gsc;
+    float* const gsc_plane = (!dense_geo && c->late_rescale) ? nullptr : c->d_gsc;
     const uint32_t* const starts_for_maps = gsc_plane ? nullptr : c->d_starts;
     if (c->dynamic || !c->blocks_valid) {
         // the fused block kernel: univariate chains that have the GPU to themselves, unless compression is weak (the

@@ -203,10 +203,25 @@ __global__ __launch_bounds__(256) void hml_k_emission_mv(const float2* __restric
                                                          hml_model* __restrict__ mdl, float2* __restrict__ bstat,
                                                          float* __restrict__ em, float* __restrict__ gsc,
                                                          float* __restrict__ eprobe, int mixture, const hml_layout lay) {
+    // the model's parameters once per workgroup (round 3: read per block through the writable pointer every value was a
+    // cache round trip of its own, and the quotient a double division per state and dimension - hml_inner_product takes
+    // it through the reciprocal the parameter kernel keeps, with the division where the product could round differently:
+    // the same float)
+    __shared__ float s_mu[HML_MAX_K], s_var[HML_MAX_K], s_logNs[K], s_logA[K];
+    __shared__ double s_rvar[HML_MAX_K];
+    __shared__ uint8_t s_map[K][HML_MAX_D];
+    __shared__ uint64_t s_tab[32];
     const uint32_t B = mdl->B;
     const int D = mdl->D;
     const uint64_t T = mdl->T;
     const bool self = mdl->self_trans != 0 && !mixture;
+    if (threadIdx.x < (unsigned)mdl->P) { s_mu[threadIdx.x] = mdl->mu[threadIdx.x]; s_var[threadIdx.x] = mdl->var[threadIdx.x]; s_rvar[threadIdx.x] = mdl->rvar2[threadIdx.x]; }
+    if (threadIdx.x < (unsigned)K) {
+        s_logNs[threadIdx.x] = mdl->logNs[threadIdx.x]; s_logA[threadIdx.x] = mdl->logA[threadIdx.x];
+        for (int d = 0; d < HML_MAX_D; ++d) s_map[threadIdx.x][d] = mdl->map[threadIdx.x][d];
+    }
+    if (threadIdx.x >= 64 && threadIdx.x < 96) s_tab[threadIdx.x - 64] = HML_EXP2F_TAB[threadIdx.x - 64];
+    __syncthreads();
     const uint32_t stride = gridDim.x * blockDim.x;
     for (uint32_t b = blockIdx.x * blockDim.x + threadIdx.x; b < B; b += stride) {
         const uint32_t st = starts[b], en = starts[b + 1];
@@ -227,22 +242,21 @@ __global__ __launch_bounds__(256) void hml_k_emission_mv(const float2* __restric
         for (int s = 0; s < K; ++s) {
             float r = 0.0f;
             for (int d = 0; d < D; ++d) {
-                const int pp = mdl->map[s][d];
-                const double ipd = (2.0 * (double)mdl->mu[pp] * (double)sx[d] - (double)sq[d]) / (2.0 * (double)mdl->var[pp]);
-                const float ip = (float)ipd;
+                const int pp = s_map[s][d];
+                const float ip = hml_inner_product(s_mu[pp], s_var[pp], s_rvar[pp], sx[d], sq[d]);
                 if (!hml_isfinite(ip)) hml_raise(mdl, HML_DEVERR_IP_NOT_FINITE, ip);
                 r += ip;
             }
-            float e = r - N * mdl->logNs[s];
-            if (self) e += (N - 1.0f) * mdl->logA[s];
+            float e = r - N * s_logNs[s];
+            if (self) e += (N - 1.0f) * s_logA[s];
             E[s] = e;
             maxE = (e < maxE) ? maxE : e;
         }
 #pragma unroll
         for (int s = 0; s < K; ++s) {
             if (eprobe) eprobe[(uint64_t)b * K + s] = E[s];
-            em[hml_bk(lay, b, K, s)] = hml_expf(E[s] - maxE);
-            if (!mixture) gsc[hml_bk(lay, b, K, s)] = self ? hml_expf((N - 1.0f) * mdl->logA[s]) : 1.0f;
+            em[hml_bk(lay, b, K, s)] = hml_expf_tab(E[s] - maxE, s_tab);
+            if (!mixture && gsc) gsc[hml_bk(lay, b, K, s)] = self ? hml_expf_tab((N - 1.0f) * s_logA[s], s_tab) : 1.0f;   // (no plane: the backward maps rescale, hml_bwd_row_load)
         }
     }
 }
