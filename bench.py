@@ -324,7 +324,7 @@ def main():
                                     "latency: three dependent memory round trips + one inter-workgroup hand-off per launch",
                          "profile_pair": None if dense_workload else
                                          "rocprofv3 adds 1.5-2 us to every dispatch of this kernel: the line that pairs with "
-                                         "profiles/round2_kernel_stats_c3_bench.csv is profiles/round2_bench_c3_under_rocprof.json",
+                                         "profiles/round3_kernel_stats_c3_bench.csv is profiles/round3_bench_c3_under_rocprof.json",
                          "algorithmic_bytes_per_launch": algo_bytes,
                          "algorithmic_equivalent_gbs": algo_bytes / scan_avg_s / 1e9,
                          "algorithmic_speedup_vs_peak_float_stream": algo_bytes / scan_avg_s / 1e9 / HBM_PEAK_GBS,
@@ -527,7 +527,7 @@ def main():
                                      "note": "aggregate of two independent chains on one GPU; the headline value is one chain per GPU"}
         v3, ms3 = several(3)
         out["three_chains_one_gpu"] = {"value": v3, "unit": "block-updates/s", "chains": 3, "ms_per_sweep_round": ms3,
-                                       "note": "profiles/round2_chains_per_gpu.txt: the aggregate peaks at three chains per GPU"}
+                                       "note": "profiles/round3_chains_batched.txt (and round2_chains_per_gpu.txt): the aggregate peaks at three chains per GPU"}
         # eight chains in ONE set of launches by one host thread (hml_iterate_many: the chain is the grid's second dimension)
         group = []
         for r in range(8):
