@@ -299,6 +299,8 @@ int hml_create(hml_ctx** out, int device, uint64_t seed, uint32_t chain_id, void
     if (const char* e = getenv("HML_FUSED_BLOCKS")) { c->fused_blocks = atoi(e) != 0; c->fused_keep = atoi(e) == 2; }   // 0: a GPU shared with other processes
     if (const char* e = getenv("HML_TRELLIS_FUSED")) c->tre_fused = atoi(e) != 0;
     if (const char* e = getenv("HML_TRELLIS_L")) { const int l = atoi(e); c->tre_L = (l <= 0) ? 0u : (l >= HML_TRE_MAX_L) ? (uint32_t)HML_TRE_MAX_L : (l < 32) ? 32u : (uint32_t)l / 32u * 32u; }   // a multiple of 32
+    if (const char* e = getenv("HML_TRELLIS_CKPT")) c->tre_ckpt = atoi(e) != 0;
+    if (const char* e = getenv("HML_STAGE_BITS")) c->stage_bits = atoi(e) != 0;
     if (const char* e = getenv("HML_TRELLIS_ROWS")) c->tre_rows = atoi(e) != 0;   // 0: round 2's first pass (hml_k_trellis_tile) for comparison
     if (const char* e = getenv("HML_LATE_RESCALE")) c->late_rescale = atoi(e) != 0;
     if (const char* e = getenv("HML_COMPAT")) c->compat = atoi(e) != 0;   // option "compat" for unmodified callers (`hammlet -compat`)
@@ -315,7 +317,7 @@ static void free_all(hml_ctx* c) {
     void* ptrs[] = {c->d_group_word, c->d_summary, c->d_w, c->d_coeff, c->d_ia, c->d_stage, c->d_span_count, c->d_starts, c->d_bstat,
                     c->d_em, c->d_gsc, c->d_rows, c->d_eprobe, c->d_aprobe, c->d_entry, c->d_exitA, c->d_redo, c->d_touched, c->d_fb, c->d_coarse1,
                     c->d_smap, c->d_cmap, c->d_scmap, c->d_super, c->d_bentry2, c->d_bentry, c->d_q, c->d_partial, c->d_diff, c->d_boundary, c->d_mdl,
-                    c->d_redo2, c->d_tre_bitmap, c->d_mt, c->d_crows, c->d_many};
+                    c->d_redo2, c->d_tre_bitmap, c->d_tre_ckpt, c->d_mt, c->d_crows, c->d_many};
     for (void* p : ptrs) if (p) hipFree(p);
     if (c->h_B) hipHostFree(c->h_B);
     c->h_B = nullptr;
@@ -560,11 +562,16 @@ static void launch_compact_pair(hml_ctx* c, int mode, float thr) {
     // the summary scan skips unopened groups; when most groups would be opened (weak compression) the plain
     // float stream is the better access pattern - both give the same blocks
     const bool dense = !c->summary_always && c->B_hint && (uint64_t)c->B_hint * 24u > c->T;
+    // ... and with B ~ T the scan stages the flags themselves (512 bytes per span) instead of 16-bit offsets (2 bytes per block)
+    const bool bits = dense && c->stage_bits;
     {
         ProfScope ps(c, "blocks_compact", 1);
         if (c->use_keys && !dense) {
             hipLaunchKernelGGL(hml_k_compact_scan_summary, dim3(n_groups), dim3(256), 0, c->stream, c->d_summary, c->d_w,
                                (uint32_t)c->T, c->d_mdl, thr, mode, c->key_base, c->d_stage, c->d_span_count, c->d_coarse1);
+        } else if (bits) {
+            hipLaunchKernelGGL(hml_k_compact_scan_bits, dim3((c->n_spans + 3) / 4), dim3(256), 0, c->stream, c->d_w, (uint32_t)c->T,
+                               c->d_mdl, thr, mode, (unsigned long long*)c->d_stage, c->d_span_count);
         } else {
             hipLaunchKernelGGL(hml_k_compact_scan, dim3((c->n_spans + 3) / 4), dim3(256), 0, c->stream, c->d_w, (uint32_t)c->T,
                                c->d_mdl, thr, mode, c->d_stage, c->d_span_count);
@@ -575,6 +582,10 @@ static void launch_compact_pair(hml_ctx* c, int mode, float thr) {
         if (!(c->use_keys && !dense))
             hipLaunchKernelGGL(hml_k_group_totals, dim3((n_groups + 255) / 256), dim3(256), 0, c->stream, c->d_span_count,
                                c->n_spans, c->d_coarse1);
+        if (bits)
+            hipLaunchKernelGGL(hml_k_compact_scatter_bits, dim3(n_groups), dim3(256), 0, c->stream, (const unsigned long long*)c->d_stage,
+                               c->d_span_count, c->d_coarse1, c->n_spans, (uint32_t)c->T, c->d_mdl, c->d_starts, c->d_hB);
+        else
         hipLaunchKernelGGL(hml_k_compact_scatter, dim3(n_groups), dim3(256), 0, c->stream, c->d_stage, c->d_span_count,
                            c->d_coarse1, c->n_spans, (uint32_t)c->T, c->d_mdl, c->d_starts, c->d_hB);
     }
@@ -713,6 +724,8 @@ int hml_set_model(hml_ctx* c, int K, const float nig4[4], float a_off, float a_d
     HIPCHK(hipMemsetAsync(c->d_touched, 0, bchunks * sizeof(uint32_t), c->stream));
     HIPCHK(hipMalloc(&c->d_redo2, bchunks * sizeof(uint32_t)));
     HIPCHK(hipMalloc(&c->d_tre_bitmap, (bchunks / 32 + 2) * sizeof(uint32_t)));
+    // (checkpoints of the fused trellis path: (L / 64 - 1) x ceil(B / L) <= T / 64 + 16 vectors of K + 1 words)
+    HIPCHK(hipMalloc(&c->d_tre_ckpt, (T / 64 + 64) * (uint64_t)(K + 1) * sizeof(uint32_t)));
     HIPCHK(hipMalloc(&c->d_q, T * sizeof(int16_t)));
     HIPCHK(hipMalloc(&c->d_partial, (uint64_t)HML_REDUCE_GROUPS * K * 2 * sizeof(double)));
     HIPCHK(hipMemsetAsync(c->d_partial, 0, (uint64_t)HML_REDUCE_GROUPS * K * 2 * sizeof(double), c->stream));
@@ -736,6 +749,8 @@ int hml_set_model(hml_ctx* c, int K, const float nig4[4], float a_off, float a_d
     }
     m.max_state_recorded = -1;
     m.tre_fused = (c->tre_fused && c->D == 1) ? 1u : 0u;
+    m.tre_hi_shift = 17u; m.tre_lo_shift = 20u;
+    if (const char* e = getenv("HML_TRE_REFIT_SHIFTS")) { unsigned a = 17, b = 20; if (sscanf(e, "%u,%u", &a, &b) == 2 && a < 32 && b < 32) { m.tre_hi_shift = a; m.tre_lo_shift = b; } }
     m.fwd_W0 = (uint32_t)c->fwdW;
     m.fwd_W = m.fwd_W_burnin = (uint32_t)std::max(c->fwdW, c->fwdW_init);
     m.fwd_burnin_sweeps = c->fwd_burnin_sweeps;
@@ -890,12 +905,16 @@ static int tre_candidates(const hml_ctx* c, uint32_t hint, uint32_t* out) {
         }
         return n;
     }
+    // (the hint is the last sweep's block count with a quarter of headroom - what the grids are sized for; the rounds are
+    // counted over the blocks themselves)
+    const uint32_t blocks = hint > 1024u ? (uint32_t)(((uint64_t)hint - 1024u) * 4u / 5u) : hint;
     for (uint32_t rounds = 1; rounds <= 8u && n < 6; ++rounds) {
         const double waves = 0.985 * (double)c->tre_slots * rounds;              // (a little air: one wavefront too many costs a round)
-        uint32_t l = (uint32_t)((double)hint / (64.0 * waves)) + 1u;
+        uint32_t l = (uint32_t)((double)blocks / (64.0 * waves)) + 1u;
         l = (l + 31u) / 32u * 32u;
         if (l < (uint32_t)HML_TRE_MIN_L) l = HML_TRE_MIN_L;
-        if (l > 512u) continue;                                                    // (refits of longer chunks cost more than their warm-up saves)
+        // (without checkpoints a refit walks its whole chunk: beyond 512 rows that costs more than the warm-up saves)
+        if (l > (c->tre_ckpt ? (uint32_t)HML_TRE_MAX_L : 512u)) continue;
         bool seen = false;
         for (int i = 0; i < n; ++i) seen = seen || out[i] == l;
         if (!seen) out[n++] = l;
@@ -1065,7 +1084,7 @@ static int sweep_k(hml_ctx* c, char method, bool record) {
         bool measure = false;
         if (c->tre_rows && c->tre_slots == 0) {   // wavefront slots of the first pass on this device (asked once)
             int per_cu = 0, cus = 0;
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, hml_k_trellis_rows<KK>, 64 * HML_TR2_WAVES, 0) == hipSuccess &&
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, hml_k_trellis_rows<KK, false>, 64 * HML_TR2_WAVES, 0) == hipSuccess &&
                 hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device) == hipSuccess && per_cu > 0 && cus > 0)
                 c->tre_slots = per_cu * cus * HML_TR2_WAVES;
             else { (void)hipGetLastError(); c->tre_slots = -1; }
@@ -1074,6 +1093,7 @@ static int sweep_k(hml_ctx* c, char method, bool record) {
         const uint32_t TL = tre_pick_L(c, hint, capst != hipStreamCaptureStatusNone, &measure);
         hipEvent_t tev0 = nullptr, tev1 = nullptr;
         if (measure) { tev0 = ev_get(c); tev1 = ev_get(c); hipEventRecord(tev0, s); }
+        if (c->graph_tre_L != TL && getenv("HML_TRELLIS_TUNE_DEBUG")) fprintf(stderr, "[trellis] chunk length %u for %u blocks (%d wavefront slots)\n", TL, hint, c->tre_slots);
         c->graph_tre_L = TL;
         const uint64_t tchunks = ((uint64_t)hint + TL - 1) / TL;
         const uint64_t tgroups = (tchunks + HML_TRE_NCH - 1) / HML_TRE_NCH;
@@ -1081,9 +1101,13 @@ static int sweep_k(hml_ctx* c, char method, bool record) {
         float* ap = c->probes ? c->d_aprobe : nullptr;
         {
             ProfScope ps(c, "trellis");
-            if (c->tre_rows)
-                hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_trellis_rows<KK>), dim3(grid_for(tgroups, HML_TR2_WAVES, 4, 1 << 20)), dim3(64 * HML_TR2_WAVES), 0, s,
-                                   c->d_ia, c->d_starts, c->d_mdl, c->d_mdl, c->d_bstat, c->d_smap, c->d_cmap, c->d_entry, c->d_exitA, c->d_fb, ep, ap, TL);
+            // (nearly every block a single position: the filter step shares the candidate maps' sums, hml_k_trellis_rows.h)
+            if (c->tre_rows && hint > 1024u && ((uint64_t)hint - 1024u) * 8u >= c->T * 9u)   // (last sweep's blocks >= 0.9 T; the hint carries 25 % headroom)
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_trellis_rows<KK, true>), dim3(grid_for(tgroups, HML_TR2_WAVES, 4, 1 << 20)), dim3(64 * HML_TR2_WAVES), 0, s,
+                                   c->d_ia, c->d_starts, c->d_mdl, c->d_mdl, c->d_bstat, c->d_smap, c->d_cmap, c->d_entry, c->d_exitA, c->d_fb, ep, ap, c->d_tre_ckpt, TL);
+            else if (c->tre_rows)
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_trellis_rows<KK, false>), dim3(grid_for(tgroups, HML_TR2_WAVES, 4, 1 << 20)), dim3(64 * HML_TR2_WAVES), 0, s,
+                                   c->d_ia, c->d_starts, c->d_mdl, c->d_mdl, c->d_bstat, c->d_smap, c->d_cmap, c->d_entry, c->d_exitA, c->d_fb, ep, ap, c->d_tre_ckpt, TL);
             else
             hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_trellis_tile<KK>), dim3(grid_for(tgroups, 1, 16, 1 << 20)), dim3(64), 0, s,
                                c->d_ia, c->d_starts, c->d_mdl, c->d_mdl, c->d_bstat, c->d_smap, c->d_cmap, c->d_entry, c->d_exitA, c->d_fb, ep, ap, TL);
@@ -1101,8 +1125,8 @@ static int sweep_k(hml_ctx* c, char method, bool record) {
             for (uint32_t round = 0; round < 4u; ++round, in_a ^= 1) {
                 uint32_t* lin = in_a ? c->d_redo : c->d_redo2;
                 uint32_t* lout = in_a ? c->d_redo2 : c->d_redo;
-                hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_trellis_refit<KK>), dim3(1024), dim3(64), 0, s, c->d_ia, c->d_starts, c->d_mdl, c->d_smap,
-                                   c->d_cmap, c->d_entry, c->d_exitA, c->d_fb, ep, ap, lin, in_a, TL);
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_trellis_refit<KK>), dim3(4096), dim3(64), 0, s, c->d_ia, c->d_starts, c->d_mdl, c->d_smap,
+                                   c->d_cmap, c->d_entry, c->d_exitA, c->d_fb, ep, ap, lin, in_a, (c->tre_rows && c->tre_ckpt) ? c->d_tre_ckpt : nullptr, TL);
                 hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_trellis_verify_list<KK>), dim3(64), dim3(256), 0, s, c->d_mdl, c->d_entry, c->d_exitA,
                                    lin, lout, c->d_touched, in_a, round, TL);
             }

@@ -64,6 +64,7 @@ struct hml_ctx {
     uint32_t* d_redo = nullptr;    // backward chunks that failed the forward verification (list for the repair step)
     uint32_t* d_redo2 = nullptr;   // second list of stale chunks and the bitmap of the sequential finisher (fused trellis path)
     uint32_t* d_tre_bitmap = nullptr;
+    uint32_t* d_tre_ckpt = nullptr;      // the first pass's forward vectors every 64 rows of a chunk (hml_k_trellis_rows.h): where a refit may stop
     bool late_rescale = true;      // strongly compressed univariate sweeps: no plane of rescale factors (HML_LATE_RESCALE=0: keep it)
     uint32_t tre_L = 0;            // its chunk length (0: chosen from the number of blocks, then by measurement; HML_TRELLIS_L, option "trellis_L")
     // The best chunk length depends on how the wavefronts of hml_k_trellis_tile (64 chunks each, resident for the whole
@@ -77,6 +78,8 @@ struct hml_ctx {
     uint64_t tre_dense_sweeps = 0; // fused-trellis sweeps of this chain so far
     uint32_t graph_tre_L = 0;      // chunk length of the captured sweep
     int tre_slots = 0;             // wavefronts of hml_k_trellis_rows the device holds at once (0: not asked yet, -1: unknown)
+    bool stage_bits = true;        // weakly compressed sweeps stage block-start FLAGS between scan and scatter (HML_STAGE_BITS=0: 16-bit offsets)
+    bool tre_ckpt = true;          // refits stop where they meet the first pass's checkpoint again (HML_TRELLIS_CKPT=0: always the whole chunk)
     bool tre_rows = true;          // its first pass is hml_k_trellis_rows (round 3); HML_TRELLIS_ROWS=0: hml_k_trellis_tile (round 2)
     bool tre_fused = true;         // weakly compressed FB sweeps take the fused trellis kernels (HML_TRELLIS_FUSED=0: the separate ones)
     uint32_t* d_touched = nullptr; // backward chunks whose rows the repair recomputed, tagged with the sweep

@@ -370,6 +370,134 @@ __global__ __launch_bounds__(256) void hml_k_compact_scatter(const uint16_t* __r
 
 
 // ------------------------------------------------------------------------------------------
+// K4 for weakly compressed input (most positions start a block): the scan stages FLAGS, not offsets.  With B ~ T the 16-bit
+// offsets above are 2 B per block written and read again; the flags of a span are 4096 bits = 64 words, whatever the
+// number of blocks: the 64 ballots of the scan (iteration it, component j -> word 4 it + j, bit l = position
+// 256 it + 4 l + j of the span), written as one 512-byte line.  The scatter kernel reads the line back, ranks the flags
+// with the same ballot arithmetic and hands the starts of 256 positions at a time to memory through a per-wavefront LDS
+// buffer, so that the stores are contiguous runs.  Same starts[] as the offset form, bit for bit (test_gpu_parity.py).
+// Reference: Blocks<BreakpointArray>::next, src/Blocks/BreakpointArray.hpp:216-235.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void hml_wave_lds_order() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+__global__ __launch_bounds__(256) void hml_k_compact_scan_bits(const float* __restrict__ w, uint32_t T,
+                                                               const hml_model* __restrict__ mdl, float thr_override,
+                                                               int use_override, unsigned long long* __restrict__ stage_bits,
+                                                               uint32_t* __restrict__ span_count) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint32_t span = blockIdx.x * 4u + (uint32_t)wave;
+    const uint64_t base = (uint64_t)span * HML_SPAN;
+    if (base >= T) return;
+    const float thr = use_override ? thr_override : mdl->thr;
+    uint32_t running = 0;
+    unsigned long long mine = 0ull;   // word `lane` of the span's 64
+    if (base + HML_SPAN <= T) {
+        hml_f4 v[16];
+        const hml_f4* __restrict__ p = reinterpret_cast<const hml_f4*>(w + base) + lane;
+#pragma unroll
+        for (int it = 0; it < 16; ++it) v[it] = __builtin_nontemporal_load(p + it * 64);
+#pragma unroll
+        for (int it = 0; it < 16; ++it) {
+            bool f0 = !(v[it].x < thr);
+            const bool f1 = !(v[it].y < thr), f2 = !(v[it].z < thr), f3 = !(v[it].w < thr);
+            if (span == 0 && it == 0 && lane == 0) f0 = true;   // position 0 always starts a block
+            const unsigned long long m0 = __ballot(f0), m1 = __ballot(f1), m2 = __ballot(f2), m3 = __ballot(f3);
+            mine = (lane == 4 * it) ? m0 : (lane == 4 * it + 1) ? m1 : (lane == 4 * it + 2) ? m2 : (lane == 4 * it + 3) ? m3 : mine;
+            running += __popcll(m0) + __popcll(m1) + __popcll(m2) + __popcll(m3);
+        }
+    } else {
+        for (int it = 0; it < 16; ++it) {
+            bool f[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint64_t t = base + (uint64_t)it * 256u + (uint64_t)lane * 4u + j;
+                f[j] = (t < T) ? (t == 0 || !(w[t] < thr)) : false;
+            }
+            const unsigned long long m0 = __ballot(f[0]), m1 = __ballot(f[1]), m2 = __ballot(f[2]), m3 = __ballot(f[3]);
+            mine = (lane == 4 * it) ? m0 : (lane == 4 * it + 1) ? m1 : (lane == 4 * it + 2) ? m2 : (lane == 4 * it + 3) ? m3 : mine;
+            running += __popcll(m0) + __popcll(m1) + __popcll(m2) + __popcll(m3);
+        }
+    }
+    stage_bits[(uint64_t)span * 64u + (uint32_t)lane] = mine;
+    if (lane == 0) span_count[span] = running;
+}
+
+__global__ __launch_bounds__(256) void hml_k_compact_scatter_bits(const unsigned long long* __restrict__ stage_bits,
+                                                                  const uint32_t* __restrict__ span_count,
+                                                                  const uint32_t* __restrict__ group_total, uint32_t n_spans,
+                                                                  uint32_t T, hml_model* __restrict__ mdl,
+                                                                  uint32_t* __restrict__ starts, uint32_t* __restrict__ host_B) {
+    static_assert(4 * HML_SUM_SPANS == HML_GROUP_SPANS && HML_GROUP_SPANS <= 64, "one workgroup per span group");
+    __shared__ uint32_t part[4];
+    __shared__ uint32_t buf[4][256];   // per wavefront: the starts of 256 positions, in order
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint32_t g = blockIdx.x;
+    const uint32_t first = g * HML_GROUP_SPANS;
+    uint32_t acc = 0u;
+    for (uint32_t i = threadIdx.x; i < g; i += 256u) acc += group_total[i];
+    const uint32_t cnt_l = ((uint32_t)lane < HML_GROUP_SPANS && first + (uint32_t)lane < n_spans) ? span_count[first + (uint32_t)lane] : 0u;
+    acc = hml_wave_sum_u32(acc);
+    if (lane == 0) part[wave] = acc;
+    __syncthreads();
+    const uint32_t before_group = part[0] + part[1] + part[2] + part[3];
+    uint32_t incl = cnt_l;
+#pragma unroll
+    for (int d = 1; d < HML_GROUP_SPANS; d <<= 1) {
+        const uint32_t o = __shfl_up(incl, d);
+        if (lane >= d) incl += o;
+    }
+    const uint32_t excl_l = before_group + incl - cnt_l;
+    uint32_t* const mybuf = buf[wave];
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    // the flag words of the wavefront's spans, all in flight
+    unsigned long long word[HML_SUM_SPANS];
+#pragma unroll
+    for (int k = 0; k < HML_SUM_SPANS; ++k) {
+        const uint32_t span = first + (uint32_t)wave * HML_SUM_SPANS + (uint32_t)k;
+        word[k] = (span < n_spans) ? stage_bits[(uint64_t)span * 64u + (uint32_t)lane] : 0ull;
+    }
+#pragma unroll
+    for (int k = 0; k < HML_SUM_SPANS; ++k) {
+        const uint32_t in_group = (uint32_t)wave * HML_SUM_SPANS + (uint32_t)k;
+        const uint32_t span = first + in_group;
+        if (span >= n_spans) break;   // wave-uniform
+        const uint32_t cnt = __shfl(cnt_l, (int)in_group);
+        const uint32_t off = __shfl(excl_l, (int)in_group);
+        const uint32_t base = span * (uint32_t)HML_SPAN;
+        const uint32_t wlo = (uint32_t)word[k], whi = (uint32_t)(word[k] >> 32);
+        uint32_t running = 0u;
+        for (int it = 0; it < 16; ++it) {   // wave-uniform
+            unsigned long long m[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                m[j] = ((unsigned long long)(uint32_t)__shfl((int)whi, 4 * it + j) << 32) | (unsigned long long)(uint32_t)__shfl((int)wlo, 4 * it + j);
+            const uint32_t n_it = (uint32_t)(__popcll(m[0]) + __popcll(m[1]) + __popcll(m[2]) + __popcll(m[3]));
+            if (n_it == 0u) continue;
+            uint32_t pos = (uint32_t)(__popcll(m[0] & lt) + __popcll(m[1] & lt) + __popcll(m[2] & lt) + __popcll(m[3] & lt));
+            const uint32_t t0 = base + (uint32_t)it * 256u + (uint32_t)lane * 4u;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if ((m[j] >> lane) & 1ull) mybuf[pos++] = t0 + (uint32_t)j;
+            hml_wave_lds_order();
+            for (uint32_t i = (uint32_t)lane; i < n_it; i += 64u) starts[off + running + i] = mybuf[i];
+            hml_wave_lds_order();
+            running += n_it;
+        }
+        if (span == n_spans - 1u && lane == 0) {
+            const uint32_t B = off + cnt;
+            mdl->B = B;
+            hml_warmup_for_many_blocks(mdl, B);
+            starts[B] = T;
+            if (host_B) __hip_atomic_store(host_B, B, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
+
+
+// ------------------------------------------------------------------------------------------
 // K5 block_stats - Statistics<IntegralArray,Normal>::addBlockStats / setStats (reference
 // src/Statistics/IntegralArray.hpp:104-124,198-212) with KahanAggregator (src/KahanAggregator.hpp:26-45):
 //   pos = Kahan(IA[start], IA[c] for every cell boundary c in (start,end));  neg = IA[end] unless

@@ -311,7 +311,7 @@ __device__ __forceinline__ void hml_b_params(hml_model* __restrict__ mdl, const 
                 // every block pays for the warm-up - so the warm-up follows the refit count down to a few per
                 // ten thousand chunks instead of insisting on none: +8 above B / 2^17 refits (or a sequential finish),
                 // -8 below B / 2^20
-                const unsigned long long hi = (unsigned long long)(mdl->B >> 17) + 16ull, lo = (unsigned long long)(mdl->B >> 20) + 2ull;
+                const unsigned long long hi = (unsigned long long)(mdl->B >> mdl->tre_hi_shift) + 16ull, lo = (unsigned long long)(mdl->B >> mdl->tre_lo_shift) + 2ull;
                 if (serial != 0ull || refits > hi) W = (W + 8u < 64u) ? W + 8u : 64u;
                 else if (refits < lo) W = (W > 16u) ? W - 8u : 8u;
                 if (W > 64u) W = 64u;

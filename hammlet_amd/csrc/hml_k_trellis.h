@@ -413,9 +413,11 @@ __global__ __launch_bounds__(64) void hml_k_trellis_refit(const float2* __restri
                                                           unsigned long long* __restrict__ fmap, float* __restrict__ entry,
                                                           float* __restrict__ exitv, uint32_t* __restrict__ fb_count,
                                                           float* __restrict__ eprobe, float* __restrict__ aprobe,
-                                                          const uint32_t* __restrict__ list, int list_is_a, uint32_t L) {
+                                                          const uint32_t* __restrict__ list, int list_is_a,
+                                                          uint32_t* __restrict__ ckpt, uint32_t L) {
     __shared__ float sm_e[K * 65];
     __shared__ unsigned long long sm_m[64];
+    __shared__ uint32_t sm_met[2];   // lane 0 met the checkpoint again | the fallbacks the old rows had counted up to it
     const uint32_t n = list_is_a ? mdl->fwd_mismatch : mdl->fwd_mismatch2;
     if (blockIdx.x == 0 && threadIdx.x == 0) {   // the other list is written next (hml_k_trellis_verify_list): empty it
         if (list_is_a) mdl->fwd_mismatch2 = 0u; else mdl->fwd_mismatch = 0u;
@@ -429,6 +431,7 @@ __global__ __launch_bounds__(64) void hml_k_trellis_refit(const float2* __restri
     hml_fwd_ctx<K> cx;
     hml_fwd_ctx_load<K>(cx, mdl, sm_A);
     const uint32_t B = cx.B;
+    const uint32_t C = (B + L - 1u) / L;
     const uint32_t Wt = hml_tre_warmup(mdl);
     const unsigned long long epoch = mdl->epoch;
     const hml_key key = mdl->key;
@@ -446,6 +449,7 @@ __global__ __launch_bounds__(64) void hml_k_trellis_refit(const float2* __restri
         }
         uint32_t nfb = 0u;
         unsigned long long m = HML_MAP_IDENTITY;
+        bool stopped = false;
         for (uint32_t bb = first; bb < last; bb += 64u) {
             const uint32_t b = bb + (uint32_t)lane;
             uint32_t nb = 0u;
@@ -474,6 +478,24 @@ __global__ __launch_bounds__(64) void hml_k_trellis_refit(const float2* __restri
                         if (aprobe) aprobe[(uint64_t)(bb + l + 1u) * K + s] = alpha[s];
                     }
                 }
+                // The first pass left its forward vector after every 64 rows of the chunk (hml_k_trellis_rows).  Where the
+                // refitted filter meets it again, bit for bit, every later row of the chunk - emission terms, filter,
+                // uniforms, candidate maps - is what it was: the refit stops there.  (A filter that started a few rows
+                // too early to have forgotten its start has nearly always done so 64 rows later.)
+                uint32_t met = 0u, old_nfb = 0u;
+                if (ckpt && bb + 64u < last) {
+                    uint32_t* const ck = ckpt + (uint64_t)((bb - first) / 64u) * (uint32_t)(K + 1) * C + f;
+                    met = 1u;
+#pragma unroll
+                    for (int s = 0; s < K; ++s) {
+                        if (ck[(uint64_t)s * C] != hml_f2u(alpha[s])) met = 0u;
+                        ck[(uint64_t)s * C] = hml_f2u(alpha[s]);
+                    }
+                    old_nfb = ck[(uint64_t)K * C];
+                    ck[(uint64_t)K * C] = nfb;
+                }
+                sm_met[0] = met;
+                sm_met[1] = old_nfb;
             }
             __syncthreads();
             if (b < last) {
@@ -492,12 +514,33 @@ __global__ __launch_bounds__(64) void hml_k_trellis_refit(const float2* __restri
             __syncthreads();
             if (lane == 0)
                 for (uint32_t l = 0; l < 64u && bb + l < last; ++l) m = hml_map_compose<K>(m, sm_m[l]);
+            const bool met = sm_met[0] != 0u;
             __syncthreads();
+            if (met) {   // workgroup-uniform
+                // the rest of the chunk stands: its maps (in memory) complete the chunk map, its end vector and the fallbacks
+                // counted behind the checkpoint stay
+                for (uint32_t b2 = bb + 64u; b2 < last; b2 += 64u) {
+                    const uint32_t b = b2 + (uint32_t)lane;
+                    unsigned long long mp = (b < last) ? hml_tre_load_cand<K>(cand, (uint64_t)b + 1u) : HML_MAP_IDENTITY;
+#pragma unroll
+                    for (int d = 1; d < 64; d <<= 1) {
+                        unsigned long long o = hml_shfl_down_u64(mp, d);
+                        if (lane + d >= 64) o = HML_MAP_IDENTITY;
+                        mp = hml_map_compose<K>(mp, o);
+                    }
+                    m = hml_map_compose<K>(m, mp);   // (lane 0 holds the product of the 64 maps in row order)
+                }
+                stopped = true;
+                break;
+            }
         }
         if (lane == 0) {
             fmap[f] = m;
+            if (stopped) nfb += fb_count[f] - sm_met[1];
+            else {
 #pragma unroll
-            for (int s = 0; s < K; ++s) exitv[(uint64_t)f * K + s] = alpha[s];
+                for (int s = 0; s < K; ++s) exitv[(uint64_t)f * K + s] = alpha[s];
+            }
             const uint32_t old = fb_count[f];
             fb_count[f] = nfb;
             if (nfb != old) atomicAdd(&mdl->uniform_fallbacks, (unsigned long long)(long long)((int)nfb - (int)old));
@@ -641,28 +684,36 @@ __global__ __launch_bounds__(64) void hml_k_trellis_states(const unsigned long l
         }
         const uint64_t first = (uint64_t)f * L;
         const uint64_t last = active ? ((first + L < B) ? first + L : (uint64_t)B) : first;
-        for (int rel0 = (int)L - RB; rel0 >= 0; rel0 -= RB) {   // batches from the chunks' ends down (L is a multiple of 32)
-            // lane = (chunk, row): half a wavefront reads one chunk's 32 consecutive maps; all 32 loads of a lane in flight
-            map_t v[RB];
+        // lane = (chunk, row): half a wavefront reads one chunk's 32 consecutive maps; all 32 loads of a lane in flight, and the
+        // NEXT batch's loads are issued before the current batch is walked (the walk and the stores hide their latency)
+        auto fetch = [&](int rel0, map_t (&v)[RB]) {
 #pragma unroll
             for (int k = 0; k < RB; ++k) {
                 const int slot = k * 64 + lane;
                 const int c = slot / RB, r = slot % RB;
                 const uint64_t b = (uint64_t)(f0 + (uint32_t)c) * L + (uint32_t)rel0 + (uint32_t)r;   // row t = b + 1
-                v[k] = (f0 + (uint32_t)c < NC && b < B) ? cm[b + 1u] : (map_t)0;
+                v[k] = (rel0 >= 0 && f0 + (uint32_t)c < NC && b < B) ? cm[b + 1u] : (map_t)0;
             }
+        };
+        map_t v[RB];
+        fetch((int)L - RB, v);
+        for (int rel0 = (int)L - RB; rel0 >= 0; rel0 -= RB) {   // batches from the chunks' ends down (L is a multiple of 32)
 #pragma unroll
             for (int k = 0; k < RB; ++k) {
                 const int slot = k * 64 + lane;
                 sm_m[(slot / RB) * PITCH + (slot % RB)] = v[k];
             }
             __syncthreads();
+            fetch(rel0 - RB, v);
             if (active) {
+                map_t mine[RB];
+#pragma unroll
+                for (int r = 0; r < RB; ++r) mine[r] = sm_m[lane * PITCH + r];
+#pragma unroll
                 for (int r = RB - 1; r >= 0; --r) {
                     const uint64_t b = first + (uint32_t)rel0 + (uint32_t)r;
-                    if (b >= last) continue;
-                    x = (unsigned)(((unsigned long long)sm_m[lane * PITCH + r] >> (4u * x)) & 15ull);   // q_t = cand_t(q_{t+1})
-                    sm_q[lane * (RB + 2) + r] = (int16_t)x;
+                    if (b < last) x = (unsigned)(((unsigned long long)mine[r] >> (4u * x)) & 15ull);   // q_t = cand_t(q_{t+1})
+                    sm_q[lane * (RB + 2) + r] = (int16_t)x;   // (rows beyond the chunk's end are not stored below)
                 }
             }
             __syncthreads();

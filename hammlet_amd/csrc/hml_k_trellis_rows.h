@@ -173,7 +173,8 @@ __device__ __forceinline__ void hml_tr2_energies_literal(const hml_model* __rest
 // NaN) or when the row holds a negative sign (the count form and ForwardBackward.hpp:147-149 both need the literal form
 // then): the caller takes hml_tre_cand_u, which agrees with this function wherever `unsure` stays clear.
 template <int K>
-__device__ __forceinline__ typename hml_tre_map<K>::stored hml_tr2_maps(const float (&row)[K], const hml_amat<K>& A, float uf, bool& unsure) {
+__device__ __forceinline__ typename hml_tre_map<K>::stored hml_tr2_maps(const float (&row)[K], const hml_amat<K>& A, float uf, bool& unsure,
+                                                                        float (&total)[K]) {
     typedef typename hml_tre_map<K>::stored map_t;
     map_t map = 0;
     uint32_t sign = 0u;
@@ -186,6 +187,7 @@ __device__ __forceinline__ typename hml_tre_map<K>::stored hml_tr2_maps(const fl
         float acc = 0.0f;
 #pragma unroll
         for (int i = 0; i < K; ++i) { acc += row[i] * A[i * K + x]; s[i] = acc; }
+        total[x] = acc;   // sum_i row_i A(i, x), added in index order: what the next filter step forms from this row (hml_tr2_step)
         const float t = uf * acc;
         const float margin = acc * 7.62939453125e-06f;   // 2^-17
         bad = bad || !(acc > 7.888609052210118e-31f) || !(acc < 3.4028234663852886e38f);   // 2^-100 < sum < inf
@@ -236,16 +238,22 @@ __device__ __forceinline__ float hml_tr2_quotient(float f, double Zd, double r) 
 }
 
 // one step of the recursion (hml_fwd_step) with the five quotients taken through one reciprocal
+// (pred_j = sum_i alpha_i A(i, j) in index order - hml_tr2_predict, or the totals hml_tr2_maps formed from the same row)
 template <int K>
-__device__ __forceinline__ bool hml_tr2_step(const hml_fwd_ctx<K>& cx, float (&alpha)[K], const float (&e)[K]) {
-    float f[K];
+__device__ __forceinline__ void hml_tr2_predict(const hml_fwd_ctx<K>& cx, const float (&alpha)[K], float (&pred)[K]) {
 #pragma unroll
     for (int j = 0; j < K; ++j) {
         float tt = 0.0f;
 #pragma unroll
         for (int i = 0; i < K; ++i) tt += alpha[i] * cx.A[i * K + j];
-        f[j] = e[j] * tt;
+        pred[j] = tt;
     }
+}
+template <int K>
+__device__ __forceinline__ bool hml_tr2_step(const hml_fwd_ctx<K>& cx, float (&alpha)[K], const float (&e)[K], const float (&pred)[K]) {
+    float f[K];
+#pragma unroll
+    for (int j = 0; j < K; ++j) f[j] = e[j] * pred[j];
     float Z = 0.0f;
 #pragma unroll
     for (int j = 0; j < K; ++j) Z += f[j];
@@ -262,12 +270,14 @@ __device__ __forceinline__ bool hml_tr2_step(const hml_fwd_ctx<K>& cx, float (&a
     return false;
 }
 
-template <int K>
+// SHARE (the host's choice for sweeps over nearly uncompressed input, results the same): see `pred` below
+template <int K, bool SHARE>
 __global__ __launch_bounds__(64 * HML_TR2_WAVES) __attribute__((amdgpu_waves_per_eu(K <= 8 ? HML_TR2_WPE : 1, K <= 8 ? HML_TR2_WPE : 8)))
 void hml_k_trellis_rows(const float2* __restrict__ ia, const uint32_t* __restrict__ starts, hml_model* __restrict__ mdl,
                         const hml_model* __restrict__ mdl_ro, float2* __restrict__ bstat, unsigned long long* __restrict__ cand,
                         unsigned long long* __restrict__ fmap, float* __restrict__ entry, float* __restrict__ exitv,
-                        uint32_t* __restrict__ fb_count, float* __restrict__ eprobe, float* __restrict__ aprobe, uint32_t L) {
+                        uint32_t* __restrict__ fb_count, float* __restrict__ eprobe, float* __restrict__ aprobe,
+                        uint32_t* __restrict__ ckpt, uint32_t L) {
     constexpr int R = HML_TR2_R, SLOTW = hml_tr2<K>::SLOTW, PITCH = hml_tr2<K>::PITCH, SX = hml_tr2<K>::SX;
     typedef typename hml_tre_map<K>::stored map_t;
     static_assert(R % 2 == 0 && HML_TRE_MIN_L % R == 0 && HML_TRE_HALO % R == 0, "row pairs share a Philox block; chunks and warm-ups are whole batches");
@@ -312,6 +322,14 @@ void hml_k_trellis_rows(const float2* __restrict__ ia, const uint32_t* __restric
         for (int s = 0; s < K; ++s) alpha[s] = (ws == 0ll) ? mdl_ro->pi[s] : cx.invK;
         uint32_t nfb = 0u;
         map_t cmap = (map_t)HML_MAP_IDENTITY;
+        // The candidate maps of a row and the filter step of the next row both start from sum_i alpha_i A(i, x), added in
+        // index order: where the row went into its maps unrescaled (every block of the wavefront's rows a single position -
+        // uncompressed input), the step takes the maps' totals instead of forming the K x K products again (SHARE; on
+        // compressed input some lane nearly always holds a longer block, and the bookkeeping would only cost).
+        float pred[K];
+        bool pred_ok = false;   // pred[] holds the totals of this lane's previous row
+#pragma unroll
+        for (int s = 0; s < K; ++s) pred[s] = 0.0f;
         for (int rel0 = -Wr; rel0 < (int)L; rel0 += R) {   // wave-uniform
             // ---------------- in: 64 chunks x 16 rows -> (N, Sx, Sxx) in the tile; two halves of 8 slots, each with its
             // block starts, then its integral-array gathers, in flight together (no branch in between: slots without a
@@ -410,7 +428,11 @@ void hml_k_trellis_rows(const float2* __restrict__ ia, const uint32_t* __restric
 #pragma unroll
                         for (int s = 0; s < K; ++s) alpha[s] = 0.5f * alpha[s] + 0.1f * e[s];
                     } else
-                    fb = hml_tr2_step<K>(cx, alpha, e);
+                    {
+                        if (!SHARE || __ballot(!pred_ok) != 0ull) hml_tr2_predict<K>(cx, alpha, pred);   // (the same values where pred_ok holds)
+                        fb = hml_tr2_step<K>(cx, alpha, e, pred);
+                        pred_ok = false;
+                    }
                     if (rel0 >= 0) {
                         if (fb) nfb++;
                         const uint32_t t = b + 1u;
@@ -426,7 +448,9 @@ void hml_k_trellis_rows(const float2* __restrict__ ia, const uint32_t* __restric
                         for (int s = 0; s < K; ++s) row[s] = alpha[s];
                         // the reference rescales row t < B after step t + 1 has consumed it (ForwardBackward.hpp:115-119); blocks of
                         // one position have the factor expf(0) = 1, and a wavefront that holds nothing else skips the step
+                        bool rescaled = false;   // wave-uniform
                         if (self && __ballot(nb != 1u && t < B) != 0ull) {
+                            rescaled = true;
                             if (t < B) {
 #pragma unroll
                                 for (int s = 0; s < K; ++s)
@@ -436,7 +460,15 @@ void hml_k_trellis_rows(const float2* __restrict__ ia, const uint32_t* __restric
                         bool unsure = false;
                         map_t cm;
                         if (HML_TR2_SKIP & 8) cm = (map_t)(hml_f2u(row[0]) ^ hml_f2u(row[1]) ^ hml_f2u((float)u)) & (map_t)0x11111u;
-                        else cm = hml_tr2_maps<K>(row, cx.A, (float)u, unsure);
+                        else {
+                            float total[K];
+                            cm = hml_tr2_maps<K>(row, cx.A, (float)u, unsure, total);
+                            if (SHARE && !rescaled) {
+#pragma unroll
+                                for (int s = 0; s < K; ++s) pred[s] = total[s];
+                                pred_ok = true;
+                            }
+                        }
                         if (__builtin_expect(unsure || t >= B, 0)) cm = (map_t)hml_tre_cand_u<K>(row, cx.A, mdl, t, B, u);   // (also the last row's constant map)
                         uint32_t* const w = tile + lane * PITCH + r * SLOTW;
                         w[0] = (uint32_t)cm;
@@ -444,6 +476,15 @@ void hml_k_trellis_rows(const float2* __restrict__ ia, const uint32_t* __restric
                         if (HML_TR2_SKIP & 32) cmap ^= cm; else
                         cmap = hml_tr2_compose<K>(cmap, cm);
                     }
+                }
+                // a checkpoint every 64 rows inside the chunk: the forward vector (and the fallbacks so far) a refit of this
+                // chunk compares with - from where it meets them again, bit for bit, the rest of the chunk stands
+                // (hml_k_trellis_refit).  Plane-major, the chunk fastest: consecutive lanes write consecutive words.
+                if (rel0 >= 0 && ((rel0 + R) & 63) == 0 && rel0 + R < (int)L) {   // wave-uniform
+                    uint32_t* const ck = ckpt + (uint64_t)((uint32_t)(rel0 + R) / 64u - 1u) * (uint32_t)(K + 1) * C + f;
+#pragma unroll
+                    for (int s = 0; s < K; ++s) ck[(uint64_t)s * C] = hml_f2u(alpha[s]);
+                    ck[(uint64_t)K * C] = nfb;
                 }
             }
             hml_wave_lds_fence();

@@ -103,6 +103,7 @@ struct hml_model {
     uint32_t fwd_quiet_need;     // sweeps without a single refit before the warm-up shrinks by a quarter (HML_FWD_QUIET)
     uint32_t tre_fused;          // weakly compressed FB sweeps take the fused trellis kernels (hml_k_trellis.h): stale chunks are
                                  // refitted in parallel there, so the warm-up follows a different rule (hml_k_params)
+    uint32_t tre_hi_shift, tre_lo_shift;   // ... the warm-up grows above B >> hi refits per sweep and shrinks below B >> lo
     unsigned long long fwd_refits_seen, fwd_serial_seen;
     unsigned long long dbg_t[12];   // wall_clock64 stamps of the parameter kernel's stages (printed by hml_sync with HML_PARAMS_DEBUG)
 };

@@ -687,18 +687,22 @@ def test_fused_block_kernel_retires_itself_after_an_expired_wait(hml, monkeypatc
     assert g.profile_get("blocks_scatter")[1] >= 10
 
 
-@pytest.mark.parametrize("chunk,fused", [(32, 1), (96, 1), (128, 1), (256, 1), (512, 1), (32, 0), (96, 2)])
+@pytest.mark.parametrize("chunk,fused", [(32, 1), (96, 1), (128, 1), (256, 1), (512, 1), (1024, 1), (32, 0), (96, 2), (256, 3)])
 def test_fused_trellis_repair_paths_on_twin_states(hml, monkeypatch, chunk, fused):
     """The fused trellis kernels of weakly compressed sweeps (hml_k_trellis.h; HML_TRELLIS_FUSED=0 runs the separate
     kernels for comparison) on the adversarial twin-state parameters: an uncompressed trace on which the filter hardly
     forgets, so most chunks are stale after the first pass, the parallel refits run four rounds and the sequential
     finisher walks long chains - and forward rows, states and parameters must still be the checker's, bit for bit, for
-    every chunk length."""
+    every chunk length.  (Round 3: refits stop where they meet the first pass's checkpoint again, the filter step shares
+    the candidate maps' sums on uncompressed input, the scan stages flags - all on by default here.)"""
     monkeypatch.setenv("HML_DENSE_MIN_BLOCKS", "1")
     monkeypatch.setenv("HML_TRELLIS_L", str(chunk))
     monkeypatch.setenv("HML_TRELLIS_FUSED", "1" if fused else "0")
     if fused == 2:
         monkeypatch.setenv("HML_TRELLIS_ROWS", "0")     # round 2's first pass (hml_k_trellis_tile), kept for comparison
+    if fused == 3:
+        monkeypatch.setenv("HML_TRELLIS_CKPT", "0")     # refits walk their whole chunk (no checkpoints to stop at) ...
+        monkeypatch.setenv("HML_STAGE_BITS", "0")       # ... and the block scan stages 16-bit offsets, as in rounds 1-2
     T, K = 300_000, 3
     x = ol.trace(T, 3, 1)
     xx, o, g = make_pair(hml, T, K, 0, 1, x=x, weight_mult=1e9)
@@ -731,6 +735,34 @@ def test_fused_trellis_repair_paths_on_twin_states(hml, monkeypatch, chunk, fuse
     compare_state(o, g)
     seg, cnt = g.marginals_rle()
     assert hml.marginals_text(seg, cnt) == o.text("marginals")
+
+
+@pytest.mark.parametrize("chunk,ckpt", [(256, 1), (96, 1), (1024, 1), (256, 0)])
+def test_refits_on_ordinary_parameters_stop_at_the_checkpoints(hml, monkeypatch, chunk, ckpt):
+    """A short warm-up (8 rows) on an ordinary uncompressed trace: many chunks fail verification, and their refits meet
+    the first pass's forward vector again within a few dozen rows - where they stop (hml_k_trellis_refit, checkpoints every
+    64 rows; HML_TRELLIS_CKPT=0 walks the whole chunk).  Forward rows, states, parameters: the checker's, bit for bit."""
+    monkeypatch.setenv("HML_DENSE_MIN_BLOCKS", "1")
+    monkeypatch.setenv("HML_TRELLIS_L", str(chunk))
+    monkeypatch.setenv("HML_TRELLIS_CKPT", str(ckpt))
+    monkeypatch.setenv("HML_FWD_WARMUP", "8")
+    T, K = 600_000, 4
+    xx, o, g = make_pair(hml, T, K, 5, 3, weight_mult=1e9)
+    setup_model(o, g, K)
+    o.token("F")
+    g.sample_prior()
+    o.set_probes(True)
+    g.enable_probes(True)
+    s0 = g.stats()
+    for _ in range(3):
+        o.iterate("F", 1, 0)
+        g.iterate("F", 1, 0)
+        g.sync()
+        assert np.array_equal(bits(o.forward_rows()), bits(g.forward_rows()))
+        assert np.array_equal(o.states(), g.states())
+    compare_state(o, g)
+    s1 = g.stats()
+    assert s1["forward_refits"] - s0["forward_refits"] >= 10
 
 
 def test_trellis_chunk_length_is_measured_and_changes_nothing(hml, monkeypatch, capfd):
