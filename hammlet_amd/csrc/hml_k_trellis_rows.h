@@ -133,23 +133,37 @@ template <int K>
 __device__ __forceinline__ bool hml_tr2_energies(const hml_tr2_params<K>& p, bool self, float sx, float sq, float N, float (&E)[K]) {
     const double sxd = (double)sx, sqd = (double)sq;
     const float N1 = N - 1.0f;
-    bool flagged = false;
+    // per state: the distance of the double's low 29 bits from a float midpoint, and of its exponent from the safe range;
+    // their minimum / maximum over the states are tested once (one comparison each instead of three per state)
+    uint32_t near_min = 0xffffffffu, ex_max = 0u;
 #pragma unroll
     for (int s = 0; s < K; ++s) {
         const double num = p.mu2[s] * sxd - sqd;
         const double ipd = num * p.rvar[s];
         const uint64_t bits = hml_d2u(ipd);
-        const uint32_t low = (uint32_t)bits & 0x1fffffffu;
-        const uint32_t ex = (uint32_t)(bits >> 52) & 0x7ffu;
-        const bool close = (low - 0x0ffffffcu) <= 8u;                       // within 4 ulp of a float midpoint
-        const bool outside = (ex - 923u) > 227u;                           // |ip| < 2^-100, > 2^127, inf / NaN, or 0
-        flagged = flagged || close || (outside && ipd != 0.0);
+        const uint32_t low = ((uint32_t)bits & 0x1fffffffu) - 0x0ffffffcu;             // <= 8: within 4 ulp of a float midpoint
+        const uint32_t ex = ((uint32_t)(bits >> 32) & 0x7ff00000u) - (923u << 20);      // > 227 << 20 (+ mantissa bits: masked off): |ip| < 2^-100, > 2^127, inf / NaN, or 0
+        near_min = (low < near_min) ? low : near_min;
+        ex_max = (ex > ex_max) ? ex : ex_max;
         const float ip = (float)ipd;
         float e = (0.0f + ip) - N * p.logN[s];
         if (self) e += N1 * p.logA[s];
         E[s] = e;
     }
-    return flagged;
+    // (a product that is exactly zero is outside the exponent range but exact: such blocks - zero coverage - are looked at
+    // state by state in the rare branch only)
+    if (__builtin_expect(near_min <= 8u || ex_max > (227u << 20), 0)) {
+        if (near_min <= 8u) return true;
+        bool flagged = false;
+#pragma unroll
+        for (int s = 0; s < K; ++s) {
+            const double ipd = (p.mu2[s] * sxd - sqd) * p.rvar[s];
+            const uint32_t ex = (uint32_t)(hml_d2u(ipd) >> 52) & 0x7ffu;
+            flagged = flagged || (((ex - 923u) > 227u) && ipd != 0.0);
+        }
+        return flagged;
+    }
+    return false;
 }
 
 // the same terms literally (hml_inner_product divides where it must and "not finite" is raised, EFD.hpp:23-33)
@@ -181,8 +195,14 @@ __device__ __forceinline__ typename hml_tre_map<K>::stored hml_tr2_maps(const fl
 #pragma unroll
     for (int s = 0; s < K; ++s) sign |= hml_f2u(row[s]);
     bool bad = (sign >> 31) != 0u;
+    // the number of negative differences is the number of set sign bits: each difference shifts its sign into a code word
+    // (one v_alignbit instead of a comparison and an add-with-carry), and the count is the word's population count - taken
+    // for all successor states at once where K - 1 <= 4 signs fit a nibble (K <= 5), per successor state beyond.
+    // (A NaN difference has an arbitrary sign: `bad` is set for it below.)
+    uint32_t code_all = 0u;
 #pragma unroll
-    for (int x = 0; x < K; ++x) {
+    for (int xx = 0; xx < K; ++xx) {
+        const int x = K - 1 - xx;   // (the last successor state first: its nibble ends up on top)
         float s[K];
         float acc = 0.0f;
 #pragma unroll
@@ -191,14 +211,22 @@ __device__ __forceinline__ typename hml_tre_map<K>::stored hml_tr2_maps(const fl
         const float t = uf * acc;
         const float margin = acc * 7.62939453125e-06f;   // 2^-17
         bad = bad || !(acc > 7.888609052210118e-31f) || !(acc < 3.4028234663852886e38f);   // 2^-100 < sum < inf
-        uint32_t res = 0u;
+        uint32_t code = (K == 5) ? code_all : 0u;   // (K = 5: four signs per successor state, the nibbles line up by themselves)
 #pragma unroll
         for (int i = 0; i < K - 1; ++i) {
             const float d = s[i] - t;
             bad = bad || !(__builtin_fabsf(d) > margin);
-            res += (d < 0.0f) ? 1u : 0u;
+            code = __builtin_amdgcn_alignbit(code, hml_f2u(d), 31);   // (code << 1) | sign(d)
         }
-        map |= (map_t)res << (4 * x);
+        if (K == 5) code_all = code;
+        else if (K < 5) code_all = (code_all << 4) | code;
+        else map |= (map_t)(uint32_t)__builtin_popcount(code) << (4 * x);
+    }
+    if (K <= 5) {
+        // population count of every nibble
+        uint32_t c = code_all - ((code_all >> 1) & 0x55555555u);
+        c = (c & 0x33333333u) + ((c >> 2) & 0x33333333u);
+        map = (map_t)c;
     }
     unsure = bad;
     return map;

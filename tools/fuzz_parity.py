@@ -31,7 +31,13 @@ for it in range(n_cfg):
     os.environ["HML_FWD_CHUNK_DENSE"] = str(int(rng.choice([8, 16, 32])))
     # round 2's switches: fused trellis path and its chunk length, late rescale, forward chunk length
     os.environ["HML_TRELLIS_FUSED"] = str(int(rng.choice([1, 1, 1, 0])))
-    os.environ["HML_TRELLIS_L"] = str(int(rng.choice([0, 32, 64, 96, 160, 256])))
+    os.environ["HML_TRELLIS_L"] = str(int(rng.choice([0, 32, 64, 96, 160, 256, 544, 1024])))
+    # round 3's switches: first pass (rows | tile), checkpointed refits, flag staging of the dense scan, a short warm-up
+    os.environ["HML_TRELLIS_ROWS"] = str(int(rng.choice([1, 1, 1, 0])))
+    os.environ["HML_TRELLIS_CKPT"] = str(int(rng.choice([1, 1, 0])))
+    os.environ["HML_STAGE_BITS"] = str(int(rng.choice([1, 1, 0])))
+    if rng.random() < 0.3: os.environ["HML_FWD_WARMUP"] = str(int(rng.choice([4, 8, 16])))
+    else: os.environ.pop("HML_FWD_WARMUP", None)
     os.environ["HML_LATE_RESCALE"] = str(int(rng.choice([1, 1, 0])))
     os.environ["HML_FWD_CHUNK"] = str(int(rng.choice([4, 4, 1, 2, 8])))
     seed = int(rng.integers(0, 1 << 30))
