@@ -194,11 +194,14 @@ __device__ __forceinline__ typename hml_tre_map<K>::stored hml_tr2_maps(const fl
     uint32_t sign = 0u;
 #pragma unroll
     for (int s = 0; s < K; ++s) sign |= hml_f2u(row[s]);
-    bool bad = (sign >> 31) != 0u;
-    // the number of negative differences is the number of set sign bits: each difference shifts its sign into a code word
+    // The number of negative differences is the number of set sign bits: each difference shifts its sign into a code word
     // (one v_alignbit instead of a comparison and an add-with-carry), and the count is the word's population count - taken
     // for all successor states at once where K - 1 <= 4 signs fit a nibble (K <= 5), per successor state beyond.
-    // (A NaN difference has an arbitrary sign: `bad` is set for it below.)
+    // The doubts are gathered as NUMBERS, not as booleans (a chain of `bad = bad || ...` over 4 K comparisons is compiled
+    // into three or four vector instructions per comparison that build the flags bit by bit): `worst` is the smallest
+    // |difference| - margin (a close call somewhere if not positive), `lowest` the smallest sum, `sums` their sum (a NaN or
+    // an infinite sum makes it one: minima skip NaNs, sums do not) - three comparisons per row decide.
+    float worst = 3.4028234663852886e38f, lowest = 3.4028234663852886e38f, sums = 0.0f;
     uint32_t code_all = 0u;
 #pragma unroll
     for (int xx = 0; xx < K; ++xx) {
@@ -210,14 +213,17 @@ __device__ __forceinline__ typename hml_tre_map<K>::stored hml_tr2_maps(const fl
         total[x] = acc;   // sum_i row_i A(i, x), added in index order: what the next filter step forms from this row (hml_tr2_step)
         const float t = uf * acc;
         const float margin = acc * 7.62939453125e-06f;   // 2^-17
-        bad = bad || !(acc > 7.888609052210118e-31f) || !(acc < 3.4028234663852886e38f);   // 2^-100 < sum < inf
+        lowest = __builtin_fminf(lowest, acc);
+        sums += acc;
         uint32_t code = (K == 5) ? code_all : 0u;   // (K = 5: four signs per successor state, the nibbles line up by themselves)
+        float nearest = 3.4028234663852886e38f;
 #pragma unroll
         for (int i = 0; i < K - 1; ++i) {
             const float d = s[i] - t;
-            bad = bad || !(__builtin_fabsf(d) > margin);
+            nearest = __builtin_fminf(nearest, __builtin_fabsf(d));
             code = __builtin_amdgcn_alignbit(code, hml_f2u(d), 31);   // (code << 1) | sign(d)
         }
+        worst = __builtin_fminf(worst, nearest - margin);
         if (K == 5) code_all = code;
         else if (K < 5) code_all = (code_all << 4) | code;
         else map |= (map_t)(uint32_t)__builtin_popcount(code) << (4 * x);
@@ -228,7 +234,8 @@ __device__ __forceinline__ typename hml_tre_map<K>::stored hml_tr2_maps(const fl
         c = (c & 0x33333333u) + ((c >> 2) & 0x33333333u);
         map = (map_t)c;
     }
-    unsure = bad;
+    // a negative sign in the row | a close call | a sum that is tiny | a sum that is not finite (2^-100 < sum < FLT_MAX each)
+    unsure = ((sign >> 31) != 0u) | !(worst > 0.0f) | !(lowest > 7.888609052210118e-31f) | !(sums < 3.4028234663852886e38f);
     return map;
 }
 
