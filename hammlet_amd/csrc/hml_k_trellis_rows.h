@@ -93,7 +93,7 @@ __device__ __forceinline__ void hml_tr2_params_fill(hml_tr2_params<K>& p, const 
         p.mu2[tid] = 2.0 * (double)mdl_ro->mu[tid];
         p.rvar[tid] = mdl_ro->rvar2[tid];
         p.logN[tid] = mdl_ro->logN[tid];
-        p.logA[tid] = mdl_ro->logA[tid];
+        p.logA[tid] = mdl_ro->self_trans ? mdl_ro->logA[tid] : 0.0f;   // (no self-transition term: (N - 1) * 0 = +0 leaves E as it is)
     }
 }
 
@@ -102,7 +102,7 @@ __device__ __forceinline__ void hml_tr2_params_fill(hml_tr2_params<K>& p, const 
 // the smallest float, which rounds to the same 0.  NOT for a NaN (the clamp would swallow it): the caller looks for one
 // among the arguments of a block and takes hml_expf_tab then.
 __device__ __forceinline__ float hml_tr2_expf_nonpos(float x, const uint64_t* tab) {
-    const float xc = __builtin_fmaxf(x, -104.0f);
+    const float xc = __builtin_amdgcn_fmed3f(x, -104.0f, 0.0f);   // max(x, -104) for x <= 0 in one instruction (no canonicalising copy)
     const double xd = (double)xc;
     const double InvLn2N = 0x1.71547652b82fep+0 * 32.0;
     const double Shift = 0x1.8p52;
@@ -114,10 +114,12 @@ __device__ __forceinline__ float hml_tr2_expf_nonpos(float x, const uint64_t* ta
     const uint32_t ki = (uint32_t)hml_d2u(kd);   // (the table index and the exponent adjustment only take its low 17 bits)
     kd = kd - Shift;
     const double r = z - kd;
-    const uint64_t tw = tab[ki & 31u];
-    // t = tab + (ki << 47): the shifted word has nothing below bit 47, so only the high half moves
-    const uint32_t thi = (uint32_t)(tw >> 32) + (ki << 15);
-    const double s = hml_u2d(((uint64_t)thi << 32) | (uint32_t)tw);
+    // t = tab + (ki << 47): the shifted word has nothing below bit 47, so only the high half moves (as a register pair:
+    // composing the 64-bit integer first costs four copies and a 64-bit add)
+    typedef uint32_t hml_u32x2 __attribute__((ext_vector_type(2)));
+    hml_u32x2 tw = reinterpret_cast<const hml_u32x2*>(tab)[ki & 31u];
+    tw.y += ki << 15;
+    const double s = __builtin_bit_cast(double, tw);
     z = C0 * r + C1;
     const double r2 = r * r;
     double y = C2 * r + 1.0;
@@ -147,7 +149,7 @@ __device__ __forceinline__ bool hml_tr2_energies(const hml_tr2_params<K>& p, boo
         ex_max = (ex > ex_max) ? ex : ex_max;
         const float ip = (float)ipd;
         float e = (0.0f + ip) - N * p.logN[s];
-        if (self) e += N1 * p.logA[s];
+        e += N1 * p.logA[s];   // (logA = 0 without self transitions: adds +0)
         E[s] = e;
     }
     // (a product that is exactly zero is outside the exponent range but exact: such blocks - zero coverage - are looked at
@@ -246,8 +248,14 @@ __device__ __forceinline__ typename hml_tre_map<K>::stored hml_tr2_compose(typen
     map_t r = 0;
 #pragma unroll
     for (int x = 0; x < K; ++x) {
-        const uint32_t y = (uint32_t)(g >> (4 * x)) & 15u;
-        r |= ((f >> (4u * y)) & (map_t)15) << (4 * x);
+        if (sizeof(map_t) == 4) {
+            // bit-field extracts with a register offset (v_bfe_u32) instead of shift, mask, shift, mask
+            const uint32_t off = (x == 0) ? ((uint32_t)g << 2) & 60u : ((uint32_t)g >> (4 * x - 2)) & 60u;   // 4 g(x)
+            r |= (map_t)(__builtin_amdgcn_ubfe((uint32_t)f, off, 4u) << (4 * x));
+        } else {
+            const uint32_t y = (uint32_t)(g >> (4 * x)) & 15u;
+            r |= ((f >> (4u * y)) & (map_t)15) << (4 * x);
+        }
     }
     return r;
 }
@@ -375,12 +383,14 @@ void hml_k_trellis_rows(const float2* __restrict__ ia, const uint32_t* __restric
                 bool have[R / 2];
 #pragma unroll
                 for (int k = 0; k < R / 2; ++k) {
+                    // (32-bit: the first block cf of a chunk fc < C is below B < 2^32; row off < L of the chunk is a block if it
+                    // lies inside the warm-up window, at or behind block 0 and before B - the chunk's own end is never nearer)
                     const int c = (half * (R / 2) + k) * CPS + sc;
-                    const long long cf = (long long)(f0 + (uint32_t)c) * L;
-                    const long long b = cf + rel0 + sr;
-                    const long long cl = (cf + L < (long long)B) ? cf + L : (long long)B;
-                    have[k] = f0 + (uint32_t)c < C && b >= 0ll && b < cl && rel0 + sr >= -(int)Wt;
-                    const uint32_t bb = have[k] ? (uint32_t)b : 0u;
+                    const uint32_t fc = f0 + (uint32_t)c;
+                    const uint32_t cf = fc * L;
+                    const int off = rel0 + sr;
+                    have[k] = fc < C && off >= -(int)Wt && ((off < 0) ? cf >= (uint32_t)(-off) : (uint32_t)off < B - cf);
+                    const uint32_t bb = have[k] ? cf + (uint32_t)off : 0u;
                     if (HML_TR2_SKIP & 64) { st[k] = bb; en[k] = bb + 1u; } else {
                     st[k] = starts[bb];
                     en[k] = starts[bb + 1u]; }
@@ -441,9 +451,12 @@ void hml_k_trellis_rows(const float2* __restrict__ ia, const uint32_t* __restric
                         for (int s = 0; s < K; ++s) E[s] = sx * (0.001f * (float)(s + 1)) - sq;
                     } else
                     if (__builtin_expect(hml_tr2_energies<K>(p, self, sx, sq, N, E), 0)) hml_tr2_energies_literal<K>(mdl_ro, mdl, self, sx, sq, N, E);
-                    float maxE = -3.40282346638528859812e+38f;   // numeric_limits<float>::lowest()
+                    // std::max in state order from numeric_limits<float>::lowest() (ForwardBackward.hpp:78-81) is the largest term
+                    // unless one is a NaN (which the comparison chain lets through and then forgets); v_max3 skips NaNs, and the
+                    // NaN shows in the sum below, where the chain is then walked literally
+                    float maxE = -3.40282346638528859812e+38f;
 #pragma unroll
-                    for (int s = 0; s < K; ++s) maxE = (E[s] < maxE) ? maxE : E[s];
+                    for (int s = 0; s < K; ++s) maxE = __builtin_fmaxf(maxE, E[s]);
                     float xs[K], xsum = 0.0f;
 #pragma unroll
                     for (int s = 0; s < K; ++s) { xs[s] = E[s] - maxE; xsum += xs[s]; }   // every term <= 0 or NaN: the sum is a NaN only if a term is
@@ -452,8 +465,11 @@ void hml_k_trellis_rows(const float2* __restrict__ ia, const uint32_t* __restric
                         for (int s = 0; s < K; ++s) e[s] = 1.0f + 0.01f * xs[s];
                     } else
                     if (__builtin_expect(xsum != xsum, 0)) {
+                        maxE = -3.40282346638528859812e+38f;
 #pragma unroll
-                        for (int s = 0; s < K; ++s) e[s] = hml_expf_tab(xs[s], etab);
+                        for (int s = 0; s < K; ++s) maxE = (E[s] < maxE) ? maxE : E[s];
+#pragma unroll
+                        for (int s = 0; s < K; ++s) e[s] = hml_expf_tab(E[s] - maxE, etab);
                     } else {
 #pragma unroll
                         for (int s = 0; s < K; ++s) e[s] = hml_tr2_expf_nonpos(xs[s], etab);
@@ -528,10 +544,11 @@ void hml_k_trellis_rows(const float2* __restrict__ ia, const uint32_t* __restric
 #pragma unroll
                 for (int k = 0; k < R; ++k) {
                     const int c = k * CPS + sc;
-                    const long long cf = (long long)(f0 + (uint32_t)c) * L;
-                    const long long b = cf + rel0 + sr;
-                    const long long cl = (cf + L < (long long)B) ? cf + L : (long long)B;
-                    if (f0 + (uint32_t)c < C && b < cl) {
+                    const uint32_t fc = f0 + (uint32_t)c;
+                    const uint32_t cf = fc * L;
+                    const uint32_t off = (uint32_t)(rel0 + sr);   // (rel0 >= 0 here)
+                    const uint32_t b = cf + off;
+                    if (fc < C && off < B - cf) {
                         const uint32_t* const w = tile + c * PITCH + sr * SLOTW;
                         unsigned long long cm = w[0];
                         if (SLOTW == 4) cm |= (unsigned long long)w[1] << 32;
