@@ -227,10 +227,11 @@ def main():
         return ch, t1 - t0, s1["block_updates"] - s0["block_updates"], s0, s1
 
     # headline leg: the library's default path - the block structure is recomputed in every sweep (dynamic blocks)
-    # weakly compressed workloads (config 5: millions of blocks per sweep) spend their time in the trellis tile kernel:
-    # every launch is bracketed there (15 pairs of events per 7 ms sweep)
+    # weakly compressed workloads (config 5: millions of blocks per sweep) spend their time in the first trellis pass
+    # (hml_k_trellis_rows): the same level-1 brackets, every 32nd launch (bracketing every family of every sweep, as
+    # rounds 1-2 did there, costs the timed region 3 %)
     dense_workload = levels is None
-    chain, elapsed, blocks, st0, st1 = run_leg(weight_summary=True, profile_level=2 if dense_workload else 1)
+    chain, elapsed, blocks, st0, st1 = run_leg(weight_summary=True, profile_level=1)
     roof_family = "trellis" if dense_workload else "blocks_compact"
     scan_ms, scan_n = chain.profile_get(roof_family)           # HIP events around the kernel's launches
     null_ms, null_n = chain.profile_get("event_null")          # empty brackets recorded right behind them
@@ -239,8 +240,8 @@ def main():
         # the timed region brackets every 32nd launch of the roofline kernel (a bracket costs ~5 us of stream time): with few
         # steps that is one sample or none.  A short pass OUTSIDE the timed region, same chain, same level, tops the sample
         # up to MIN_BRACKETS launches; kernel_avg_us is the average over all of them.
-        per = 1 if dense_workload else 32
-        chain.profile_enable(2 if dense_workload else 1)
+        per = 32
+        chain.profile_enable(1)
         chain.iterate("F", (MIN_BRACKETS - scan_n) * per, 0)
         chain.sync()
         chain.profile_enable(0)
@@ -320,7 +321,7 @@ def main():
                          "empty_bracket_us": 1e6 * null_s, "launches": scan_n, "launches_in_timed_region": brackets_timed,
                          "launches_note": "HIP events on the chain's stream; launches beyond those of the timed region come from a "
                                           "short extra pass of the same chain outside it (at least %d in all)" % MIN_BRACKETS,
-                         "limiter": "vector issue: about 600 VALU instructions per block-row, 40 %% of them double precision (DESIGN.md 3a)" if dense_workload else
+                         "limiter": "vector issue: about 530 VALU instructions per block-row, a third of them double precision (DESIGN.md 3a)" if dense_workload else
                                     "latency: three dependent memory round trips + one inter-workgroup hand-off per launch",
                          "profile_pair": None if dense_workload else
                                          "rocprofv3 adds 1.5-2 us to every dispatch of this kernel: the line that pairs with "
@@ -341,7 +342,7 @@ def main():
         fam_kernel = dict(FAMILY_KERNEL)
         n_extra = 200
         if dense_workload:
-            fam_kernel = {"blocks_compact": "hml_k_compact_scan", "blocks_scatter": "hml_k_compact_scatter", "trellis": DENSE_KERNEL,
+            fam_kernel = {"blocks_compact": "hml_k_compact_scan_bits", "blocks_scatter": "hml_k_compact_scatter_bits", "trellis": DENSE_KERNEL,
                           "trellis_repair": "hml_k_trellis_verify + refit + serial", "backward_chain": "hml_k_trellis_super + chain + states",
                           "counts": "hml_k_counts_dense", "params": "hml_k_params"}
             n_extra = 10
@@ -582,7 +583,7 @@ def main():
         u1 = ch.stats()
         bu = u1["block_updates"] - u0["block_updates"]
         Bu = bu / n_u
-        fams = {"blocks_compact": "hml_k_compact_scan", "blocks_scatter": "hml_k_compact_scatter", "trellis": DENSE_KERNEL, "trellis_repair": "hml_k_trellis_verify + refit + serial",
+        fams = {"blocks_compact": "hml_k_compact_scan_bits", "blocks_scatter": "hml_k_compact_scatter_bits", "trellis": DENSE_KERNEL, "trellis_repair": "hml_k_trellis_verify + refit + serial",
                 "backward_chain": "hml_k_trellis_super + chain + states", "counts": "hml_k_counts_dense", "params": "hml_k_params"}
         ch.profile_enable(2)
         ch.iterate("F", 10, 0)
@@ -608,7 +609,7 @@ def main():
                                    "sweep_frac": (4.0 * T + Bu * (36 + 8 * K)) / ((t1 - t0) / n_u) / 1e9 / HBM_PEAK_GBS,
                                    "kernels": dense_tab,
                                    "note": "B = T: the fused trellis path (hml_k_trellis_rows.h) - bound by vector issue: SQ_INSTS_VALU of the "
-                                           "first pass = about 700 wavefront instructions per 64 blocks and warm-up row (profiles/round3_sq_counters_c3u.txt); DESIGN.md 3a"}
+                                           "first pass = about 530 wavefront instructions per 64 blocks and warm-up row (profiles/round3_sq_counters_c3u.txt); DESIGN.md 3a"}
         ch.close()
         chain = None
 

@@ -95,7 +95,8 @@ struct ProfScope {
     ProfScope(hml_ctx* c_, const char* n, int level = 2) : c(c_), name(n), on(c_->profiling >= level) {
         // level 1 (the bench's timed region): bracket every 32nd launch only - two event records cost ~6 us of
         // stream time, a visible share of an 80 us sweep
-        if (on && c->profiling == 1 && (c->prof_tick++ & 31u) != 0u) on = false;
+        // (a counter per family: the weakly compressed sweep has two level-1 families, block scan and first trellis pass)
+        if (on && c->profiling == 1 && (c->prof[name].tick++ & 31u) != 0u) on = false;
         if (on) { a = ev_get(c); b = ev_get(c); hipEventRecord(a, c->stream); }
     }
     ~ProfScope() {
@@ -1100,7 +1101,7 @@ static int sweep_k(hml_ctx* c, char method, bool record) {
         float* ep = c->probes ? c->d_eprobe : nullptr;
         float* ap = c->probes ? c->d_aprobe : nullptr;
         {
-            ProfScope ps(c, "trellis");
+            ProfScope ps(c, "trellis", 1);
             // (nearly every block a single position: the filter step shares the candidate maps' sums, hml_k_trellis_rows.h)
             if (c->tre_rows && hint > 1024u && ((uint64_t)hint - 1024u) * 8u >= c->T * 9u)   // (last sweep's blocks >= 0.9 T; the hint carries 25 % headroom)
                 hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_trellis_rows<KK, true>), dim3(grid_for(tgroups, HML_TR2_WAVES, 4, 1 << 20)), dim3(64 * HML_TR2_WAVES), 0, s,

@@ -14,7 +14,7 @@
 #include "hml_host_common.hpp"
 #include "hml_state.h"
 
-struct ProfAcc { double ms = 0; uint64_t n = 0; std::vector<std::pair<hipEvent_t, hipEvent_t>> pending; };
+struct ProfAcc { double ms = 0; uint64_t n = 0; uint32_t tick = 0; std::vector<std::pair<hipEvent_t, hipEvent_t>> pending; };
 
 struct hml_ctx {
     int device = 0;

@@ -684,6 +684,9 @@ __global__ __launch_bounds__(256) void hml_k_counts_dense(int16_t* __restrict__ 
 #pragma unroll
     for (int s = 0; s < K; ++s) { n_pos[s] = 0ull; n_blk[s] = 0u; n_stay[s] = 0u; }
     const uint32_t nchunks = (B + HML_REDUCE_CHUNK - 1u) / HML_REDUCE_CHUNK;
+    // uncompressed input (every position a block of its own: B = T): the block lengths are all 1 and starts[] is not read -
+    // 4 of the pass's 14 bytes per block
+    const bool unit_blocks = (B == mdl->T);
     struct in_t { unsigned long long m1, m0; uint32_t e1, e0, s1, s0; float2 v; int16_t q1, q0; };
     auto fetch = [&](uint32_t b, in_t& r) {
         r.m1 = r.m0 = 0ull; r.e1 = r.e0 = 0u; r.s1 = r.s0 = 0u; r.v = make_float2(0.0f, 0.0f); r.q1 = r.q0 = 0;
@@ -695,7 +698,8 @@ __global__ __launch_bounds__(256) void hml_k_counts_dense(int16_t* __restrict__ 
                 r.q1 = q[b];
                 if (b != 0) r.q0 = q[b - 1];
             }
-            r.s1 = starts[b + 1]; r.s0 = starts[b];
+            if (unit_blocks) r.s1 = 1u;
+            else { r.s1 = starts[b + 1]; r.s0 = starts[b]; }
             r.v = bstat[b];
         }
     };
