@@ -442,7 +442,30 @@ __device__ __forceinline__ void hml_fwd_ctx_load(hml_fwd_ctx<K>& cx, const hml_m
     cx.B = mdl->B;
 }
 
-// one step of the recursion (reference ForwardBackward.hpp:88-112); alpha is updated in place
+// f / Z, correctly rounded to float like the IEEE division it stands for, from a double reciprocal r of Z (relative error
+// below 2^-27 is enough): q1 = f r, then one correction step q2 = q1 + (f - q1 Z) r with the residual from a fused
+// multiply-add, which leaves q2 within 2^-53 q of the quotient q - and EQUAL to q whenever q is a double (r's error enters
+// squared).  (float)q2 is the division's result: if q is a double nothing was rounded before the conversion; otherwise q is
+// not a float midpoint, and no quotient of two floats lies closer to one than 2^-49 q (numerator minus midpoint times
+// denominator is a non-zero multiple of the unit both are multiples of; holds for the sub-normal grid as well), so q2 is on
+// q's side of it.  Five divisions of the filter step were 55 of its 101 instructions; tools/div_check.hip and
+// test_quotient_by_reciprocal compare with the division itself, exact ties on the sub-normal grid included.
+__device__ __forceinline__ double hml_tr2_reciprocal(double Zd) {
+    double r = __builtin_amdgcn_rcp(Zd);
+    const double e = __builtin_fma(-Zd, r, 1.0);
+    return __builtin_fma(r, e, r);
+}
+__device__ __forceinline__ float hml_tr2_quotient(float f, double Zd, double r) {
+    const double fd = (double)f;
+    const double q1 = fd * r;
+    const double rho = __builtin_fma(-q1, Zd, fd);
+    return (float)__builtin_fma(rho, r, q1);
+}
+
+// one step of the recursion (reference ForwardBackward.hpp:88-112); alpha is updated in place.  The K divisions by the
+// normaliser (an IEEE float division is eleven instructions: 55 of the step's ~125 at K = 5, and the filter is a chain of
+// dependent steps) go through ONE double reciprocal where the normaliser is a positive finite float - the same floats
+// (hml_tr2_quotient, round 3: first in the weakly compressed sweep's first pass, now in every form of the filter).
 template <int K>
 __device__ __forceinline__ bool hml_fwd_step(const hml_fwd_ctx<K>& cx, float (&alpha)[K], const float (&e)[K]) {
     float f[K];
@@ -456,10 +479,17 @@ __device__ __forceinline__ bool hml_fwd_step(const hml_fwd_ctx<K>& cx, float (&a
     float Z = 0.0f;
 #pragma unroll
     for (int j = 0; j < K; ++j) Z += f[j];
-    const bool ok = (Z != 0.0f);
+    if (__builtin_expect(!(Z > 0.0f) || !(Z < 3.4028234663852886e38f), 0)) {   // 0: the uniform vector; negative, infinite or NaN: whatever the division says
+        const bool ok = (Z != 0.0f);
 #pragma unroll
-    for (int j = 0; j < K; ++j) alpha[j] = ok ? f[j] / Z : cx.invK;
-    return !ok;
+        for (int j = 0; j < K; ++j) alpha[j] = ok ? f[j] / Z : cx.invK;
+        return !ok;
+    }
+    const double Zd = (double)Z;
+    const double r = hml_tr2_reciprocal(Zd);
+#pragma unroll
+    for (int j = 0; j < K; ++j) alpha[j] = hml_tr2_quotient(f[j], Zd, r);
+    return false;
 }
 
 // Runs the recursion over blocks [b0, b1) in batches so that the (recursion-independent) loads of the

@@ -260,25 +260,7 @@ __device__ __forceinline__ typename hml_tre_map<K>::stored hml_tr2_compose(typen
     return r;
 }
 
-// f / Z, correctly rounded to float like the IEEE division it stands for, from a double reciprocal r of Z (relative error
-// below 2^-27 is enough): q1 = f r, then one correction step q2 = q1 + (f - q1 Z) r with the residual from a fused
-// multiply-add, which leaves q2 within 2^-53 q of the quotient q - and EQUAL to q whenever q is a double (r's error enters
-// squared).  (float)q2 is the division's result: if q is a double nothing was rounded before the conversion; otherwise q is
-// not a float midpoint, and no quotient of two floats lies closer to one than 2^-49 q (numerator minus midpoint times
-// denominator is a non-zero multiple of the unit both are multiples of; holds for the sub-normal grid as well), so q2 is on
-// q's side of it.  Five divisions of the filter step were 55 of its 101 instructions; tools/div_check.hip and
-// test_quotient_by_reciprocal compare with the division itself, exact ties on the sub-normal grid included.
-__device__ __forceinline__ double hml_tr2_reciprocal(double Zd) {
-    double r = __builtin_amdgcn_rcp(Zd);
-    const double e = __builtin_fma(-Zd, r, 1.0);
-    return __builtin_fma(r, e, r);
-}
-__device__ __forceinline__ float hml_tr2_quotient(float f, double Zd, double r) {
-    const double fd = (double)f;
-    const double q1 = fd * r;
-    const double rho = __builtin_fma(-q1, Zd, fd);
-    return (float)__builtin_fma(rho, r, q1);
-}
+// (hml_tr2_reciprocal / hml_tr2_quotient: the quotients of the filter step through one double reciprocal - hml_k_forward.h)
 
 // one step of the recursion (hml_fwd_step) with the five quotients taken through one reciprocal
 // (pred_j = sum_i alpha_i A(i, j) in index order - hml_tr2_predict, or the totals hml_tr2_maps formed from the same row)
