@@ -63,19 +63,42 @@ def _run(cmd, verbose):
         raise RuntimeError("hipcc failed:\n" + "\n".join(errs[:40]))
 
 
-def build_library(force=False, verbose=False):
-    """every hammlet_amd/csrc/*.hip -> object (hipcc --offload-arch=gfx950 -c) -> hammlet_amd/libhammlet_hip.so"""
+K_STATES = range(2, 17)   # numbers of states the kernels are compiled for (HML_MAX_K = 16)
+
+
+def _objects():
+    """(source, object name, extra flags) of every object of the library: each csrc/*.hip once - except hml_capi.hip, which
+    is compiled once for the C ABI and everything independent of the number of states (-DHML_TU_CORE) and once per number of
+    states for the sweep (-DHML_TU_K=k): sixteen objects with their own code objects, built in parallel and loaded on demand
+    (csrc/hml_capi.hip, top)."""
+    out = []
+    for u in sorted(f for f in os.listdir(CSRC) if f.endswith(".hip")):
+        if u == "hml_capi.hip":
+            out.append((u, "hml_capi.o", ["-DHML_TU_CORE"]))
+            out += [(u, "hml_capi_k%d.o" % k, ["-DHML_TU_K=%d" % k]) for k in K_STATES]
+        else:
+            out.append((u, u[:-4] + ".o", []))
+    return out
+
+
+def build_library(force=False, verbose=False, jobs=None):
+    """hammlet_amd/csrc/*.hip -> objects (hipcc --offload-arch=gfx950 -c, in parallel) -> hammlet_amd/libhammlet_hip.so"""
+    from concurrent.futures import ThreadPoolExecutor
     os.makedirs(OBJ_DIR, exist_ok=True)
-    units = sorted(f for f in os.listdir(CSRC) if f.endswith(".hip"))
-    objs, relink = [], force or not os.path.exists(LIB_PATH)
-    for u in units:
-        src = os.path.join(CSRC, u)
-        obj = os.path.join(OBJ_DIR, u[:-4] + ".o")
+    todo, objs = [], []
+    fallback = _sources()
+    for u, o, extra in _objects():
+        src, obj = os.path.join(CSRC, u), os.path.join(OBJ_DIR, o)
         dep = obj[:-2] + ".d"
-        if force or _newer(obj, _deps(dep, _sources())):
-            _run([_hipcc()] + HIPCC_FLAGS + ["-MMD", "-MF", dep, "-c", "-o", obj, src], verbose)
-            relink = True
         objs.append(obj)
+        if force or _newer(obj, _deps(dep, fallback)):
+            todo.append([_hipcc()] + HIPCC_FLAGS + extra + ["-MMD", "-MF", dep, "-c", "-o", obj, src])
+    relink = force or bool(todo) or not os.path.exists(LIB_PATH)
+    if todo:
+        # (each hipcc is single-threaded; memory: ~1.5 GB per per-K object)
+        with ThreadPoolExecutor(max_workers=jobs or max(1, min(8, os.cpu_count() or 1))) as ex:
+            list(ex.map(lambda cmd: _run(cmd, verbose), todo))
+    # objects of an earlier layout (one object for all numbers of states) must not be linked in
     if relink or _newer(LIB_PATH, objs):
         _run([_hipcc()] + HIPCC_FLAGS + ["-shared", "-o", LIB_PATH] + objs, verbose)
     return LIB_PATH

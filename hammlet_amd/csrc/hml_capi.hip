@@ -30,38 +30,51 @@
 #include "hml_host_common.hpp"
 #include "hml_ctx.hpp"
 
+// This file is compiled in one of three ways (hammlet_amd/build.py):
+//   -DHML_TU_CORE : the C ABI and everything that does not depend on the number of states K (one object);
+//   -DHML_TU_K=k  : the sweep for k states - the kernels templated on K and the host code that launches them - behind a table
+//                   of function pointers (fifteen objects, k = 2 ... 16, compiled in parallel);
+//   neither       : both in one object (development builds for one K: -DHML_ONLY_K=k, tools/dev_build.py).
+// Every object carries its own code object, and the HIP runtime loads a code object when the first kernel of it is
+// launched: a run with K states loads the core's (construction, block scan, marginals) and the one of its K (1-2 MB each)
+// instead of one 19 MB object with every kernel for 2 ... 16 states - 45 ms of a short run's start-up - and the
+// library builds in a fifth of the time.  Kernels that are not templates have internal linkage (HML_KERNEL) so that the
+// objects may each hold the ones they launch.
+#if defined(HML_TU_K)
+#define HML_IN_CORE 0
+#else
+#define HML_IN_CORE 1
+#endif
+#if defined(HML_TU_CORE)
+#define HML_IN_K 0
+#else
+#define HML_IN_K 1
+#endif
+#if defined(HML_TU_K) && defined(HML_TU_CORE)
+#error "HML_TU_K and HML_TU_CORE exclude each other"
+#endif
+
+#if HML_IN_CORE
 static thread_local std::string g_err;
 int hml_set_err(int code, const std::string& msg) { g_err = msg; return code; }
+#else
+int hml_set_err(int code, const std::string& msg);
+#endif
 static int set_err(int code, const std::string& msg) { return hml_set_err(code, msg); }
 
-// -DHML_ONLY_K=5: development builds that instantiate the sweep for one number of states only (the full library takes
-// minutes to compile; tools/dev_build.py)
-#ifdef HML_ONLY_K
-#define HML_DISPATCH_K(KV, ...)                                                   \
-    switch (KV) {                                                                 \
-        case HML_ONLY_K: { constexpr int KK = HML_ONLY_K; __VA_ARGS__; } break;   \
-        default: return set_err(HML_ERR_ARG, "this development build only knows one number of states"); \
-    }
-#else
-#define HML_DISPATCH_K(KV, ...)                                                   \
-    switch (KV) {                                                                 \
-        case 2: { constexpr int KK = 2; __VA_ARGS__; } break;                     \
-        case 3: { constexpr int KK = 3; __VA_ARGS__; } break;                     \
-        case 4: { constexpr int KK = 4; __VA_ARGS__; } break;                     \
-        case 5: { constexpr int KK = 5; __VA_ARGS__; } break;                     \
-        case 6: { constexpr int KK = 6; __VA_ARGS__; } break;                     \
-        case 7: { constexpr int KK = 7; __VA_ARGS__; } break;                     \
-        case 8: { constexpr int KK = 8; __VA_ARGS__; } break;                     \
-        case 9: { constexpr int KK = 9; __VA_ARGS__; } break;                     \
-        case 10: { constexpr int KK = 10; __VA_ARGS__; } break;                   \
-        case 11: { constexpr int KK = 11; __VA_ARGS__; } break;                   \
-        case 12: { constexpr int KK = 12; __VA_ARGS__; } break;                   \
-        case 13: { constexpr int KK = 13; __VA_ARGS__; } break;                   \
-        case 14: { constexpr int KK = 14; __VA_ARGS__; } break;                   \
-        case 15: { constexpr int KK = 15; __VA_ARGS__; } break;                   \
-        case 16: { constexpr int KK = 16; __VA_ARGS__; } break;                   \
-        default: return set_err(HML_ERR_ARG, "number of states must be in [2,16]"); \
-    }
+// what the core calls of the K-dependent part: one table per number of states (defined at the end of this file)
+struct hml_ktab {
+    int (*sweep)(hml_ctx* c, char method, bool record);
+    int (*iterate_many)(hml_ctx* const* cs, int n, uint64_t first, uint64_t iterations, uint64_t thinning, uint64_t* done);
+    void (*params)(hml_ctx* c, int mode);        // hml_k_params<K>: 1 = draw from the priors, 2 = Theta's constructor draw
+    void (*compat_draw)(hml_ctx* c, int mode);   // hml_k_compat_draw<K> (reference-compatible chains)
+    void (*derive)(hml_ctx* c);                  // hml_k_derive<K>
+};
+
+// the table of K states, or nullptr (outside [2, 16]; a development build knows one K only: -DHML_ONLY_K=5, tools/dev_build.py)
+#if HML_IN_CORE
+static const hml_ktab* ktab(int K);
+#define HML_KTAB(KV, tab) const hml_ktab* tab = ktab(KV); if (!tab) return set_err(HML_ERR_ARG, "number of states must be in [2,16]")
 #endif
 
 // Live contexts per device.  The fused block kernel hands block offsets from workgroup to workgroup inside one launch
@@ -72,15 +85,22 @@ static int set_err(int code, const std::string& msg) { return hml_set_err(code, 
 // firmware's time slicing untangled them).  So while more than one context is alive on a device every sweep takes the
 // scan + scatter pair, which has no such hand-off.
 #include <atomic>
-static std::atomic<int> g_live_ctx[64];
-static bool shares_device(const hml_ctx* c);
+#if HML_IN_CORE
+std::atomic<int> hml_live_ctx[64];
+#else
+extern std::atomic<int> hml_live_ctx[64];
+#endif
+#define g_live_ctx hml_live_ctx
+static bool shares_device(const hml_ctx* c) { return c->device < 64 && g_live_ctx[c->device].load() > 1; }
 
 // ------------------------------------------------------------------------------------------------
 static int ctx_bind(hml_ctx* c) {
     HIPCHK(hipSetDevice(c->device));
     return 0;
 }
+#if HML_IN_CORE
 int hml_ctx_bind(hml_ctx* c) { return ctx_bind(c); }
+#endif
 
 static hipEvent_t ev_get(hml_ctx* c) {
     if (!c->ev_pool.empty()) { hipEvent_t e = c->ev_pool.back(); c->ev_pool.pop_back(); return e; }
@@ -150,7 +170,9 @@ static int fetch_model(hml_ctx* c, hml_model* out) {
     HIPCHK(hipStreamSynchronize(c->stream));
     return 0;
 }
+#if HML_IN_CORE
 int hml_ctx_fetch_model(hml_ctx* c, hml_model* out) { return fetch_model(c, out); }
+#endif
 
 static int check_device_error(hml_ctx* c) {
     hml_model m;
@@ -163,10 +185,11 @@ static int check_device_error(hml_ctx* c) {
 }
 
 
+#if HML_IN_CORE   // ---- (core) debug probe, context life cycle, construction
 // ------------------------------------------------------------------------------------------------
 // hml_debug_eval: evaluates one of the shared host/device functions on the GPU (parity probe for
 // hml_math.h / hml_dist.h: the tests compare with the same function compiled by gcc).
-__global__ void hml_k_debug_eval(int fn, const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out,
+HML_KERNEL void hml_k_debug_eval(int fn, const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out,
                                  uint64_t n, uint64_t seed) {
     if (fn == 24) {   // gamma draw with ONE active lane per wavefront (divergence-free control)
         const uint64_t nw = ((uint64_t)gridDim.x * blockDim.x) >> 6;
@@ -312,8 +335,6 @@ int hml_create(hml_ctx** out, int device, uint64_t seed, uint32_t chain_id, void
     return 0;
 }
 
-static bool shares_device(const hml_ctx* c) { return c->device < 64 && g_live_ctx[c->device].load() > 1; }
-
 static void free_all(hml_ctx* c) {
     void* ptrs[] = {c->d_group_word, c->d_summary, c->d_w, c->d_coeff, c->d_ia, c->d_stage, c->d_span_count, c->d_starts, c->d_bstat,
                     c->d_em, c->d_gsc, c->d_rows, c->d_eprobe, c->d_aprobe, c->d_entry, c->d_exitA, c->d_redo, c->d_touched, c->d_fb, c->d_coarse1,
@@ -358,7 +379,7 @@ static int build_keys(hml_ctx* c) {
     return 0;
 }
 
-__global__ void hml_k_max_inplace(float* __restrict__ a, const float* __restrict__ b, uint64_t n) {
+HML_KERNEL void hml_k_max_inplace(float* __restrict__ a, const float* __restrict__ b, uint64_t n) {
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) { const float x = a[i], y = b[i]; a[i] = (x < y) ? y : x; }   // std::max(x, y)
 }
@@ -555,6 +576,9 @@ int hml_set_weights(hml_ctx* c, const float* w, uint64_t T) {
     return 0;
 }
 
+}  // extern "C"
+#endif   // HML_IN_CORE
+
 // ---------------------------------------------------------------------------------------- blocks
 // K4: scan (the HBM-bound kernel) + scatter with in-kernel offsets
 static void launch_compact_pair(hml_ctx* c, int mode, float thr) {
@@ -611,6 +635,8 @@ static void refresh_hint(hml_ctx* c) {
     if (b) c->B_hint = b + b / 4 + 1024;
 }
 
+#if HML_IN_CORE   // ---- (core) explicit blocks, priors, model
+extern "C" {
 int hml_create_blocks(hml_ctx* c, float threshold) {
     if (!c || !c->loaded) return set_err(HML_ERR_ARG, "no observations loaded");
     if (int r = ctx_bind(c)) return r;
@@ -774,11 +800,11 @@ int hml_set_model(hml_ctx* c, int K, const float nig4[4], float a_off, float a_d
         HIPCHK(hipMemcpyAsync(c->d_mt, &h, sizeof h, hipMemcpyHostToDevice, c->stream));
         HIPCHK(hipMalloc(&c->d_crows, (T + 1) * K * sizeof(float)));
         HIPCHK(hipStreamSynchronize(c->stream));
-        HML_DISPATCH_K(K, hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_compat_draw<KK>), dim3(1), dim3(64), 0, c->stream, c->d_mdl, (hml_mt_state*)c->d_mt, 2));
+        { HML_KTAB(K, kt); kt->compat_draw(c, 2); }
         KLAUNCH_CHECK();
         return 0;
     }
-    HML_DISPATCH_K(K, hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_params<KK>), dim3(1), dim3(1024), 0, c->stream, c->d_mdl, c->d_partial, 2));
+    { HML_KTAB(K, kt); kt->params(c, 2); }
     KLAUNCH_CHECK();
     return 0;
 }
@@ -787,16 +813,15 @@ int hml_sample_prior(hml_ctx* c) {
     if (!c || !c->model_set) return set_err(HML_ERR_ARG, "model not set");
     if (int r = ctx_bind(c)) return r;
     if (c->compat) {
-        HML_DISPATCH_K(c->K, hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_compat_draw<KK>), dim3(1), dim3(64), 0, c->stream, c->d_mdl, (hml_mt_state*)c->d_mt, 1));
-    } else
-    HML_DISPATCH_K(c->K, hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_params<KK>), dim3(1), dim3(1024), 0, c->stream, c->d_mdl, c->d_partial, 1));
+        HML_KTAB(c->K, kt); kt->compat_draw(c, 1);
+    } else { HML_KTAB(c->K, kt); kt->params(c, 1); }
     KLAUNCH_CHECK();
     if (c->dynamic) c->blocks_valid = false;
     c->hint_stale = true;
     return 0;
 }
 
-__global__ __launch_bounds__(64) void hml_k_set_self_trans(hml_model* mdl, int on) {
+HML_KERNEL __launch_bounds__(64) void hml_k_set_self_trans(hml_model* mdl, int on) {
     if (threadIdx.x == 0) mdl->self_trans = on;
 }
 
@@ -849,6 +874,9 @@ int hml_enable_probes(hml_ctx* c, int on) {
 }
 
 // ---------------------------------------------------------------------------------------- sweeps
+}  // extern "C"
+#endif   // HML_IN_CORE
+
 static int ensure_marginal_buffers(hml_ctx* c) {
     if (c->d_diff) return 0;
     const uint64_t n = (uint64_t)c->K * (c->T + 1);
@@ -860,10 +888,13 @@ static int ensure_marginal_buffers(hml_ctx* c) {
     return 0;
 }
 
-}  // extern "C"
 
+
+#if HML_IN_CORE
 int hml_ctx_ensure_marginal_buffers(hml_ctx* c) { return ensure_marginal_buffers(c); }
+#endif
 
+#if HML_IN_K
 // Tile size and grid of the fused block kernel: the smallest number of 2^17-position batches per workgroup with which
 // the whole grid is resident at once (the workgroups wait for lower-numbered ones inside the launch).  False when even
 // the largest tile does not fit: those traces take the scan + scatter launches.
@@ -888,6 +919,8 @@ static bool fused_geometry(hml_ctx* c, uint32_t* n_sub, uint32_t* n_wg) {
     *n_wg = (uint32_t)((c->T + m * HML_FUSED_SUB_POSITIONS - 1) / (m * HML_FUSED_SUB_POSITIONS));
     return true;
 }
+
+#endif   // HML_IN_K
 
 // ---- chunk length of the fused trellis path (hml_ctx.hpp: tre_autotune)
 #define HML_TRE_TUNE_AFTER 48u   // sweeps before the measurement: the filter's warm-up length has settled by then
@@ -968,6 +1001,7 @@ static void tre_tune_report(hml_ctx* c, uint32_t hint, float ms) {
     }
 }
 
+#if HML_IN_K
 // A sweep of the reference-compatible mode (hml_k_compat.h): block starts and block statistics by the default path's
 // kernels, everything order-dependent by one lane in the reference's order, the marginals by hml_k_record.
 template <int KK>
@@ -1241,9 +1275,12 @@ static int sweep_k(hml_ctx* c, char method, bool record) {
     return 0;
 }
 
+#endif   // HML_IN_K
+
+#if HML_IN_CORE
 static int sweep_dispatch(hml_ctx* c, char method, bool record) {
-    HML_DISPATCH_K(c->K, return sweep_k<KK>(c, method, record));
-    return 0;
+    HML_KTAB(c->K, kt);
+    return kt->sweep(c, method, record);
 }
 
 extern "C" {
@@ -1296,7 +1333,7 @@ int hml_iterate(hml_ctx* c, char method, uint64_t iterations, uint64_t thinning)
                 continue;
             }
         }
-        HML_DISPATCH_K(c->K, if (int r = sweep_k<KK>(c, method, record)) return r);
+        if (int r = sweep_dispatch(c, method, record)) return r;
         if (record && c->cb) {
             HIPCHK(hipStreamSynchronize(c->stream));
             if (int r = check_device_error(c)) return r;
@@ -1307,6 +1344,7 @@ int hml_iterate(hml_ctx* c, char method, uint64_t iterations, uint64_t thinning)
 }
 
 }  // extern "C"
+#endif   // HML_IN_CORE
 
 // ---- several chains of one device in one set of launches (hml_k_many.h) ----
 static bool many_eligible(hml_ctx* const* cs, int n, char method) {
@@ -1327,6 +1365,7 @@ static bool many_sparse(hml_ctx* c) {
     return !(c->B_hint >= c->dense_min_blocks) && !(!c->summary_always && c->B_hint && (uint64_t)c->B_hint * 24u > c->T);
 }
 
+#if HML_IN_K
 template <int KK>
 static int iterate_many_k(hml_ctx* const* cs, int n, uint64_t first, uint64_t iterations, uint64_t thinning, uint64_t* done) {
     hml_ctx* c0 = cs[0];
@@ -1400,6 +1439,9 @@ static int iterate_many_k(hml_ctx* const* cs, int n, uint64_t first, uint64_t it
     return 0;
 }
 
+#endif   // HML_IN_K
+
+#if HML_IN_CORE   // ---- (core) the rest of the C ABI
 extern "C" int hml_iterate_many(hml_ctx* const* cs, int n, char method, uint64_t iterations, uint64_t thinning) {
     if (!cs || n < 1) return set_err(HML_ERR_ARG, "no contexts");
     for (int i = 0; i < n; ++i) if (!cs[i] || !cs[i]->model_set) return set_err(HML_ERR_ARG, "model not set");
@@ -1417,7 +1459,7 @@ extern "C" int hml_iterate_many(hml_ctx* const* cs, int n, char method, uint64_t
             if (c->graph_exec) { hipGraphExecDestroy(c->graph_exec); c->graph_exec = nullptr; }
         }
         int r = 0;
-        HML_DISPATCH_K(cs[0]->K, r = iterate_many_k<KK>(cs, n, 0, iterations, thinning, &done));
+        { HML_KTAB(cs[0]->K, kt); r = kt->iterate_many(cs, n, 0, iterations, thinning, &done); }
         if (r) return r;
         // the other chains' streams continue behind the batch
         hipEvent_t ev = ev_get(cs[0]);
@@ -1575,7 +1617,7 @@ int hml_set_parameters(hml_ctx* c, const float* mean_var, const float* A, const 
     memcpy(m.A, A, (size_t)K * K * sizeof(float));
     memcpy(m.pi, pi, (size_t)K * sizeof(float));
     HIPCHK(hipMemcpyAsync(c->d_mdl, &m, sizeof m, hipMemcpyHostToDevice, c->stream));
-    HML_DISPATCH_K(K, hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_derive<KK>), dim3(1), dim3(64), 0, c->stream, c->d_mdl));
+    { HML_KTAB(K, kt); kt->derive(c); }
     KLAUNCH_CHECK();
     HIPCHK(hipStreamSynchronize(c->stream));
     if (c->dynamic) c->blocks_valid = false;
@@ -1885,3 +1927,52 @@ int hml_synth_depth(float* x, int16_t* states, uint64_t T, double depth, double 
 }
 
 }  // extern "C"
+
+#endif   // HML_IN_CORE
+
+// ------------------------------------------------------------------------------------------------
+// The K-dependent part behind its table (one per object: -DHML_TU_K=k; a development build: -DHML_ONLY_K=k; else all).
+#if HML_IN_K
+// (the tables are not `const`: the device pass of the compiler takes a constant with constant initialisers for a device
+// constant as well and then looks for the host functions it points to; a plain host variable is only parsed there - which is
+// what instantiates the kernels that sweep_k<K> launches)
+#define HML_DEFINE_KTAB(KK)                                                                                                        \
+    static void hml_kt_params_##KK(hml_ctx* c, int mode) {                                                                         \
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_params<KK>), dim3(1), dim3(1024), 0, c->stream, c->d_mdl, c->d_partial, mode);    \
+    }                                                                                                                              \
+    static void hml_kt_compat_draw_##KK(hml_ctx* c, int mode) {                                                                    \
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_compat_draw<KK>), dim3(1), dim3(64), 0, c->stream, c->d_mdl, (hml_mt_state*)c->d_mt, mode); \
+    }                                                                                                                              \
+    static void hml_kt_derive_##KK(hml_ctx* c) {                                                                                   \
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_derive<KK>), dim3(1), dim3(64), 0, c->stream, c->d_mdl);                          \
+    }                                                                                                                              \
+    extern hml_ktab hml_ktab_##KK;                                                                                                 \
+    hml_ktab hml_ktab_##KK = {&sweep_k<KK>, &iterate_many_k<KK>, &hml_kt_params_##KK, &hml_kt_compat_draw_##KK, &hml_kt_derive_##KK};
+#if defined(HML_TU_K)
+#define HML_DEFINE_KTAB_(K) HML_DEFINE_KTAB(K)
+HML_DEFINE_KTAB_(HML_TU_K)
+#elif defined(HML_ONLY_K)
+#define HML_DEFINE_KTAB_(K) HML_DEFINE_KTAB(K)
+HML_DEFINE_KTAB_(HML_ONLY_K)
+#else
+HML_DEFINE_KTAB(2) HML_DEFINE_KTAB(3) HML_DEFINE_KTAB(4) HML_DEFINE_KTAB(5) HML_DEFINE_KTAB(6) HML_DEFINE_KTAB(7) HML_DEFINE_KTAB(8) HML_DEFINE_KTAB(9)
+HML_DEFINE_KTAB(10) HML_DEFINE_KTAB(11) HML_DEFINE_KTAB(12) HML_DEFINE_KTAB(13) HML_DEFINE_KTAB(14) HML_DEFINE_KTAB(15) HML_DEFINE_KTAB(16)
+#endif
+#endif   // HML_IN_K
+
+#if HML_IN_CORE
+#if defined(HML_ONLY_K)
+#define HML_DECLARE_KTAB_(K) extern hml_ktab hml_ktab_##K; static const hml_ktab* ktab(int k) { return k == K ? &hml_ktab_##K : nullptr; }
+#define HML_DECLARE_KTAB(K) HML_DECLARE_KTAB_(K)
+HML_DECLARE_KTAB(HML_ONLY_K)
+#else
+#define HML_EXT_KTAB(K) extern hml_ktab hml_ktab_##K;
+HML_EXT_KTAB(2) HML_EXT_KTAB(3) HML_EXT_KTAB(4) HML_EXT_KTAB(5) HML_EXT_KTAB(6) HML_EXT_KTAB(7) HML_EXT_KTAB(8) HML_EXT_KTAB(9)
+HML_EXT_KTAB(10) HML_EXT_KTAB(11) HML_EXT_KTAB(12) HML_EXT_KTAB(13) HML_EXT_KTAB(14) HML_EXT_KTAB(15) HML_EXT_KTAB(16)
+static const hml_ktab* ktab(int k) {
+    static const hml_ktab* const tabs[17] = {nullptr, nullptr, &hml_ktab_2, &hml_ktab_3, &hml_ktab_4, &hml_ktab_5, &hml_ktab_6, &hml_ktab_7, &hml_ktab_8,
+                                             &hml_ktab_9, &hml_ktab_10, &hml_ktab_11, &hml_ktab_12, &hml_ktab_13, &hml_ktab_14, &hml_ktab_15, &hml_ktab_16};
+    return (k >= 2 && k <= 16) ? tabs[k] : nullptr;
+}
+#endif
+#endif   // HML_IN_CORE

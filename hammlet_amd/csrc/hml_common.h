@@ -12,6 +12,9 @@
 #include <hip/hip_runtime.h>
 #define HML_HD __host__ __device__ __forceinline__
 #define HML_HDM __host__ __device__ __forceinline__
+// a kernel: internal linkage, so that every object of the library (hml_capi.hip is compiled once for the core and once per
+// number of states) holds - and loads - its own copy of the kernels it launches
+#define HML_KERNEL static __global__
 #else
 #define HML_HD static inline
 #define HML_HDM inline

@@ -253,7 +253,7 @@ __device__ __forceinline__ void hml_b_backward_maps(const float* __restrict__ ro
 }
 // the kernel: hml_b_backward_maps over one chain (hml_k_many.h runs it over several chains in one launch)
 template <int K>
-__global__ __launch_bounds__(256) void hml_k_backward_maps(const float* __restrict__ rows, hml_model* __restrict__ mdl,
+HML_KERNEL __launch_bounds__(256) void hml_k_backward_maps(const float* __restrict__ rows, hml_model* __restrict__ mdl,
                                                            unsigned long long* __restrict__ smap,
                                                            unsigned long long* __restrict__ cmap, const hml_layout lay,
                                                            const float* __restrict__ entry, const float* __restrict__ exitv,
@@ -386,7 +386,7 @@ __device__ __forceinline__ void hml_b_backward_chain(unsigned long long* __restr
 }
 // the kernel: hml_b_backward_chain over one chain (hml_k_many.h runs it over several chains in one launch)
 template <int K>
-__global__ __launch_bounds__(1024) void hml_k_backward_chain(unsigned long long* __restrict__ cmap, hml_model* __restrict__ mdl,
+HML_KERNEL __launch_bounds__(1024) void hml_k_backward_chain(unsigned long long* __restrict__ cmap, hml_model* __restrict__ mdl,
                                                              uint8_t* __restrict__ entry_state, const float* __restrict__ em,
                                                              const float* __restrict__ gsc, float* __restrict__ rows,
                                                              float* __restrict__ aprobe, float* __restrict__ entry,
@@ -403,7 +403,7 @@ __global__ __launch_bounds__(1024) void hml_k_backward_chain(unsigned long long*
 // its super-chunk], super[S] = scmap[64 S] -, the one-workgroup chain runs over the super maps only (super_level = 1),
 // and the state entering chunk c follows from its super-chunk's: entry[c] = scmap[c + 1](entry2[S]).
 template <int K>
-__global__ __launch_bounds__(256) void hml_k_backward_super(const unsigned long long* __restrict__ cmap, const hml_model* __restrict__ mdl,
+HML_KERNEL __launch_bounds__(256) void hml_k_backward_super(const unsigned long long* __restrict__ cmap, const hml_model* __restrict__ mdl,
                                                             unsigned long long* __restrict__ scmap, unsigned long long* __restrict__ super) {
     const uint32_t NC = (mdl->B + HML_BWD_CHUNK - 1u) / HML_BWD_CHUNK;
     const uint32_t NS = (NC + 63u) / 64u;
@@ -423,7 +423,7 @@ __global__ __launch_bounds__(256) void hml_k_backward_super(const unsigned long 
     }
 }
 
-__global__ __launch_bounds__(256) void hml_k_backward_entries(const unsigned long long* __restrict__ scmap, const uint8_t* __restrict__ entry2,
+HML_KERNEL __launch_bounds__(256) void hml_k_backward_entries(const unsigned long long* __restrict__ scmap, const uint8_t* __restrict__ entry2,
                                                               const hml_model* __restrict__ mdl, uint8_t* __restrict__ entry_state) {
     const uint32_t NC = (mdl->B + HML_BWD_CHUNK - 1u) / HML_BWD_CHUNK;
     const uint32_t stride = gridDim.x * blockDim.x;
@@ -440,7 +440,7 @@ __global__ __launch_bounds__(256) void hml_k_backward_entries(const unsigned lon
 // `em` holds the weights written by the emission kernel in mixture mode.
 // ------------------------------------------------------------------------------------------
 template <int K>
-__global__ __launch_bounds__(256) void hml_k_mixture(const float* __restrict__ em, const hml_model* __restrict__ mdl,
+HML_KERNEL __launch_bounds__(256) void hml_k_mixture(const float* __restrict__ em, const hml_model* __restrict__ mdl,
                                                      int16_t* __restrict__ q, const hml_layout lay) {
     const uint32_t B = mdl->B;
     const unsigned long long epoch = mdl->epoch;
@@ -647,7 +647,7 @@ __device__ __forceinline__ void hml_b_counts(int16_t* __restrict__ q, const uint
 }
 // the kernel: hml_b_counts over one chain (hml_k_many.h runs it over several chains in one launch)
 template <int K, bool FB, bool MV = false>
-__global__ __launch_bounds__(256) void hml_k_counts(int16_t* __restrict__ q, const uint32_t* __restrict__ starts,
+HML_KERNEL __launch_bounds__(256) void hml_k_counts(int16_t* __restrict__ q, const uint32_t* __restrict__ starts,
                                                     const float2* __restrict__ bstat, hml_model* __restrict__ mdl,
                                                     double* __restrict__ partial ,
                                                     const unsigned long long* __restrict__ smap,
@@ -662,7 +662,7 @@ __global__ __launch_bounds__(256) void hml_k_counts(int16_t* __restrict__ q, con
 // changes of state - rare - in LDS), loads one chunk ahead, nothing but the lane's own accumulators in the loop.
 // ------------------------------------------------------------------------------------------
 template <int K, bool FB>
-__global__ __launch_bounds__(256) void hml_k_counts_dense(int16_t* __restrict__ q, const uint32_t* __restrict__ starts,
+HML_KERNEL __launch_bounds__(256) void hml_k_counts_dense(int16_t* __restrict__ q, const uint32_t* __restrict__ starts,
                                                           const float2* __restrict__ bstat, hml_model* __restrict__ mdl,
                                                           double* __restrict__ partial /*[K][2][GROUPS]: plane (state, sum | sum of squares), one double per group*/,
                                                           const unsigned long long* __restrict__ smap,
@@ -808,7 +808,7 @@ __device__ __forceinline__ void hml_b_record(const int16_t* __restrict__ q, cons
     }
 }
 // the kernel: hml_b_record over one chain (hml_k_many.h runs it over several chains in one launch)
-__global__ __launch_bounds__(256) void hml_k_record(const int16_t* __restrict__ q, const uint32_t* __restrict__ starts,
+HML_KERNEL __launch_bounds__(256) void hml_k_record(const int16_t* __restrict__ q, const uint32_t* __restrict__ starts,
                                                     hml_model* __restrict__ mdl, int32_t* __restrict__ diff,
                                                     uint32_t* __restrict__ boundary) {
     hml_b_record(q, starts, mdl, diff, boundary);

@@ -28,7 +28,7 @@
 
 typedef float hml_f4 __attribute__((ext_vector_type(4)));
 
-__global__ __launch_bounds__(256) void hml_k_compact_scan(const float* __restrict__ w, uint32_t T,
+HML_KERNEL __launch_bounds__(256) void hml_k_compact_scan(const float* __restrict__ w, uint32_t T,
                                                           const hml_model* __restrict__ mdl, float thr_override,
                                                           int use_override, uint16_t* __restrict__ stage,
                                                           uint32_t* __restrict__ span_count) {
@@ -105,7 +105,7 @@ HML_HD uint32_t hml_weight_key(float w, int32_t base) {
 }
 
 // one thread per group: four float4 loads, one byte out
-__global__ __launch_bounds__(256) void hml_k_build_summary(const float* __restrict__ w, uint64_t T, int32_t base,
+HML_KERNEL __launch_bounds__(256) void hml_k_build_summary(const float* __restrict__ w, uint64_t T, int32_t base,
                                                            uint8_t* __restrict__ summary) {
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     const uint64_t n16 = (T + 15) / 16;
@@ -281,7 +281,7 @@ __device__ __forceinline__ void hml_b_compact_scan_summary(const uint8_t* __rest
     if (threadIdx.x == 0) group_total[blockIdx.x] = wave_total[0] + wave_total[1] + wave_total[2] + wave_total[3];
 }
 // the kernel: hml_b_compact_scan_summary over one chain (hml_k_many.h runs it over several chains in one launch)
-__global__ __launch_bounds__(256) void hml_k_compact_scan_summary(const uint8_t* __restrict__ summary, const float* __restrict__ w,
+HML_KERNEL __launch_bounds__(256) void hml_k_compact_scan_summary(const uint8_t* __restrict__ summary, const float* __restrict__ w,
                                                                   uint32_t T, const hml_model* __restrict__ mdl,
                                                                   float thr_override, int use_override, int32_t base,
                                                                   uint16_t* __restrict__ stage,
@@ -298,7 +298,7 @@ __device__ __forceinline__ uint32_t hml_wave_sum_u32(uint32_t v) {
 }
 
 // block count of every group of HML_GROUP_SPANS spans, for the float scan (the summary scan writes its own)
-__global__ __launch_bounds__(256) void hml_k_group_totals(const uint32_t* __restrict__ span_count, uint32_t n_spans,
+HML_KERNEL __launch_bounds__(256) void hml_k_group_totals(const uint32_t* __restrict__ span_count, uint32_t n_spans,
                                                           uint32_t* __restrict__ group_total) {
     const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t first = g * HML_GROUP_SPANS;
@@ -360,7 +360,7 @@ __device__ __forceinline__ void hml_b_compact_scatter(const uint16_t* __restrict
     }
 }
 // the kernel: hml_b_compact_scatter over one chain (hml_k_many.h runs it over several chains in one launch)
-__global__ __launch_bounds__(256) void hml_k_compact_scatter(const uint16_t* __restrict__ stage,
+HML_KERNEL __launch_bounds__(256) void hml_k_compact_scatter(const uint16_t* __restrict__ stage,
                                                              const uint32_t* __restrict__ span_count,
                                                              const uint32_t* __restrict__ group_total, uint32_t n_spans,
                                                              uint32_t T, hml_model* __restrict__ mdl,
@@ -383,7 +383,7 @@ __device__ __forceinline__ void hml_wave_lds_order() {
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
-__global__ __launch_bounds__(256) void hml_k_compact_scan_bits(const float* __restrict__ w, uint32_t T,
+HML_KERNEL __launch_bounds__(256) void hml_k_compact_scan_bits(const float* __restrict__ w, uint32_t T,
                                                                const hml_model* __restrict__ mdl, float thr_override,
                                                                int use_override, unsigned long long* __restrict__ stage_bits,
                                                                uint32_t* __restrict__ span_count) {
@@ -425,7 +425,7 @@ __global__ __launch_bounds__(256) void hml_k_compact_scan_bits(const float* __re
     if (lane == 0) span_count[span] = running;
 }
 
-__global__ __launch_bounds__(256) void hml_k_compact_scatter_bits(const unsigned long long* __restrict__ stage_bits,
+HML_KERNEL __launch_bounds__(256) void hml_k_compact_scatter_bits(const unsigned long long* __restrict__ stage_bits,
                                                                   const uint32_t* __restrict__ span_count,
                                                                   const uint32_t* __restrict__ group_total, uint32_t n_spans,
                                                                   uint32_t T, hml_model* __restrict__ mdl,
@@ -527,7 +527,7 @@ __device__ __forceinline__ void hml_block_stats_one(const float2* __restrict__ i
     q = pq - nq;
 }
 
-__global__ __launch_bounds__(256) void hml_k_block_stats(const float2* __restrict__ ia,
+HML_KERNEL __launch_bounds__(256) void hml_k_block_stats(const float2* __restrict__ ia,
                                                          const uint32_t* __restrict__ starts,
                                                          const hml_model* __restrict__ mdl,
                                                          float2* __restrict__ bstat) {

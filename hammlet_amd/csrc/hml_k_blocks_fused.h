@@ -80,7 +80,7 @@ __device__ __forceinline__ unsigned long long hml_fused_tile_word(const uint8_t*
 }
 
 template <int K>
-__global__ __launch_bounds__(HML_FUSED_WAVES * 64, 6) void hml_k_blocks_fused(const uint8_t* __restrict__ summary, const float* __restrict__ w,
+HML_KERNEL __launch_bounds__(HML_FUSED_WAVES * 64, 6) void hml_k_blocks_fused(const uint8_t* __restrict__ summary, const float* __restrict__ w,
                                                           const float2* __restrict__ ia, uint32_t T,
                                                           hml_model* __restrict__ mdl, int32_t base,
                                                           unsigned long long* __restrict__ group_word,

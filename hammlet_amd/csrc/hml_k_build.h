@@ -18,7 +18,7 @@
 #define HML_MAXLET_LOG_TILE 10
 #define HML_MAXLET_TILE 1024
 
-__global__ __launch_bounds__(256) void hml_k_maxlet(const float* __restrict__ in, uint64_t n, int base,
+HML_KERNEL __launch_bounds__(256) void hml_k_maxlet(const float* __restrict__ in, uint64_t n, int base,
                                                     float* __restrict__ coeff, uint64_t T,
                                                     float* __restrict__ out_sums, const float* __restrict__ norm) {
     __shared__ float s[HML_MAXLET_TILE];
@@ -87,7 +87,7 @@ __global__ __launch_bounds__(256) void hml_k_maxlet(const float* __restrict__ in
 //   for i = m/2 .. 1:  e = max(e, c[t-i]);  if (t+i < T) e = max(e, (t+2i < T) ? c[t+i] : inf)
 // w[0] = inf.  Then w *= multiplier (src/main.cpp:332-334).
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void hml_k_weights(const float* __restrict__ c, float* __restrict__ w, uint64_t T,
+HML_KERNEL __launch_bounds__(256) void hml_k_weights(const float* __restrict__ c, float* __restrict__ w, uint64_t T,
                                                      float multiplier) {
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     const float inf = HML_INF_F;
@@ -111,7 +111,7 @@ __global__ __launch_bounds__(256) void hml_k_weights(const float* __restrict__ c
     }
 }
 
-__global__ __launch_bounds__(256) void hml_k_scale(float* __restrict__ w, uint64_t T, float multiplier) {
+HML_KERNEL __launch_bounds__(256) void hml_k_scale(float* __restrict__ w, uint64_t T, float multiplier) {
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < T; t += stride) w[t] = w[t] * multiplier;
 }
@@ -127,7 +127,7 @@ __global__ __launch_bounds__(256) void hml_k_scale(float* __restrict__ w, uint64
 // ------------------------------------------------------------------------------------------
 #define HML_IA_SEG 1024
 
-__global__ __launch_bounds__(256) void hml_k_integral(const float* __restrict__ x, float2* __restrict__ ia, uint64_t T) {
+HML_KERNEL __launch_bounds__(256) void hml_k_integral(const float* __restrict__ x, float2* __restrict__ ia, uint64_t T) {
     __shared__ float xs[4][HML_IA_SEG];
     __shared__ float2 os[4][HML_IA_SEG];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;

@@ -120,7 +120,7 @@ __device__ __forceinline__ void hml_compat_derive(hml_model* mdl, int K) {
 
 // mode 1: theta, pi, A from the (reset) priors (main.cpp:393-401); mode 2: Theta's constructor draw (Theta.hpp:126-127)
 template <int K>
-__global__ __launch_bounds__(64) void hml_k_compat_draw(hml_model* __restrict__ mdl, hml_mt_state* __restrict__ mts, int mode) {
+HML_KERNEL __launch_bounds__(64) void hml_k_compat_draw(hml_model* __restrict__ mdl, hml_mt_state* __restrict__ mts, int mode) {
     __shared__ uint32_t lmt[HML_MT_N];
     for (int i = threadIdx.x; i < HML_MT_N; i += 64) lmt[i] = mts->mt[i];
     __syncthreads();
@@ -138,7 +138,7 @@ __global__ __launch_bounds__(64) void hml_k_compat_draw(hml_model* __restrict__ 
 // StateSequence<ForwardBackward>::sample (ForwardBackward.hpp:16-213), 1 = StateSequence<Mixture>::sample
 // (Mixture.hpp:31-144).  rows: (B + 1) x K floats, row 0 = pi.
 template <int K>
-__global__ __launch_bounds__(64) void hml_k_compat_sweep(hml_model* __restrict__ mdl, hml_mt_state* __restrict__ mts,
+HML_KERNEL __launch_bounds__(64) void hml_k_compat_sweep(hml_model* __restrict__ mdl, hml_mt_state* __restrict__ mts,
                                                          const uint32_t* __restrict__ starts, const float2* __restrict__ bstat,
                                                          float* __restrict__ rows, int16_t* __restrict__ q, int method,
                                                          float* __restrict__ eprobe, float* __restrict__ aprobe) {

@@ -147,7 +147,7 @@ __device__ __forceinline__ void hml_emit_block_looped(const hml_emit_lds<K>& l, 
 }
 
 template <int K>
-__global__ __launch_bounds__(256) void hml_k_emission(const float2* __restrict__ bstat,
+HML_KERNEL __launch_bounds__(256) void hml_k_emission(const float2* __restrict__ bstat,
                                                       const uint32_t* __restrict__ starts, hml_model* __restrict__ mdl,
                                                       float* __restrict__ em, float* __restrict__ gsc,
                                                       float* __restrict__ eprobe, int mixture, const hml_layout lay) {
@@ -183,7 +183,7 @@ __device__ __forceinline__ void hml_b_stats_emission(const float2* __restrict__ 
 }
 // the kernel: hml_b_stats_emission over one chain (hml_k_many.h runs it over several chains in one launch)
 template <int K>
-__global__ __launch_bounds__(256) void hml_k_stats_emission(const float2* __restrict__ ia, const uint32_t* __restrict__ starts,
+HML_KERNEL __launch_bounds__(256) void hml_k_stats_emission(const float2* __restrict__ ia, const uint32_t* __restrict__ starts,
                                                             hml_model* __restrict__ mdl, float2* __restrict__ bstat,
                                                             float* __restrict__ em, float* __restrict__ gsc,
                                                             float* __restrict__ eprobe, int mixture, const hml_layout lay) {
@@ -199,7 +199,7 @@ __global__ __launch_bounds__(256) void hml_k_stats_emission(const float2* __rest
 //         - N * logNs[s]  [+ (N-1) logA_s]
 // One thread per block.  STATS: block statistics from the integral arrays first, else from the bstat planes.
 template <int K, bool STATS>
-__global__ __launch_bounds__(256) void hml_k_emission_mv(const float2* __restrict__ ia, const uint32_t* __restrict__ starts,
+HML_KERNEL __launch_bounds__(256) void hml_k_emission_mv(const float2* __restrict__ ia, const uint32_t* __restrict__ starts,
                                                          hml_model* __restrict__ mdl, float2* __restrict__ bstat,
                                                          float* __restrict__ em, float* __restrict__ gsc,
                                                          float* __restrict__ eprobe, int mixture, const hml_layout lay) {
@@ -304,7 +304,7 @@ __device__ __forceinline__ void hml_emit_values_fast(const hml_emit_params<K>& p
 
 // STATS = true: block statistics from the integral array first (hml_k_stats_emission); false: from bstat (hml_k_emission)
 template <int K, bool STATS>
-__global__ __launch_bounds__(256) void hml_k_emission_tiled(const float2* __restrict__ ia, const uint32_t* __restrict__ starts,
+HML_KERNEL __launch_bounds__(256) void hml_k_emission_tiled(const float2* __restrict__ ia, const uint32_t* __restrict__ starts,
                                                             hml_model* __restrict__ mdl, float2* __restrict__ bstat,
                                                             float* __restrict__ em, float* __restrict__ gsc,
                                                             float* __restrict__ eprobe, int mixture, const hml_layout lay) {
@@ -574,7 +574,7 @@ __device__ __forceinline__ void hml_b_forward(const float* __restrict__ em, cons
 }
 // the kernel: hml_b_forward over one chain (hml_k_many.h runs it over several chains in one launch)
 template <int K>
-__global__ __launch_bounds__(256) void hml_k_forward(const float* __restrict__ em, const float* __restrict__ gsc,
+HML_KERNEL __launch_bounds__(256) void hml_k_forward(const float* __restrict__ em, const float* __restrict__ gsc,
                                                      hml_model* __restrict__ mdl, float* __restrict__ rows,
                                                      float* __restrict__ aprobe, float* __restrict__ entry,
                                                      float* __restrict__ exitv, uint32_t* __restrict__ fb_count, int L,

@@ -37,48 +37,48 @@ struct hml_chain_dev {
     uint32_t* boundary;
 };
 
-__global__ __launch_bounds__(256) void hml_m_compact_scan_summary(const hml_chain_dev* __restrict__ cs, uint32_t T) {
+HML_KERNEL __launch_bounds__(256) void hml_m_compact_scan_summary(const hml_chain_dev* __restrict__ cs, uint32_t T) {
     const hml_chain_dev& c = cs[blockIdx.y];
     hml_b_compact_scan_summary(c.summary, c.w, T, c.mdl, 0.0f, 0, c.key_base, c.stage, c.span_count, c.coarse1);
 }
-__global__ __launch_bounds__(256) void hml_m_compact_scatter(const hml_chain_dev* __restrict__ cs, uint32_t T) {
+HML_KERNEL __launch_bounds__(256) void hml_m_compact_scatter(const hml_chain_dev* __restrict__ cs, uint32_t T) {
     const hml_chain_dev& c = cs[blockIdx.y];
     hml_b_compact_scatter(c.stage, c.span_count, c.coarse1, c.n_spans, T, c.mdl, c.starts, c.host_B);
 }
 template <int K>
-__global__ __launch_bounds__(256) void hml_m_stats_emission(const hml_chain_dev* __restrict__ cs, int with_gsc, const hml_layout lay) {
+HML_KERNEL __launch_bounds__(256) void hml_m_stats_emission(const hml_chain_dev* __restrict__ cs, int with_gsc, const hml_layout lay) {
     const hml_chain_dev& c = cs[blockIdx.y];
     hml_b_stats_emission<K>(c.ia, c.starts, c.mdl, c.bstat, c.em, with_gsc ? c.gsc : nullptr, nullptr, 0, lay);
 }
 template <int K>
-__global__ __launch_bounds__(256) void hml_m_forward(const hml_chain_dev* __restrict__ cs, int with_gsc, int L, const hml_layout lay) {
+HML_KERNEL __launch_bounds__(256) void hml_m_forward(const hml_chain_dev* __restrict__ cs, int with_gsc, int L, const hml_layout lay) {
     const hml_chain_dev& c = cs[blockIdx.y];
     hml_b_forward<K>(c.em, with_gsc ? c.gsc : nullptr, c.mdl, c.rows, nullptr, c.entry, c.exitv, c.fb, L, lay);
 }
 template <int K>
-__global__ __launch_bounds__(256) void hml_m_backward_maps(const hml_chain_dev* __restrict__ cs, int with_gsc, int L, const hml_layout lay) {
+HML_KERNEL __launch_bounds__(256) void hml_m_backward_maps(const hml_chain_dev* __restrict__ cs, int with_gsc, int L, const hml_layout lay) {
     const hml_chain_dev& c = cs[blockIdx.y];
     hml_b_backward_maps<K>(c.rows, c.mdl, c.smap, c.cmap, lay, c.entry, c.exitv, c.redo, L, with_gsc ? nullptr : c.starts, c.mdl);
 }
 template <int K>
-__global__ __launch_bounds__(1024) void hml_m_backward_chain(const hml_chain_dev* __restrict__ cs, int with_gsc, int L, const hml_layout lay) {
+HML_KERNEL __launch_bounds__(1024) void hml_m_backward_chain(const hml_chain_dev* __restrict__ cs, int with_gsc, int L, const hml_layout lay) {
     const hml_chain_dev& c = cs[blockIdx.y];
     hml_b_backward_chain<K>(c.cmap, c.mdl, c.bentry, c.em, with_gsc ? c.gsc : nullptr, c.rows, nullptr, c.entry, c.exitv, c.fb, c.redo, c.touched,
                             c.smap, L, lay, 3, 0, with_gsc ? nullptr : c.starts);
 }
 template <int K>
-__global__ __launch_bounds__(256) void hml_m_counts(const hml_chain_dev* __restrict__ cs) {
+HML_KERNEL __launch_bounds__(256) void hml_m_counts(const hml_chain_dev* __restrict__ cs) {
     const hml_chain_dev& c = cs[blockIdx.y];
     hml_b_counts<K, true, false>(c.q, c.starts, c.bstat, c.mdl, c.partial, c.smap, c.bentry);
 }
 // (only the chains whose bit is set record this sweep: a chain may have its marginals switched off)
-__global__ __launch_bounds__(256) void hml_m_record(const hml_chain_dev* __restrict__ cs, unsigned long long chains_recording) {
+HML_KERNEL __launch_bounds__(256) void hml_m_record(const hml_chain_dev* __restrict__ cs, unsigned long long chains_recording) {
     if (!((chains_recording >> blockIdx.y) & 1ull)) return;
     const hml_chain_dev& c = cs[blockIdx.y];
     hml_b_record(c.q, c.starts, c.mdl, c.diff, c.boundary);
 }
 template <int K>
-__global__ __launch_bounds__(1024) void hml_m_params(const hml_chain_dev* __restrict__ cs) {
+HML_KERNEL __launch_bounds__(1024) void hml_m_params(const hml_chain_dev* __restrict__ cs) {
     const hml_chain_dev& c = cs[blockIdx.y];
     hml_b_params<K>(c.mdl, c.partial, 0);
 }

@@ -5,7 +5,7 @@
 #include "hml_state.h"
 
 // count boundary bits per span of 4096 positions (128 words); position 0 always counts
-__global__ __launch_bounds__(256) void hml_k_marg_count(const uint32_t* __restrict__ boundary, uint32_t T,
+HML_KERNEL __launch_bounds__(256) void hml_k_marg_count(const uint32_t* __restrict__ boundary, uint32_t T,
                                                         uint32_t* __restrict__ span_count) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const uint32_t span = blockIdx.x * 4u + (uint32_t)wave;
@@ -27,7 +27,7 @@ __global__ __launch_bounds__(256) void hml_k_marg_count(const uint32_t* __restri
 }
 
 // write the boundary positions of each span, in order, at seg_start[span_offset + ...]
-__global__ __launch_bounds__(256) void hml_k_marg_scatter(const uint32_t* __restrict__ boundary, uint32_t T,
+HML_KERNEL __launch_bounds__(256) void hml_k_marg_scatter(const uint32_t* __restrict__ boundary, uint32_t T,
                                                           const uint32_t* __restrict__ span_offset,
                                                           uint32_t* __restrict__ seg_start) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -60,7 +60,7 @@ __global__ __launch_bounds__(256) void hml_k_marg_scatter(const uint32_t* __rest
 }
 
 // gather diff[s][seg_start[i]] for all states: out[i*K + s]
-__global__ __launch_bounds__(256) void hml_k_marg_gather(const int32_t* __restrict__ diff, uint32_t T, int K,
+HML_KERNEL __launch_bounds__(256) void hml_k_marg_gather(const int32_t* __restrict__ diff, uint32_t T, int K,
                                                          const uint32_t* __restrict__ seg_start, uint32_t M,
                                                          int32_t* __restrict__ out) {
     const uint64_t T1 = (uint64_t)T + 1u;
@@ -73,7 +73,7 @@ __global__ __launch_bounds__(256) void hml_k_marg_gather(const int32_t* __restri
 
 // ---- dense expansion: counts[s][t] = prefix sum over t of diff[s][t]; row K = boundary indicator ----
 // three-phase scan over chunks of 4096 positions per state
-__global__ __launch_bounds__(256) void hml_k_dense_partial(const int32_t* __restrict__ diff, uint32_t T, int K,
+HML_KERNEL __launch_bounds__(256) void hml_k_dense_partial(const int32_t* __restrict__ diff, uint32_t T, int K,
                                                            int32_t* __restrict__ chunk_sum, uint32_t n_chunks) {
     __shared__ int32_t red[4];
     const int s = blockIdx.y;
@@ -92,7 +92,7 @@ __global__ __launch_bounds__(256) void hml_k_dense_partial(const int32_t* __rest
     if (threadIdx.x == 0) chunk_sum[(uint64_t)s * n_chunks + chunk] = red[0] + red[1] + red[2] + red[3];
 }
 
-__global__ __launch_bounds__(1024) void hml_k_dense_chunkscan(int32_t* __restrict__ chunk_sum, uint32_t n_chunks) {
+HML_KERNEL __launch_bounds__(1024) void hml_k_dense_chunkscan(int32_t* __restrict__ chunk_sum, uint32_t n_chunks) {
     __shared__ int32_t part[1024];
     const int s = blockIdx.x;
     int32_t* cs = chunk_sum + (uint64_t)s * n_chunks;
@@ -114,7 +114,7 @@ __global__ __launch_bounds__(1024) void hml_k_dense_chunkscan(int32_t* __restric
     for (uint32_t i = a; i < b; ++i) { const int32_t v = cs[i]; cs[i] = run; run += v; }
 }
 
-__global__ __launch_bounds__(256) void hml_k_dense_final(const int32_t* __restrict__ diff, uint32_t T, int K,
+HML_KERNEL __launch_bounds__(256) void hml_k_dense_final(const int32_t* __restrict__ diff, uint32_t T, int K,
                                                          const int32_t* __restrict__ chunk_sum, uint32_t n_chunks,
                                                          const int32_t* __restrict__ perm, int32_t* __restrict__ out) {
     __shared__ int32_t wsum[4];
@@ -145,7 +145,7 @@ __global__ __launch_bounds__(256) void hml_k_dense_final(const int32_t* __restri
     }
 }
 
-__global__ __launch_bounds__(256) void hml_k_dense_boundary(const uint32_t* __restrict__ boundary, uint32_t T,
+HML_KERNEL __launch_bounds__(256) void hml_k_dense_boundary(const uint32_t* __restrict__ boundary, uint32_t T,
                                                             int32_t* __restrict__ out_row) {
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < T; t += stride)

@@ -44,9 +44,9 @@ __device__ __forceinline__ void hml_derive(hml_model* mdl, int tid) {
 }
 
 template <int K>
-__global__ __launch_bounds__(64) void hml_k_derive(hml_model* mdl) { hml_derive<K>(mdl, threadIdx.x); }
+HML_KERNEL __launch_bounds__(64) void hml_k_derive(hml_model* mdl) { hml_derive<K>(mdl, threadIdx.x); }
 
-__global__ __launch_bounds__(64) void hml_k_set_dynamic(hml_model* mdl, int on, int take_threshold) {
+HML_KERNEL __launch_bounds__(64) void hml_k_set_dynamic(hml_model* mdl, int on, int take_threshold) {
     if (threadIdx.x == 0) {
         mdl->dynamic = on;
         if (take_threshold) mdl->thr = mdl->thr_theta;
@@ -335,7 +335,7 @@ __device__ __forceinline__ void hml_b_params(hml_model* __restrict__ mdl, const 
 }
 // the kernel: hml_b_params over one chain (hml_k_many.h runs it over several chains in one launch)
 template <int K>
-__global__ __launch_bounds__(1024) void hml_k_params(hml_model* __restrict__ mdl, const double* __restrict__ partial,
+HML_KERNEL __launch_bounds__(1024) void hml_k_params(hml_model* __restrict__ mdl, const double* __restrict__ partial,
                                                      int mode) {
     hml_b_params<K>(mdl, partial, mode);
 }

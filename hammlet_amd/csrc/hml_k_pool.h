@@ -14,7 +14,7 @@
 
 #include "hml_state.h"
 
-__global__ __launch_bounds__(256) void hml_k_pool_export(const int32_t* __restrict__ diff, const uint32_t* __restrict__ boundary,
+HML_KERNEL __launch_bounds__(256) void hml_k_pool_export(const int32_t* __restrict__ diff, const uint32_t* __restrict__ boundary,
                                                          const hml_model* __restrict__ mdl, const int32_t* __restrict__ perm,
                                                          uint32_t T, int K, int32_t* __restrict__ payload) {
     const uint64_t T1 = (uint64_t)T + 1u;
@@ -40,13 +40,13 @@ __global__ __launch_bounds__(256) void hml_k_pool_export(const int32_t* __restri
     if (blockIdx.x == 0 && threadIdx.x == 0) tail[0] = (int32_t)mdl->n_recorded;
 }
 
-__global__ __launch_bounds__(256) void hml_k_pool_add(int32_t* __restrict__ acc, const int32_t* __restrict__ other, uint64_t n) {
+HML_KERNEL __launch_bounds__(256) void hml_k_pool_add(int32_t* __restrict__ acc, const int32_t* __restrict__ other, uint64_t n) {
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) acc[i] += other[i];
 }
 
 // pooled payload -> the context's difference arrays (states now carry the common labels)
-__global__ __launch_bounds__(256) void hml_k_pool_install_diff(const int32_t* __restrict__ payload, uint32_t T, int K,
+HML_KERNEL __launch_bounds__(256) void hml_k_pool_install_diff(const int32_t* __restrict__ payload, uint32_t T, int K,
                                                                int32_t* __restrict__ diff) {
     const uint64_t n = (uint64_t)K * ((uint64_t)T + 1u);
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
@@ -54,7 +54,7 @@ __global__ __launch_bounds__(256) void hml_k_pool_install_diff(const int32_t* __
 }
 
 // ... and the boundary bitmap (one thread per 32-bit word) plus the recorded-sweep bookkeeping of the model
-__global__ __launch_bounds__(256) void hml_k_pool_install_boundary(const int32_t* __restrict__ payload, uint32_t T, int K,
+HML_KERNEL __launch_bounds__(256) void hml_k_pool_install_boundary(const int32_t* __restrict__ payload, uint32_t T, int K,
                                                                    uint32_t* __restrict__ boundary, hml_model* __restrict__ mdl) {
     const uint64_t T1 = (uint64_t)T + 1u;
     const int32_t* __restrict__ row = payload + (uint64_t)K * T1;

@@ -13,7 +13,7 @@
 #include "hml_state.h"
 
 // phase 1: per chunk of 256 segments, the column sums of g -> chunk_sum[s * n_chunks + chunk]
-__global__ __launch_bounds__(256) void hml_k_seg_partial(const int32_t* __restrict__ g, uint32_t M, int K,
+HML_KERNEL __launch_bounds__(256) void hml_k_seg_partial(const int32_t* __restrict__ g, uint32_t M, int K,
                                                          int32_t* __restrict__ chunk_sum, uint32_t n_chunks) {
     __shared__ int32_t red[4][HML_MAX_K];
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
@@ -31,7 +31,7 @@ __global__ __launch_bounds__(256) void hml_k_seg_partial(const int32_t* __restri
 
 // phase 3 (phase 2 is hml_k_dense_chunkscan over the K rows of chunk_sum): running counts of every segment and
 // their arg-max -> seg_state[i]
-__global__ __launch_bounds__(256) void hml_k_seg_argmax(const int32_t* __restrict__ g, uint32_t M, int K,
+HML_KERNEL __launch_bounds__(256) void hml_k_seg_argmax(const int32_t* __restrict__ g, uint32_t M, int K,
                                                         const int32_t* __restrict__ chunk_base, uint32_t n_chunks,
                                                         int16_t* __restrict__ seg_state) {
     __shared__ int32_t wsum[4][HML_MAX_K];
@@ -66,7 +66,7 @@ __global__ __launch_bounds__(256) void hml_k_seg_argmax(const int32_t* __restric
 }
 
 // run starts: segment i opens a run if i == 0 or its state differs from its predecessor's; count per chunk
-__global__ __launch_bounds__(256) void hml_k_seg_run_count(const int16_t* __restrict__ seg_state, uint32_t M,
+HML_KERNEL __launch_bounds__(256) void hml_k_seg_run_count(const int16_t* __restrict__ seg_state, uint32_t M,
                                                            int32_t* __restrict__ chunk_runs) {
     __shared__ int32_t red[4];
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
@@ -79,7 +79,7 @@ __global__ __launch_bounds__(256) void hml_k_seg_run_count(const int16_t* __rest
 }
 
 // scatter, in order: run r starts at position seg_start[i] with state seg_state[i]
-__global__ __launch_bounds__(256) void hml_k_seg_run_scatter(const int16_t* __restrict__ seg_state, const uint32_t* __restrict__ seg_start,
+HML_KERNEL __launch_bounds__(256) void hml_k_seg_run_scatter(const int16_t* __restrict__ seg_state, const uint32_t* __restrict__ seg_start,
                                                              uint32_t M, const int32_t* __restrict__ chunk_base,
                                                              uint32_t* __restrict__ run_start, int16_t* __restrict__ run_state) {
     __shared__ int32_t wsum[4];

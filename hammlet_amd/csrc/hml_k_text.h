@@ -49,7 +49,7 @@ __device__ __forceinline__ uint32_t hml_text_starts(const uint8_t* __restrict__ 
     return ~ws & ((ws << 1) | prev) & 0xffffu;
 }
 
-__global__ __launch_bounds__(256) void hml_k_text_count(const uint8_t* __restrict__ text, uint32_t n_tiles,
+HML_KERNEL __launch_bounds__(256) void hml_k_text_count(const uint8_t* __restrict__ text, uint32_t n_tiles,
                                                         uint32_t* __restrict__ tile_count) {
     __shared__ uint32_t wsum[4];
     const uint32_t tile = blockIdx.x;
@@ -65,7 +65,7 @@ __global__ __launch_bounds__(256) void hml_k_text_count(const uint8_t* __restric
 }
 
 // one workgroup of 1024: tile_base = exclusive prefix of tile_count; meta->tokens = total
-__global__ __launch_bounds__(1024) void hml_k_text_scan(const uint32_t* __restrict__ tile_count, uint32_t n_tiles,
+HML_KERNEL __launch_bounds__(1024) void hml_k_text_scan(const uint32_t* __restrict__ tile_count, uint32_t n_tiles,
                                                         uint32_t* __restrict__ tile_base, hml_text_meta* __restrict__ meta) {
     __shared__ uint32_t part[1024];
     const uint32_t per = (n_tiles + 1023u) / 1024u;
@@ -85,7 +85,7 @@ __global__ __launch_bounds__(1024) void hml_k_text_scan(const uint32_t* __restri
     if (threadIdx.x == 1023u) meta->tokens = part[1023];
 }
 
-__global__ __launch_bounds__(256) void hml_k_text_parse(const uint8_t* __restrict__ text, uint32_t n_tiles,
+HML_KERNEL __launch_bounds__(256) void hml_k_text_parse(const uint8_t* __restrict__ text, uint32_t n_tiles,
                                                         const uint32_t* __restrict__ tile_base, float* __restrict__ values,
                                                         hml_text_meta* __restrict__ meta, hml_text_irr* __restrict__ irr,
                                                         uint32_t irr_cap) {

@@ -113,7 +113,7 @@ __device__ __forceinline__ unsigned long long hml_tre_cand(const float (&r)[K], 
 // the first pass: one wavefront (= one workgroup of 64 threads) per 64 chunks
 // ------------------------------------------------------------------------------------------
 template <int K>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(K <= 6 ? 4 : 1, K <= 6 ? 4 : 8))) void hml_k_trellis_tile(const float2* __restrict__ ia, const uint32_t* __restrict__ starts,
+HML_KERNEL __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(K <= 6 ? 4 : 1, K <= 6 ? 4 : 8))) void hml_k_trellis_tile(const float2* __restrict__ ia, const uint32_t* __restrict__ starts,
                                                          hml_model* __restrict__ mdl, const hml_model* __restrict__ mdl_ro,
                                                          float2* __restrict__ bstat, unsigned long long* __restrict__ cand,
                                                          unsigned long long* __restrict__ fmap, float* __restrict__ entry,
@@ -297,7 +297,7 @@ __device__ __forceinline__ bool hml_tre_exact(uint32_t f, uint32_t L, uint32_t W
 // verification: entry[f] == exit[f-1], bit for bit; stale chunks go on a list
 // ------------------------------------------------------------------------------------------
 template <int K>
-__global__ __launch_bounds__(256) void hml_k_trellis_verify(hml_model* __restrict__ mdl, const float* __restrict__ entry,
+HML_KERNEL __launch_bounds__(256) void hml_k_trellis_verify(hml_model* __restrict__ mdl, const float* __restrict__ entry,
                                                             const float* __restrict__ exitv, uint32_t* __restrict__ list, uint32_t L) {
     const uint32_t B = mdl->B;
     const uint32_t C = (B + L - 1u) / L;
@@ -315,7 +315,7 @@ __global__ __launch_bounds__(256) void hml_k_trellis_verify(hml_model* __restric
 // after a refit round: the refitted chunks and their successors are checked again; what is (still or newly) inconsistent
 // goes on the other list, once (tag[f] == gen marks chunks already listed in this round)
 template <int K>
-__global__ __launch_bounds__(256) void hml_k_trellis_verify_list(hml_model* __restrict__ mdl, const float* __restrict__ entry,
+HML_KERNEL __launch_bounds__(256) void hml_k_trellis_verify_list(hml_model* __restrict__ mdl, const float* __restrict__ entry,
                                                                  const float* __restrict__ exitv, const uint32_t* __restrict__ list_in,
                                                                  uint32_t* __restrict__ list_out, uint32_t* __restrict__ tag,
                                                                  int in_is_a, uint32_t round, uint32_t L) {
@@ -408,7 +408,7 @@ __device__ void hml_tre_chunk_sequential(const hml_emit_params<K>& p, const hml_
 // One wavefront (= workgroup) per chunk: its 64 lanes compute emission terms and candidate maps of 64 blocks at a time,
 // lane 0 runs the filter over them in between (the same arithmetic, in the same order, as the first pass).
 template <int K>
-__global__ __launch_bounds__(64) void hml_k_trellis_refit(const float2* __restrict__ ia, const uint32_t* __restrict__ starts,
+HML_KERNEL __launch_bounds__(64) void hml_k_trellis_refit(const float2* __restrict__ ia, const uint32_t* __restrict__ starts,
                                                           hml_model* __restrict__ mdl, unsigned long long* __restrict__ cand,
                                                           unsigned long long* __restrict__ fmap, float* __restrict__ entry,
                                                           float* __restrict__ exitv, uint32_t* __restrict__ fb_count,
@@ -553,7 +553,7 @@ __global__ __launch_bounds__(64) void hml_k_trellis_refit(const float2* __restri
 // from its predecessor's true end vector; the walk follows a chain while the recomputed end vector makes the next chunk
 // inconsistent.  After this pass induction from chunk 0 holds.  One workgroup of 256 threads.
 template <int K>
-__global__ __launch_bounds__(256) void hml_k_trellis_serial(const float2* __restrict__ ia, const uint32_t* __restrict__ starts,
+HML_KERNEL __launch_bounds__(256) void hml_k_trellis_serial(const float2* __restrict__ ia, const uint32_t* __restrict__ starts,
                                                             hml_model* __restrict__ mdl, unsigned long long* __restrict__ cand,
                                                             unsigned long long* __restrict__ fmap, float* __restrict__ entry,
                                                             float* __restrict__ exitv, uint32_t* __restrict__ fb_count,
@@ -605,7 +605,7 @@ __global__ __launch_bounds__(256) void hml_k_trellis_serial(const float2* __rest
 // the chain over the chunk maps, two levels (hml_k_backward_super / _chain / _entries with a chunk of L rows)
 // ------------------------------------------------------------------------------------------
 template <int K>
-__global__ __launch_bounds__(256) void hml_k_trellis_super(const unsigned long long* __restrict__ fmap, const hml_model* __restrict__ mdl,
+HML_KERNEL __launch_bounds__(256) void hml_k_trellis_super(const unsigned long long* __restrict__ fmap, const hml_model* __restrict__ mdl,
                                                            unsigned long long* __restrict__ scmap, unsigned long long* __restrict__ super, uint32_t L) {
     const uint32_t NC = (mdl->B + L - 1u) / L;
     const uint32_t NS = (NC + 63u) / 64u;
@@ -627,7 +627,7 @@ __global__ __launch_bounds__(256) void hml_k_trellis_super(const unsigned long l
 
 // one workgroup: the state entering every super-chunk (entry2[S] = state of the first row after super-chunk S)
 template <int K>
-__global__ __launch_bounds__(1024) void hml_k_trellis_chain(const unsigned long long* __restrict__ super, const hml_model* __restrict__ mdl,
+HML_KERNEL __launch_bounds__(1024) void hml_k_trellis_chain(const unsigned long long* __restrict__ super, const hml_model* __restrict__ mdl,
                                                             uint8_t* __restrict__ entry2, uint32_t L) {
     __shared__ unsigned long long P[1024];
     const uint32_t NCf = (mdl->B + L - 1u) / L;
@@ -660,7 +660,7 @@ __global__ __launch_bounds__(1024) void hml_k_trellis_chain(const unsigned long 
 // walks them in batches of 32 rows: the batch's maps come in through LDS with coalesced loads (lane = (chunk, row) again)
 // and the states leave through LDS with coalesced stores.
 template <int K>
-__global__ __launch_bounds__(64) void hml_k_trellis_states(const unsigned long long* __restrict__ cand, const unsigned long long* __restrict__ scmap,
+HML_KERNEL __launch_bounds__(64) void hml_k_trellis_states(const unsigned long long* __restrict__ cand, const unsigned long long* __restrict__ scmap,
                                                            const uint8_t* __restrict__ entry2, const hml_model* __restrict__ mdl,
                                                            int16_t* __restrict__ q, uint32_t L) {
     typedef typename hml_tre_map<K>::stored map_t;

@@ -297,7 +297,7 @@ __device__ __forceinline__ bool hml_tr2_step(const hml_fwd_ctx<K>& cx, float (&a
 
 // SHARE (the host's choice for sweeps over nearly uncompressed input, results the same): see `pred` below
 template <int K, bool SHARE>
-__global__ __launch_bounds__(64 * HML_TR2_WAVES) __attribute__((amdgpu_waves_per_eu(K <= 8 ? HML_TR2_WPE : 1, K <= 8 ? HML_TR2_WPE : 8)))
+HML_KERNEL __launch_bounds__(64 * HML_TR2_WAVES) __attribute__((amdgpu_waves_per_eu(K <= 8 ? HML_TR2_WPE : 1, K <= 8 ? HML_TR2_WPE : 8)))
 void hml_k_trellis_rows(const float2* __restrict__ ia, const uint32_t* __restrict__ starts, hml_model* __restrict__ mdl,
                         const hml_model* __restrict__ mdl_ro, float2* __restrict__ bstat, unsigned long long* __restrict__ cand,
                         unsigned long long* __restrict__ fmap, float* __restrict__ entry, float* __restrict__ exitv,
