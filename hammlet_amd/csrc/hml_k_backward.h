@@ -518,6 +518,13 @@ __device__ __forceinline__ void hml_b_counts(int16_t* __restrict__ q, const uint
     const uint32_t B = mdl->B;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t g = blockIdx.x;
+    // a group without a chunk (strongly compressed sweeps: B / 256 < 1024 groups) has nothing to add: its sums are the zeros
+    // the tree would produce, and the workgroup leaves at once (a third of the grid on config 3 - slots that the other chains
+    // of a batched launch can use)
+    if (g >= (B + HML_REDUCE_CHUNK - 1u) / HML_REDUCE_CHUNK) {   // workgroup-uniform, before any barrier
+        if (tid < 2 * K) partial[(uint64_t)tid * HML_REDUCE_GROUPS + g] = 0.0;
+        return;
+    }
     for (int i = tid; i < K * K; i += 256) h_trans[i] = 0ull;
     if (tid < K) h_occ[tid] = 0ull;
     __syncthreads();
