@@ -312,9 +312,21 @@ __device__ __forceinline__ void hml_b_params(hml_model* __restrict__ mdl, const 
                 // ten thousand chunks instead of insisting on none: +8 above B / 2^17 refits (or a sequential finish),
                 // -8 below B / 2^20
                 const unsigned long long hi = (unsigned long long)(mdl->B >> mdl->tre_hi_shift) + 16ull, lo = (unsigned long long)(mdl->B >> mdl->tre_lo_shift) + 2ull;
-                if (serial != 0ull || refits > hi) W = (W + 8u < 64u) ? W + 8u : 64u;
-                else if (refits < lo) W = (W > 16u) ? W - 8u : 8u;
-                if (W > 64u) W = 64u;
+                // The number of stale chunks is a cliff in W (a factor 10-100 per 8 rows below some length that depends on the
+                // parameters), so the band between `lo` and `hi` may hold no W at all: the rule would then step down into the
+                // cliff and back up every other sweep (K = 6 on 5e7 blocks: 61 000 refits per sweep on average, 1.0 ms of a
+                // 2.6 ms sweep).  The length that last let the refits explode is therefore remembered as a floor - W stays
+                // one step above it - and forgotten one step every 256 sweeps (the parameters move).
+                if (serial != 0ull || refits > hi) {
+                    W = (W + 8u < (uint32_t)HML_TRE_HALO_MAX) ? W + 8u : (uint32_t)HML_TRE_HALO_MAX;
+                    mdl->tre_W_floor = W;
+                    mdl->tre_floor_age = 0u;
+                } else {
+                    if (++mdl->tre_floor_age >= 256u) { mdl->tre_floor_age = 0u; mdl->tre_W_floor = (mdl->tre_W_floor > 8u) ? mdl->tre_W_floor - 8u : 0u; }
+                    const uint32_t lowest = (mdl->tre_W_floor > 8u) ? mdl->tre_W_floor : 8u;
+                    if (refits < lo && W >= lowest + 8u) W -= 8u;
+                }
+                if (W > (uint32_t)HML_TRE_HALO_MAX) W = (uint32_t)HML_TRE_HALO_MAX;
             } else
             if (serial != 0ull || refits > handful) { W = (2u * W < 1024u) ? 2u * W : 1024u; mdl->fwd_quiet = 0u; }
             else if (refits == 0ull) {

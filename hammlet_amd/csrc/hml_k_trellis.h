@@ -33,7 +33,7 @@
 
 #define HML_TRE_NCH 64      // forward chunks per wavefront = lanes of the filter
 #define HML_TRE_R 4         // rows per batch
-#define HML_TRE_HALO 64     // longest warm-up of the first pass (a multiple of HML_TRE_R)
+#define HML_TRE_HALO HML_TRE_HALO_MAX   // longest warm-up of the first pass (a multiple of HML_TRE_R and of 16; hml_state.h)
 #define HML_TRE_GTAB 64     // block sizes whose rescale factors expf((N-1) logA_s) come from a table
 #define HML_TRE_MIN_L 32    // shortest chunk (a multiple of 32; per-chunk arrays are sized for it)
 #define HML_TRE_MAX_L 1024  // longest chunk

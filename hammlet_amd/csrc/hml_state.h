@@ -6,6 +6,9 @@
 #include "hml_philox.h"
 
 // ---- fixed geometry (the CPU checker mirrors these numbers) ----
+// longest warm-up of the fused trellis path's first pass (hml_k_trellis.h; many states forget slowly: K = 10 on uncompressed
+// input needs more than the 64 rows of rounds 2-3)
+#define HML_TRE_HALO_MAX 128
 #define HML_SPAN 4096
 #define HML_GROUP_SPANS 16   // spans per group of the two-level block offset (one scatter workgroup)          // positions scanned by one wavefront in blocks_compact
 #define HML_REDUCE_CHUNK 256   // blocks per reduction chunk (one workgroup)
@@ -104,6 +107,7 @@ struct hml_model {
     uint32_t tre_fused;          // weakly compressed FB sweeps take the fused trellis kernels (hml_k_trellis.h): stale chunks are
                                  // refitted in parallel there, so the warm-up follows a different rule (hml_k_params)
     uint32_t tre_hi_shift, tre_lo_shift;   // ... the warm-up grows above B >> hi refits per sweep and shrinks below B >> lo
+    uint32_t tre_W_floor, tre_floor_age;   // ... and does not shrink below the length that last let the refits explode (forgotten slowly)
     unsigned long long fwd_refits_seen, fwd_serial_seen;
     unsigned long long dbg_t[12];   // wall_clock64 stamps of the parameter kernel's stages (printed by hml_sync with HML_PARAMS_DEBUG)
 };
