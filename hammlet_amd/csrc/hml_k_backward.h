@@ -802,8 +802,10 @@ __device__ __forceinline__ void hml_b_record(const int16_t* __restrict__ q, cons
         const int prev = (b == 0) ? -1 : (int)q[b - 1];
         if (st != prev) {
             const uint32_t t = starts[b];
-            atomicAdd(&diff[(uint64_t)st * T1 + t], 1);
-            if (prev >= 0) atomicAdd(&diff[(uint64_t)prev * T1 + t], -1);
+            // (plain read-modify-writes: cell (state, t) belongs to the one block that starts at t, and st != prev - on
+            // uncompressed input a sweep has 10^7 changes of state, and atomics to as many random lines cost 3 ms)
+            diff[(uint64_t)st * T1 + t] += 1;
+            if (prev >= 0) diff[(uint64_t)prev * T1 + t] -= 1;
             atomicOr(&boundary[t >> 5], 1u << (t & 31u));
             mx = st > mx ? st : mx;
         }

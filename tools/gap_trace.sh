@@ -4,7 +4,7 @@ cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/gaps
 rm -rf $O && mkdir -p $O
-rocprofv3 --kernel-trace --output-format csv -d $O -o run -- python3 $R/bench.py --steps 400 --warmup 400 --no-cpu-baseline --no-stream-leg --no-two-chain-leg --no-uncompressed-leg > $O/bench.json 2> $O/err.txt
+rocprofv3 --kernel-trace --output-format csv -d $O -o run -- python3 $R/bench.py --steps 400 --warmup 400 --no-cpu-baseline --no-stream-leg --no-two-chain-leg --no-uncompressed-leg --no-scheme-legs > $O/bench.json 2> $O/err.txt
 python3 - <<PY
 import csv, glob, collections
 f = glob.glob("$O/**/*kernel_trace.csv", recursive=True)[0]
