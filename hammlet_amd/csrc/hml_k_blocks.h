@@ -473,7 +473,8 @@ HML_KERNEL __launch_bounds__(256) void hml_k_compact_scatter_bits(const unsigned
             unsigned long long m[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-                m[j] = ((unsigned long long)(uint32_t)__shfl((int)whi, 4 * it + j) << 32) | (unsigned long long)(uint32_t)__shfl((int)wlo, 4 * it + j);
+                m[j] = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)whi, 4 * it + j) << 32) |
+                       (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)wlo, 4 * it + j);   // (a wave-uniform lane: v_readlane, no LDS permute)
             const uint32_t n_it = (uint32_t)(__popcll(m[0]) + __popcll(m[1]) + __popcll(m[2]) + __popcll(m[3]));
             if (n_it == 0u) continue;
             uint32_t pos = (uint32_t)(__popcll(m[0] & lt) + __popcll(m[1] & lt) + __popcll(m[2] & lt) + __popcll(m[3] & lt));
