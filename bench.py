@@ -34,23 +34,36 @@ WORKLOADS = {
 }
 
 
-PMC_FILE = "profiles/round3_pmc_hbm_traffic.json"
+PMC_FILE = "profiles/round4_pmc_hbm_traffic.json"
 # "c3u" = the uncompressed leg (same trace, every position its own block), collected with tools/time_dense.py
-PMC_FILES = {"c3_1e8_k5_dynamic": PMC_FILE, "c3u": "profiles/round3_pmc_hbm_traffic_c3u.json",
-             "c5_2.5e8_depth_k5": "profiles/round3_pmc_hbm_traffic_c5.json"}
+PMC_FILES = {"c3_1e8_k5_dynamic": PMC_FILE, "c3u": "profiles/round4_pmc_hbm_traffic_c3u.json",
+             "c5_2.5e8_depth_k5": "profiles/round4_pmc_hbm_traffic_c5.json", "c4_1e8_k10": "profiles/round4_pmc_hbm_traffic_c4.json"}
 DENSE_KERNEL = "hml_k_trellis_rows"   # first pass over the trellis of a weakly compressed sweep (hml_k_trellis_rows.h)
 MIN_BRACKETS = 32                     # launches of the roofline kernel that are bracketed by events, whatever --steps is
+LEG_MIN_STEPS = 200                   # every auxiliary leg times at least this many sweeps, whatever --steps is (the headline keeps
+                                      # the driver's --steps): a 20-sweep leg is a 1-2 ms region in which thread start-up and the first
+                                      # launches dominate (round 3's driver line showed three chains at 0.4x one chain that way)
 
-# kernel families timed by the library's event brackets (hml_profile_enable) -> the kernel each one launches in the
-# default dynamic sweep (names as rocprofv3 prints them, without template arguments)
-FAMILY_KERNEL = {
-    "blocks_compact": "hml_k_blocks_fused",
-    "forward": "hml_k_forward",
-    "backward_maps": "hml_k_backward_maps",
-    "backward_chain": "hml_k_backward_chain",
-    "counts": "hml_k_counts",
-    "params": "hml_k_params",
-}
+
+def family_kernels(K):
+    """kernel families timed by the library's event brackets (hml_profile_enable) -> the kernel INSTANTIATION each one launches
+    in the default dynamic FB sweep, as rocprofv3 prints it (round 3 matched on the name up to '<' and took the first hit:
+    hml_k_counts<5, false, false> - the mixture sweep's - for the FB sweep's hml_k_counts<5, true, false>)"""
+    return {
+        "blocks_compact": "hml_k_blocks_fused<%d>" % K,
+        "forward": "hml_k_forward<%d>" % K,
+        "backward_maps": "hml_k_backward_maps<%d>" % K,
+        "backward_chain": "hml_k_backward_chain<%d>" % K,
+        "counts": "hml_k_counts<%d, true, false>" % K,
+        "params": "hml_k_params<%d>" % K,
+    }
+
+
+def dense_kernels(K, shared_sums):
+    return {"blocks_compact": "hml_k_compact_scan_bits", "blocks_scatter": "hml_k_compact_scatter_bits",
+            "trellis": "%s<%d, %s>" % (DENSE_KERNEL, K, "true" if shared_sums else "false"),
+            "trellis_repair": "hml_k_trellis_verify + refit + serial", "backward_chain": "hml_k_trellis_super + chain + states",
+            "counts": "hml_k_counts_dense<%d, false>" % K, "params": "hml_k_params<%d>" % K}
 
 
 def pmc_table(workload):
@@ -68,11 +81,16 @@ def pmc_table(workload):
 
 
 def pmc_traffic(workload, kernel, key="bytes_fetch_doubled"):
-    """bytes per launch of `kernel` (name without template arguments): 2 x FETCH_SIZE + WRITE_SIZE, or with key = "bytes_raw"
-    FETCH_SIZE + WRITE_SIZE as counted"""
-    for name, k in pmc_table(workload).items():
-        if name.split("<")[0] == kernel:
-            return k[key]
+    """bytes per launch of `kernel`: 2 x FETCH_SIZE + WRITE_SIZE, or with key = "bytes_raw" FETCH_SIZE + WRITE_SIZE as
+    counted.  `kernel` is the full instantiation ("hml_k_counts<5, true, false>"); a bare name matches only when the profile
+    holds exactly ONE instantiation of it."""
+    tab = pmc_table(workload)
+    if kernel in tab:
+        return tab[kernel][key]
+    if "<" not in kernel:
+        hits = [k for name, k in tab.items() if name.split("<")[0] == kernel]
+        if len(hits) == 1:
+            return hits[0][key]
     return None
 
 
@@ -89,7 +107,7 @@ def host_cpu():
     return model, n
 
 
-def cpu_baseline(x, K, seed, budget_s=16.0, ref_sweeps=24):
+def cpu_baseline(x, K, seed, budget_s=16.0, ref_sweeps=24, parallel=True):
     """The CPU restatement in reference mode (sequential mt19937, glibc math, pointer-jumping block
     enumeration), timed on this box's host cores; one thread like the reference."""
     from tests import oracle_lib as ol
@@ -115,25 +133,29 @@ def cpu_baseline(x, K, seed, budget_s=16.0, ref_sweeps=24):
            "sample": "%d sweeps of the same %d-position trace (reference-mode CPU restatement, %.1f ms/sweep); one thread, "
                      "like the reference (src/main.cpp:108)" % (n, x.size, 1e3 * t / n)}
     try:
-        ref = reference_binary_baseline(x, K, seed, ref_sweeps, blocks_ref)
+        ref, par = reference_binary_baseline(x, K, seed, ref_sweeps, blocks_ref, min(8, total) if parallel else 0)
         if ref:
             out["reference_binary"] = ref
+        if par:
+            out["chain_parallel"] = par
     except Exception as e:   # the prebuilt binary is optional on the GPU box
         out["reference_binary"] = {"error": str(e)[:200]}
     return out
 
 
-def reference_binary_baseline(x, K, seed, sweeps, blocks):
+def reference_binary_baseline(x, K, seed, sweeps, blocks, n_parallel=0):
     """The UNMODIFIED reference binary (oracle/_ref/hammlet, prebuilt in the build container from the reference's own
     main.cpp; absent -> None) on the WHOLE trace as text, a bounded number of sweeps: sweep time = wall(-i F n 0) -
     wall(-i F 0 0) (start-up and the reference's text parsing, reported separately, cancel); `blocks` = the block updates of
     those sweeps, from the restatement's run of the same chain (it reproduces the reference's files byte for byte, hence its
-    block structures)."""
+    block structures).  n_parallel > 0: SURVEY.md 8d's chain-parallel CPU figure - the reference is single-threaded
+    (src/main.cpp:108), so N chains are N processes of it: the same two commands, N at a time (every process the same seed:
+    identical work, so the aggregate is N x blocks over the slowest process's sweep time)."""
     import subprocess
     import tempfile
     exe = os.path.join(REPO, "oracle", "_ref", "hammlet")
     if not os.path.exists(exe):
-        return None
+        return None, None
     from tests import oracle_lib as ol
     lib = ol.load()
     with tempfile.TemporaryDirectory(dir=os.environ.get("HML_BENCH_TMP") or None) as tmp:
@@ -144,17 +166,29 @@ def reference_binary_baseline(x, K, seed, sweeps, blocks):
         if lib.orc_write_text(xc.ctypes.data, xc.size, txt.encode(), max(1, min(16, os.cpu_count() or 1))) != 0:
             raise RuntimeError("could not write the trace as text")
 
-        def run(n):
+        def run(n, procs=1):
             t0 = time.perf_counter()
-            subprocess.run([exe, "-f", txt, "-a", "-s", str(K), "-R", str(seed), "-i", "F", str(n), "0", "-w",
-                            "-o", os.path.join(tmp, "ref-"), ".csv"], check=True, stdout=subprocess.DEVNULL)
+            ps = [subprocess.Popen([exe, "-f", txt, "-a", "-s", str(K), "-R", str(seed), "-i", "F", str(n), "0", "-w",
+                                    "-o", os.path.join(tmp, "ref%d-" % i), ".csv"], stdout=subprocess.DEVNULL) for i in range(procs)]
+            rcs = [q.wait() for q in ps]
+            if any(rcs):
+                raise RuntimeError("the reference binary failed")
             return time.perf_counter() - t0
         t_zero = run(0)
         t_n = run(sweeps)
+        par = None
+        if n_parallel > 1:
+            p_zero = run(0, n_parallel)
+            p_n = run(sweeps, n_parallel)
+            pdt = max(p_n - p_zero, 1e-9)
+            par = {"value": n_parallel * blocks / pdt, "unit": "block-updates/s", "cores": n_parallel, "kind": "reference",
+                   "sample": "%d processes of the unmodified reference binary at once (min(8, host cores) independent chains, SURVEY.md 8d), each "
+                             "on the whole %d-position trace, %d sweeps: %.1f ms per sweep-round (start-up + text parsing %.1f s, subtracted)"
+                             % (n_parallel, x.size, sweeps, 1e3 * pdt / sweeps, p_zero)}
     dt = max(t_n - t_zero, 1e-9)
     return {"value": blocks / dt, "unit": "block-updates/s", "cores": 1, "kind": "reference", "sample_positions": int(x.size),
             "sample": "unmodified reference binary on the whole %d-position trace as text, %d sweeps: %.1f ms/sweep, "
-                      "%.0f blocks/sweep (start-up + text parsing %.1f s, subtracted)" % (x.size, sweeps, 1e3 * dt / sweeps, blocks / sweeps, t_zero)}
+                      "%.0f blocks/sweep (start-up + text parsing %.1f s, subtracted)" % (x.size, sweeps, 1e3 * dt / sweeps, blocks / sweeps, t_zero)}, par
 
 
 def main():
@@ -170,6 +204,7 @@ def main():
     ap.add_argument("--no-two-chain-leg", action="store_true", help="skip the third leg (two and three chains sharing one GPU)")
     ap.add_argument("--no-scheme-legs", action="store_true", help="skip the recorded / config-2 mixture / config-2 static legs")
     ap.add_argument("--no-uncompressed-leg", action="store_true", help="skip the fourth leg (same trace, weights x 1e9: every position its own block)")
+    ap.add_argument("--no-config-legs", action="store_true", help="skip the bounded legs of BASELINE configs 4 and 5 (one chain of each on this GPU)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -203,8 +238,9 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def run_leg(weight_summary, profile_level):
+    def run_leg(weight_summary, profile_level, steps=None):
         """warm-up + K timed sweeps of a fresh chain; returns (chain, elapsed, blocks, stats0, stats1)"""
+        steps = steps or args.steps
         ch = hammlet_amd.Chain(device=local_rank, seed=args.seed, chain_id=rank)
         ch.set_option("weight_keys", 1 if weight_summary else 0)
         ch.load(x)
@@ -218,7 +254,7 @@ def main():
         ch.profile_enable(profile_level)   # HIP events around the dominant kernel only, on the chain's own stream
         barrier()
         t0 = time.perf_counter()
-        ch.iterate("F", args.steps, 0)
+        ch.iterate("F", steps, 0)
         ch.sync()
         barrier()
         t1 = time.perf_counter()
@@ -231,6 +267,9 @@ def main():
     # (hml_k_trellis_rows): the same level-1 brackets, every 32nd launch (bracketing every family of every sweep, as
     # rounds 1-2 did there, costs the timed region 3 %)
     dense_workload = levels is None
+    FAMILY_KERNEL = family_kernels(K)
+    DENSE_INST = dense_kernels(K, False)["trellis"]
+    leg_steps = max(args.steps, LEG_MIN_STEPS)
     chain, elapsed, blocks, st0, st1 = run_leg(weight_summary=True, profile_level=1)
     roof_family = "trellis" if dense_workload else "blocks_compact"
     scan_ms, scan_n = chain.profile_get(roof_family)           # HIP events around the kernel's launches
@@ -282,12 +321,12 @@ def main():
             # (DESIGN.md 3a); the estimate used without a committed profile is what the counters showed on C3u (125 B/block)
             algo_bytes = B_avg * (4.0 + 16.0 + 8.0 + 4.0)
             phys_bytes = 50.0 * B_avg
-            traffic = pmc_traffic(args.workload, DENSE_KERNEL)
+            traffic = pmc_traffic(args.workload, DENSE_INST)
             if null_n == 0:               # (profile level 2 records no empty brackets: the usual 5.3 us)
                 null_s = 5.3e-6
                 scan_avg_s = max(scan_raw_s - null_s, 1e-9)
         moved = traffic if traffic else phys_bytes
-        traffic_raw = pmc_traffic(args.workload, DENSE_KERNEL if dense_workload else FAMILY_KERNEL["blocks_compact"], "bytes_raw")
+        traffic_raw = pmc_traffic(args.workload, DENSE_INST if dense_workload else FAMILY_KERNEL["blocks_compact"], "bytes_raw")
         achieved = moved / scan_avg_s / 1e9
         sweep_bytes = 4.0 * T + B_avg * (36 + 8 * K)   # SURVEY.md 8d bytes_iter
         frac = achieved / HBM_PEAK_GBS
@@ -325,7 +364,7 @@ def main():
                                     "latency: three dependent memory round trips + one inter-workgroup hand-off per launch",
                          "profile_pair": None if dense_workload else
                                          "rocprofv3 adds 1.5-2 us to every dispatch of this kernel: the line that pairs with "
-                                         "profiles/round3_kernel_stats_c3_bench.csv is profiles/round3_bench_c3_under_rocprof.json",
+                                         "profiles/round4_kernel_stats_c3_bench.csv is profiles/round4_bench_c3_under_rocprof.json",
                          "algorithmic_bytes_per_launch": algo_bytes,
                          "algorithmic_equivalent_gbs": algo_bytes / scan_avg_s / 1e9,
                          "algorithmic_speedup_vs_peak_float_stream": algo_bytes / scan_avg_s / 1e9 / HBM_PEAK_GBS,
@@ -342,9 +381,7 @@ def main():
         fam_kernel = dict(FAMILY_KERNEL)
         n_extra = 200
         if dense_workload:
-            fam_kernel = {"blocks_compact": "hml_k_compact_scan_bits", "blocks_scatter": "hml_k_compact_scatter_bits", "trellis": DENSE_KERNEL,
-                          "trellis_repair": "hml_k_trellis_verify + refit + serial", "backward_chain": "hml_k_trellis_super + chain + states",
-                          "counts": "hml_k_counts_dense", "params": "hml_k_params"}
+            fam_kernel = dense_kernels(K, False)
             n_extra = 10
         names = list(fam_kernel)
         before = {nm: chain.profile_get(nm) for nm in names + ["event_null"]}
@@ -407,13 +444,13 @@ def main():
     # float weights - the one genuinely bandwidth-bound kernel of the path, priced against the HBM roofline
     if not args.no_stream_leg and world == 1:
         chain.close()
-        chain, el2, bl2, c0, c1 = run_leg(weight_summary=False, profile_level=1)
+        chain, el2, bl2, c0, c1 = run_leg(weight_summary=False, profile_level=1, steps=leg_steps)
         f_ms, f_n = chain.profile_get("blocks_compact")
         n_ms, n_n = chain.profile_get("event_null")
         if rank == 0 and f_n:
             f_s = max(f_ms / f_n - n_ms / max(1, n_n), 1e-6) * 1e-3
-            f_bytes = 4.0 * T + 6.0 * (bl2 / max(1, args.steps))
-            out["float_stream"] = {"value": bl2 / el2, "unit": "block-updates/s", "ms_per_step": 1e3 * el2 / args.steps,
+            f_bytes = 4.0 * T + 6.0 * (bl2 / max(1, leg_steps))
+            out["float_stream"] = {"value": bl2 / el2, "unit": "block-updates/s", "steps": leg_steps, "ms_per_step": 1e3 * el2 / leg_steps,
                                    "roofline": {"bound": "hbm", "kernel": "hml_k_compact_scan (all T float weights)",
                                                 "achieved": f_bytes / f_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                                 "frac": f_bytes / f_s / 1e9 / HBM_PEAK_GBS, "traffic": pmc_traffic(args.workload, "hml_k_compact_scan"),
@@ -424,27 +461,47 @@ def main():
     # scheme legs: what the headline's plain sweeps leave out.  (a) C3's own scheme records every 10th sweep
     # (-i F n 10, marginals on): hml_k_record inside the timed region.  (b) BASELINE config 2: 10^7 positions, scheme
     # M 100 0 S P F n 10 - mixture sweeps on dynamic blocks, then FB sweeps on a FIXED block structure (static blocks).
+    # (c) steady state: 1000 sweeps of a chain that has 64 behind it (the forward warm-up of a young chain has settled).
     if not args.no_scheme_legs and world == 1 and args.workload == "c3_1e8_k5_dynamic":
         chain.close()
         ch = hammlet_amd.Chain(device=local_rank, seed=args.seed, chain_id=rank)
         ch.load(x)
         ch.set_model(K, ch.autoprior(0.2, 0.9))
         ch.sample_prior()
-        ch.set_recording(marginals=True)
-        ch.iterate("F", args.warmup, 0)
+        ch.set_recording(marginals=False)
+        ch.iterate("F", 64, 0)
         ch.sync()
         r0 = ch.stats()
         barrier()
         t0 = time.perf_counter()
-        ch.iterate("F", args.steps, 10)
+        ch.iterate("F", 1000, 0)
         ch.sync()
         barrier()
         t1 = time.perf_counter()
         r1 = ch.stats()
-        out["recorded"] = {"value": (r1["block_updates"] - r0["block_updates"]) / (t1 - t0), "unit": "block-updates/s",
-                           "ms_per_step": 1e3 * (t1 - t0) / args.steps, "scheme": "F %d 10, marginals recorded" % args.steps,
+        bs = (r1["block_updates"] - r0["block_updates"]) / 1000.0
+        out["steady_state"] = {"value": (r1["block_updates"] - r0["block_updates"]) / (t1 - t0), "unit": "block-updates/s", "steps": 1000,
+                               "ms_per_step": 1e3 * (t1 - t0) / 1000, "forward_refits": r1["forward_refits"] - r0["forward_refits"],
+                               "forward_warmup_rows": r1["forward_warmup"],
+                               "sweep_frac": (4.0 * T + bs * (36 + 8 * K)) / ((t1 - t0) / 1000) / 1e9 / HBM_PEAK_GBS,
+                               "note": "sweeps 64..1064 of the headline's chain: the settled rate (the headline at the driver's --steps 20 --warmup 5 "
+                                       "times sweeps 5..25 of a fresh chain)"}
+        ch.set_recording(marginals=True)
+        ch.sync()
+        r0 = ch.stats()
+        barrier()
+        t0 = time.perf_counter()
+        ch.iterate("F", leg_steps, 10)
+        ch.sync()
+        barrier()
+        t1 = time.perf_counter()
+        r1 = ch.stats()
+        out["recorded"] = {"value": (r1["block_updates"] - r0["block_updates"]) / (t1 - t0), "unit": "block-updates/s", "steps": leg_steps,
+                           "ms_per_step": 1e3 * (t1 - t0) / leg_steps, "scheme": "F %d 10, marginals recorded" % leg_steps,
                            "recorded_sweeps": ch.recorded_sweeps(),
-                           "note": "the headline's chain with every 10th sweep recorded into the marginals (hml_k_record)"}
+                           "note": "BASELINE config 3 AS SPECIFIED (SURVEY.md 8d: -i F 1000 10): the steady-state chain with every 10th sweep recorded "
+                                   "into the marginals (hml_k_record inside the timed region); compare with steady_state, not with the young headline chain"}
+        out["config"]["config_3_as_specified"] = "leg `recorded` (scheme F n 10, marginals on); the headline times plain sweeps"
         ch.close()
         T2, K2, lv2, sg2, dw2, ds2 = WORKLOADS["c2_1e7_k5"]
         x2 = hammlet_amd.synth_gauss(T2, K2, lv2, sg2, dw2, ds2, nthreads=nthr)
@@ -458,35 +515,36 @@ def main():
         m0 = ch.stats()
         barrier()
         t0 = time.perf_counter()
-        ch.iterate("M", 100, 0)
+        ch.iterate("M", leg_steps, 0)
         ch.sync()
         barrier()
         t1 = time.perf_counter()
         m1 = ch.stats()
         ch.set_static_blocks()                      # S: createBlocks(theta) once
         ch.sample_prior()                           # P
-        ch.iterate("F", args.warmup, 0)
+        ch.iterate("F", max(args.warmup, 20), 0)
         ch.sync()
         f0 = ch.stats()
         barrier()
         t2 = time.perf_counter()
-        ch.iterate("F", args.steps, 10)
+        ch.iterate("F", leg_steps, 10)
         ch.sync()
         barrier()
         t3 = time.perf_counter()
         f1 = ch.stats()
-        out["c2_mixture"] = {"value": (m1["block_updates"] - m0["block_updates"]) / (t1 - t0), "unit": "block-updates/s",
-                             "ms_per_step": 1e3 * (t1 - t0) / 100, "scheme": "M 100 0 on the 10^7-position trace of config 2 (dynamic blocks)"}
-        out["c2_static"] = {"value": (f1["block_updates"] - f0["block_updates"]) / (t3 - t2), "unit": "block-updates/s",
-                            "ms_per_step": 1e3 * (t3 - t2) / args.steps, "blocks_per_sweep": (f1["block_updates"] - f0["block_updates"]) / args.steps,
-                            "scheme": "M 120 0 S P F %d 10 (BASELINE config 2: fixed wavelet block structure), marginals recorded" % args.steps,
+        out["c2_mixture"] = {"value": (m1["block_updates"] - m0["block_updates"]) / (t1 - t0), "unit": "block-updates/s", "steps": leg_steps,
+                             "ms_per_step": 1e3 * (t1 - t0) / leg_steps, "scheme": "M %d 0 on the 10^7-position trace of config 2 (dynamic blocks)" % leg_steps}
+        out["c2_static"] = {"value": (f1["block_updates"] - f0["block_updates"]) / (t3 - t2), "unit": "block-updates/s", "steps": leg_steps,
+                            "ms_per_step": 1e3 * (t3 - t2) / leg_steps, "blocks_per_sweep": (f1["block_updates"] - f0["block_updates"]) / leg_steps,
+                            "scheme": "M %d 0 S P F %d 10 (BASELINE config 2: fixed wavelet block structure), marginals recorded" % (leg_steps + 20, leg_steps),
                             "note": "latency-bound: 2 MB of block data per sweep (SURVEY.md 8d) - a launch-overhead-limited rate, not a bandwidth fraction"}
         ch.close()
         del x2
         chain = None
 
-    # third leg: two and three independent chains of the same workload on ONE GPU, each on its own stream and host thread
-    # (chain-parallel inside the GPU: a single chain is latency-bound and leaves most of the machine idle)
+    # third leg: several independent chains of the same workload on ONE GPU (chain-parallel inside the GPU: a single chain is
+    # latency-bound and leaves most of the machine idle).  Two / three chains each on its own stream and host thread; eight
+    # chains attached to ONE construction (hml_attach_observations) and batched through hml_iterate_many.
     if not args.no_two_chain_leg and world == 1:
         import threading
         if chain is not None:
@@ -501,20 +559,24 @@ def main():
                 ch.set_model(K, ch.autoprior(0.2, 0.9))
                 ch.sample_prior()
                 ch.set_recording(marginals=False)
-                ch.iterate("F", args.warmup, 0)
+                ch.iterate("F", max(args.warmup, 40), 0)
                 group.append(ch)
             for ch in group:
                 ch.sync()
             b0 = [ch.stats()["block_updates"] for ch in group]
+            # the threads exist and wait at a barrier BEFORE the clock starts
+            gate = threading.Barrier(n_chains + 1)
 
             def run(ch):
-                ch.iterate("F", args.steps, 0)
+                gate.wait()
+                ch.iterate("F", leg_steps, 0)
                 ch.sync()
             ths = [threading.Thread(target=run, args=(ch,)) for ch in group]
-            barrier()
-            t0 = time.perf_counter()
             for t in ths:
                 t.start()
+            barrier()
+            t0 = time.perf_counter()
+            gate.wait()
             for t in ths:
                 t.join()
             barrier()
@@ -522,29 +584,37 @@ def main():
             b2 = sum(ch.stats()["block_updates"] - b for ch, b in zip(group, b0))
             for ch in group:
                 ch.close()
-            return b2 / (t1 - t0), 1e3 * (t1 - t0) / args.steps
+            return b2 / (t1 - t0), 1e3 * (t1 - t0) / leg_steps
         v2, ms2 = several(2)
-        out["two_chains_one_gpu"] = {"value": v2, "unit": "block-updates/s", "chains": 2, "ms_per_sweep_round": ms2,
-                                     "note": "aggregate of two independent chains on one GPU; the headline value is one chain per GPU"}
+        out["two_chains_one_gpu"] = {"value": v2, "unit": "block-updates/s", "chains": 2, "steps": leg_steps, "ms_per_sweep_round": ms2,
+                                     "note": "aggregate of two independent chains on one GPU, a host thread and a stream each; the headline value is one chain per GPU"}
         v3, ms3 = several(3)
-        out["three_chains_one_gpu"] = {"value": v3, "unit": "block-updates/s", "chains": 3, "ms_per_sweep_round": ms3,
-                                       "note": "profiles/round3_chains_batched.txt (and round2_chains_per_gpu.txt): the aggregate peaks at three chains per GPU"}
-        # eight chains in ONE set of launches by one host thread (hml_iterate_many: the chain is the grid's second dimension)
+        out["three_chains_one_gpu"] = {"value": v3, "unit": "block-updates/s", "chains": 3, "steps": leg_steps, "ms_per_sweep_round": ms3,
+                                       "note": "three host threads, three streams (private constructions, scan + scatter launches)"}
+        # eight chains attached to one construction, ONE set of launches by one host thread (hml_iterate_many; the many-chain
+        # block kernel of hml_k_blocks_fused_many.h)
+        free0 = torch.cuda.mem_get_info()[0]
         group = []
+        mem = []
         for r in range(8):
             ch = hammlet_amd.Chain(device=local_rank, seed=args.seed, chain_id=r)
-            ch.load(x)
+            if r == 0:
+                ch.load(x)
+            else:
+                ch.attach(group[0])
             ch.set_model(K, ch.autoprior(0.2, 0.9))
             ch.sample_prior()
             ch.set_recording(marginals=False)
+            ch.sync()
             group.append(ch)
-        hammlet_amd.iterate_many(group, "F", args.warmup, 0)
+            mem.append(free0 - torch.cuda.mem_get_info()[0])
+        hammlet_amd.iterate_many(group, "F", max(args.warmup, 40), 0)
         for ch in group:
             ch.sync()
         b0 = [ch.stats()["block_updates"] for ch in group]
         barrier()
         t0 = time.perf_counter()
-        hammlet_amd.iterate_many(group, "F", args.steps, 0)
+        hammlet_amd.iterate_many(group, "F", leg_steps, 0)
         for ch in group:
             ch.sync()
         barrier()
@@ -552,66 +622,134 @@ def main():
         b8 = sum(ch.stats()["block_updates"] - b for ch, b in zip(group, b0))
         for ch in group:
             ch.close()
-        out["eight_chains_one_gpu_batched"] = {"value": b8 / (t1 - t0), "unit": "block-updates/s", "chains": 8, "ms_per_sweep_round": 1e3 * (t1 - t0) / args.steps,
-                                               "note": "hml_iterate_many: one launch per kernel for all eight chains, one host thread.  The aggregate is bounded by the "
-                                                       "GPU, not by the host's launch rate: eight chains take 4-5 times one chain's kernel times (profiles/round3_chains_batched.txt)"}
+        out["eight_chains_one_gpu_batched"] = {"value": b8 / (t1 - t0), "unit": "block-updates/s", "chains": 8, "steps": leg_steps,
+                                               "ms_per_sweep_round": 1e3 * (t1 - t0) / leg_steps,
+                                               "x_one_chain": (b8 / (t1 - t0)) / out["value"],
+                                               "device_bytes_chain_1": mem[0], "device_bytes_per_further_chain": (mem[-1] - mem[0]) / 7.0,
+                                               "note": "eight chains attached to ONE construction (hml_attach_observations), hml_iterate_many: block starts, statistics "
+                                                       "and emission terms of all chains from one pass over the shared trace (hml_m_blocks_fused), the other kernels "
+                                                       "once for all chains (the chain is the grid's second dimension); one host thread"}
 
-    # fourth leg: SURVEY 8d's stress case C3u - the same trace with the breakpoint weights multiplied by 1e9, so that
-    # every position is its own block (B = T): the regime in which the trellis itself, not the block scan, is the load
-    if not args.no_uncompressed_leg and world == 1 and args.workload == "c3_1e8_k5_dynamic":
-        if chain is not None:
-            chain.close()
+    def dense_leg(xd, Kd, scale, pmc_key, shared_sums, n_timed):
+        """a weakly compressed chain (millions of blocks per sweep: the fused trellis path, hml_k_trellis_rows.h): 64 burn-in
+        sweeps (the warm-up policy settles, sweeps 48..57 measure the candidate chunk lengths), n_timed timed ones, then ten
+        sweeps with every kernel family bracketed by events"""
         ch = hammlet_amd.Chain(device=local_rank, seed=args.seed, chain_id=rank)
-        ch.load(x)
-        ch.scale_weights(1e9)
-        ch.set_model(K, ch.autoprior(0.2, 0.9))
+        ch.load(xd)
+        if scale != 1.0:
+            ch.scale_weights(scale)
+        ch.set_model(Kd, ch.autoprior(0.2, 0.9))
         ch.sample_prior()
         ch.set_recording(marginals=False)
-        # burn-in: a fresh chain starts the dense path with the longest filter warm-up (64 rows) and the parameter
-        # kernel steps it down while the verification finds (almost) no stale chunk - about 40 sweeps to settle; sweeps
-        # 48 .. 57 then measure the candidate chunk lengths of the trellis kernels (include/hml.h "trellis_L")
-        n_u = max(20, min(100, args.steps))
         ch.iterate("F", 64, 0)
         ch.sync()
         u0 = ch.stats()
         barrier()
         t0 = time.perf_counter()
-        ch.iterate("F", n_u, 0)
+        ch.iterate("F", n_timed, 0)
         ch.sync()
         barrier()
         t1 = time.perf_counter()
         u1 = ch.stats()
         bu = u1["block_updates"] - u0["block_updates"]
-        Bu = bu / n_u
-        fams = {"blocks_compact": "hml_k_compact_scan_bits", "blocks_scatter": "hml_k_compact_scatter_bits", "trellis": DENSE_KERNEL, "trellis_repair": "hml_k_trellis_verify + refit + serial",
-                "backward_chain": "hml_k_trellis_super + chain + states", "counts": "hml_k_counts_dense", "params": "hml_k_params"}
+        Bu = bu / n_timed
+        fams = dense_kernels(Kd, shared_sums)
         ch.profile_enable(2)
         ch.iterate("F", 10, 0)
         ch.sync()
         ch.profile_enable(0)
         nb_ms, nb_n = ch.profile_get("event_null")
-        nb_us = 1e3 * nb_ms / max(1, nb_n)
+        nb_us = 1e3 * nb_ms / max(1, nb_n) if nb_n else 5.3
         dense_tab = {}
         for nm, kern in fams.items():
             ms, n = ch.profile_get(nm)
             if n:
                 us = max(1e3 * ms / n - nb_us, 0.5)
                 row = {"kernels": kern, "us_per_sweep": round(us, 1)}
-                tr = pmc_traffic("c3u", kern)
+                tr = pmc_traffic(pmc_key, kern)
                 if tr:
                     row["traffic"] = tr
+                    row["traffic_raw"] = pmc_traffic(pmc_key, kern, "bytes_raw")
                     row["frac"] = round(tr / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)
+                    row["frac_raw"] = round(row["traffic_raw"] / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)
                     assert row["frac"] <= 1.0
                 dense_tab[nm] = row
-        out["uncompressed_c3u"] = {"value": bu / (t1 - t0), "unit": "block-updates/s", "steps": n_u, "ms_per_step": 1e3 * (t1 - t0) / n_u,
-                                   "blocks_per_sweep": Bu, "forward_refits": u1["forward_refits"] - u0["forward_refits"],
-                                   "forward_warmup_rows": u1["forward_warmup"],
-                                   "sweep_frac": (4.0 * T + Bu * (36 + 8 * K)) / ((t1 - t0) / n_u) / 1e9 / HBM_PEAK_GBS,
-                                   "kernels": dense_tab,
-                                   "note": "B = T: the fused trellis path (hml_k_trellis_rows.h) - bound by vector issue: SQ_INSTS_VALU of the "
-                                           "first pass = about 530 wavefront instructions per 64 blocks and warm-up row (profiles/round3_sq_counters_c3u.txt); DESIGN.md 3a"}
+        Td = ch.T
         ch.close()
+        return {"value": bu / (t1 - t0), "unit": "block-updates/s", "steps": n_timed, "ms_per_step": 1e3 * (t1 - t0) / n_timed,
+                "positions": Td, "states": Kd, "blocks_per_sweep": Bu, "forward_refits": u1["forward_refits"] - u0["forward_refits"],
+                "forward_warmup_rows": u1["forward_warmup"],
+                "sweep_frac": (4.0 * Td + Bu * (36 + 8 * Kd)) / ((t1 - t0) / n_timed) / 1e9 / HBM_PEAK_GBS,
+                "kernels": dense_tab}
+
+    # fourth leg: SURVEY 8d's stress case C3u - the same trace with the breakpoint weights multiplied by 1e9, so that
+    # every position is its own block (B = T): the regime in which the trellis itself, not the block scan, is the load
+    if not args.no_uncompressed_leg and world == 1 and args.workload == "c3_1e8_k5_dynamic":
+        if chain is not None:
+            chain.close()
         chain = None
+        leg = dense_leg(x, K, 1e9, "c3u", True, max(30, min(100, args.steps)))
+        leg["note"] = ("B = T: the fused trellis path (hml_k_trellis_rows.h) - bound by vector issue: SQ_INSTS_VALU of the first pass = about 530 "
+                       "wavefront instructions per 64 blocks and warm-up row (profiles/round3_sq_counters_c3u.txt); DESIGN.md 3a")
+        out["uncompressed_c3u"] = leg
+
+    # fifth leg: the other single-GPU workloads of BASELINE.json, bounded (their full lines: python bench.py --workload ...)
+    if not args.no_config_legs and world == 1 and args.workload == "c3_1e8_k5_dynamic":
+        if chain is not None:
+            chain.close()
+        chain = None
+        # config 4's workload on one GPU: 10^8 positions, 10 states, strongly compressed, dynamic blocks
+        T4, K4, lv4, sg4, dw4, ds4 = WORKLOADS["c4_1e8_k10"]
+        x4 = hammlet_amd.synth_gauss(T4, K4, lv4, sg4, dw4, ds4, nthreads=nthr)
+        ch = hammlet_amd.Chain(device=local_rank, seed=args.seed, chain_id=rank)
+        ch.load(x4)
+        ch.set_model(K4, ch.autoprior(0.2, 0.9))
+        ch.sample_prior()
+        ch.set_recording(marginals=False)
+        ch.iterate("F", 64, 0)
+        ch.sync()
+        r0 = ch.stats()
+        barrier()
+        t0 = time.perf_counter()
+        ch.iterate("F", 400, 0)
+        ch.sync()
+        barrier()
+        t1 = time.perf_counter()
+        r1 = ch.stats()
+        b4 = (r1["block_updates"] - r0["block_updates"]) / 400.0
+        fk4 = family_kernels(K4)
+        ch.profile_enable(2)
+        ch.iterate("F", 100, 0)
+        ch.sync()
+        ch.profile_enable(0)
+        tab4 = {}
+        for nm, kern in fk4.items():
+            ms, n = ch.profile_get(nm)
+            if n:
+                us = max(1e3 * ms / n - 5.3, 0.5)   # (level-2 brackets: minus the usual empty bracket)
+                row = {"kernel_us": round(us, 2)}
+                tr = pmc_traffic("c4_1e8_k10", kern)
+                if tr:
+                    row["traffic"] = tr
+                    row["traffic_raw"] = pmc_traffic("c4_1e8_k10", kern, "bytes_raw")
+                    row["frac"] = round(tr / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)
+                    row["frac_raw"] = round(row["traffic_raw"] / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)
+                tab4[kern] = row
+        ch.close()
+        del x4
+        out["c4_1e8_k10"] = {"value": (r1["block_updates"] - r0["block_updates"]) / (t1 - t0), "unit": "block-updates/s", "steps": 400,
+                             "ms_per_step": 1e3 * (t1 - t0) / 400, "positions": T4, "states": K4, "blocks_per_sweep": b4,
+                             "forward_refits": r1["forward_refits"] - r0["forward_refits"],
+                             "sweep_frac": (4.0 * T4 + b4 * (36 + 8 * K4)) / ((t1 - t0) / 400) / 1e9 / HBM_PEAK_GBS,
+                             "kernels": tab4,
+                             "note": "BASELINE config 4's workload on ONE GPU (one of its 8 chains): sweeps 64..464; latency-bound like the headline"}
+        # config 5's workload on one GPU: 2.5 10^8 simulated read-depth positions, 5 states, weakly compressed
+        T5, K5, _, sg5, dw5, ds5 = WORKLOADS["c5_2.5e8_depth_k5"]
+        x5 = hammlet_amd.synth_depth(T5, depth=dw5, ln_sigma=sg5, seed=ds5, nthreads=nthr)
+        leg = dense_leg(x5, K5, 1.0, "c5_2.5e8_depth_k5", False, 40)
+        del x5
+        leg["note"] = "BASELINE config 5's workload on ONE GPU (one of its 8 chains): simulated WGS read depth, the fused trellis path; sweeps 64..104"
+        out["c5_2.5e8_depth_k5"] = leg
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(x, K, args.seed)

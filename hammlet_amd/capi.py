@@ -38,6 +38,7 @@ SIGNATURES = {
     "hml_destroy": (None, [_P]),
     "hml_load_observations": (C.c_int, [_P, _P, C.c_uint64]),
     "hml_load_observations_device": (C.c_int, [_P, _P, C.c_uint64]),
+    "hml_attach_observations": (C.c_int, [_P, _P]),
     "hml_text_open": (C.c_int, [C.POINTER(_P), C.c_int, C.c_uint64]),
     "hml_text_close": (None, [_P]),
     "hml_text_buffer": (C.c_int, [_P, C.POINTER(_P), C.POINTER(C.c_uint64)]),
@@ -105,7 +106,7 @@ SIGNATURES = {
 }
 
 
-ABI_VERSION = 2   # hml_abi_version() of include/hml.h this mirror was written against
+ABI_VERSION = 3   # hml_abi_version() of include/hml.h this mirror was written against
 
 
 def load_library(path=None):
@@ -238,6 +239,11 @@ class Chain:
     def load_device(self, ptr, T):
         self.T = int(T)
         _check(self.lib.hml_load_observations_device(self.h, ptr, T))
+
+    def attach(self, source):
+        """hml_attach_observations: share `source`'s construction (same device) instead of loading a copy"""
+        _check(self.lib.hml_attach_observations(self.h, source.h))
+        self.T, self.D, self.P = source.T, source.D, source.P
 
     def noise_sigma(self):
         v = C.c_double()

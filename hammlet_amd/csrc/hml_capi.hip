@@ -15,6 +15,7 @@
 #include "hml_k_backward.h"
 #include "hml_k_blocks.h"
 #include "hml_k_blocks_fused.h"
+#include "hml_k_blocks_fused_many.h"
 #include "hml_k_build.h"
 #include "hml_k_forward.h"
 #include "hml_k_marginals.h"
@@ -68,7 +69,7 @@ struct hml_ktab {
     int (*iterate_many)(hml_ctx* const* cs, int n, uint64_t first, uint64_t iterations, uint64_t thinning, uint64_t* done);
     void (*params)(hml_ctx* c, int mode);        // hml_k_params<K>: 1 = draw from the priors, 2 = Theta's constructor draw
     void (*compat_draw)(hml_ctx* c, int mode);   // hml_k_compat_draw<K> (reference-compatible chains)
-    void (*derive)(hml_ctx* c);                  // hml_k_derive<K>
+    void (*derive)(hml_ctx* c);                  // hml_k_derive<K>; reference-compatible chains: hml_k_compat_derive<K> (glibc's logf)
 };
 
 // the table of K states, or nullptr (outside [2, 16]; a development build knows one K only: -DHML_ONLY_K=5, tools/dev_build.py)
@@ -275,7 +276,7 @@ HML_KERNEL void hml_k_debug_eval(int fn, const float* __restrict__ a, const floa
 extern "C" {
 
 const char* hml_last_error(void) { return g_err.c_str(); }
-uint32_t hml_abi_version(void) { return 2; }   // 2: hml_stats.fused_fallbacks, hml_allreduce_marginals_perm, hml_pool_permutation, option "compat"
+uint32_t hml_abi_version(void) { return 3; }   // 2: hml_stats.fused_fallbacks, hml_allreduce_marginals_perm, hml_pool_permutation, option "compat"; 3: hml_attach_observations
 const char* hml_device_arch(void) { return "gfx950"; }
 int hml_device_count(int* n) {
     if (!n) return set_err(HML_ERR_ARG, "null argument");
@@ -316,6 +317,7 @@ int hml_create(hml_ctx** out, int device, uint64_t seed, uint32_t chain_id, void
     if (const char* e = getenv("HML_FWD_WARMUP")) c->fwdW = c->fwdW_init = std::max(0, atoi(e));
     if (const char* e = getenv("HML_FWD_BURNIN_SWEEPS")) c->fwd_burnin_sweeps = (uint32_t)std::max(0, atoi(e));
     if (const char* e = getenv("HML_FWD_QUIET")) c->fwd_quiet_need = (uint32_t)std::max(1, atoi(e));
+    if (const char* e = getenv("HML_FWD_CHUNK_MANY")) { int l = std::max(1, atoi(e)); int sh = 0; while ((1 << (sh + 1)) <= l && sh < 6) ++sh; c->fwdL_many = 1 << sh; }
     if (const char* e = getenv("HML_FWD_CHUNK_DENSE")) { int l = std::max(1, atoi(e)); int sh = 0; while ((1 << (sh + 1)) <= l && sh < 10) ++sh; c->fwdL_dense = 1 << sh; }
     if (const char* e = getenv("HML_DENSE_MIN_BLOCKS")) c->dense_min_blocks = (uint32_t)strtoul(e, nullptr, 10);
     if (const char* e = getenv("HML_USE_GRAPH")) c->use_graph = atoi(e) != 0;
@@ -335,11 +337,37 @@ int hml_create(hml_ctx** out, int device, uint64_t seed, uint32_t chain_id, void
     return 0;
 }
 
+// the shared construction: the last context that holds it frees it
+static void trace_release(hml_ctx* c) {
+    if (c->trace) {
+        if (c->trace->refs.fetch_sub(1) == 1) {
+            void* ptrs[] = {c->trace->d_w, c->trace->d_summary, c->trace->d_coeff, c->trace->d_ia};
+            for (void* p : ptrs) if (p) hipFree(p);
+            delete c->trace;
+        }
+        c->trace = nullptr;
+    } else {
+        // (a load that failed before the trace object existed)
+        void* ptrs[] = {c->d_w, c->d_summary, c->d_coeff, c->d_ia};
+        for (void* p : ptrs) if (p) hipFree(p);
+    }
+    c->d_w = nullptr; c->d_summary = nullptr; c->d_coeff = nullptr; c->d_ia = nullptr;
+}
+static bool trace_shared(const hml_ctx* c) { return c->trace && c->trace->refs.load() > 1; }
+
+// the buffers hml_set_model allocates
+static void free_sweep_buffers(hml_ctx* c) {
+    void** ptrs[] = {(void**)&c->d_em, (void**)&c->d_gsc, (void**)&c->d_rows, (void**)&c->d_entry, (void**)&c->d_exitA, (void**)&c->d_redo, (void**)&c->d_touched,
+                     (void**)&c->d_fb, (void**)&c->d_smap, (void**)&c->d_cmap, (void**)&c->d_scmap, (void**)&c->d_super, (void**)&c->d_bentry2, (void**)&c->d_bentry,
+                     (void**)&c->d_q, (void**)&c->d_partial, (void**)&c->d_redo2, (void**)&c->d_tre_bitmap, (void**)&c->d_tre_ckpt, (void**)&c->d_mt, (void**)&c->d_crows};
+    for (void** p : ptrs) if (*p) { hipFree(*p); *p = nullptr; }
+}
+
 static void free_all(hml_ctx* c) {
-    void* ptrs[] = {c->d_group_word, c->d_summary, c->d_w, c->d_coeff, c->d_ia, c->d_stage, c->d_span_count, c->d_starts, c->d_bstat,
-                    c->d_em, c->d_gsc, c->d_rows, c->d_eprobe, c->d_aprobe, c->d_entry, c->d_exitA, c->d_redo, c->d_touched, c->d_fb, c->d_coarse1,
-                    c->d_smap, c->d_cmap, c->d_scmap, c->d_super, c->d_bentry2, c->d_bentry, c->d_q, c->d_partial, c->d_diff, c->d_boundary, c->d_mdl,
-                    c->d_redo2, c->d_tre_bitmap, c->d_tre_ckpt, c->d_mt, c->d_crows, c->d_many};
+    trace_release(c);
+    free_sweep_buffers(c);
+    void* ptrs[] = {c->d_group_word, c->d_stage, c->d_span_count, c->d_starts, c->d_bstat, c->d_eprobe, c->d_aprobe, c->d_coarse1,
+                    c->d_diff, c->d_boundary, c->d_mdl, c->d_many};
     for (void* p : ptrs) if (p) hipFree(p);
     if (c->h_B) hipHostFree(c->h_B);
     c->h_B = nullptr;
@@ -384,13 +412,31 @@ HML_KERNEL void hml_k_max_inplace(float* __restrict__ a, const float* __restrict
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) { const float x = a[i], y = b[i]; a[i] = (x < y) ? y : x; }   // std::max(x, y)
 }
 
+// the per-chain block-structure buffers (every context has its own; the construction above them may be shared)
+static int alloc_block_buffers(hml_ctx* c) {
+    const uint64_t T = c->T;
+    c->n_spans = (uint32_t)((T + HML_SPAN - 1) / HML_SPAN);
+    HIPCHK(hipMalloc(&c->d_stage, (uint64_t)c->n_spans * HML_SPAN * sizeof(uint16_t)));
+    HIPCHK(hipMalloc(&c->d_span_count, c->n_spans * sizeof(uint32_t)));
+    HIPCHK(hipMalloc(&c->d_starts, (T + 1) * sizeof(uint32_t)));
+    HIPCHK(hipMalloc(&c->d_coarse1, ((c->n_spans + HML_GROUP_SPANS - 1) / HML_GROUP_SPANS + 1u) * sizeof(uint32_t)));
+    {
+        const uint64_t n_tiles = (T + HML_FUSED_SUB_POSITIONS - 1) / HML_FUSED_SUB_POSITIONS;   // (tiles of one batch: the most there can be)
+        HIPCHK(hipMalloc(&c->d_group_word, (n_tiles + 1) * sizeof(unsigned long long)));
+        HIPCHK(hipMemsetAsync(c->d_group_word, 0, (n_tiles + 1) * sizeof(unsigned long long), c->stream));
+        if (getenv("HML_FUSED_DEBUG")) { HIPCHK(hipMalloc(&c->d_dbg, 4096 * 8 * 8)); HIPCHK(hipMemset(c->d_dbg, 0, 4096 * 8 * 8)); }
+    }
+    HIPCHK(hipMalloc(&c->d_bstat, T * (uint64_t)c->D * sizeof(float2)));
+    return 0;
+}
+
 // d_x[d], h_x[d]: the observations of dimension d (T values each), on the device and on the host
 static int build_from_device_x(hml_ctx* c, const float* const* d_x, const float* const* h_x) {
     const uint64_t T = c->T;
     const int D = c->D;
     {   // what an earlier load that failed half-way may have left behind
-        void** stale[] = {(void**)&c->d_w, (void**)&c->d_coeff, (void**)&c->d_ia, (void**)&c->d_summary, (void**)&c->d_stage, (void**)&c->d_span_count,
-                          (void**)&c->d_starts, (void**)&c->d_coarse1, (void**)&c->d_group_word, (void**)&c->d_bstat};
+        trace_release(c);
+        void** stale[] = {(void**)&c->d_stage, (void**)&c->d_span_count, (void**)&c->d_starts, (void**)&c->d_coarse1, (void**)&c->d_group_word, (void**)&c->d_bstat};
         for (void** q : stale) if (*q) { hipFree(*q); *q = nullptr; }
     }
     // noise estimate (src/main.cpp:303-311): f64 accumulation, in index order, of the finest-level
@@ -467,20 +513,10 @@ static int build_from_device_x(hml_ctx* c, const float* const* d_x, const float*
             KLAUNCH_CHECK();
         }
     }
-    // block-structure buffers
-    c->n_spans = (uint32_t)((T + HML_SPAN - 1) / HML_SPAN);
-    HIPCHK(hipMalloc(&c->d_stage, (uint64_t)c->n_spans * HML_SPAN * sizeof(uint16_t)));
-    HIPCHK(hipMalloc(&c->d_span_count, c->n_spans * sizeof(uint32_t)));
-    HIPCHK(hipMalloc(&c->d_starts, (T + 1) * sizeof(uint32_t)));
-    HIPCHK(hipMalloc(&c->d_coarse1, ((c->n_spans + HML_GROUP_SPANS - 1) / HML_GROUP_SPANS + 1u) * sizeof(uint32_t)));
-    {
-        const uint64_t n_tiles = (T + HML_FUSED_SUB_POSITIONS - 1) / HML_FUSED_SUB_POSITIONS;   // (tiles of one batch: the most there can be)
-        HIPCHK(hipMalloc(&c->d_group_word, (n_tiles + 1) * sizeof(unsigned long long)));
-        HIPCHK(hipMemsetAsync(c->d_group_word, 0, (n_tiles + 1) * sizeof(unsigned long long), c->stream));
-        if (getenv("HML_FUSED_DEBUG")) { HIPCHK(hipMalloc(&c->d_dbg, 4096 * 4 * 8)); HIPCHK(hipMemset(c->d_dbg, 0, 4096 * 4 * 8)); }
-    }
-    HIPCHK(hipMalloc(&c->d_bstat, T * (uint64_t)D * sizeof(float2)));
+    if (int r = alloc_block_buffers(c)) return r;
     HIPCHK(hipStreamSynchronize(c->stream));
+    c->trace = new hml_trace();
+    c->trace->d_w = c->d_w; c->trace->d_summary = c->d_summary; c->trace->d_coeff = c->d_coeff; c->trace->d_ia = c->d_ia;
     c->loaded = true;
     return 0;
 }
@@ -545,6 +581,35 @@ int hml_load_observations_device(hml_ctx* c, const void* x_dev, uint64_t T) {
     return build_from_device_x(c, d_dim, h_dim);
 }
 
+// A second chain over the SAME observations on the same device: shares the source's read-only construction (weights,
+// summary, coefficients, integral arrays - reference counted) instead of building a private copy; block structure and sweep
+// buffers stay per chain.  The reference holds one chain per process over its one trace (src/main.cpp:108,338-343).
+int hml_attach_observations(hml_ctx* c, hml_ctx* src) {
+    if (!c || !src) return set_err(HML_ERR_ARG, "null argument");
+    if (c == src) return set_err(HML_ERR_ARG, "a context cannot be attached to itself");
+    if (!src->loaded || !src->trace) return set_err(HML_ERR_ARG, "the source context has no observations loaded");
+    if (c->loaded) return set_err(HML_ERR_ARG, "observations already loaded");
+    if (c->device != src->device) return set_err(HML_ERR_ARG, "contexts that share observations must live on one device");
+    if (c->use_keys != src->use_keys) return set_err(HML_ERR_ARG, "option weight_keys differs from the source context's");
+    if (int r = ctx_bind(c)) return r;
+    HIPCHK(hipStreamSynchronize(src->stream));   // (a weight multiplier still on its way)
+    trace_release(c);
+    {
+        void** stale[] = {(void**)&c->d_stage, (void**)&c->d_span_count, (void**)&c->d_starts, (void**)&c->d_coarse1, (void**)&c->d_group_word, (void**)&c->d_bstat};
+        for (void** q : stale) if (*q) { hipFree(*q); *q = nullptr; }
+    }
+    c->T = src->T; c->D = src->D;
+    if (c->P == 0 || c->D > 1) c->P = src->P;
+    c->sigma = src->sigma; c->key_base = src->key_base; c->key_scale = src->key_scale;
+    c->trace = src->trace;
+    c->trace->refs.fetch_add(1);
+    c->d_w = src->d_w; c->d_summary = src->d_summary; c->d_coeff = src->d_coeff; c->d_ia = src->d_ia;
+    if (int r = alloc_block_buffers(c)) { trace_release(c); return r; }
+    HIPCHK(hipStreamSynchronize(c->stream));
+    c->loaded = true;
+    return 0;
+}
+
 int hml_noise_sigma(hml_ctx* c, double* sigma) {
     if (!c || !c->loaded) return set_err(HML_ERR_ARG, "no observations loaded");
     *sigma = c->sigma;
@@ -553,6 +618,7 @@ int hml_noise_sigma(hml_ctx* c, double* sigma) {
 
 int hml_scale_weights(hml_ctx* c, float mult) {
     if (!c || !c->loaded) return set_err(HML_ERR_ARG, "no observations loaded");
+    if (trace_shared(c)) return set_err(HML_ERR_ARG, "the weights are shared with attached contexts: scale them before hml_attach_observations");
     if (int r = ctx_bind(c)) return r;
     hipLaunchKernelGGL(hml_k_scale, dim3(grid_for(c->T, 256, 1, 65536)), dim3(256), 0, c->stream, c->d_w, c->T, mult);
     KLAUNCH_CHECK();
@@ -565,6 +631,7 @@ int hml_scale_weights(hml_ctx* c, float mult) {
 int hml_set_weights(hml_ctx* c, const float* w, uint64_t T) {
     if (!c || !c->loaded || !w) return set_err(HML_ERR_ARG, "no observations loaded");
     if (T != c->T) return set_err(HML_ERR_MODEL, "Block structure and statistics have different number of data points!");
+    if (trace_shared(c)) return set_err(HML_ERR_ARG, "the weights are shared with attached contexts: set them before hml_attach_observations");
     if (int r = ctx_bind(c)) return r;
     HIPCHK(hipMemcpyAsync(c->d_w, w, T * sizeof(float), hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
@@ -713,11 +780,13 @@ int hml_set_model(hml_ctx* c, int K, const float nig4[4], float a_off, float a_d
     if (!(nig4[0] > 0)) return set_err(HML_ERR_MODEL, "Alpha (" + std::to_string(nig4[0]) + ") must be positive!");
     if (!(nig4[1] > 0)) return set_err(HML_ERR_MODEL, "Beta (" + std::to_string(nig4[1]) + ") must be positive!");
     if (!(nig4[3] > 0)) return set_err(HML_ERR_MODEL, "Nu (" + std::to_string(nig4[3]) + ")must be positive!");
+    HML_KTAB(K, kt);   // (before anything is allocated: a development build knows one K only)
     if (int r = ctx_bind(c)) return r;
+    free_sweep_buffers(c);   // (what an earlier call that failed half-way left behind)
     c->K = K;
     const uint64_t T = c->T;
     const uint64_t layChunks = (T + c->fwdL - 1) / c->fwdL + 1;
-    const int minL = std::min(c->fwdL, c->fwdL_dense);
+    const int minL = std::min(std::min(c->fwdL, c->fwdL_dense), c->fwdL_many);
     const uint64_t maxChunks = (T + minL - 1) / minL + 1;   // per-chunk arrays serve either geometry
     {
         int sh = 0; while ((1 << sh) < c->fwdL) ++sh;
@@ -730,6 +799,12 @@ int hml_set_model(hml_ctx* c, int K, const float nig4[4], float a_off, float a_d
         c->lay_dense.lshift = (uint32_t)sh;
         c->lay_dense.cstride = (uint32_t)(((T + c->fwdL_dense - 1) / c->fwdL_dense + 1 + 63) / 64 * 64);
         plane = std::max(plane, (uint64_t)c->fwdL_dense * K * c->lay_dense.cstride);
+    }
+    {
+        int sh = 0; while ((1 << sh) < c->fwdL_many) ++sh;
+        c->lay_many.lshift = (uint32_t)sh;
+        c->lay_many.cstride = (uint32_t)(((T + c->fwdL_many - 1) / c->fwdL_many + 1 + 63) / 64 * 64);
+        plane = std::max(plane, (uint64_t)c->fwdL_many * K * c->lay_many.cstride);
     }
     HIPCHK(hipMalloc(&c->d_em, plane * sizeof(float)));
     HIPCHK(hipMalloc(&c->d_gsc, plane * sizeof(float)));
@@ -786,26 +861,28 @@ int hml_set_model(hml_ctx* c, int K, const float nig4[4], float a_off, float a_d
     // keep the block count of an earlier enumeration (autoprior) out of the model: B = 0
     HIPCHK(hipMemcpyAsync(c->d_mdl, &m, sizeof m, hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
-    c->model_set = true;
     c->dynamic = true;
     c->hint_stale = true;
     // Theta's constructor samples once from the prior (src/Theta.hpp:126-127)
     if (c->compat) {
         // reference-compatible mode (hml_k_compat.h): the reference's engine, seeded like `rng_t RNG(seed)` (main.cpp:107-108),
-        // and a plain (B + 1) x K trellis
-        if (c->D != 1) return set_err(HML_ERR_ARG, "the reference-compatible mode (option compat) is for univariate models");
+        // and a plain (B + 1) x K trellis.  Chain 0 is the reference's run at this seed; further chains of a run (`-chains N`,
+        // chain ids 1, 2, ...) are the reference's runs at seed + chain id - N copies of one chain would pool to N times its
+        // marginals.
         hml_mt_state h;
-        hml_mt_seed(&h, c->seed);
+        hml_mt_seed(&h, c->seed + (uint64_t)c->chain);
         HIPCHK(hipMalloc(&c->d_mt, sizeof(hml_mt_state)));
         HIPCHK(hipMemcpyAsync(c->d_mt, &h, sizeof h, hipMemcpyHostToDevice, c->stream));
         HIPCHK(hipMalloc(&c->d_crows, (T + 1) * K * sizeof(float)));
         HIPCHK(hipStreamSynchronize(c->stream));
-        { HML_KTAB(K, kt); kt->compat_draw(c, 2); }
+        kt->compat_draw(c, 2);
         KLAUNCH_CHECK();
+        c->model_set = true;
         return 0;
     }
-    { HML_KTAB(K, kt); kt->params(c, 2); }
+    kt->params(c, 2);
     KLAUNCH_CHECK();
+    c->model_set = true;
     return 0;
 }
 
@@ -1353,7 +1430,7 @@ static bool many_eligible(hml_ctx* const* cs, int n, char method) {
     for (int i = 0; i < n; ++i) {
         const hml_ctx* c = cs[i];
         if (!c->model_set || c->device != a->device || c->K != a->K || c->T != a->T || c->D != 1 || c->compat || !c->dynamic || !c->use_keys ||
-            c->probes || c->profiling || c->fwdL != a->fwdL || c->late_rescale != a->late_rescale || c->n_spans != a->n_spans)
+            c->probes || c->profiling || c->fwdL != a->fwdL || c->fwdL_many != a->fwdL_many || c->late_rescale != a->late_rescale || c->n_spans != a->n_spans)
             return false;
         for (int j = 0; j < i; ++j) if (cs[j] == c) return false;
     }
@@ -1371,8 +1448,8 @@ static int iterate_many_k(hml_ctx* const* cs, int n, uint64_t first, uint64_t it
     hml_ctx* c0 = cs[0];
     hipStream_t s = c0->stream;
     const uint32_t T = (uint32_t)c0->T;
-    const int L = c0->fwdL;
-    const hml_layout lay = c0->lay;
+    const int L = c0->fwdL_many;
+    const hml_layout lay = c0->lay_many;
     const int with_gsc = c0->late_rescale ? 0 : 1;
     const uint32_t n_groups = (c0->n_spans + HML_GROUP_SPANS - 1) / HML_GROUP_SPANS;
     const bool records = thinning > 0 && thinning <= iterations;
@@ -1404,20 +1481,60 @@ static int iterate_many_k(hml_ctx* const* cs, int n, uint64_t first, uint64_t it
     HIPCHK(hipMemcpyAsync(c0->d_many, h.data(), n * sizeof(hml_chain_dev), hipMemcpyHostToDevice, s));
     HIPCHK(hipStreamSynchronize(s));   // (the staging vector goes out of scope below)
     const hml_chain_dev* d_cs = (const hml_chain_dev*)c0->d_many;
+    // Chains attached to ONE trace (hml_attach_observations) take the many-chain block kernel: block starts, statistics and
+    // emission terms of every chain from one pass over the shared summary / weights / integral array (hml_k_blocks_fused_many.h).
+    // Its workgroups wait for lower-numbered ones inside the launch, so the whole grid must be resident - the tile grows
+    // with the trace like the single-chain kernel's (fused_geometry).
+    bool fm = c0->trace != nullptr && c0->fused_blocks;
+    for (int k = 0; k < n; ++k) fm = fm && cs[k]->trace == c0->trace && cs[k]->fused_blocks && cs[k]->key_base == c0->key_base;
+    uint32_t fm_sub = 0u, fm_wg = 0u;
+    if (fm) {
+        if (c0->fm_slots == 0) {
+            int per_cu = 0, cus = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, hml_m_blocks_fused<KK>, HML_FUSED_WAVES * 64, 0) != hipSuccess ||
+                hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c0->device) != hipSuccess || per_cu <= 0 || cus <= 0) {
+                (void)hipGetLastError();
+                c0->fm_slots = -1;
+            } else c0->fm_slots = per_cu * cus;
+            if (const char* e = getenv("HML_FUSED_MANY_SLOTS")) c0->fm_slots = atoi(e);   // (tests: force larger tiles)
+        }
+        const uint64_t batches = (c0->T + HML_FUSED_SUB_POSITIONS - 1) / HML_FUSED_SUB_POSITIONS;
+        const uint64_t m = c0->fm_slots > 0 ? (batches + (uint64_t)c0->fm_slots - 1) / (uint64_t)c0->fm_slots : HML_FUSED_MAX_SUB + 1;
+        if (m > HML_FUSED_MAX_SUB) fm = false;
+        else { fm_sub = (uint32_t)m; fm_wg = (uint32_t)((c0->T + m * HML_FUSED_SUB_POSITIONS - 1) / (m * HML_FUSED_SUB_POSITIONS)); }
+    }
     for (uint64_t i = first; i < iterations; ++i) {
         for (int k = 0; k < n; ++k) if (!many_sparse(cs[k])) { *done = i; return 0; }   // a chain left the strongly compressed regime: the caller goes on one by one
         const bool record = thinning > 0 && ((i + 1) % thinning == 0);
         uint32_t hint = 0;
         for (int k = 0; k < n; ++k) hint = std::max(hint, cs[k]->B_hint ? cs[k]->B_hint : (uint32_t)std::min<uint64_t>(T, 1u << 20));
         const unsigned ny = (unsigned)n;
-        hipLaunchKernelGGL(hml_m_compact_scan_summary, dim3(n_groups, ny), dim3(256), 0, s, d_cs, T);
-        hipLaunchKernelGGL(hml_m_compact_scatter, dim3(n_groups, ny), dim3(256), 0, s, d_cs, T);
         const unsigned gB = (unsigned)grid_for(hint, 256, 64, 16384);
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_m_stats_emission<KK>), dim3(gB, ny), dim3(256), 0, s, d_cs, with_gsc, lay);
+        // (a bounded wait of the block kernel expired - somebody else is using the GPU: the scan + scatter launches from here on)
+        if (fm) for (int k = 0; k < n; ++k) if (cs[k]->h_B[1] && !cs[k]->fused_keep) fm = false;
+        if (fm) {
+            for (int k0 = 0; k0 < n; k0 += HML_FM_MAX_CHAINS) {
+                const int nk = std::min(n - k0, (int)HML_FM_MAX_CHAINS);
+                hml_fm_args fa;
+                memset(&fa, 0, sizeof fa);
+                for (int k = 0; k < nk; ++k) {
+                    hml_ctx* c = cs[k0 + k];
+                    hml_fm_chain& f = fa.c[k];
+                    f.mdl = c->d_mdl; f.group_word = c->d_group_word; f.stage = c->d_stage; f.starts = c->d_starts; f.bstat = c->d_bstat;
+                    f.em = c->d_em; f.gsc = with_gsc ? c->d_gsc : nullptr; f.host_words = c->d_hB;
+                }
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_m_blocks_fused<KK>), dim3(fm_wg), dim3(HML_FUSED_WAVES * 64), 0, s, c0->d_summary, c0->d_w, c0->d_ia,
+                                   T, c0->key_base, fa, nk, lay, fm_sub, c0->fused_spin_limit, c0->d_dbg);
+            }
+        } else {
+            hipLaunchKernelGGL(hml_m_compact_scan_summary, dim3(n_groups, ny), dim3(256), 0, s, d_cs, T);
+            hipLaunchKernelGGL(hml_m_compact_scatter, dim3(n_groups, ny), dim3(256), 0, s, d_cs, T);
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_m_stats_emission<KK>), dim3(gB, ny), dim3(256), 0, s, d_cs, with_gsc, lay);
+        }
         const uint64_t chunks = ((uint64_t)hint + L - 1) / L;
         hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_m_forward<KK>), dim3((unsigned)grid_for(chunks, 256, 16, 1 << 20), ny), dim3(256), 0, s, d_cs, with_gsc, L, lay);
         const uint64_t bch = ((uint64_t)hint + HML_BWD_CHUNK - 1) / HML_BWD_CHUNK;
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_m_backward_maps<KK>), dim3((unsigned)grid_for(bch * 64, 256, 16, 1 << 18), ny), dim3(256), 0, s, d_cs, with_gsc, L, lay);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_m_backward_maps<KK>), dim3((unsigned)grid_for((bch + 1) / 2 * 64, 256, 16, 1 << 18), ny), dim3(256), 0, s, d_cs, with_gsc, L, lay);   // (a wavefront per two chunks)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_m_backward_chain<KK>), dim3(1, ny), dim3(1024), 0, s, d_cs, with_gsc, L, lay);
         hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_m_counts<KK>), dim3(HML_REDUCE_GROUPS, ny), dim3(256), 0, s, d_cs);
         if (record && rec_mask) hipLaunchKernelGGL(hml_m_record, dim3(gB, ny), dim3(256), 0, s, d_cs, rec_mask);
@@ -1521,7 +1638,19 @@ int hml_sync(hml_ctx* c) {
     if (!c) return set_err(HML_ERR_ARG, "null context");
     if (int r = ctx_bind(c)) return r;
     HIPCHK(hipStreamSynchronize(c->stream));
-    if (c->d_dbg) {
+    if (c->d_dbg && getenv("HML_FUSED_DEBUG") && atoi(getenv("HML_FUSED_DEBUG")) == 2) {
+        // the many-chain block kernel's stamps (8 words per workgroup): start | phase A done | first gathers requested | offsets known | end
+        std::vector<unsigned long long> h(4096 * 8);
+        hipMemcpy(h.data(), c->d_dbg, h.size() * 8, hipMemcpyDeviceToHost);
+        uint32_t n = 0; while (n < 4096 && h[n * 8]) ++n;
+        unsigned long long t0 = ~0ull; for (uint32_t i = 0; i < n; ++i) t0 = std::min(t0, h[i * 8]);
+        double mx[5] = {0, 0, 0, 0, 0}, av[5] = {0, 0, 0, 0, 0};
+        if (n) for (uint32_t i = 0; i < n; ++i) for (int k = 0; k < 5; ++k) { const double d = (double)(h[i * 8 + k] - t0) * 0.01; mx[k] = std::max(mx[k], d); av[k] += d / n; }
+        if (n) fprintf(stderr, "[fused-many dbg] n=%u start avg %.2f max %.2f | phaseA avg %.2f max %.2f | requested avg %.2f max %.2f | offsets avg %.2f max %.2f | end avg %.2f max %.2f (us)\n",
+                n, av[0], mx[0], av[1], mx[1], av[2], mx[2], av[3], mx[3], av[4], mx[4]);
+        if (n) for (uint32_t i : {0u, n / 4, n / 2, n - 1}) if (i < n) fprintf(stderr, "   wg %u: %.2f %.2f %.2f %.2f %.2f | wavefront 0: parameters in LDS %.2f, weights arrived %.2f, its lists done %.2f\n", i, (h[i*8]-t0)*0.01, (h[i*8+1]-t0)*0.01, (h[i*8+2]-t0)*0.01, (h[i*8+3]-t0)*0.01, (h[i*8+4]-t0)*0.01,
+                                                                                  (h[i*8+5]-t0)*0.01, (h[i*8+6]-t0)*0.01, (h[i*8+7]-t0)*0.01);
+    } else if (c->d_dbg) {
         std::vector<unsigned long long> h(4096 * 4);
         hipMemcpy(h.data(), c->d_dbg, h.size() * 8, hipMemcpyDeviceToHost);
         const uint32_t n = (uint32_t)std::min<uint64_t>(4096, (c->T + HML_FUSED_SUB_POSITIONS - 1) / HML_FUSED_SUB_POSITIONS);
@@ -1944,7 +2073,8 @@ int hml_synth_depth(float* x, int16_t* states, uint64_t T, double depth, double 
         hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_compat_draw<KK>), dim3(1), dim3(64), 0, c->stream, c->d_mdl, (hml_mt_state*)c->d_mt, mode); \
     }                                                                                                                              \
     static void hml_kt_derive_##KK(hml_ctx* c) {                                                                                   \
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_derive<KK>), dim3(1), dim3(64), 0, c->stream, c->d_mdl);                          \
+        if (c->compat) hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_compat_derive<KK>), dim3(1), dim3(64), 0, c->stream, c->d_mdl);     \
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_derive<KK>), dim3(1), dim3(64), 0, c->stream, c->d_mdl);                     \
     }                                                                                                                              \
     extern hml_ktab hml_ktab_##KK;                                                                                                 \
     hml_ktab hml_ktab_##KK = {&sweep_k<KK>, &iterate_many_k<KK>, &hml_kt_params_##KK, &hml_kt_compat_draw_##KK, &hml_kt_derive_##KK};

@@ -5,6 +5,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <map>
 #include <string>
 #include <utility>
@@ -13,6 +14,18 @@
 #include "../../include/hml.h"
 #include "hml_host_common.hpp"
 #include "hml_state.h"
+
+// The read-only construction of one observation trace on one device - breakpoint weights, their group summary, maxlet
+// coefficients, integral array(s) - shared by every chain that was attached to it (hml_attach_observations): the chains of a
+// run read the same trace, their block sets are nested by threshold, and private copies (0.8 GB of integral array per chain at
+// 10^8 positions) only defeat the caches.  Freed with the last context that holds it.
+struct hml_trace {
+    std::atomic<int> refs{1};
+    float* d_w = nullptr;
+    uint8_t* d_summary = nullptr;
+    float* d_coeff = nullptr;
+    float2* d_ia = nullptr;
+};
 
 struct ProfAcc { double ms = 0; uint64_t n = 0; uint32_t tick = 0; std::vector<std::pair<hipEvent_t, hipEvent_t>> pending; };
 
@@ -29,7 +42,8 @@ struct hml_ctx {
     bool dynamic = true;
     bool blocks_valid = false;     // starts/bstat describe the current threshold
     double sigma = 0;
-    // construction
+    // construction (owned by `trace`; the pointers below are this context's view of it)
+    hml_trace* trace = nullptr;
     float* d_w = nullptr;
     uint8_t* d_summary = nullptr;  // largest key of every 16-position group (what the scan streams)
     int32_t key_base = 0;
@@ -111,12 +125,18 @@ struct hml_ctx {
     // of the work - in their own chunk-transposed layout; which geometry a sweep uses never changes its results
     int fwdL_dense = 16;
     hml_layout lay_dense = {4, 0};
+    // chains batched by hml_iterate_many are bound by throughput, not latency: chunks of 8 pay the warm-up over twice as many
+    // blocks (20 filter steps per 8 blocks instead of 16 per 4; measured with eight chains of config 3: 0.181 against 0.188 ms
+    // per round; 16 and 32 are slower again - too few wavefronts).  HML_FWD_CHUNK_MANY.
+    int fwdL_many = 8;
+    hml_layout lay_many = {3, 0};
     uint32_t dense_min_blocks = 1u << 22;
     bool graph_dense = false;
     bool probes = false;
     bool rec_marginals = true;
     hml_record_cb cb = nullptr;
     void* cb_user = nullptr;
+    int fm_slots = 0;              // workgroups of the many-chain block kernel that are resident at once (0: not asked yet)
     void* d_many = nullptr;        // hml_iterate_many: the chains' pointers (hml_chain_dev), kept by the first chain of a batch
     int many_cap = 0;
     bool compat = false;           // option "compat": sweeps exactly as the reference computes them (hml_k_compat.h)

@@ -264,6 +264,118 @@ HML_KERNEL __launch_bounds__(256) void hml_k_backward_maps(const float* __restri
 }
 
 
+// The same maps with TWO rows per lane: a wavefront owns two consecutive backward chunks (128 rows), lane l the rows
+// 2 l' + 1 and 2 l' + 2 (l' = l mod 32) of chunk 2 w + l / 32.  Blocks 2 m and 2 m + 1 share Philox block m of the sweep
+// (hml_cat_uniform_pair), so the lane pays for ten rounds ONCE for its two rows, and the suffix scan runs over 32 pairs per
+// chunk (five steps for two rows instead of six for one).  Same smap / cmap / fail list as hml_b_backward_maps - the
+// chunks stay 64 rows, every consumer is unchanged.  For chains batched by hml_iterate_many, where the kernel is bound by
+// vector issue (eight chains: 35.6 us with one row per lane).  Reference: ForwardBackward.hpp:133-162, Trellis.hpp:61-66.
+template <int K>
+__device__ __forceinline__ unsigned long long hml_bwd_row_map(const float (&r)[K], hml_model* __restrict__ mdl, const hml_bwd_ctx<K>& bx,
+                                                              uint32_t t, uint32_t B, double u) {
+    if (t > B) return HML_MAP_IDENTITY;
+    unsigned long long map = 0ull;
+    // "Negative backward variable!" (ForwardBackward.hpp:147-149), checked once per row (see hml_bwd_chunk_maps)
+#pragma unroll
+    for (int i = 0; i < K; ++i)
+        if (r[i] < 0.0f) hml_raise(mdl, HML_DEVERR_NEG_BACKWARD, r[i]);
+    if (t == B) {
+        const unsigned long long st = (unsigned long long)hml_categorical_k<K>(r, u);
+#pragma unroll
+        for (int x = 0; x < K; ++x) map |= st << (4 * x);
+    } else {
+#pragma unroll
+        for (int x = 0; x < K; ++x) {
+            float w[K];
+#pragma unroll
+            for (int i = 0; i < K; ++i) w[i] = r[i] * bx.A[i * K + x];
+            map |= (unsigned long long)hml_categorical_k<K>(w, u) << (4 * x);
+        }
+    }
+    return map;
+}
+// row t (1-based) of the trellis as the backward pass reads it (hml_bwd_row_load for one row)
+template <int K>
+__device__ __forceinline__ void hml_bwd_row_load_t(const float* __restrict__ rows, const hml_layout lay, uint32_t t, uint32_t B, float (&r)[K],
+                                                   const uint32_t* __restrict__ starts, const hml_bwd_ctx<K>& bx) {
+    uint32_t st = 0u, en = 1u;
+    if (starts && t < B) { st = starts[t - 1u]; en = starts[t]; }
+#pragma unroll
+    for (int i = 0; i < K; ++i) r[i] = (t <= B) ? rows[hml_bk(lay, t - 1u, K, i)] : 0.0f;
+    if (starts && t < B && bx.self) {
+        const float N = (float)(en - st);
+#pragma unroll
+        for (int i = 0; i < K; ++i) r[i] = r[i] * hml_expf((N - 1.0f) * bx.logA[i]);
+    }
+}
+template <int K>
+__device__ __forceinline__ void hml_b_backward_maps2(const float* __restrict__ rows, hml_model* __restrict__ mdl,
+                                                            unsigned long long* __restrict__ smap,
+                                                            unsigned long long* __restrict__ cmap, const hml_layout lay,
+                                                            const float* __restrict__ entry, const float* __restrict__ exitv,
+                                                            uint32_t* __restrict__ fail_list, int L,
+                                                            const uint32_t* __restrict__ starts,
+                                                            const hml_model* __restrict__ mdl_ro) {
+    const uint32_t B = mdl_ro->B;
+    const uint32_t nchunks = (B + HML_BWD_CHUNK - 1u) / HML_BWD_CHUNK;
+    const uint32_t npairs = (nchunks + 1u) / 2u;
+    const int lane = threadIdx.x & 63, li = lane & 31, half = lane >> 5;
+    const uint32_t wave_global = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
+    const unsigned long long epoch = mdl_ro->epoch;
+    const hml_key key = mdl_ro->key;
+    const int W = (int)mdl_ro->fwd_W;
+    __shared__ float sm_A[hml_amat<K>::LDS_FLOATS];
+    hml_amat_fill<K>(sm_A, mdl_ro, (int)threadIdx.x, (int)blockDim.x);
+    hml_bwd_ctx<K> bx;
+    hml_bwd_ctx_load<K>(bx, mdl_ro, sm_A);
+    const uint32_t C = (B + (uint32_t)L - 1u) / (uint32_t)L;
+    for (uint32_t pw = wave_global; pw < npairs; pw += nwaves) {
+        const uint32_t c = 2u * pw + (uint32_t)half;                          // this lane's backward chunk
+        const uint32_t t0 = c * HML_BWD_CHUNK + 2u * (uint32_t)li + 1u;      // its rows: t0, t0 + 1 (blocks 2 m, 2 m + 1 of pair m)
+        float r0[K], r1[K];
+        hml_bwd_row_load_t<K>(rows, lay, t0, B, r0, starts, bx);              // in flight together with the verification's loads
+        hml_bwd_row_load_t<K>(rows, lay, t0 + 1u, B, r1, starts, bx);
+        // forward chunks that overlap blocks [64 c, 64 c + 64): up to 64 of them, 32 lanes
+        bool ok = true;
+        if (c < nchunks) {
+            const uint32_t f0 = (c * HML_BWD_CHUNK) / (uint32_t)L;
+            const uint32_t f1 = (c * HML_BWD_CHUNK + HML_BWD_CHUNK - 1u) / (uint32_t)L;
+            for (uint32_t f = f0 + (uint32_t)li; f <= f1 && f < C; f += 32u) {
+                if (hml_fwd_chunk_exact(f, L, W)) continue;
+                uint32_t differ = 0u;   // (no short circuit: the 2 K loads travel together)
+#pragma unroll
+                for (int s = 0; s < K; ++s) differ |= hml_f2u(entry[(uint64_t)f * K + s]) ^ hml_f2u(exitv[(uint64_t)(f - 1) * K + s]);
+                ok = ok && differ == 0u;
+            }
+        }
+        const unsigned long long failed = __ballot(!ok);
+        const bool my_fail = (half ? (failed >> 32) : (failed & 0xffffffffull)) != 0ull;
+        if (my_fail && li == 0 && c < nchunks) fail_list[atomicAdd(&mdl->fwd_mismatch, 1u)] = c;   // at most one entry per backward chunk
+        if ((failed & 0xffffffffull) != 0ull && (failed >> 32) != 0ull) continue;   // both chunks failed (wave-uniform): nothing to compute here
+        double u0, u1;
+        hml_cat_uniform_pair(key, epoch, (t0 - 1u) >> 1, u0, u1);
+        const bool live = !my_fail && c < nchunks;
+        const unsigned long long m0 = live ? hml_bwd_row_map<K>(r0, mdl, bx, t0, B, u0) : HML_MAP_IDENTITY;
+        const unsigned long long m1 = live ? hml_bwd_row_map<K>(r1, mdl, bx, t0 + 1u, B, u1) : HML_MAP_IDENTITY;
+        // suffix scan of the pairs within each half of the wavefront
+        unsigned long long P = hml_map_compose<K>(m0, m1);
+#pragma unroll
+        for (int d = 1; d < 32; d <<= 1) {
+            unsigned long long o = hml_shfl_down_u64(P, d);
+            if (li + d >= 32) o = HML_MAP_IDENTITY;
+            P = hml_map_compose<K>(P, o);
+        }
+        unsigned long long later = hml_shfl_down_u64(P, 1);   // the pairs behind this one
+        if (li == 31) later = HML_MAP_IDENTITY;
+        if (live) {
+            if (t0 <= B) smap[t0] = P;
+            if (t0 + 1u <= B) smap[t0 + 1u] = hml_map_compose<K>(m1, later);
+            if (li == 0) cmap[c] = P;
+        }
+    }
+}
+
 // K7b repair + chain, one workgroup.  Normally only the chain: compose the chunk maps from the last chunk down,
 // entry[c] = state of the first row of chunk c+1 (entry of the last chunk is a dummy 0: its map is constant).
 // When a verification failed, the forward repair (hml_fwd_repair) and the maps of the affected chunks come first.
@@ -541,7 +653,10 @@ __device__ __forceinline__ void hml_b_counts(int16_t* __restrict__ q, const uint
     const uint32_t nchunks = (B + HML_REDUCE_CHUNK - 1u) / HML_REDUCE_CHUNK;
     // with one or two chunks per workgroup (strongly compressed sweeps) the fold at the end would cost more than it
     // saves: the counts then go straight to LDS
-    const bool direct = nchunks <= 2u * HML_REDUCE_GROUPS;
+#ifndef HML_COUNTS_DIRECT_CHUNKS
+#define HML_COUNTS_DIRECT_CHUNKS (2u * HML_REDUCE_GROUPS)
+#endif
+    const bool direct = nchunks <= HML_COUNTS_DIRECT_CHUNKS;
     // one chunk of loads ahead
     struct in_t { unsigned long long m1, m0; uint32_t e1, e0, s1, s0; float2 v; int16_t q1, q0; };
     auto fetch = [&](uint32_t c, in_t& r) {

@@ -103,19 +103,30 @@ __device__ __forceinline__ void hml_compat_draw_pi_A(hml_model* mdl, hml_mt_src&
 // logNormalizer, log A_ss and the threshold of the current parameters with the reference's logf (hml_derive's values)
 __device__ __forceinline__ void hml_compat_derive(hml_model* mdl, int K) {
     float mv = HML_INF_F;
-    for (int k = 0; k < K; ++k) {
+    const int P = mdl->P, D = mdl->D;
+    for (int k = 0; k < P; ++k) {   // per emission parameter (EFD.hpp:35-38; threshold: Theta.hpp:227-234)
         const float m = mdl->mu[k], v = mdl->var[k];
-        const float ln = hml_glibc_logf(mdl->sd[k]) + m * m / (2 * v);
-        mdl->logN[k] = ln;
-        mdl->logNs[k] = 0.0f + ln;
-        mdl->logA[k] = hml_glibc_logf(mdl->A[k * K + k]);
+        mdl->logN[k] = hml_glibc_logf(mdl->sd[k]) + m * m / (2 * v);
         mv = (v < mv) ? v : mv;
+    }
+    for (int k = 0; k < K; ++k) {
+        // theta.logNormalizer(state): float sum over the state's parameters from 0, in dimension order (Theta.hpp:148-158)
+        float r = 0.0f;
+        for (int d = 0; d < D; ++d) r += mdl->logN[mdl->map[k][d]];
+        mdl->logNs[k] = r;
+        mdl->logA[k] = hml_glibc_logf(mdl->A[k * K + k]);
     }
     const float l = hml_glibc_logf((float)mdl->T);
     const float arg = 2 * l * mv;
     const float t = HML_SQRTF(arg);
     mdl->thr_theta = t;
     if (mdl->dynamic) mdl->thr = t;
+}
+
+// after hml_set_parameters: the derived values of injected parameters with the mode's own logf
+template <int K>
+HML_KERNEL __launch_bounds__(64) void hml_k_compat_derive(hml_model* __restrict__ mdl) {
+    if (threadIdx.x == 0) hml_compat_derive(mdl, K);
 }
 
 // mode 1: theta, pi, A from the (reset) priors (main.cpp:393-401); mode 2: Theta's constructor draw (Theta.hpp:126-127)
@@ -126,7 +137,7 @@ HML_KERNEL __launch_bounds__(64) void hml_k_compat_draw(hml_model* __restrict__ 
     __syncthreads();
     if (threadIdx.x != 0) return;
     hml_mt_src src{lmt, mts->idx};
-    hml_compat_draw_theta(mdl, src, K);
+    hml_compat_draw_theta(mdl, src, mdl->P);
     if (mode != 2) hml_compat_draw_pi_A(mdl, src, K);
     hml_compat_derive(mdl, K);
     mdl->epoch += 1ull;
@@ -152,6 +163,21 @@ HML_KERNEL __launch_bounds__(64) void hml_k_compat_sweep(hml_model* __restrict__
     hml_mt_src src{lmt, mts->idx};
     const uint32_t B = mdl->B;
     const bool self = mdl->self_trans != 0;
+    const int P = mdl->P, D = mdl->D;                 // "-s C P D": P emission parameters over D data dimensions (Mapping.hpp:53-137)
+    const uint64_t dstride = mdl->stat_stride;        // block statistics: one plane per dimension
+    // innerProduct(y, theta.value(), theta.mapping(s)) (EFD.hpp:83-93): float sum over the dimensions from 0, every term
+    // the univariate product (EFD.hpp:23-32: double inside)
+    auto ip_state = [&](uint32_t b, int s) -> float {
+        float r = 0.0f;
+        for (int d = 0; d < D; ++d) {
+            const float2 st = bstat[(uint64_t)d * dstride + b];
+            const int pp = mdl->map[s][d];
+            const float ip = (float)((2.0 * (double)mdl->mu[pp] * (double)st.x - (double)st.y) / (2.0 * (double)mdl->var[pp]));
+            if (!hml_isfinite(ip)) hml_raise(mdl, HML_DEVERR_IP_NOT_FINITE, ip);
+            r += ip;
+        }
+        return r;
+    };
     for (int s = 0; s < K; ++s) {
         s_logA[s] = self ? mdl->logA[s] : 0.0f;
         s_logN[s] = mdl->logNs[s];
@@ -167,12 +193,9 @@ HML_KERNEL __launch_bounds__(64) void hml_k_compat_sweep(hml_model* __restrict__
         for (uint32_t t = 1; t <= B; ++t) {
             const uint32_t b = t - 1u;
             const float N = (float)(starts[t] - starts[b]);
-            const float2 st = bstat[b];
             float maxE = -3.40282346638528859812e+38f;
             for (int s = 0; s < K; ++s) {
-                const float ip = (float)((2.0 * (double)mdl->mu[s] * (double)st.x - (double)st.y) / (2.0 * (double)mdl->var[s]));   // EFD.hpp:23-32
-                if (!hml_isfinite(ip)) hml_raise(mdl, HML_DEVERR_IP_NOT_FINITE, ip);
-                float E = (0.0f + ip) - N * s_logN[s];
+                float E = ip_state(b, s) - N * s_logN[s];
                 if (self) E += (N - 1.0f) * s_logA[s];
                 fwd[s] = E;
                 maxE = (E < maxE) ? maxE : E;
@@ -210,12 +233,9 @@ HML_KERNEL __launch_bounds__(64) void hml_k_compat_sweep(hml_model* __restrict__
         // ---- mixture (Mixture.hpp:54-112): one draw per block in block order, no transitions
         for (uint32_t b = 0; b < B; ++b) {
             const float N = (float)(starts[b + 1u] - starts[b]);   // (size_t N, converted where it meets a float)
-            const float2 st = bstat[b];
             float maxE = -3.40282346638528859812e+38f;
             for (int s = 0; s < K; ++s) {
-                const float ip = (float)((2.0 * (double)mdl->mu[s] * (double)st.x - (double)st.y) / (2.0 * (double)mdl->var[s]));
-                if (!hml_isfinite(ip)) hml_raise(mdl, HML_DEVERR_IP_NOT_FINITE, ip);
-                const float E = (0.0f + ip) - N * s_logN[s];
+                const float E = ip_state(b, s) - N * s_logN[s];
                 s_w[s] = E;
                 maxE = (E < maxE) ? maxE : E;
                 if (eprobe) eprobe[(uint64_t)b * K + s] = E;
@@ -238,17 +258,21 @@ HML_KERNEL __launch_bounds__(64) void hml_k_compat_sweep(hml_model* __restrict__
             s_occ[s] = (unsigned long long)((float)s_occ[s] + N);
         }
         s_trans[prevs * K + s] += 1ull;
-        const float2 st = bstat[b];
-        { const float y = st.x - s_es[s], t = s_ps[s] + y; s_es[s] = (t - s_ps[s]) - y; s_ps[s] = t; }
-        { const float y = st.y - s_eq[s], t = s_pq[s] + y; s_eq[s] = (t - s_pq[s]) - y; s_pq[s] = t; }
-        s_n[s] += n;
+        // stats[mapping[state][d]].add(y.suffStat(d), N) for every dimension in order (ForwardBackward.hpp:189-192)
+        for (int d = 0; d < D; ++d) {
+            const int pp = mdl->map[s][d];
+            const float2 st = bstat[(uint64_t)d * dstride + b];
+            { const float y = st.x - s_es[pp], t = s_ps[pp] + y; s_es[pp] = (t - s_ps[pp]) - y; s_ps[pp] = t; }
+            { const float y = st.y - s_eq[pp], t = s_pq[pp] + y; s_eq[pp] = (t - s_pq[pp]) - y; s_pq[pp] = t; }
+            s_n[pp] += n;
+        }
         prevs = s;
     }
     // ---- conjugate updates (Conjugate.hpp:121-168,178-205)
-    for (int k = 0; k < K; ++k) {
+    for (int k = 0; k < K; ++k) mdl->last_occ[k] = s_occ[k];
+    for (int k = 0; k < P; ++k) {   // tau_theta.addObservation per parameter (ForwardBackward.hpp:202-207)
         const float sum = s_ps[k] - 0.0f, sumSq = s_pq[k] - 0.0f;   // KahanAggregator::sum(): positive part minus the (empty) negative part
         mdl->last_sum[k] = sum; mdl->last_sumsq[k] = sumSq;
-        mdl->last_occ[k] = s_occ[k];
         if (s_n[k] > 0ull) {
             if (sumSq < 0.0f) hml_raise(mdl, HML_DEVERR_NEG_SUMSQ, sumSq);
             const double N = (double)s_n[k];
@@ -273,7 +297,7 @@ HML_KERNEL __launch_bounds__(64) void hml_k_compat_sweep(hml_model* __restrict__
         mdl->dirPi[i] += (float)s_occ[i];
     }
     // ---- theta, pi, A (HMM.hpp:111-115), derived values
-    hml_compat_draw_theta(mdl, src, K);
+    hml_compat_draw_theta(mdl, src, P);
     hml_compat_draw_pi_A(mdl, src, K);
     hml_compat_derive(mdl, K);
     mdl->uniform_fallbacks += nfb;

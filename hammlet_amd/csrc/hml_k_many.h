@@ -58,7 +58,7 @@ HML_KERNEL __launch_bounds__(256) void hml_m_forward(const hml_chain_dev* __rest
 template <int K>
 HML_KERNEL __launch_bounds__(256) void hml_m_backward_maps(const hml_chain_dev* __restrict__ cs, int with_gsc, int L, const hml_layout lay) {
     const hml_chain_dev& c = cs[blockIdx.y];
-    hml_b_backward_maps<K>(c.rows, c.mdl, c.smap, c.cmap, lay, c.entry, c.exitv, c.redo, L, with_gsc ? nullptr : c.starts, c.mdl);
+    hml_b_backward_maps2<K>(c.rows, c.mdl, c.smap, c.cmap, lay, c.entry, c.exitv, c.redo, L, with_gsc ? nullptr : c.starts, c.mdl);   // (two rows per lane)
 }
 template <int K>
 HML_KERNEL __launch_bounds__(1024) void hml_m_backward_chain(const hml_chain_dev* __restrict__ cs, int with_gsc, int L, const hml_layout lay) {

@@ -56,6 +56,16 @@ void hml_destroy(hml_ctx* ctx);
 int hml_load_observations(hml_ctx* ctx, const float* x, uint64_t n_values);
 int hml_load_observations_device(hml_ctx* ctx, const void* x_dev, uint64_t T);
 
+/* A further chain over the SAME observations on the same GPU (chains outnumbering GPUs: `hammlet -chains N`, several
+ * chains per rank): `ctx` shares `source`'s read-only construction - breakpoint weights and their summary, maxlet
+ * coefficients, integral arrays; reference counted, freed with the last context - instead of uploading and building a copy
+ * of its own; block structure, sweep buffers, model and marginals stay per chain.  Chains of one run read the same trace
+ * and their block sets are nested by threshold, so their gathers then hit the same cache lines (hml_iterate_many batches
+ * such chains through ONE block kernel).  Replaces hml_load_observations for `ctx`; dimensions (hml_set_dimensions) are taken
+ * from the source.  hml_scale_weights / hml_set_weights are refused while the weights are shared: apply them to the source
+ * first.  The reference builds the construction once per process for its single chain (src/main.cpp:286-343). */
+int hml_attach_observations(hml_ctx* ctx, hml_ctx* source);
+
 /* Text input: the values that `while ( input >> v )` extracts from a whitespace-separated decimal stream
  * (src/wavelet.hpp:131, called from src/main.cpp:266-291), converted on the GPU chunk by chunk.  The result is
  * bit-identical to the stream extraction, including where it stops: tokens the device cannot decide with proof

@@ -116,12 +116,64 @@ def test_compat_chain_is_the_reference_chain(hml, T, K, seed, scheme):
     assert hml.marginals_text(seg, cnt) == o.text("marginals")
 
 
-@pytest.mark.parametrize("case", sorted(k for k, v in MANIFEST.items() if v.get("dims", 1) == 1))
+@pytest.mark.parametrize("P,D,T,seed,scheme", [
+    (2, 2, 30000, 5, [("F", 20, 1)]),
+    (3, 2, 20000, 6, [("M", 10, 1), ("S",), ("P",), ("F", 12, 2), ("D",), ("F", 6, 1)]),
+    (2, 3, 20000, 7, [("F", 10, 1)]),
+])
+def test_compat_multivariate_chain_is_the_reference_chain(hml, P, D, T, seed, scheme):
+    """`-s C P D` in the reference-compatible mode through the C ABI: per-parameter Kahan sums in dimension order, the
+    state's log-normaliser as the float sum of its parameters', theta drawn per parameter from the one mt19937 stream -
+    blocks, states, parameter bits, transition matrix and marginals equal the checker's REFERENCE mode."""
+    K = P ** D
+    x = np.stack([ol.trace(T, P, seed + 40 + d) for d in range(D)], axis=1).reshape(-1)
+    o = ol.OracleChain(K=K, seed=seed, rng=ol.RNG_MT, math=ol.MATH_LIBM, reduce=ol.REDUCE_REF)
+    o.set_dimensions(D, P)
+    o.load(x)
+    o.autoprior()
+    o.init_model()
+    o.set_record(marginals=True)
+    g = hml.Chain(device=0, seed=seed)
+    g.set_option("compat", 1)
+    g.set_dimensions(D, P)
+    g.load(x)
+    g.set_model(K, g.autoprior(0.2, 0.9))
+    pending = True
+    for tok in scheme:
+        o.token(tok[0])
+        if pending:
+            g.sample_prior()
+            pending = False
+        if tok[0] == "P":
+            pending = True
+        elif tok[0] == "S":
+            g.set_static_blocks()
+        elif tok[0] == "D":
+            g.set_dynamic(True)
+        else:
+            o.iterate(tok[0], tok[1], tok[2])
+            g.iterate(tok[0], tok[1], tok[2])
+            g.sync()
+            assert np.array_equal(o.blocks(), g.blocks())
+            assert np.array_equal(o.states(), g.states())
+            assert np.array_equal(bits(o.theta()), bits(g.theta()))
+            Ao, pio = o.transitions()
+            Ag, pig = g.transitions()
+            assert np.array_equal(bits(Ao), bits(Ag)) and np.array_equal(bits(pio), bits(pig))
+    seg, cnt = g.marginals_rle()
+    assert hml.marginals_text(seg, cnt) == o.text("marginals")
+
+
+@pytest.mark.parametrize("case", sorted(MANIFEST))
 def test_cli_compat_writes_the_reference_binarys_files(case):
     """`hammlet -compat` with the flags of a golden run against the files the UNMODIFIED REFERENCE BINARY wrote for them
-    (tests/golden/<case>/, oracle/_ref/hammlet in the build container): byte for byte, from the GPU."""
+    (tests/golden/<case>/, oracle/_ref/hammlet in the build container): byte for byte, from the GPU - all 19 runs: the
+    15 univariate ones and (round 4) the four multivariate / shared-parameter runs `-s C P D` (reference
+    src/Mapping.hpp:53-137, src/EFD.hpp:83-93, src/StateSequence/ForwardBackward.hpp:189-207)."""
     m = MANIFEST[case]
     x = ol.trace(m["T"], m["trace_levels"], m["data_seed"])
+    if m.get("dims", 1) > 1:   # dimension d = the generator with data seed + d, interleaved by position (tests/test_oracle_golden.py)
+        x = np.stack([ol.trace(m["T"], m["trace_levels"], m["data_seed"] + d) for d in range(m["dims"])], axis=1).reshape(-1)
     with tempfile.TemporaryDirectory() as tmp:
         raw = os.path.join(tmp, "in.f32")
         x.tofile(raw)

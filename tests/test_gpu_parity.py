@@ -458,6 +458,91 @@ def test_batched_chains_are_the_chains_run_alone(hml, K, n_chains):
         g.close()
 
 
+@pytest.mark.parametrize("K,n_chains,T,slots,spin", [(5, 8, 300_000, None, None), (3, 2, 300_000, None, None), (10, 3, 200_000, None, None),
+                                                     (5, 9, 140_000, None, None), (4, 3, 1_200_000, 3, None), (5, 4, 300_000, None, 0),
+                                                     (16, 2, 70_000, None, None)])
+def test_attached_chains_batched_through_the_many_chain_block_kernel(hml, monkeypatch, K, n_chains, T, slots, spin):
+    """hml_attach_observations + hml_iterate_many: chains that share ONE construction (weights, summary, integral array)
+    take hml_m_blocks_fused (hml_k_blocks_fused_many.h) - block starts, block statistics and emission terms of all chains
+    from one pass over the shared trace - and every chain must stay, bit for bit, the chain the checker runs alone:
+    eight chains (one launch), nine (two launches), many states (parameters from LDS), tiles of several batches (slots = 3
+    forces n_sub > 1), every tile word computed by the waiting workgroup (spin limit 0), integral-array cells crossed."""
+    if slots is not None:
+        monkeypatch.setenv("HML_FUSED_MANY_SLOTS", str(slots))
+    if spin is not None:
+        monkeypatch.setenv("HML_FUSED_SPIN_LIMIT", str(spin))
+        monkeypatch.setenv("HML_FUSED_BLOCKS", "2")   # keep the kernel although every wait "expires"
+    x = ol.trace(T, K, 12)
+    pairs = []
+    for chain in range(n_chains):
+        o = ol.OracleChain(K=K, seed=9, chain=chain, rng=ol.RNG_CTR, math=ol.MATH_DEV, reduce=ol.REDUCE_DEV)
+        o.load(x)
+        g = hml.Chain(device=0, seed=9, chain_id=chain)
+        if chain == 0:
+            g.load(x)
+        else:
+            g.attach(pairs[0][1])
+        setup_model(o, g, K)
+        o.token("F")
+        g.sample_prior()
+        o.set_record(marginals=True)
+        pairs.append((o, g))
+    gs = [g for _, g in pairs]
+    # shared, not copied: the weights are refused while attached contexts hold them
+    with pytest.raises(hml.HmlError):
+        gs[0].scale_weights(2.0)
+    for method, iters, thin in (("F", 14, 0), ("F", 8, 4), ("P", 0, 0), ("F", 6, 3), ("M", 3, 1), ("F", 4, 1)):
+        if method == "P":
+            for o, g in pairs:
+                o.token("P")
+                o.token("F")
+                g.sample_prior()
+            continue
+        for o, _ in pairs:
+            o.iterate(method, iters, thin)
+        hml.iterate_many(gs, method, iters, thin)
+        for chain, (o, g) in enumerate(pairs):
+            g.sync()
+            compare_state(o, g, what="attached chain %d" % chain)
+            so, qo = o.block_stats()
+            sg, qg = g.block_stats()
+            assert np.array_equal(bits(so), bits(sg)) and np.array_equal(bits(qo), bits(qg)), chain
+    for o, g in pairs:
+        seg, cnt = g.marginals_rle()
+        assert hml.marginals_text(seg, cnt) == o.text("marginals")
+        if spin == 0:
+            assert g.stats()["fused_fallbacks"] > 0
+    assert not np.array_equal(gs[0].theta(), gs[1].theta())
+    # an attached chain alone (hml_iterate) is the same chain; the source may go first - the construction lives on
+    o, g = pairs[-1]
+    gs[0].close()
+    o.iterate("F", 5, 1)
+    g.iterate("F", 5, 1)
+    g.sync()
+    compare_state(o, g, what="attached chain after its source was destroyed")
+    for g in gs[1:]:
+        g.close()
+
+
+def test_attach_observations_argument_checks(hml):
+    x = ol.trace(20_000, 3, 1)
+    a = hml.Chain(device=0, seed=1)
+    b = hml.Chain(device=0, seed=1, chain_id=1)
+    with pytest.raises(hml.HmlError):
+        b.attach(a)                      # nothing loaded yet
+    a.load(x)
+    with pytest.raises(hml.HmlError):
+        a.attach(a)
+    b.attach(a)
+    with pytest.raises(hml.HmlError):
+        b.attach(a)                      # already loaded
+    assert b.noise_sigma() == a.noise_sigma()
+    assert np.array_equal(bits(a.weights()), bits(b.weights()))
+    assert np.array_equal(bits(a.autoprior()), bits(b.autoprior()))
+    a.close()
+    b.close()
+
+
 @pytest.mark.parametrize("dense_L,min_blocks", [(16, 1000), (32, 1000), (64, 50000), (8, 1)])
 def test_dense_forward_geometry_is_invisible_in_the_results(hml, monkeypatch, dense_L, min_blocks):
     """Sweeps with many blocks run the forward pass with longer chunks in their own layout (HML_FWD_CHUNK_DENSE,

@@ -1,6 +1,7 @@
 """Several independent chains on ONE GPU: aggregate block-updates/s - each chain on its own stream and host thread, or (mode
 "many") all chains in one set of launches by one host thread (hml_iterate_many).
-    python tools/multi_chain.py [chains] [sweeps] [workload] [threads|many]"""
+    python tools/multi_chain.py [chains] [sweeps] [workload] [threads|many|attached]
+"attached" = mode "many" over contexts that share ONE construction (hml_attach_observations): the many-chain block kernel."""
 import os, sys, threading, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench, hammlet_amd
@@ -13,7 +14,10 @@ x = hammlet_amd.synth_gauss(T, K, levels, sigma, dwell, data_seed, nthreads=8)
 chains = []
 for r in range(R):
     ch = hammlet_amd.Chain(device=0, seed=1, chain_id=r)
-    ch.load(x)
+    if mode == "attached" and r > 0:
+        ch.attach(chains[0])
+    else:
+        ch.load(x)
     ch.set_model(K, ch.autoprior(0.2, 0.9))
     ch.sample_prior()
     ch.set_recording(marginals=False)
@@ -21,19 +25,25 @@ for r in range(R):
     chains.append(ch)
 for ch in chains:
     ch.sync()
-s0 = [ch.stats() for ch in chains]
-def run(ch):
-    ch.iterate("F", n, 0)
-    ch.sync()
-ths = [threading.Thread(target=run, args=(ch,)) for ch in chains]
-t0 = time.perf_counter()
-if mode == "many":
-    hammlet_amd.iterate_many(chains, "F", n, 0)
-    for ch in chains: ch.sync()
-else:
-    for t in ths: t.start()
-    for t in ths: t.join()
-t1 = time.perf_counter()
-blocks = sum(ch.stats()["block_updates"] - s["block_updates"] for ch, s in zip(chains, s0))
+reps = int(os.environ.get("REPS", "5")) if mode in ("many", "attached") else 1
+times, blocks_all = [], []
+for rep in range(reps):
+    s0 = [ch.stats() for ch in chains]
+    def run(ch):
+        ch.iterate("F", n, 0)
+        ch.sync()
+    ths = [threading.Thread(target=run, args=(ch,)) for ch in chains]
+    t0 = time.perf_counter()
+    if mode in ("many", "attached"):
+        hammlet_amd.iterate_many(chains, "F", n, 0)
+        for ch in chains: ch.sync()
+    else:
+        for t in ths: t.start()
+        for t in ths: t.join()
+    t1 = time.perf_counter()
+    times.append(t1 - t0)
+    blocks_all.append(sum(ch.stats()["block_updates"] - s["block_updates"] for ch, s in zip(chains, s0)))
+i = min(range(reps), key=lambda k: times[k])
+dt, blocks = times[i], blocks_all[i]
 print("[%s] " % mode + "%d chains x %d sweeps on one GPU: %.4f ms per sweep-round, %.3e block-updates/s aggregate (%.3e per chain)" % (
-    R, n, 1e3 * (t1 - t0) / n, blocks / (t1 - t0), blocks / (t1 - t0) / R))
+    R, n, 1e3 * dt / n, blocks / dt, blocks / dt / R) + ("   [best of %d: %s ms]" % (reps, " ".join("%.4f" % (1e3 * t / n) for t in times)) if reps > 1 else ""))
