@@ -86,3 +86,40 @@ def test_summary_and_float_stream_give_identical_chains(hml, big_trace):
     assert a[5]["block_updates"] == b[5]["block_updates"]
     assert np.array_equal(a[6][0].view(np.uint32), b[6][0].view(np.uint32))
     assert np.array_equal(a[6][1].view(np.uint32), b[6][1].view(np.uint32))
+
+
+def test_compat_chain_at_full_size_is_the_reference_chain(hml, big_trace):
+    """The reference-compatible mode at BASELINE config 3's FULL size (10^8 positions, 5 states, dynamic blocks): eight sweeps
+    of a compat chain against the checker's REFERENCE mode (sequential mt19937, glibc arithmetic, float Kahan sums in block
+    order, `size_t += float` counts - the mode that reproduces the unmodified reference binary's files byte for byte,
+    also by hand at this size: DESIGN.md 2) - block structure, state sequence, parameter bits, transition matrix, and the
+    counts, which exceed 2^24 here and therefore ROUND in the reference (src/StateSequence/ForwardBackward.hpp:183-187)."""
+    x = big_trace
+    seed = 9
+    o = ol.OracleChain(K=K, seed=seed, rng=ol.RNG_MT, math=ol.MATH_LIBM, reduce=ol.REDUCE_REF)
+    o.load(x)
+    o.autoprior()
+    o.init_model()
+    o.token("F")
+    g = hml.Chain(device=0, seed=seed)
+    g.set_option("compat", 1)
+    g.load(x)
+    g.set_model(K, g.autoprior(0.2, 0.9))
+    g.sample_prior()
+    for n in (3, 5):
+        o.iterate("F", n, 0)
+        g.iterate("F", n, 0)
+        g.sync()
+        assert np.array_equal(o.blocks(), g.blocks())
+        assert np.array_equal(o.states(), g.states())
+        assert np.array_equal(o.theta().view(np.uint32), g.theta().view(np.uint32))
+        Ao, pio = o.transitions()
+        Ag, pig = g.transitions()
+        assert np.array_equal(Ao.view(np.uint32), Ag.view(np.uint32)) and np.array_equal(pio.view(np.uint32), pig.view(np.uint32))
+        to, oo, so, qo, _ = o.counts()
+        tg, og, sg, qg, _ = g.counts()
+        assert np.array_equal(to, tg) and np.array_equal(oo, og)
+        assert np.array_equal(so.view(np.uint32), sg.view(np.uint32)) and np.array_equal(qo.view(np.uint32), qg.view(np.uint32))
+    assert int(og.max()) > (1 << 24)   # the regime in which the reference's counts round
+    g.close()
+    o.close()

@@ -1,0 +1,14 @@
+"""A bounded sample of the randomised differential run inside `-m gpu` (the thousands of configurations of
+tools/fuzz_parity.py were builder-run only): 300 random configurations at a fixed seed - sizes around the structural
+edges, 2-16 states, 1-3 data dimensions, random schemes of M / F / S / D / P tokens, priors, weight multipliers, read-depth
+input, every switchable kernel path - GPU against the checker in device mode after each: blocks, state sequences,
+parameter bits, marginals text.  About 20 seconds."""
+import pytest
+
+from tests.fuzz_util import fuzz
+
+pytestmark = pytest.mark.gpu
+
+
+def test_bounded_fuzz_against_the_checker(hml):
+    assert fuzz(hml, 300, 20261004) == 300

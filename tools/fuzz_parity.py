@@ -6,83 +6,9 @@ import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import hammlet_amd as hml
-from tests import oracle_lib as ol
-from tests.test_gpu_parity import run_both
+
+from tests.fuzz_util import fuzz
 
 n_cfg = int(sys.argv[1]) if len(sys.argv) > 1 else 100
-rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
-bits = lambda a: np.ascontiguousarray(a, np.float32).view(np.uint32)
-t_start = time.time()
-for it in range(n_cfg):
-    D = int(rng.choice([1, 1, 1, 2, 2, 3]))
-    if D == 1:
-        P = None; K = int(rng.integers(2, 17))
-    else:
-        P = int(rng.choice([2, 3, 4] if D == 2 else [2])); K = P ** D
-    T = int(rng.choice([17, 1000, 4097, 30000, 65535, 65537, 120000, 300000]))
-    if K > 8 or D > 1:
-        T = min(T, 120000)
-    dense = bool(rng.random() < 0.3)
-    mult = float(rng.choice([1.0, 1.0, 1.5, 1e9 if T <= 65537 else 1.0]))
-    self_trans = bool(rng.random() < 0.8)
-    kw = dict(t_off=float(rng.choice([0.5, 0.1, 1.0])), t_diag=float(rng.choice([0.5, 10.0])), pi_alpha=float(rng.choice([0.5, 2.0])),
-              e_var=float(rng.choice([0.2, 0.1])), e_p=float(rng.choice([0.9, 0.8])), self_trans=self_trans, weight_mult=mult)
-    os.environ["HML_DENSE_MIN_BLOCKS"] = "500" if dense else str(1 << 22)
-    os.environ["HML_FWD_CHUNK_DENSE"] = str(int(rng.choice([8, 16, 32])))
-    # round 2's switches: fused trellis path and its chunk length, late rescale, forward chunk length
-    os.environ["HML_TRELLIS_FUSED"] = str(int(rng.choice([1, 1, 1, 0])))
-    os.environ["HML_TRELLIS_L"] = str(int(rng.choice([0, 32, 64, 96, 160, 256, 544, 1024])))
-    # round 3's switches: first pass (rows | tile), checkpointed refits, flag staging of the dense scan, a short warm-up
-    os.environ["HML_TRELLIS_ROWS"] = str(int(rng.choice([1, 1, 1, 0])))
-    os.environ["HML_TRELLIS_CKPT"] = str(int(rng.choice([1, 1, 0])))
-    os.environ["HML_STAGE_BITS"] = str(int(rng.choice([1, 1, 0])))
-    if rng.random() < 0.3: os.environ["HML_FWD_WARMUP"] = str(int(rng.choice([4, 8, 16])))
-    else: os.environ.pop("HML_FWD_WARMUP", None)
-    os.environ["HML_LATE_RESCALE"] = str(int(rng.choice([1, 1, 0])))
-    os.environ["HML_FWD_CHUNK"] = str(int(rng.choice([4, 4, 1, 2, 8])))
-    seed = int(rng.integers(0, 1 << 30))
-    levels = min(K if D == 1 else P, 5)
-    if rng.random() < 0.2 and D == 1:
-        x = ol.synth_depth(T, seed=int(rng.integers(1, 100)))
-    else:
-        x = np.stack([ol.trace(T, levels, int(rng.integers(1, 1000)) + d) for d in range(D)], axis=1).reshape(-1)
-    scheme = []
-    for _ in range(int(rng.integers(1, 5))):
-        tok = rng.choice(["F", "F", "M", "S", "D", "P"])
-        scheme.append((str(tok), int(rng.integers(1, 9)), int(rng.integers(0, 3))) if tok in ("F", "M") else str(tok))
-    if not isinstance(scheme[-1], tuple):   # the probes (blocks, states) describe the last SWEEP; end with one
-        scheme.append(("F", int(rng.integers(1, 5)), 1))
-    o = ol.OracleChain(K=K, seed=seed, rng=ol.RNG_CTR, math=ol.MATH_DEV, reduce=ol.REDUCE_DEV, **kw)
-    g = hml.Chain(device=0, seed=seed)
-    if D > 1:
-        o.set_dimensions(D, P); g.set_dimensions(D, P)
-    g.set_option("weight_keys", int(rng.choice([1, 1, 2, 0])))
-    o.load(x); g.load(x)
-    if mult != 1.0:
-        g.scale_weights(mult)
-    try:
-        po = o.autoprior()
-    except RuntimeError as err:
-        # a degenerate draw (e.g. 17 positions in one block): the reference's own exception - the GPU must raise it too
-        try:
-            g.autoprior(kw["e_var"], kw["e_p"])
-            print("%3d DIFF: the checker raised %r, the GPU did not" % (it, str(err))); sys.exit(1)
-        except hml.HmlError as gerr:
-            assert str(err) in str(gerr), (str(err), str(gerr))
-        print("%3d ok  (both raise: %s)" % (it, err), flush=True)
-        g.close(); o.close()
-        continue
-    pg = g.autoprior(kw["e_var"], kw["e_p"])
-    assert np.array_equal(bits(po), bits(pg)), ("autoprior", it)
-    o.init_model()
-    g.set_model(K, pg, kw["t_off"], kw["t_diag"], kw["pi_alpha"], self_trans)
-    o.set_record(marginals=True)
-    g._pending_prior = True
-    run_both(o, g, scheme)
-    ok = (np.array_equal(o.blocks(), g.blocks()) and np.array_equal(o.states(), g.states()) and np.array_equal(bits(o.theta()), bits(g.theta()))
-          and hml.marginals_text(*g.marginals_rle()) == o.text("marginals"))
-    print("%3d %s T=%d K=%d D=%d dense=%d mult=%g self=%d scheme=%s  B=%d  %.0f s" % (it, "ok " if ok else "DIFF", T, K, D, dense, mult, self_trans, scheme, len(g.blocks()) - 1, time.time() - t_start), flush=True)
-    if not ok:
-        sys.exit(1)
-    g.close(); o.close()
+fuzz(hml, n_cfg, int(sys.argv[2]) if len(sys.argv) > 2 else 1, log=lambda s: print(s, flush=True))
 print("all %d configurations identical" % n_cfg)
