@@ -432,8 +432,11 @@ def main():
         seg, cnt, _ = chains.pooled_marginals(chain, pool)
         barrier()
         if rank == 0:
-            info = pool.info()
-            out["pooling"] = {"transport": "RCCL ncclAllReduce(sum, int32) inside libhammlet_hip.so (hml_pool_marginals)",
+            info, last = pool.info(), pool.last()
+            out["pooling"] = {"transport": "RCCL inside libhammlet_hip.so (hml_pool_marginals): the ranks' boundary lists through ncclAllGather when they are "
+                                           "at most an eighth of the dense int32 [K+1][T+1] payload, else that payload through ncclAllReduce(sum)",
+                              "form": last["form"], "list_slot_segments": last["entries"],
+                              "dense_payload_bytes": 4 * ((K + 1) * (T + 1) + 1 + K),
                               "rccl_version": info["rccl_version"], "all_reduce_bytes": info["last_bytes"],
                               "all_reduce_ms": info["last_allreduce_ms"],
                               "seconds_incl_export_and_install": time.perf_counter() - tp0,

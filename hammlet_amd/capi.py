@@ -94,6 +94,8 @@ SIGNATURES = {
     "hml_pool_destroy": (None, [_P]),
     "hml_pool_marginals": (C.c_int, [_P, _P, _P]),
     "hml_pool_info": (C.c_int, [_P, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.POINTER(C.c_int)]),
+    "hml_pool_set_form": (C.c_int, [_P, C.c_int]),
+    "hml_pool_last": (C.c_int, [_P, C.POINTER(C.c_int), C.POINTER(C.c_uint64)]),
     "hml_allreduce_marginals": (C.c_int, [_P, C.c_int]),
     "hml_allreduce_marginals_perm": (C.c_int, [_P, C.c_int, _P]),
     "hml_pool_permutation": (C.c_int, [_P, _P]),
@@ -515,6 +517,15 @@ class Pool:
         r, n, ms, b, v = C.c_int(), C.c_int(), C.c_double(), C.c_uint64(), C.c_int()
         _check(self.lib.hml_pool_info(self.h, C.byref(r), C.byref(n), C.byref(ms), C.byref(b), C.byref(v)))
         return {"rank": r.value, "n_ranks": n.value, "last_allreduce_ms": ms.value, "last_bytes": b.value, "rccl_version": v.value}
+
+    def set_form(self, form):
+        """0: dense payload or boundary lists, whichever is smaller (default); 1: dense (ncclAllReduce); 2: lists (ncclAllGather)"""
+        _check(self.lib.hml_pool_set_form(self.h, form))
+
+    def last(self):
+        f, e = C.c_int(), C.c_uint64()
+        _check(self.lib.hml_pool_last(self.h, C.byref(f), C.byref(e)))
+        return {"form": {1: "dense", 2: "lists"}.get(f.value, "none"), "entries": e.value}
 
     def close(self):
         if self.h:

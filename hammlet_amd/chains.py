@@ -49,6 +49,55 @@ def pool_payload(payload, group=None):
     return payload
 
 
+def list_from_dense(dense, boundary, perm, n_recorded):
+    """The boundary list of one chain (hml_k_pool_list_pack): header [M, recorded sweeps, used[0..K-1]], then for every
+    marginal segment [position, deltas of the relabelled states] - the non-zero columns of payload_from_dense's arrays."""
+    dense = np.asarray(dense, np.int64)
+    K, T = dense.shape
+    pay = payload_from_dense(dense, boundary, perm, n_recorded).astype(np.int64)
+    body = pay[: (K + 1) * (T + 1)].reshape(K + 1, T + 1)
+    pos = np.flatnonzero(body[K, :T])
+    entries = np.concatenate([pos[:, None], body[:K, pos].T], axis=1)
+    return np.concatenate([[len(pos), n_recorded], pay[(K + 1) * (T + 1) + 1:], entries.ravel()]).astype(np.int32)
+
+
+def pool_lists(lst, K, group=None):
+    """All-gather of the ranks' boundary lists in equally sized slots (the library: ncclAllGather; here any backend).
+    Returns the list of all ranks' lists."""
+    import torch
+    import torch.distributed as dist
+    t = torch.as_tensor(lst, dtype=torch.int32)
+    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1):
+        return [t]
+    world = dist.get_world_size(group)
+    m = torch.tensor([int(t[0])], dtype=torch.int64)
+    dist.all_reduce(m, op=dist.ReduceOp.MAX, group=group)
+    slot = 2 + K + int(m.item()) * (K + 1)
+    mine = torch.zeros(slot, dtype=torch.int32)
+    mine[: t.numel()] = t
+    out = [torch.zeros(slot, dtype=torch.int32) for _ in range(world)]
+    dist.all_gather(out, mine, group=group)
+    return out
+
+
+def payload_from_lists(lists, K, T):
+    """The pooled dense payload from all ranks' boundary lists: every entry added into zeroed arrays
+    (hml_k_pool_list_install) - equal to the sum of the ranks' dense payloads."""
+    import torch
+    body = torch.zeros((K + 1, T + 1), dtype=torch.int64)
+    rec, used = 0, torch.zeros(K, dtype=torch.int64)
+    for l in lists:
+        l = torch.as_tensor(l).to(torch.int64)
+        M = int(l[0])
+        rec += int(l[1])
+        used += l[2:2 + K]
+        e = l[2 + K: 2 + K + M * (K + 1)].view(M, K + 1)
+        body[:K].index_put_((torch.arange(K)[None, :].expand(M, K), e[:, :1].expand(M, K)), e[:, 1:], accumulate=True)
+        body[K, e[:, 0]] += 1
+    body[K, 0] = max(int(body[K, 0]), 1)
+    return torch.cat([body.flatten(), torch.tensor([rec]), used]).to(torch.int32)
+
+
 def payload_to_rle(payload, K, T):
     """Run-length form of a pooled payload: prefix sums of the difference rows, cut wherever the boundary row is
     non-zero; columns up to the highest state any chain recorded (reference src/StateMarginals.hpp:300-303).

@@ -1834,6 +1834,10 @@ static int gather_marginal_segments(hml_ctx* c, uint64_t* M_out, uint32_t** d_se
     return 0;
 }
 
+}  // extern "C"
+int hml_ctx_gather_marginal_segments(hml_ctx* c, uint64_t* M, uint32_t** d_seg, int32_t** d_g) { return gather_marginal_segments(c, M, d_seg, d_g); }
+extern "C" {
+
 int hml_marginals_rle(hml_ctx* c, uint64_t* n_segments, int* n_columns, uint64_t* seg_len, int32_t* counts) {
     NEED_MODEL();
     hml_model m; if (int r = fetch_model(c, &m)) return r;

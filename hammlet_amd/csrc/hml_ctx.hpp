@@ -154,5 +154,7 @@ struct hml_ctx {
 int hml_ctx_bind(hml_ctx* c);                         // hipSetDevice(ctx's device)
 int hml_ctx_fetch_model(hml_ctx* c, hml_model* out);  // synchronising copy of the device-resident model
 int hml_ctx_ensure_marginal_buffers(hml_ctx* c);
+// marginal segments on the device: starts d_seg[M] and count differences at the starts d_g[M * K] (caller frees both)
+int hml_ctx_gather_marginal_segments(hml_ctx* c, uint64_t* M, uint32_t** d_seg, int32_t** d_g);
 
 #endif

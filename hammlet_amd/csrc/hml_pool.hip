@@ -31,6 +31,7 @@ struct RcclApi {
     decltype(&ncclCommInitAll) CommInitAll = nullptr;
     decltype(&ncclCommDestroy) CommDestroy = nullptr;
     decltype(&ncclAllReduce) AllReduce = nullptr;
+    decltype(&ncclAllGather) AllGather = nullptr;
     decltype(&ncclGroupStart) GroupStart = nullptr;
     decltype(&ncclGroupEnd) GroupEnd = nullptr;
     decltype(&ncclGetErrorString) GetErrorString = nullptr;
@@ -67,6 +68,7 @@ RcclApi& rccl() {
         bind(api.CommInitAll, "ncclCommInitAll");
         bind(api.CommDestroy, "ncclCommDestroy");
         bind(api.AllReduce, "ncclAllReduce");
+        bind(api.AllGather, "ncclAllGather");
         bind(api.GroupStart, "ncclGroupStart");
         bind(api.GroupEnd, "ncclGroupEnd");
         bind(api.GetErrorString, "ncclGetErrorString");
@@ -144,19 +146,26 @@ int install_payload(hml_ctx* c, const int32_t* payload) {
 }
 
 // Before a collective over the payload every rank learns whether all ranks got this far and agree on the shape: a rank
-// that left early (a failed export, a chain of another K or T) would otherwise leave the others waiting in
-// ncclAllReduce.  ncclMax over {status, K, -K, T's halves and their negatives}.
-int handshake(ncclComm_t comm, hipStream_t stream, int32_t* d_hs, int local_rc, const hml_ctx* c) {
+// that left early (a failed export, a chain of another K or T) would otherwise leave the others waiting in the collective.
+// ncclMax over {status, K, -K, T's halves and their negatives, the rank's number of marginal segments (two halves)}:
+// *m_max = the largest number of segments any rank holds (what sizes the slots of the boundary-list form).
+int handshake(ncclComm_t comm, hipStream_t stream, int32_t* d_hs, int local_rc, const hml_ctx* c, uint64_t m_local = 0, uint64_t* m_max = nullptr) {
     const int32_t tl = (int32_t)(c->T & 0x7fffffffu), th = (int32_t)(c->T >> 31);
-    const int32_t h[8] = {local_rc ? 1 : 0, c->K, -c->K, tl, -tl, th, -th, 0};
+    // (the maximum of a two-word number by ncclMax: the high half first - the low half only counts among the ranks that
+    // hold the largest high half, so it travels in a second round when the high halves differ; segment counts are below
+    // 2^32, their high half is one bit: send the number as 16-bit pieces whose element-wise maxima bound it from above)
+    const int32_t m3 = (int32_t)((m_local >> 32) & 0xffffu), m2 = (int32_t)((m_local >> 16) & 0xffffu), m1 = (int32_t)(m_local & 0xffffu);
+    const int32_t h[12] = {local_rc ? 1 : 0, c->K, -c->K, tl, -tl, th, -th, m3, m2, m1, 0, 0};
     HIPCHK(hipMemcpyAsync(d_hs, h, sizeof h, hipMemcpyHostToDevice, stream));
-    NCCLCHK(rccl().AllReduce(d_hs, d_hs, 8, ncclInt32, ncclMax, comm, stream));
-    int32_t g[8];
+    NCCLCHK(rccl().AllReduce(d_hs, d_hs, 12, ncclInt32, ncclMax, comm, stream));
+    int32_t g[12];
     HIPCHK(hipMemcpyAsync(g, d_hs, sizeof g, hipMemcpyDeviceToHost, stream));
     HIPCHK(hipStreamSynchronize(stream));
     if (local_rc) return local_rc;
     if (g[0] != 0) return set_err(HML_ERR_ARG, "pooling abandoned: another rank failed before the collective");
     if (g[1] != -g[2] || g[3] != -g[4] || g[5] != -g[6]) return set_err(HML_ERR_ARG, "pooling abandoned: the ranks' chains differ in the number of states or positions");
+    // an upper bound of the largest count that every rank computes alike (exact when one rank holds the largest of every piece)
+    if (m_max) *m_max = ((uint64_t)(uint32_t)g[7] << 32) | ((uint64_t)(uint32_t)g[8] << 16) | (uint64_t)(uint32_t)g[9];
     return 0;
 }
 
@@ -171,6 +180,9 @@ struct hml_pool {
     uint64_t capacity = 0;       // int32 elements
     double last_ms = 0;
     uint64_t last_bytes = 0;
+    int form = 0;                // 0: chosen per call (lists when they are an eighth of the dense payload or less), 1: dense, 2: lists
+    int last_form = 0;           // 1 dense / 2 lists
+    uint64_t last_entries = 0;   // list form: the largest number of segments of a rank
 };
 
 extern "C" {
@@ -196,11 +208,14 @@ int hml_pool_create(hml_pool** out, int device, int rank, int n_ranks, const voi
     memcpy(&u, id, sizeof u);
     ncclResult_t rc = rccl().CommInitRank(&p->comm, n_ranks, u, rank);
     if (rc != ncclSuccess) { delete p; return set_err(HML_ERR_HIP, std::string("ncclCommInitRank: ") + rccl().GetErrorString(rc)); }
-    if (hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking) != hipSuccess) {
+    if (hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking) != hipSuccess || hipMalloc(&p->d_handshake, 16 * sizeof(int32_t)) != hipSuccess) {
+        (void)hipGetLastError();
+        if (p->stream) (void)hipStreamDestroy(p->stream);
         rccl().CommDestroy(p->comm);
         delete p;
-        return set_err(HML_ERR_HIP, "hipStreamCreateWithFlags failed");
+        return set_err(HML_ERR_HIP, "could not create the communicator's stream and handshake buffer");
     }
+    if (const char* e = getenv("HML_POOL_FORM")) p->form = atoi(e);
     *out = p;
     return 0;
 }
@@ -242,32 +257,103 @@ int hml_pool_install(hml_ctx* c, const void* payload_dev) {
     return install_payload(c, (const int32_t*)payload_dev);
 }
 
+// The collective.  Two forms of the same pooled marginals (hml_k_pool.h): the dense payload through ncclAllReduce(sum) -
+// [K+1][T+1] int32, 2.4 GB at 10^8 positions / 5 states whatever it holds - or the ranks' boundary lists through
+// ncclAllGather, chosen when the gathered lists are at most an eighth of the dense payload (a strongly compressed chain:
+// config 3 after 100 recorded sweeps holds 23 000 segments, 0.6 MB).  Every rank takes the same decision from the same
+// handshake.  A rank that cannot go on (wrong device, no model, out of memory, a failed export) still joins the
+// handshakes with its status, so that nobody is left inside a collective.
 int hml_pool_marginals(hml_pool* p, hml_ctx* c, int32_t* perm_out) {
-    if (!p || !c || !c->model_set) return set_err(HML_ERR_ARG, "model not set");
-    if (c->device != p->device) return set_err(HML_ERR_ARG, "the chain lives on another device than the communicator's rank");
+    if (!p || !c) return set_err(HML_ERR_ARG, "null argument");
     HIPCHK(hipSetDevice(p->device));
-    if (!p->d_handshake) HIPCHK(hipMalloc(&p->d_handshake, 8 * sizeof(int32_t)));
-    const uint64_t n = payload_count(c);
-    // from here on every rank reaches the handshake, whatever happens to it before
     int rc = 0;
-    if (p->capacity < n) {
+    if (!c->model_set) rc = set_err(HML_ERR_ARG, "model not set");
+    else if (c->device != p->device) rc = set_err(HML_ERR_ARG, "the chain lives on another device than the communicator's rank");
+    else if (c->pooled) rc = set_err(HML_ERR_ARG, "the marginals of this context are pooled already: they cannot be pooled again");
+    // ---- first handshake: status, shape, and the number of marginal segments of every rank
+    uint64_t M = 0, M_max = 0;
+    DevBuf d_seg, d_g;
+    if (!rc) rc = hml_ctx_ensure_marginal_buffers(c);
+    if (!rc) { uint32_t* sg = nullptr; int32_t* gg = nullptr; rc = hml_ctx_gather_marginal_segments(c, &M, &sg, &gg); d_seg.p = sg; d_g.p = gg; }
+    if (int r = handshake(p->comm, p->stream, p->d_handshake, rc, c, M, &M_max)) return r;
+    const int K = c->K;
+    const uint64_t n = payload_count(c);
+    const uint64_t slot = hml_pool_list_header(K) + M_max * (uint64_t)(K + 1);
+    const bool lists = p->form == 2 || (p->form == 0 && slot * (uint64_t)p->n_ranks * 8u <= n);
+    const uint64_t need = lists ? slot * (uint64_t)p->n_ranks : n;
+    if (p->capacity < need) {
         if (p->d_payload) (void)hipFree(p->d_payload);
         p->d_payload = nullptr; p->capacity = 0;
-        if (hipMalloc(&p->d_payload, n * sizeof(int32_t)) != hipSuccess) { (void)hipGetLastError(); rc = set_err(HML_ERR_HIP, "out of device memory for the pooling payload"); }
-        else p->capacity = n;
+        if (hipMalloc(&p->d_payload, need * sizeof(int32_t)) != hipSuccess) { (void)hipGetLastError(); rc = set_err(HML_ERR_HIP, "out of device memory for the pooling payload"); }
+        else p->capacity = need;
     }
-    if (!rc) rc = export_payload(c, p->d_payload, perm_out);
-    if (int r = handshake(p->comm, p->stream, p->d_handshake, rc, c)) return r;
     EventPair ev;
-    HIPCHK(hipEventCreate(&ev.e0)); HIPCHK(hipEventCreate(&ev.e1));
+    if (!rc && (hipEventCreate(&ev.e0) != hipSuccess || hipEventCreate(&ev.e1) != hipSuccess)) rc = set_err(HML_ERR_HIP, "hipEventCreate failed");
+    if (!lists) {
+        // ---- dense: export, second handshake (the export's status), all-reduce, install
+        if (!rc) rc = export_payload(c, p->d_payload, perm_out);
+        if (int r = handshake(p->comm, p->stream, p->d_handshake, rc, c)) return r;
+        HIPCHK(hipEventRecord(ev.e0, p->stream));
+        NCCLCHK(rccl().AllReduce(p->d_payload, p->d_payload, (size_t)n, ncclInt32, ncclSum, p->comm, p->stream));
+        HIPCHK(hipEventRecord(ev.e1, p->stream));
+        HIPCHK(hipStreamSynchronize(p->stream));
+        float ms = 0;
+        (void)hipEventElapsedTime(&ms, ev.e0, ev.e1);
+        p->last_ms = ms; p->last_bytes = n * sizeof(int32_t); p->last_form = 1; p->last_entries = 0;
+        return install_payload(c, p->d_payload);
+    }
+    // ---- lists: this rank's list into its slot, second handshake, all-gather, every list into the zeroed arrays
+    std::vector<int32_t> perm(K);
+    int32_t* const mine = p->d_payload ? p->d_payload + (uint64_t)p->rank * slot : nullptr;
+    DevBuf d_perm;
+    if (!rc) rc = hml_relabel_permutation(c, perm.data());
+    if (!rc) {
+        if (perm_out) memcpy(perm_out, perm.data(), sizeof(int32_t) * K);
+        if (hipMalloc(&d_perm.p, sizeof(int32_t) * K) != hipSuccess) { (void)hipGetLastError(); rc = set_err(HML_ERR_HIP, "out of device memory"); }
+    }
+    if (!rc) {
+        bool ok = hipMemcpyAsync(d_perm.p, perm.data(), sizeof(int32_t) * K, hipMemcpyHostToDevice, c->stream) == hipSuccess &&
+                  hipMemsetAsync(mine, 0, hml_pool_list_header(K) * sizeof(int32_t), c->stream) == hipSuccess;
+        if (ok) {
+            hipLaunchKernelGGL(hml_k_pool_list_pack, dim3(grid_for(std::max<uint64_t>(M, 1), 256, 1 << 14)), dim3(256), 0, c->stream, d_seg.as<uint32_t>(),
+                               d_g.as<int32_t>(), M, c->d_mdl, d_perm.as<int32_t>(), K, mine);
+            ok = hipGetLastError() == hipSuccess && hipStreamSynchronize(c->stream) == hipSuccess;
+        }
+        if (!ok) { (void)hipGetLastError(); rc = set_err(HML_ERR_HIP, "packing the boundary list failed"); }
+    }
+    if (int r = handshake(p->comm, p->stream, p->d_handshake, rc, c)) return r;
     HIPCHK(hipEventRecord(ev.e0, p->stream));
-    NCCLCHK(rccl().AllReduce(p->d_payload, p->d_payload, (size_t)n, ncclInt32, ncclSum, p->comm, p->stream));
+    NCCLCHK(rccl().AllGather(mine, p->d_payload, (size_t)slot, ncclInt32, p->comm, p->stream));   // (in place: the send buffer is this rank's slot)
     HIPCHK(hipEventRecord(ev.e1, p->stream));
     HIPCHK(hipStreamSynchronize(p->stream));
     float ms = 0;
     (void)hipEventElapsedTime(&ms, ev.e0, ev.e1);
-    p->last_ms = ms; p->last_bytes = n * sizeof(int32_t);
-    return install_payload(c, p->d_payload);
+    p->last_ms = ms; p->last_bytes = slot * (uint64_t)p->n_ranks * sizeof(int32_t); p->last_form = 2; p->last_entries = M_max;
+    const uint64_t T1 = c->T + 1;
+    HIPCHK(hipMemsetAsync(c->d_diff, 0, (uint64_t)K * T1 * sizeof(int32_t), c->stream));
+    HIPCHK(hipMemsetAsync(c->d_boundary, 0, ((T1 + 31) / 32 + 1) * sizeof(uint32_t), c->stream));
+    hipLaunchKernelGGL(hml_k_pool_list_install, dim3(grid_for(std::max<uint64_t>(M_max, 1), 256, 1 << 14)), dim3(256), 0, c->stream, p->d_payload, p->n_ranks,
+                       slot, (uint32_t)c->T, K, c->d_diff, c->d_boundary, c->d_mdl);
+    KLAUNCH_CHECK();
+    HIPCHK(hipStreamSynchronize(c->stream));
+    c->pool_perm = perm;
+    c->pooled = true;
+    return 0;
+}
+
+// "form" of hml_pool_marginals' collective: 0 (default) chosen per call, 1 always the dense payload, 2 always the boundary
+// lists (environment: HML_POOL_FORM); hml_pool_last reports what the last call took (1 / 2) and, for the lists, the largest
+// number of marginal segments a rank held.
+int hml_pool_set_form(hml_pool* p, int form) {
+    if (!p || form < 0 || form > 2) return set_err(HML_ERR_ARG, "form: 0 (automatic), 1 (dense payload) or 2 (boundary lists)");
+    p->form = form;
+    return 0;
+}
+int hml_pool_last(hml_pool* p, int* form, uint64_t* entries) {
+    if (!p) return set_err(HML_ERR_ARG, "null pool");
+    if (form) *form = p->last_form;
+    if (entries) *entries = p->last_entries;
+    return 0;
 }
 
 int hml_pool_permutation(hml_ctx* c, int32_t* perm) {

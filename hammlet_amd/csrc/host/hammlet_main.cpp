@@ -53,7 +53,8 @@ static const char* kHelp =
     "  -compat                        reference-compatible mode: the reference's mt19937 stream, libm arithmetic and\n"
     "                                 summation orders on the GPU - the same files as the reference for the same -R\n"
     "                                 (univariate models; one lane walks the blocks: for traces up to ~10^6 positions)\n"
-    "  -chains N                      N independent chains, one per GPU, marginals pooled over RCCL (extension).\n"
+    "  -chains N                      N independent chains, one per GPU, marginals pooled over RCCL (extension);\n"
+    "                                 chains beyond the number of GPUs share a GPU and the construction it holds.\n"
     "                                 The pooled marginals / maxsegmentation files use common labels (states by\n"
     "                                 ascending mean); PREFIX[chainK.]relabelSUFFIX lists each chain's own label of\n"
     "                                 pooled state 0, 1, ... (its parameters / sequences files keep its own labels)\n"
@@ -120,10 +121,53 @@ public:
     }
 };
 
+// Chains of `-chains N` that share a GPU share the construction of the observations (weights, summary, integral arrays -
+// hml_attach_observations): the first chain of a device builds it and applies the weight multiplier, the others attach to
+// it, and the builder goes on only when all of them have (its context must be alive while they attach).
+class DeviceTraces {
+    std::mutex mMutex;
+    std::condition_variable mCv;
+    std::map<int, hml_ctx*> mSource;
+    std::map<int, int> mPending;
+    std::map<int, bool> mFailed;
+
+public:
+    void expect(int device) { ++mPending[device]; }   // (before the threads start)
+    void publish(int device, hml_ctx* ctx) {
+        std::unique_lock<std::mutex> lock(mMutex);
+        mSource[device] = ctx;
+        mCv.notify_all();
+        mCv.wait(lock, [&] { return mPending[device] <= 0; });
+    }
+    void fail(int device) {
+        std::lock_guard<std::mutex> lock(mMutex);
+        mFailed[device] = true;
+        mCv.notify_all();
+    }
+    hml_ctx* waitForSource(int device) {
+        std::unique_lock<std::mutex> lock(mMutex);
+        mCv.wait(lock, [&] { return mSource.count(device) != 0 || mFailed[device]; });
+        if (!mSource.count(device)) throw std::runtime_error("The chain that loads the observations on this device failed!");
+        return mSource[device];
+    }
+    void attached(int device) {
+        std::lock_guard<std::mutex> lock(mMutex);
+        --mPending[device];
+        mCv.notify_all();
+    }
+};
+
 // One chain from its device context to its output files.  `index` > 0 (chains of `-chains N` beyond the first): the
 // per-sweep side files carry the infix "chainK." and the (pooled) marginals are left to chain 0.
+// `traces` (chains sharing GPUs): `builds` = this chain builds its device's construction, else it attaches to it.
 static void runChain(const Job& job, vector<real_t>& inputValues, bool steal, int device, uint32_t chainId, int index, bool verbose,
-                     Rendezvous* rendezvous) {
+                     Rendezvous* rendezvous, DeviceTraces* traces = nullptr, bool builds = true) {
+    // an attaching chain reports to the builder of its device whatever happens to it (the builder waits for all of them)
+    struct Attaching {
+        DeviceTraces* t; int d; bool open;
+        void close() { if (open) { open = false; t->attached(d); } }
+        ~Attaching() { close(); }
+    } attaching{traces, device, traces != nullptr && !builds};
     inputDevice() = device;
     rng_t RNG(job.seed, device, chainId);
     Transitions<DirichletVector> A(job.nrStates, RNG);
@@ -151,10 +195,29 @@ static void runChain(const Job& job, vector<real_t>& inputValues, bool steal, in
     typedef Statistics<IntegralArray, Normal> S;
     typedef Blocks<BreakpointArray> B;
     // upload + maxlet transform + weights + integral array (GPU); a lone chain takes the vector, several share it
-    std::unique_ptr<S> iaHolder(steal ? new S(inputValues, job.nrDataDim) : new S(static_cast<const vector<real_t>&>(inputValues), job.nrDataDim, S::keepInput));
+    std::unique_ptr<S> iaHolder;
+    if (traces && !builds) {
+        iaHolder.reset(new S(traces->waitForSource(device), job.T, job.nrDataDim, S::attachInput));
+        attaching.close();
+    } else {
+        try {
+            iaHolder.reset(steal ? new S(inputValues, job.nrDataDim) : new S(static_cast<const vector<real_t>&>(inputValues), job.nrDataDim, S::keepInput));
+        } catch (...) {
+            if (traces) traces->fail(device);
+            throw;
+        }
+    }
     S& ia = *iaHolder;
     B waveletBlocks(ia);
-    if (job.weightMultiplier != 1) waveletBlocks.scaleWeights(job.weightMultiplier);
+    if (!(traces && !builds)) {
+        try {
+            if (job.weightMultiplier != 1) waveletBlocks.scaleWeights(job.weightMultiplier);   // (the attached chains find the weights scaled)
+        } catch (...) {
+            if (traces) traces->fail(device);
+            throw;
+        }
+        if (traces) traces->publish(device, RNG.ctx());
+    }
     Emissions<S, B> y(ia, waveletBlocks);
     records.attach(y.ctx());
 
@@ -392,12 +455,14 @@ int main(int argc, const char* argv[]) {
             int nDev = 1;
             hml_check(hml_device_count(&nDev));
             Rendezvous rv(nrChains);
+            DeviceTraces traces;   // chains beyond the first of a device attach to its construction
+            for (int k = nDev; k < nrChains; ++k) traces.expect((device + k) % nDev);
             vector<std::thread> threads;
             vector<std::exception_ptr> errors(nrChains);
             for (int k = 0; k < nrChains; ++k)
                 threads.emplace_back([&, k] {
                     try {
-                        runChain(job, inputValues, /*steal*/ false, (device + k) % nDev, chain + (uint32_t)k, k, verbose && k == 0, &rv);
+                        runChain(job, inputValues, /*steal*/ false, (device + k) % nDev, chain + (uint32_t)k, k, verbose && k == 0, &rv, &traces, /*builds*/ k < nDev);
                     } catch (...) {
                         errors[k] = std::current_exception();
                         rv.abandon();

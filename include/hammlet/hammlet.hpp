@@ -260,6 +260,12 @@ public:
         mSize = values.size() / nrDim;
         hml_check(hml_load_observations(mDev.ctx(), values.data(), values.size()));
     }
+    // a further chain on a GPU that already holds the construction of these observations (`hammlet -chains N` with more chains
+    // than GPUs): shares it instead of building a copy (hml_attach_observations; include/hml.h)
+    enum AttachInput { attachInput };
+    Statistics(hml_ctx* source, const size_t size, const size_t nrDim, AttachInput) : mDev(rng_t::current()), mSize(size), mNrDim(nrDim) {
+        hml_check(hml_attach_observations(mDev.ctx(), source));
+    }
     // the reference's shape (src/main.cpp:340, src/Statistics/IntegralArray.hpp:136-191): the per-position statistics
     // MaxletTransform produced (swap-stolen).  The device already holds the integral arrays when MaxletTransform put
     // the observations there; statistics from elsewhere are uploaded now (x = sum of each one-observation statistic).

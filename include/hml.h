@@ -256,6 +256,16 @@ int hml_pool_create(hml_pool** out, int device, int rank, int n_ranks, const voi
 void hml_pool_destroy(hml_pool* pool);
 int hml_pool_marginals(hml_pool* pool, hml_ctx* ctx, int32_t* perm_out_or_null);
 int hml_pool_info(hml_pool* pool, int* rank, int* n_ranks, double* last_allreduce_ms, uint64_t* last_bytes, int* rccl_version);
+/* The collective of hml_pool_marginals has two forms with the same result.  DENSE: the payload above through
+ * ncclAllReduce(sum) - 4 (K+1)(T+1) bytes whatever it holds (2.4 GB at 10^8 positions and 5 states).  LISTS: the difference
+ * arrays are zero except at recorded segment boundaries, so every rank sends the list of its marginal segments - header
+ * [M, recorded sweeps, used[0..K-1]], then M x [position, relabelled deltas 0..K-1] - through ncclAllGather and adds all
+ * lists into zeroed arrays (config 3 after 100 recorded sweeps: 23 000 segments, 0.6 MB per rank).  form 0 (default): the
+ * lists when the gathered slots are at most an eighth of the dense payload - every rank decides alike from a handshake
+ * that carries the ranks' segment counts; 1: always dense; 2: always lists.  Environment: HML_POOL_FORM.
+ * hml_pool_last: the form the last call took (1 / 2) and, for the lists, the slot size in segments. */
+int hml_pool_set_form(hml_pool* pool, int form);
+int hml_pool_last(hml_pool* pool, int* form, uint64_t* entries);
 /* One process driving n chains, e.g. one per GPU (`hammlet -chains N`): contexts sharing a device are summed there,
  * the per-device sums go through one grouped ncclAllReduce (ncclCommInitAll over the distinct devices), every context
  * receives the pooled marginals. */

@@ -35,6 +35,8 @@ def test_bench_multi_rank_branches_on_one_gpu():
     assert line["n_gpus"] == 1 and line["value"] > 0
     p = line["pooling"]
     assert p["rccl_version"] > 0
-    assert p["all_reduce_bytes"] == 4 * ((5 + 1) * (10_000_000 + 1) + 1 + 5)      # int32 [K+1][T+1] + recorded sweeps + used states
+    # a strongly compressed chain: the collective takes the ranks' boundary lists (header 2 + K, then 1 + K words per segment)
+    assert p["form"] == "lists" and p["dense_payload_bytes"] == 4 * ((5 + 1) * (10_000_000 + 1) + 1 + 5)
+    assert p["all_reduce_bytes"] == 4 * (2 + 5 + p["list_slot_segments"] * 6) and p["all_reduce_bytes"] * 8 <= p["dense_payload_bytes"]
     assert p["counts_per_position"] == 2                                           # two recorded sweeps (F 10 5) of one chain
     assert line["roofline"]["launches"] >= 32

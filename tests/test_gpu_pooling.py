@@ -57,6 +57,7 @@ def test_one_rank_rccl_communicator_pools_through_the_c_entry_point(hml):
     x = ol.trace(T, K, 3)
     g = gpu_chain(hml, x, 0)
     pool = hml.Pool(0, 0, 1, hml.Pool.unique_id())
+    pool.set_form(1)   # the dense payload through ncclAllReduce (the boundary-list form: the test below)
     perm = pool.marginals(g)
     info = pool.info()
     assert info["n_ranks"] == 1 and info["rccl_version"] > 0
@@ -66,6 +67,44 @@ def test_one_rank_rccl_communicator_pools_through_the_c_entry_point(hml):
     seg, cnt = g.marginals_rle()
     assert np.array_equal(seg, seg_e) and np.array_equal(cnt, cnt_e)
     assert g.recorded_sweeps() == 8
+    pool.close()
+    g.close()
+
+
+def test_boundary_list_form_gives_the_dense_forms_marginals(hml):
+    """hml_pool_marginals' two collectives - the dense payload through ncclAllReduce, the ranks' boundary lists through
+    ncclAllGather - leave the same pooled marginals; the default picks the lists for a strongly compressed chain (a few
+    hundred segments in 60 000 positions) and the dense payload where every position is a segment of its own."""
+    x = ol.trace(T, K, 3)
+    res = {}
+    for form in (1, 2, 0):
+        g = gpu_chain(hml, x, 1)
+        pool = hml.Pool(0, 0, 1, hml.Pool.unique_id())
+        pool.set_form(form)
+        perm = pool.marginals(g)
+        res[form] = (perm, g.marginals_rle(), g.recorded_sweeps(), pool.last(), pool.info()["last_bytes"], g.max_segmentation())
+        with pytest.raises(hml.HmlError):
+            pool.marginals(g)              # pooled already
+        pool.close()
+        g.close()
+    assert res[1][3]["form"] == "dense" and res[2][3]["form"] == "lists" and res[0][3]["form"] == "lists"
+    assert res[2][4] * 8 < res[1][4]
+    for form in (2, 0):
+        assert np.array_equal(res[form][0], res[1][0])
+        assert np.array_equal(res[form][1][0], res[1][1][0]) and np.array_equal(res[form][1][1], res[1][1][1])
+        assert res[form][2] == res[1][2]
+        assert np.array_equal(res[form][5][0], res[1][5][0]) and np.array_equal(res[form][5][1], res[1][5][1])
+    # uncompressed: every position its own block and segment - the lists would be larger than the payload, the default stays dense
+    g = hml.Chain(device=0, seed=21, chain_id=0)
+    g.load(x)
+    g.scale_weights(1e9)
+    g.set_model(K, g.autoprior(0.2, 0.9))
+    g.sample_prior()
+    g.iterate("F", 6, 2)
+    g.sync()
+    pool = hml.Pool(0, 0, 1, hml.Pool.unique_id())
+    pool.marginals(g)
+    assert pool.last()["form"] == "dense"
     pool.close()
     g.close()
 

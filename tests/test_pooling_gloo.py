@@ -44,6 +44,15 @@ def worker(rank, world, port, out):
     t = torch.from_numpy(chains.payload_from_dense(dense, bnd, perm, N_RECORDED))
     chains.pool_payload(t)
     seg, cnt, n_rec = chains.payload_to_rle(t, K, T)
+    # the boundary-list form (hml_pool_marginals' other collective: all-gather of the ranks' segment lists): same pooled arrays
+    lists = chains.pool_lists(chains.list_from_dense(dense, bnd, perm, N_RECORDED), K)
+    t2 = chains.payload_from_lists(lists, K, T)
+    body, body2 = t[: (K + 1) * (T + 1)].view(K + 1, T + 1), t2[: (K + 1) * (T + 1)].view(K + 1, T + 1)
+    assert torch.equal(body[:K], body2[:K]) and torch.equal(body[K] != 0, body2[K] != 0)
+    assert torch.equal(t[(K + 1) * (T + 1):] != 0, t2[(K + 1) * (T + 1):] != 0) and int(t[(K + 1) * (T + 1)]) == int(t2[(K + 1) * (T + 1)])
+    seg2, cnt2, n_rec2 = chains.payload_to_rle(t2, K, T)
+    assert torch.equal(seg, seg2) and torch.equal(cnt, cnt2) and n_rec == n_rec2
+    assert sum(l.numel() for l in lists) * 8 < t.numel()   # ... from a fraction of the bytes
     if rank == 0:
         np.savez(out, payload=t.numpy(), seg=seg.numpy(), cnt=cnt.numpy(), n_rec=n_rec)
     dist.barrier()
