@@ -67,15 +67,13 @@ K_STATES = range(2, 17)   # numbers of states the kernels are compiled for (HML_
 
 
 def _objects():
-    """(source, object name, extra flags) of every object of the library: each csrc/*.hip once - except hml_capi.hip, which
-    is compiled once for the C ABI and everything independent of the number of states (-DHML_TU_CORE) and once per number of
-    states for the sweep (-DHML_TU_K=k): sixteen objects with their own code objects, built in parallel and loaded on demand
-    (csrc/hml_capi.hip, top)."""
+    """(source, object name, extra flags) of every object of the library: each csrc/*.hip once - except hml_sweep.hip, the sweep
+    for K states, which is compiled once per number of states (-DHML_TU_K=k): fifteen objects with their own code objects,
+    built in parallel and loaded on demand (csrc/hml_capi_shared.hpp, top)."""
     out = []
     for u in sorted(f for f in os.listdir(CSRC) if f.endswith(".hip")):
-        if u == "hml_capi.hip":
-            out.append((u, "hml_capi.o", ["-DHML_TU_CORE"]))
-            out += [(u, "hml_capi_k%d.o" % k, ["-DHML_TU_K=%d" % k]) for k in K_STATES]
+        if u == "hml_sweep.hip":
+            out += [(u, "hml_sweep_k%d.o" % k, ["-DHML_TU_K=%d" % k]) for k in K_STATES]
         else:
             out.append((u, u[:-4] + ".o", []))
     return out

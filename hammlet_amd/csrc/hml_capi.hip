@@ -1,192 +1,19 @@
 // libhammlet_hip.so - C ABI (include/hml.h) over the gfx950 kernels.  Host side only orchestrates:
 // allocation, launches on the context's stream, and the few inherently sequential one-time steps of
 // the reference's driver (noise estimate src/main.cpp:303-311, autoPrior src/AutoPriors.hpp:86-110).
-#include <hip/hip_runtime.h>
+#include "hml_capi_shared.hpp"
 
-#include <algorithm>
-#include <cmath>
-#include <cstdio>
-#include <cstring>
-#include <map>
-#include <string>
-#include <vector>
-
-#include "../../include/hml.h"
-#include "hml_k_backward.h"
-#include "hml_k_blocks.h"
-#include "hml_k_blocks_fused.h"
-#include "hml_k_blocks_fused_many.h"
-#include "hml_k_build.h"
-#include "hml_k_forward.h"
-#include "hml_k_marginals.h"
-#include "hml_k_segment.h"
-#include "hml_k_trellis.h"
-#include "hml_k_trellis_rows.h"
-#include "hml_k_compat.h"
-#include "hml_k_many.h"
-#include "hml_k_params.h"
-#include "hml_state.h"
-#include "hml_synth_host.hpp"
-
-#include "hml_host_common.hpp"
-#include "hml_ctx.hpp"
-
-// This file is compiled in one of three ways (hammlet_amd/build.py):
-//   -DHML_TU_CORE : the C ABI and everything that does not depend on the number of states K (one object);
-//   -DHML_TU_K=k  : the sweep for k states - the kernels templated on K and the host code that launches them - behind a table
-//                   of function pointers (fifteen objects, k = 2 ... 16, compiled in parallel);
-//   neither       : both in one object (development builds for one K: -DHML_ONLY_K=k, tools/dev_build.py).
-// Every object carries its own code object, and the HIP runtime loads a code object when the first kernel of it is
-// launched: a run with K states loads the core's (construction, block scan, marginals) and the one of its K (1-2 MB each)
-// instead of one 19 MB object with every kernel for 2 ... 16 states - 45 ms of a short run's start-up - and the
-// library builds in a fifth of the time.  Kernels that are not templates have internal linkage (HML_KERNEL) so that the
-// objects may each hold the ones they launch.
-#if defined(HML_TU_K)
-#define HML_IN_CORE 0
-#else
-#define HML_IN_CORE 1
-#endif
-#if defined(HML_TU_CORE)
-#define HML_IN_K 0
-#else
-#define HML_IN_K 1
-#endif
-#if defined(HML_TU_K) && defined(HML_TU_CORE)
-#error "HML_TU_K and HML_TU_CORE exclude each other"
-#endif
-
-#if HML_IN_CORE
 static thread_local std::string g_err;
 int hml_set_err(int code, const std::string& msg) { g_err = msg; return code; }
-#else
-int hml_set_err(int code, const std::string& msg);
-#endif
-static int set_err(int code, const std::string& msg) { return hml_set_err(code, msg); }
-
-// what the core calls of the K-dependent part: one table per number of states (defined at the end of this file)
-struct hml_ktab {
-    int (*sweep)(hml_ctx* c, char method, bool record);
-    int (*iterate_many)(hml_ctx* const* cs, int n, uint64_t first, uint64_t iterations, uint64_t thinning, uint64_t* done);
-    void (*params)(hml_ctx* c, int mode);        // hml_k_params<K>: 1 = draw from the priors, 2 = Theta's constructor draw
-    void (*compat_draw)(hml_ctx* c, int mode);   // hml_k_compat_draw<K> (reference-compatible chains)
-    void (*derive)(hml_ctx* c);                  // hml_k_derive<K>; reference-compatible chains: hml_k_compat_derive<K> (glibc's logf)
-};
 
 // the table of K states, or nullptr (outside [2, 16]; a development build knows one K only: -DHML_ONLY_K=5, tools/dev_build.py)
-#if HML_IN_CORE
 static const hml_ktab* ktab(int K);
 #define HML_KTAB(KV, tab) const hml_ktab* tab = ktab(KV); if (!tab) return set_err(HML_ERR_ARG, "number of states must be in [2,16]")
-#endif
 
-// Live contexts per device.  The fused block kernel hands block offsets from workgroup to workgroup inside one launch
-// (a workgroup spins on the words of lower-numbered ones); that is safe while all lower-numbered workgroups are resident
-// or finished, which in-order dispatch guarantees for ONE kernel on the GPU.  With two chains sweeping the same GPU at
-// once the eight XCDs can fill up with the late workgroups of one launch and the early ones of the other, each waiting
-// for workgroups that cannot be dispatched (observed once under the profiler: two launches stalled for 27 s until the
-// firmware's time slicing untangled them).  So while more than one context is alive on a device every sweep takes the
-// scan + scatter pair, which has no such hand-off.
-#include <atomic>
-#if HML_IN_CORE
 std::atomic<int> hml_live_ctx[64];
-#else
-extern std::atomic<int> hml_live_ctx[64];
-#endif
-#define g_live_ctx hml_live_ctx
-static bool shares_device(const hml_ctx* c) { return c->device < 64 && g_live_ctx[c->device].load() > 1; }
-
-// ------------------------------------------------------------------------------------------------
-static int ctx_bind(hml_ctx* c) {
-    HIPCHK(hipSetDevice(c->device));
-    return 0;
-}
-#if HML_IN_CORE
 int hml_ctx_bind(hml_ctx* c) { return ctx_bind(c); }
-#endif
-
-static hipEvent_t ev_get(hml_ctx* c) {
-    if (!c->ev_pool.empty()) { hipEvent_t e = c->ev_pool.back(); c->ev_pool.pop_back(); return e; }
-    hipEvent_t e;
-    hipEventCreate(&e);
-    return e;
-}
-
-struct ProfScope {
-    hml_ctx* c; const char* name; hipEvent_t a = nullptr, b = nullptr;
-    bool on;
-    ProfScope(hml_ctx* c_, const char* n, int level = 2) : c(c_), name(n), on(c_->profiling >= level) {
-        // level 1 (the bench's timed region): bracket every 32nd launch only - two event records cost ~6 us of
-        // stream time, a visible share of an 80 us sweep
-        // (a counter per family: the weakly compressed sweep has two level-1 families, block scan and first trellis pass)
-        if (on && c->profiling == 1 && (c->prof[name].tick++ & 31u) != 0u) on = false;
-        if (on) { a = ev_get(c); b = ev_get(c); hipEventRecord(a, c->stream); }
-    }
-    ~ProfScope() {
-        if (!on) return;
-        hipEventRecord(b, c->stream);
-        c->prof[name].pending.push_back({a, b});
-        if (c->profiling == 1) {
-            // an empty bracket right behind: what two event records measure with nothing in between ("event_null")
-            hipEvent_t n0 = ev_get(c), n1 = ev_get(c);
-            hipEventRecord(n0, c->stream);
-            hipEventRecord(n1, c->stream);
-            c->prof["event_null"].pending.push_back({n0, n1});
-        }
-    }
-};
-
-// device scratch that is released on every path out of a function
-struct DevScratch {
-    void* p = nullptr;
-    ~DevScratch() { if (p) hipFree(p); }
-    template <typename T> T* as() const { return static_cast<T*>(p); }
-};
-
-static int grid_for(uint64_t items, int per_block, int lo, int hi) {
-    uint64_t g = (items + per_block - 1) / per_block;
-    if (g < (uint64_t)lo) g = lo;
-    if (g > (uint64_t)hi) g = hi;
-    return (int)g;
-}
-
-static const char* deverr_text(uint32_t code, float v, char* buf, size_t n) {
-    switch (code) {
-        case HML_DEVERR_IP_NOT_FINITE: snprintf(buf, n, "Result of Normal inner product is not finite!"); break;
-        case HML_DEVERR_NEG_BACKWARD: snprintf(buf, n, "Negative backward variable!"); break;
-        case HML_DEVERR_NEG_SUMSQ: snprintf(buf, n, "Sum of squares is negative (%s)!", std::to_string(v).c_str()); break;
-        case HML_DEVERR_NIG_ALPHA: snprintf(buf, n, "Alpha (%s) must be positive!", std::to_string(v).c_str()); break;
-        case HML_DEVERR_NIG_BETA: snprintf(buf, n, "Beta (%s) must be positive!", std::to_string(v).c_str()); break;
-        case HML_DEVERR_NIG_NU: snprintf(buf, n, "Nu (%s)must be positive!", std::to_string(v).c_str()); break;
-        case HML_DEVERR_NIG_MU0: snprintf(buf, n, "Mu0 (%s)  must be finite!", std::to_string(v).c_str()); break;
-        case HML_DEVERR_MEAN_NOT_FINITE: snprintf(buf, n, "Mean (%s) must be set to a finite value!", std::to_string(v).c_str()); break;
-        case HML_DEVERR_VAR_NOT_FINITE: snprintf(buf, n, "Variance(%s) must be set to a finite value!", std::to_string(v).c_str()); break;
-        case HML_DEVERR_VAR_NOT_POSITIVE: snprintf(buf, n, "Variance (%s) must be positive!", std::to_string(v).c_str()); break;
-        case HML_DEVERR_TOO_MANY_RECORDS: snprintf(buf, n, "Too many recorded iterations for the marginal counters!"); break;
-        default: snprintf(buf, n, "device error %u", code);
-    }
-    return buf;
-}
-
-static int fetch_model(hml_ctx* c, hml_model* out) {
-    HIPCHK(hipMemcpyAsync(out, c->d_mdl, sizeof(hml_model), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
-    return 0;
-}
-#if HML_IN_CORE
 int hml_ctx_fetch_model(hml_ctx* c, hml_model* out) { return fetch_model(c, out); }
-#endif
 
-static int check_device_error(hml_ctx* c) {
-    hml_model m;
-    if (int r = fetch_model(c, &m)) return r;
-    if (m.err_code != 0) {
-        char buf[256];
-        return set_err(HML_ERR_MODEL, deverr_text(m.err_code, m.err_value, buf, sizeof buf));
-    }
-    return 0;
-}
-
-
-#if HML_IN_CORE   // ---- (core) debug probe, context life cycle, construction
 // ------------------------------------------------------------------------------------------------
 // hml_debug_eval: evaluates one of the shared host/device functions on the GPU (parity probe for
 // hml_math.h / hml_dist.h: the tests compare with the same function compiled by gcc).
@@ -644,65 +471,7 @@ int hml_set_weights(hml_ctx* c, const float* w, uint64_t T) {
 }
 
 }  // extern "C"
-#endif   // HML_IN_CORE
 
-// ---------------------------------------------------------------------------------------- blocks
-// K4: scan (the HBM-bound kernel) + scatter with in-kernel offsets
-static void launch_compact_pair(hml_ctx* c, int mode, float thr) {
-    // mode 0: model threshold; 1: explicit threshold
-    const uint32_t n_groups = (c->n_spans + HML_GROUP_SPANS - 1) / HML_GROUP_SPANS;
-    // the summary scan skips unopened groups; when most groups would be opened (weak compression) the plain
-    // float stream is the better access pattern - both give the same blocks
-    const bool dense = !c->summary_always && c->B_hint && (uint64_t)c->B_hint * 24u > c->T;
-    // ... and with B ~ T the scan stages the flags themselves (512 bytes per span) instead of 16-bit offsets (2 bytes per block)
-    const bool bits = dense && c->stage_bits;
-    {
-        ProfScope ps(c, "blocks_compact", 1);
-        if (c->use_keys && !dense) {
-            hipLaunchKernelGGL(hml_k_compact_scan_summary, dim3(n_groups), dim3(256), 0, c->stream, c->d_summary, c->d_w,
-                               (uint32_t)c->T, c->d_mdl, thr, mode, c->key_base, c->d_stage, c->d_span_count, c->d_coarse1);
-        } else if (bits) {
-            hipLaunchKernelGGL(hml_k_compact_scan_bits, dim3((c->n_spans + 3) / 4), dim3(256), 0, c->stream, c->d_w, (uint32_t)c->T,
-                               c->d_mdl, thr, mode, (unsigned long long*)c->d_stage, c->d_span_count);
-        } else {
-            hipLaunchKernelGGL(hml_k_compact_scan, dim3((c->n_spans + 3) / 4), dim3(256), 0, c->stream, c->d_w, (uint32_t)c->T,
-                               c->d_mdl, thr, mode, c->d_stage, c->d_span_count);
-        }
-    }
-    {
-        ProfScope ps(c, "blocks_scatter");
-        if (!(c->use_keys && !dense))
-            hipLaunchKernelGGL(hml_k_group_totals, dim3((n_groups + 255) / 256), dim3(256), 0, c->stream, c->d_span_count,
-                               c->n_spans, c->d_coarse1);
-        if (bits)
-            hipLaunchKernelGGL(hml_k_compact_scatter_bits, dim3(n_groups), dim3(256), 0, c->stream, (const unsigned long long*)c->d_stage,
-                               c->d_span_count, c->d_coarse1, c->n_spans, (uint32_t)c->T, c->d_mdl, c->d_starts, c->d_hB);
-        else
-        hipLaunchKernelGGL(hml_k_compact_scatter, dim3(n_groups), dim3(256), 0, c->stream, c->d_stage, c->d_span_count,
-                           c->d_coarse1, c->n_spans, (uint32_t)c->T, c->d_mdl, c->d_starts, c->d_hB);
-    }
-}
-
-static int launch_compact(hml_ctx* c, bool use_override, float thr) {
-    launch_compact_pair(c, use_override ? 1 : 0, thr);
-    KLAUNCH_CHECK();
-    {
-        ProfScope ps(c, "block_stats");
-        const uint32_t hint = c->B_hint ? c->B_hint : (uint32_t)std::min<uint64_t>(c->T, 1u << 20);
-        for (int d = 0; d < c->D; ++d)   // the same enumeration for every dimension (dimension-major planes)
-            hipLaunchKernelGGL(hml_k_block_stats, dim3(grid_for(hint, 256, 64, 16384)), dim3(256), 0, c->stream,
-                               c->d_ia + (uint64_t)d * (c->T + 1), c->d_starts, c->d_mdl, c->d_bstat + (uint64_t)d * c->T);
-    }
-    KLAUNCH_CHECK();
-    return 0;
-}
-
-static void refresh_hint(hml_ctx* c) {
-    const uint32_t b = *(volatile uint32_t*)c->h_B;
-    if (b) c->B_hint = b + b / 4 + 1024;
-}
-
-#if HML_IN_CORE   // ---- (core) explicit blocks, priors, model
 extern "C" {
 int hml_create_blocks(hml_ctx* c, float threshold) {
     if (!c || !c->loaded) return set_err(HML_ERR_ARG, "no observations loaded");
@@ -952,409 +721,9 @@ int hml_enable_probes(hml_ctx* c, int on) {
 
 // ---------------------------------------------------------------------------------------- sweeps
 }  // extern "C"
-#endif   // HML_IN_CORE
 
-static int ensure_marginal_buffers(hml_ctx* c) {
-    if (c->d_diff) return 0;
-    const uint64_t n = (uint64_t)c->K * (c->T + 1);
-    HIPCHK(hipMalloc(&c->d_diff, n * sizeof(int32_t)));
-    HIPCHK(hipMemsetAsync(c->d_diff, 0, n * sizeof(int32_t), c->stream));
-    const uint64_t words = (c->T + 1 + 31) / 32 + 1;
-    HIPCHK(hipMalloc(&c->d_boundary, words * sizeof(uint32_t)));
-    HIPCHK(hipMemsetAsync(c->d_boundary, 0, words * sizeof(uint32_t), c->stream));
-    return 0;
-}
-
-
-
-#if HML_IN_CORE
 int hml_ctx_ensure_marginal_buffers(hml_ctx* c) { return ensure_marginal_buffers(c); }
-#endif
 
-#if HML_IN_K
-// Tile size and grid of the fused block kernel: the smallest number of 2^17-position batches per workgroup with which
-// the whole grid is resident at once (the workgroups wait for lower-numbered ones inside the launch).  False when even
-// the largest tile does not fit: those traces take the scan + scatter launches.
-template <int KK>
-static bool fused_geometry(hml_ctx* c, uint32_t* n_sub, uint32_t* n_wg) {
-    if (c->fused_slots == 0) {
-        int per_cu = 0, cus = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, hml_k_blocks_fused<KK>, HML_FUSED_WAVES * 64, 0) != hipSuccess ||
-            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device) != hipSuccess || per_cu <= 0 || cus <= 0) {
-            (void)hipGetLastError();
-            c->fused_slots = -1;
-        } else {
-            c->fused_slots = per_cu * cus;
-        }
-        if (const char* e = getenv("HML_FUSED_SLOTS")) c->fused_slots = atoi(e);   // (tests: force larger tiles / an oversized grid)
-    }
-    if (c->fused_slots <= 0) return false;
-    const uint64_t batches = (c->T + HML_FUSED_SUB_POSITIONS - 1) / HML_FUSED_SUB_POSITIONS;
-    const uint64_t m = (batches + (uint64_t)c->fused_slots - 1) / (uint64_t)c->fused_slots;
-    if (m > HML_FUSED_MAX_SUB) return false;
-    *n_sub = (uint32_t)m;
-    *n_wg = (uint32_t)((c->T + m * HML_FUSED_SUB_POSITIONS - 1) / (m * HML_FUSED_SUB_POSITIONS));
-    return true;
-}
-
-#endif   // HML_IN_K
-
-// ---- chunk length of the fused trellis path (hml_ctx.hpp: tre_autotune)
-#define HML_TRE_TUNE_AFTER 48u   // sweeps before the measurement: the filter's warm-up length has settled by then
-// Candidates.  The wavefronts of the first pass (64 chunks each) all do the same work and stay resident from launch to
-// exit, so the pass takes a whole number of ROUNDS over the machine's wavefront slots: the chunk lengths worth measuring
-// are those that fill 1, 2, 3 ... rounds almost completely (longer chunks = a smaller warm-up share, but longer refits of
-// the chunks that fail verification).  hml_k_trellis_tile (HML_TRELLIS_ROWS=0) keeps round 2's list.
-static uint32_t tre_default_L_old(uint32_t hint) { return hint >= (1u << 26) ? 128u : hint >= (1u << 24) ? 64u : (uint32_t)HML_TRE_MIN_L; }
-static int tre_candidates(const hml_ctx* c, uint32_t hint, uint32_t* out) {
-    int n = 0;
-    if (!c->tre_rows || c->tre_slots <= 0) {
-        const uint32_t L0 = tre_default_L_old(hint);
-        for (uint32_t q = 4; q <= 8; ++q) {   // L0 * {1, 1.25, 1.5, 1.75, 2}, multiples of 32
-            const uint32_t l = L0 * q / 4u;
-            if (l % 32u == 0u && l <= 256u) out[n++] = l;
-        }
-        return n;
-    }
-    // (the hint is the last sweep's block count with a quarter of headroom - what the grids are sized for; the rounds are
-    // counted over the blocks themselves)
-    const uint32_t blocks = hint > 1024u ? (uint32_t)(((uint64_t)hint - 1024u) * 4u / 5u) : hint;
-    for (uint32_t rounds = 1; rounds <= 8u && n < 6; ++rounds) {
-        const double waves = 0.985 * (double)c->tre_slots * rounds;              // (a little air: one wavefront too many costs a round)
-        uint32_t l = (uint32_t)((double)blocks / (64.0 * waves)) + 1u;
-        l = (l + 31u) / 32u * 32u;
-        if (l < (uint32_t)HML_TRE_MIN_L) l = HML_TRE_MIN_L;
-        // (without checkpoints a refit walks its whole chunk: beyond 512 rows that costs more than the warm-up saves)
-        if (l > (c->tre_ckpt ? (uint32_t)HML_TRE_MAX_L : 512u)) continue;
-        bool seen = false;
-        for (int i = 0; i < n; ++i) seen = seen || out[i] == l;
-        if (!seen) out[n++] = l;
-        if (l == (uint32_t)HML_TRE_MIN_L) break;
-    }
-    if (n == 0) out[n++] = 512u;
-    return n;
-}
-static uint32_t tre_default_L(const hml_ctx* c, uint32_t hint) {   // until the measurement: two rounds where there are blocks for them
-    if (!c->tre_rows || c->tre_slots <= 0) return tre_default_L_old(hint);
-    uint32_t cand[8];
-    const int n = tre_candidates(c, hint, cand);
-    return cand[n > 1 ? 1 : 0];
-}
-static bool tre_tuned_for(const hml_ctx* c, uint32_t hint) {
-    return c->tre_tuned_L && hint <= c->tre_tuned_hint + c->tre_tuned_hint / 8u && hint + hint / 8u >= c->tre_tuned_hint;
-}
-// does the next fused-trellis sweep measure a candidate?  (it then runs outside any graph and waits for its own events)
-static bool tre_wants_measurement(const hml_ctx* c, uint32_t hint) {
-    return !c->tre_L && c->tre_autotune && !tre_tuned_for(c, hint) && c->tre_dense_sweeps >= HML_TRE_TUNE_AFTER;
-}
-// the chunk length of the next sweep; *measure: bracket the trellis kernels with events and report (tre_tune_report)
-static uint32_t tre_pick_L(hml_ctx* c, uint32_t hint, bool capturing, bool* measure) {
-    *measure = false;
-    if (c->tre_L) return c->tre_L;
-    if (tre_tuned_for(c, hint)) return c->tre_tuned_L;
-    if (capturing || !tre_wants_measurement(c, hint)) return c->tre_tuned_L ? c->tre_tuned_L : tre_default_L(c, hint);
-    uint32_t cand[8];
-    const int n = tre_candidates(c, hint, cand);
-    if (n < 2) { c->tre_tuned_L = cand[0]; c->tre_tuned_hint = hint; return cand[0]; }
-    if (c->tre_tune_step < 0) { c->tre_tune_step = 0; for (float& v : c->tre_tune_ms) v = 3.4e38f; }
-    *measure = true;
-    return cand[c->tre_tune_step % n];
-}
-static void tre_tune_report(hml_ctx* c, uint32_t hint, float ms) {
-    uint32_t cand[8];
-    const int n = tre_candidates(c, hint, cand);
-    const int i = c->tre_tune_step % n;
-    c->tre_tune_ms[i] = std::min(c->tre_tune_ms[i], ms);
-    if (++c->tre_tune_step < 2 * n) return;
-    int best = 0;
-    for (int k = 1; k < n; ++k) if (c->tre_tune_ms[k] < c->tre_tune_ms[best]) best = k;
-    c->tre_tuned_L = cand[best];
-    c->tre_tuned_hint = hint;
-    c->tre_tune_step = -1;
-    if (getenv("HML_TRELLIS_TUNE_DEBUG")) {
-        fprintf(stderr, "[trellis tune] %u blocks:", hint);
-        for (int k = 0; k < n; ++k) fprintf(stderr, " L=%u %.3f ms", cand[k], c->tre_tune_ms[k]);
-        fprintf(stderr, " -> L=%u\n", cand[best]);
-    }
-}
-
-#if HML_IN_K
-// A sweep of the reference-compatible mode (hml_k_compat.h): block starts and block statistics by the default path's
-// kernels, everything order-dependent by one lane in the reference's order, the marginals by hml_k_record.
-template <int KK>
-static int sweep_compat(hml_ctx* c, char method, bool record) {
-    hipStream_t s = c->stream;
-    if (c->dynamic || !c->blocks_valid) {
-        if (int r = launch_compact(c, false, 0.0f)) return r;   // starts, block count, block statistics at the model's threshold
-        if (!c->dynamic) c->blocks_valid = true;
-    }
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_compat_sweep<KK>), dim3(1), dim3(64), 0, s, c->d_mdl, (hml_mt_state*)c->d_mt, c->d_starts, c->d_bstat,
-                       c->d_crows, c->d_q, method == HML_METHOD_MIXTURE ? 1 : 0, c->probes ? c->d_eprobe : nullptr, c->probes ? c->d_aprobe : nullptr);
-    if (record && c->rec_marginals) {
-        if (c->pooled) return set_err(HML_ERR_ARG, "the marginals of this context are pooled (common labels, several chains): further sweeps cannot be recorded into them");
-        if (int r = ensure_marginal_buffers(c)) return r;
-        refresh_hint(c);
-        const uint32_t hint = c->B_hint ? c->B_hint : (uint32_t)std::min<uint64_t>(c->T, 1u << 20);
-        hipLaunchKernelGGL(hml_k_record, dim3(grid_for(hint, 256, 64, 16384)), dim3(256), 0, s, c->d_q, c->d_starts, c->d_mdl, c->d_diff, c->d_boundary);
-    }
-    KLAUNCH_CHECK();
-    return 0;
-}
-
-template <int KK>
-static int sweep_k(hml_ctx* c, char method, bool record) {
-    if (c->compat) return sweep_compat<KK>(c, method, record);
-    hipStream_t s = c->stream;
-    const bool mix = (method == HML_METHOD_MIXTURE);
-    const uint32_t T = (uint32_t)c->T;
-    bool emitted = false, fused = false;
-    // The block count of the sweep sizes the grids and picks the forward geometry, and the host only knows the count of
-    // an earlier sweep (it enqueues far ahead of the device).  Right after the parameters were replaced that count
-    // means nothing - the first sweeps of a weakly compressed chain then ran in the geometry of a strongly compressed
-    // one (177 ms instead of 19 ms each on C5, for as many sweeps as were enqueued at once) - so the block structure is
-    // enumerated once ahead of the sweep and waited for.
-    if (c->hint_stale && (c->dynamic || !c->blocks_valid)) {
-        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-        if (hipStreamIsCapturing(s, &cap) == hipSuccess && cap == hipStreamCaptureStatusNone) {
-            launch_compact_pair(c, 0, 0.0f);
-            KLAUNCH_CHECK();
-            HIPCHK(hipStreamSynchronize(s));
-        }
-    }
-    c->hint_stale = false;
-    // forward geometry of this sweep, fixed before its first launch
-    refresh_hint(c);
-    const bool dense_geo = c->B_hint >= c->dense_min_blocks;
-    // weakly compressed univariate FB sweeps: emission terms, filter and candidate maps fused per tile (hml_k_trellis.h)
-    const bool trellis = dense_geo && !mix && c->D == 1 && c->tre_fused;
-    const int L = dense_geo ? c->fwdL_dense : c->fwdL;
-    const hml_layout lay = dense_geo ? c->lay_dense : c->lay;
-    // strongly compressed univariate sweeps keep no plane of rescale factors: the forward rows stay unscaled and the
-    // backward maps apply the factor where they read a row (hml_bwd_row_load) - 3.5 of the block kernel's 11 MB of
-    // stores at 10^8 positions, and what a dependent launch waits for is the write-back of its predecessor's stores
-    float* const gsc_plane = (!dense_geo && c->late_rescale) ? nullptr : c->d_gsc;
-    const uint32_t* const starts_for_maps = gsc_plane ? nullptr : c->d_starts;
-    if (c->dynamic || !c->blocks_valid) {
-        // the fused block kernel: univariate chains that have the GPU to themselves, unless compression is weak (the
-        // float stream is the better access pattern then), the kernel reported a bounded wait that expired (someone
-        // else is using the GPU: h_B[1]), or the trace is too long for a resident grid (hml_fused_geometry)
-        uint32_t n_sub = 0u, n_wg = 0u;
-        if (c->h_B[1] && !c->fused_keep) c->fused_blocks = false;
-        if (c->D == 1 && c->use_keys && c->fused_blocks && !shares_device(c) &&
-            !(!c->summary_always && c->B_hint && (uint64_t)c->B_hint * 24u > c->T) && fused_geometry<KK>(c, &n_sub, &n_wg)) {
-            // K4 + K5 + K6a in one launch (hml_k_blocks_fused.h)
-            ProfScope ps(c, "blocks_compact", 1);
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_blocks_fused<KK>), dim3(n_wg), dim3(HML_FUSED_WAVES * 64), 0, s, c->d_summary, c->d_w, c->d_ia,
-                               T, c->d_mdl, c->key_base, c->d_group_word, c->d_stage, c->d_starts, c->d_bstat, c->d_em,
-                               gsc_plane, c->probes ? c->d_eprobe : nullptr, mix ? 1 : 0, lay, c->d_hB, n_sub, c->fused_spin_limit, c->d_dbg, c->d_mdl);
-            fused = true;
-        } else {
-            launch_compact_pair(c, 0, 0.0f);
-        }
-        if (!fused && !trellis) {
-            refresh_hint(c);
-            const uint32_t h0 = c->B_hint ? c->B_hint : (uint32_t)std::min<uint64_t>(c->T, 1u << 20);
-            ProfScope ps(c, "stats_emission");
-            if (c->D > 1)
-                hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_emission_mv<KK, true>), dim3(grid_for(h0, 256, 64, 16384)), dim3(256), 0, s,
-                                   c->d_ia, c->d_starts, c->d_mdl, c->d_bstat, c->d_em, gsc_plane, c->probes ? c->d_eprobe : nullptr,
-                                   mix ? 1 : 0, lay);
-            else if (dense_geo && L <= hml_emit_tile<KK>::MAXL)
-                hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_emission_tiled<KK, true>), dim3(grid_for(h0, hml_emit_tile<KK>::BLOCKS, 64, 65536)),
-                                   dim3(256), 0, s, c->d_ia, c->d_starts, c->d_mdl, c->d_bstat, c->d_em, gsc_plane,
-                                   c->probes ? c->d_eprobe : nullptr, mix ? 1 : 0, lay);
-            else
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_stats_emission<KK>), dim3(grid_for(h0, 256, 64, 16384)), dim3(256), 0, s,
-                               c->d_ia, c->d_starts, c->d_mdl, c->d_bstat, c->d_em, gsc_plane, c->probes ? c->d_eprobe : nullptr,
-                               mix ? 1 : 0, lay);
-        }
-        KLAUNCH_CHECK();
-        emitted = true;
-        if (!c->dynamic) c->blocks_valid = true;
-    }
-    refresh_hint(c);
-    const uint32_t hint = c->B_hint ? c->B_hint : (uint32_t)std::min<uint64_t>(c->T, 1u << 20);
-    const int gB = grid_for(hint, 256, 64, 16384);
-    if (!emitted && !trellis) {
-        ProfScope ps(c, "emission");
-        if (c->D > 1)
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_emission_mv<KK, false>), dim3(gB), dim3(256), 0, s, c->d_ia, c->d_starts, c->d_mdl,
-                               c->d_bstat, c->d_em, gsc_plane, c->probes ? c->d_eprobe : nullptr, mix ? 1 : 0, lay);
-        else if (dense_geo && L <= hml_emit_tile<KK>::MAXL)
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_emission_tiled<KK, false>), dim3(grid_for(hint, hml_emit_tile<KK>::BLOCKS, 64, 65536)),
-                               dim3(256), 0, s, c->d_ia, c->d_starts, c->d_mdl, c->d_bstat, c->d_em, gsc_plane,
-                               c->probes ? c->d_eprobe : nullptr, mix ? 1 : 0, lay);
-        else
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_emission<KK>), dim3(gB), dim3(256), 0, s, c->d_bstat, c->d_starts, c->d_mdl,
-                           c->d_em, gsc_plane, c->probes ? c->d_eprobe : nullptr, mix ? 1 : 0, lay);
-    }
-    if (trellis) {
-        // chunk length by the number of blocks: the warm-up (emission terms included) is paid once per chunk, and a
-        // wavefront takes 64 chunks - long chunks where there are enough blocks to fill the machine with wavefronts anyway
-        hipStreamCaptureStatus capst = hipStreamCaptureStatusNone;
-        (void)hipStreamIsCapturing(s, &capst);
-        bool measure = false;
-        if (c->tre_rows && c->tre_slots == 0) {   // wavefront slots of the first pass on this device (asked once)
-            int per_cu = 0, cus = 0;
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, hml_k_trellis_rows<KK, false>, 64 * HML_TR2_WAVES, 0) == hipSuccess &&
-                hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device) == hipSuccess && per_cu > 0 && cus > 0)
-                c->tre_slots = per_cu * cus * HML_TR2_WAVES;
-            else { (void)hipGetLastError(); c->tre_slots = -1; }
-            if (const char* e = getenv("HML_TRELLIS_SLOTS")) c->tre_slots = atoi(e);
-        }
-        const uint32_t TL = tre_pick_L(c, hint, capst != hipStreamCaptureStatusNone, &measure);
-        hipEvent_t tev0 = nullptr, tev1 = nullptr;
-        if (measure) { tev0 = ev_get(c); tev1 = ev_get(c); hipEventRecord(tev0, s); }
-        if (c->graph_tre_L != TL && getenv("HML_TRELLIS_TUNE_DEBUG")) fprintf(stderr, "[trellis] chunk length %u for %u blocks (%d wavefront slots)\n", TL, hint, c->tre_slots);
-        c->graph_tre_L = TL;
-        const uint64_t tchunks = ((uint64_t)hint + TL - 1) / TL;
-        const uint64_t tgroups = (tchunks + HML_TRE_NCH - 1) / HML_TRE_NCH;
-        float* ep = c->probes ? c->d_eprobe : nullptr;
-        float* ap = c->probes ? c->d_aprobe : nullptr;
-        {
-            ProfScope ps(c, "trellis", 1);
-            // (nearly every block a single position: the filter step shares the candidate maps' sums, hml_k_trellis_rows.h)
-            if (c->tre_rows && hint > 1024u && ((uint64_t)hint - 1024u) * 8u >= c->T * 9u)   // (last sweep's blocks >= 0.9 T; the hint carries 25 % headroom)
-                hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_trellis_rows<KK, true>), dim3(grid_for(tgroups, HML_TR2_WAVES, 4, 1 << 20)), dim3(64 * HML_TR2_WAVES), 0, s,
-                                   c->d_ia, c->d_starts, c->d_mdl, c->d_mdl, c->d_bstat, c->d_smap, c->d_cmap, c->d_entry, c->d_exitA, c->d_fb, ep, ap, c->d_tre_ckpt, TL);
-            else if (c->tre_rows)
-                hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_trellis_rows<KK, false>), dim3(grid_for(tgroups, HML_TR2_WAVES, 4, 1 << 20)), dim3(64 * HML_TR2_WAVES), 0, s,
-                                   c->d_ia, c->d_starts, c->d_mdl, c->d_mdl, c->d_bstat, c->d_smap, c->d_cmap, c->d_entry, c->d_exitA, c->d_fb, ep, ap, c->d_tre_ckpt, TL);
-            else
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_trellis_tile<KK>), dim3(grid_for(tgroups, 1, 16, 1 << 20)), dim3(64), 0, s,
-                               c->d_ia, c->d_starts, c->d_mdl, c->d_mdl, c->d_bstat, c->d_smap, c->d_cmap, c->d_entry, c->d_exitA, c->d_fb, ep, ap, TL);
-        }
-#if HML_TR2_SKIP
-        if (!getenv("HML_DEV_KEEP_REPAIR")) { /* development builds with row stages disabled: the rows are wrong anyway, and repairing them would take for ever */ } else
-#endif
-        {
-            // verification, four rounds of parallel refits from the predecessors' end vectors (the lists of stale chunks
-            // alternate between d_redo and d_redo2), then the sequential finisher: each exits at once when its list is empty
-            ProfScope ps(c, "trellis_repair");
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_trellis_verify<KK>), dim3(grid_for(tchunks, 256, 16, 1 << 14)), dim3(256), 0, s, c->d_mdl,
-                               c->d_entry, c->d_exitA, c->d_redo, TL);
-            int in_a = 1;
-            for (uint32_t round = 0; round < 4u; ++round, in_a ^= 1) {
-                uint32_t* lin = in_a ? c->d_redo : c->d_redo2;
-                uint32_t* lout = in_a ? c->d_redo2 : c->d_redo;
-                hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_trellis_refit<KK>), dim3(4096), dim3(64), 0, s, c->d_ia, c->d_starts, c->d_mdl, c->d_smap,
-                                   c->d_cmap, c->d_entry, c->d_exitA, c->d_fb, ep, ap, lin, in_a, (c->tre_rows && c->tre_ckpt) ? c->d_tre_ckpt : nullptr, TL);
-                hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_trellis_verify_list<KK>), dim3(64), dim3(256), 0, s, c->d_mdl, c->d_entry, c->d_exitA,
-                                   lin, lout, c->d_touched, in_a, round, TL);
-            }
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_trellis_serial<KK>), dim3(1), dim3(256), 0, s, c->d_ia, c->d_starts, c->d_mdl, c->d_smap,
-                               c->d_cmap, c->d_entry, c->d_exitA, c->d_fb, ep, ap, in_a ? c->d_redo : c->d_redo2, in_a, c->d_tre_bitmap, TL);
-        }
-        {
-            ProfScope ps(c, "backward_chain");
-            const uint64_t supers = (tchunks + 63) / 64;
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_trellis_super<KK>), dim3(grid_for(supers * 64, 256, 16, 1 << 16)), dim3(256), 0, s, c->d_cmap,
-                               c->d_mdl, c->d_scmap, c->d_super, TL);
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_trellis_chain<KK>), dim3(1), dim3(1024), 0, s, c->d_super, c->d_mdl, c->d_bentry2, TL);
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_trellis_states<KK>), dim3(grid_for(tgroups, 1, 16, 1 << 20)), dim3(64), 0, s, c->d_smap,
-                               c->d_scmap, c->d_bentry2, c->d_mdl, c->d_q, TL);
-        }
-        if (measure) {
-            // a measuring sweep (a few per chain): wait for the trellis kernels and note what this chunk length cost
-            hipEventRecord(tev1, s);
-            float ms = 0.0f;
-            const bool ok = hipEventSynchronize(tev1) == hipSuccess && hipEventElapsedTime(&ms, tev0, tev1) == hipSuccess;
-            c->ev_pool.push_back(tev0);
-            c->ev_pool.push_back(tev1);
-            if (ok) tre_tune_report(c, hint, ms); else { (void)hipGetLastError(); c->tre_autotune = false; }
-        }
-        c->tre_dense_sweeps++;
-        {
-            ProfScope ps(c, "counts");
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_counts_dense<KK, false>), dim3(HML_REDUCE_GROUPS), dim3(256), 0, s, c->d_q,
-                               c->d_starts, c->d_bstat, c->d_mdl, c->d_partial, (const unsigned long long*)nullptr, (const uint8_t*)nullptr);
-        }
-    } else if (!mix) {
-        const uint64_t chunks = ((uint64_t)hint + L - 1) / L;
-        const int gF = grid_for(chunks, 256, 16, 1 << 20);
-        {
-            ProfScope ps(c, "forward");
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_forward<KK>), dim3(gF), dim3(256), 0, s, c->d_em, gsc_plane, c->d_mdl, c->d_rows,
-                               c->probes ? c->d_aprobe : nullptr, c->d_entry, c->d_exitA, c->d_fb, L, lay);
-        }
-        {
-            // backward maps (verifies the forward chunks on the way), then one workgroup: repair if a check failed,
-            // and the chain over the chunk maps
-            const uint64_t bch = ((uint64_t)hint + HML_BWD_CHUNK - 1) / HML_BWD_CHUNK;
-            {
-                ProfScope ps(c, "backward_maps");
-                hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_backward_maps<KK>), dim3(grid_for(bch * 64, 256, 16, 1 << 18)), dim3(256), 0,
-                                   s, c->d_rows, c->d_mdl, c->d_smap, c->d_cmap, lay, c->d_entry, c->d_exitA, c->d_redo, L, starts_for_maps, c->d_mdl);
-            }
-            ProfScope ps(c, "backward_chain");
-            if (!dense_geo) {
-                hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_backward_chain<KK>), dim3(1), dim3(1024), 0, s, c->d_cmap, c->d_mdl,
-                                   c->d_bentry, c->d_em, gsc_plane, c->d_rows, c->probes ? c->d_aprobe : nullptr, c->d_entry,
-                                   c->d_exitA, c->d_fb, c->d_redo, c->d_touched, c->d_smap, L, lay, 3, 0, starts_for_maps);
-            } else {
-                // millions of backward chunks: repair step alone, then the two-level chain
-                hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_backward_chain<KK>), dim3(1), dim3(1024), 0, s, c->d_cmap, c->d_mdl,
-                                   c->d_bentry, c->d_em, gsc_plane, c->d_rows, c->probes ? c->d_aprobe : nullptr, c->d_entry,
-                                   c->d_exitA, c->d_fb, c->d_redo, c->d_touched, c->d_smap, L, lay, 1, 0, starts_for_maps);
-                hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_backward_super<KK>), dim3(grid_for(bch, 256, 16, 1 << 16)), dim3(256), 0, s,
-                                   c->d_cmap, c->d_mdl, c->d_scmap, c->d_super);
-                hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_backward_chain<KK>), dim3(1), dim3(1024), 0, s, c->d_super, c->d_mdl,
-                                   c->d_bentry2, c->d_em, gsc_plane, c->d_rows, c->probes ? c->d_aprobe : nullptr, c->d_entry,
-                                   c->d_exitA, c->d_fb, c->d_redo, c->d_touched, c->d_smap, L, lay, 2, 1, starts_for_maps);
-                hipLaunchKernelGGL(hml_k_backward_entries, dim3(grid_for(bch, 256, 16, 1 << 16)), dim3(256), 0, s, c->d_scmap,
-                                   c->d_bentry2, c->d_mdl, c->d_bentry);
-            }
-        }
-        {
-            ProfScope ps(c, "counts");
-            if (c->D > 1)
-                hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_counts<KK, true, true>), dim3(HML_REDUCE_GROUPS), dim3(256), 0, s, c->d_q,
-                                   c->d_starts, c->d_bstat, c->d_mdl, c->d_partial, c->d_smap, c->d_bentry);
-            else if (dense_geo)   // hundreds of chunks per workgroup: one wavefront per chunk (same tree, bit for bit)
-                hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_counts_dense<KK, true>), dim3(HML_REDUCE_GROUPS), dim3(256), 0, s, c->d_q,
-                                   c->d_starts, c->d_bstat, c->d_mdl, c->d_partial, c->d_smap, c->d_bentry);
-            else
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_counts<KK, true>), dim3(HML_REDUCE_GROUPS), dim3(256), 0, s, c->d_q,
-                               c->d_starts, c->d_bstat, c->d_mdl, c->d_partial, c->d_smap, c->d_bentry);
-        }
-    } else {
-        {
-            ProfScope ps(c, "mixture");
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_mixture<KK>), dim3(gB), dim3(256), 0, s, c->d_em, c->d_mdl, c->d_q, lay);
-        }
-        {
-            ProfScope ps(c, "counts");
-            if (c->D > 1)
-                hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_counts<KK, false, true>), dim3(HML_REDUCE_GROUPS), dim3(256), 0, s, c->d_q,
-                                   c->d_starts, c->d_bstat, c->d_mdl, c->d_partial, (const unsigned long long*)nullptr,
-                                   (const uint8_t*)nullptr);
-            else if (dense_geo)
-                hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_counts_dense<KK, false>), dim3(HML_REDUCE_GROUPS), dim3(256), 0, s, c->d_q,
-                                   c->d_starts, c->d_bstat, c->d_mdl, c->d_partial, (const unsigned long long*)nullptr,
-                                   (const uint8_t*)nullptr);
-            else
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_counts<KK, false>), dim3(HML_REDUCE_GROUPS), dim3(256), 0, s, c->d_q,
-                               c->d_starts, c->d_bstat, c->d_mdl, c->d_partial, (const unsigned long long*)nullptr,
-                               (const uint8_t*)nullptr);
-        }
-    }
-    if (record && c->rec_marginals) {
-        if (c->pooled) return set_err(HML_ERR_ARG, "the marginals of this context are pooled (common labels, several chains): further sweeps cannot be recorded into them");
-        if (int r = ensure_marginal_buffers(c)) return r;
-        ProfScope ps(c, "marginals");
-        hipLaunchKernelGGL(hml_k_record, dim3(gB), dim3(256), 0, s, c->d_q, c->d_starts, c->d_mdl, c->d_diff, c->d_boundary);
-    }
-    {
-        ProfScope ps(c, "params");
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_params<KK>), dim3(1), dim3(1024), 0, s, c->d_mdl, c->d_partial, 0);
-    }
-    KLAUNCH_CHECK();
-    return 0;
-}
-
-#endif   // HML_IN_K
-
-#if HML_IN_CORE
 static int sweep_dispatch(hml_ctx* c, char method, bool record) {
     HML_KTAB(c->K, kt);
     return kt->sweep(c, method, record);
@@ -1421,144 +790,7 @@ int hml_iterate(hml_ctx* c, char method, uint64_t iterations, uint64_t thinning)
 }
 
 }  // extern "C"
-#endif   // HML_IN_CORE
 
-// ---- several chains of one device in one set of launches (hml_k_many.h) ----
-static bool many_eligible(hml_ctx* const* cs, int n, char method) {
-    if (n < 2 || n > 64 || method != HML_METHOD_FB) return false;
-    const hml_ctx* a = cs[0];
-    for (int i = 0; i < n; ++i) {
-        const hml_ctx* c = cs[i];
-        if (!c->model_set || c->device != a->device || c->K != a->K || c->T != a->T || c->D != 1 || c->compat || !c->dynamic || !c->use_keys ||
-            c->probes || c->profiling || c->fwdL != a->fwdL || c->fwdL_many != a->fwdL_many || c->late_rescale != a->late_rescale || c->n_spans != a->n_spans)
-            return false;
-        for (int j = 0; j < i; ++j) if (cs[j] == c) return false;
-    }
-    return true;
-}
-// weakly compressed sweeps (either criterion of sweep_k / launch_compact_pair) keep their own kernels: not batched
-static bool many_sparse(hml_ctx* c) {
-    refresh_hint(c);
-    return !(c->B_hint >= c->dense_min_blocks) && !(!c->summary_always && c->B_hint && (uint64_t)c->B_hint * 24u > c->T);
-}
-
-#if HML_IN_K
-template <int KK>
-static int iterate_many_k(hml_ctx* const* cs, int n, uint64_t first, uint64_t iterations, uint64_t thinning, uint64_t* done) {
-    hml_ctx* c0 = cs[0];
-    hipStream_t s = c0->stream;
-    const uint32_t T = (uint32_t)c0->T;
-    const int L = c0->fwdL_many;
-    const hml_layout lay = c0->lay_many;
-    const int with_gsc = c0->late_rescale ? 0 : 1;
-    const uint32_t n_groups = (c0->n_spans + HML_GROUP_SPANS - 1) / HML_GROUP_SPANS;
-    const bool records = thinning > 0 && thinning <= iterations;
-    unsigned long long rec_mask = 0ull;
-    for (int i = 0; i < n; ++i) {
-        if (records && cs[i]->rec_marginals) {
-            if (cs[i]->pooled) return set_err(HML_ERR_ARG, "the marginals of a context are pooled (common labels, several chains): further sweeps cannot be recorded into them");
-            if (int r = ensure_marginal_buffers(cs[i])) return r;
-            rec_mask |= 1ull << i;
-        }
-    }
-    // the chains' pointers, in device memory of chain 0 (kept for the next call)
-    std::vector<hml_chain_dev> h(n);
-    for (int i = 0; i < n; ++i) {
-        hml_ctx* c = cs[i];
-        hml_chain_dev& d = h[i];
-        d.summary = c->d_summary; d.w = c->d_w; d.ia = c->d_ia; d.key_base = c->key_base; d.n_spans = c->n_spans;
-        d.stage = c->d_stage; d.span_count = c->d_span_count; d.coarse1 = c->d_coarse1; d.starts = c->d_starts; d.host_B = c->d_hB;
-        d.bstat = c->d_bstat; d.mdl = c->d_mdl; d.em = c->d_em; d.gsc = c->d_gsc; d.rows = c->d_rows; d.entry = c->d_entry; d.exitv = c->d_exitA;
-        d.fb = c->d_fb; d.redo = c->d_redo; d.touched = c->d_touched; d.smap = c->d_smap; d.cmap = c->d_cmap; d.bentry = c->d_bentry;
-        d.q = c->d_q; d.partial = c->d_partial; d.diff = c->d_diff; d.boundary = c->d_boundary;
-    }
-    if (c0->many_cap < n) {
-        if (c0->d_many) HIPCHK(hipFree(c0->d_many));
-        c0->d_many = nullptr; c0->many_cap = 0;
-        HIPCHK(hipMalloc(&c0->d_many, n * sizeof(hml_chain_dev)));
-        c0->many_cap = n;
-    }
-    HIPCHK(hipMemcpyAsync(c0->d_many, h.data(), n * sizeof(hml_chain_dev), hipMemcpyHostToDevice, s));
-    HIPCHK(hipStreamSynchronize(s));   // (the staging vector goes out of scope below)
-    const hml_chain_dev* d_cs = (const hml_chain_dev*)c0->d_many;
-    // Chains attached to ONE trace (hml_attach_observations) take the many-chain block kernel: block starts, statistics and
-    // emission terms of every chain from one pass over the shared summary / weights / integral array (hml_k_blocks_fused_many.h).
-    // Its workgroups wait for lower-numbered ones inside the launch, so the whole grid must be resident - the tile grows
-    // with the trace like the single-chain kernel's (fused_geometry).
-    bool fm = c0->trace != nullptr && c0->fused_blocks;
-    for (int k = 0; k < n; ++k) fm = fm && cs[k]->trace == c0->trace && cs[k]->fused_blocks && cs[k]->key_base == c0->key_base;
-    uint32_t fm_sub = 0u, fm_wg = 0u;
-    if (fm) {
-        if (c0->fm_slots == 0) {
-            int per_cu = 0, cus = 0;
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, hml_m_blocks_fused<KK>, HML_FUSED_WAVES * 64, 0) != hipSuccess ||
-                hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c0->device) != hipSuccess || per_cu <= 0 || cus <= 0) {
-                (void)hipGetLastError();
-                c0->fm_slots = -1;
-            } else c0->fm_slots = per_cu * cus;
-            if (const char* e = getenv("HML_FUSED_MANY_SLOTS")) c0->fm_slots = atoi(e);   // (tests: force larger tiles)
-        }
-        const uint64_t batches = (c0->T + HML_FUSED_SUB_POSITIONS - 1) / HML_FUSED_SUB_POSITIONS;
-        const uint64_t m = c0->fm_slots > 0 ? (batches + (uint64_t)c0->fm_slots - 1) / (uint64_t)c0->fm_slots : HML_FUSED_MAX_SUB + 1;
-        if (m > HML_FUSED_MAX_SUB) fm = false;
-        else { fm_sub = (uint32_t)m; fm_wg = (uint32_t)((c0->T + m * HML_FUSED_SUB_POSITIONS - 1) / (m * HML_FUSED_SUB_POSITIONS)); }
-    }
-    for (uint64_t i = first; i < iterations; ++i) {
-        for (int k = 0; k < n; ++k) if (!many_sparse(cs[k])) { *done = i; return 0; }   // a chain left the strongly compressed regime: the caller goes on one by one
-        const bool record = thinning > 0 && ((i + 1) % thinning == 0);
-        uint32_t hint = 0;
-        for (int k = 0; k < n; ++k) hint = std::max(hint, cs[k]->B_hint ? cs[k]->B_hint : (uint32_t)std::min<uint64_t>(T, 1u << 20));
-        const unsigned ny = (unsigned)n;
-        const unsigned gB = (unsigned)grid_for(hint, 256, 64, 16384);
-        // (a bounded wait of the block kernel expired - somebody else is using the GPU: the scan + scatter launches from here on)
-        if (fm) for (int k = 0; k < n; ++k) if (cs[k]->h_B[1] && !cs[k]->fused_keep) fm = false;
-        if (fm) {
-            for (int k0 = 0; k0 < n; k0 += HML_FM_MAX_CHAINS) {
-                const int nk = std::min(n - k0, (int)HML_FM_MAX_CHAINS);
-                hml_fm_args fa;
-                memset(&fa, 0, sizeof fa);
-                for (int k = 0; k < nk; ++k) {
-                    hml_ctx* c = cs[k0 + k];
-                    hml_fm_chain& f = fa.c[k];
-                    f.mdl = c->d_mdl; f.group_word = c->d_group_word; f.stage = c->d_stage; f.starts = c->d_starts; f.bstat = c->d_bstat;
-                    f.em = c->d_em; f.gsc = with_gsc ? c->d_gsc : nullptr; f.host_words = c->d_hB;
-                }
-                hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_m_blocks_fused<KK>), dim3(fm_wg), dim3(HML_FUSED_WAVES * 64), 0, s, c0->d_summary, c0->d_w, c0->d_ia,
-                                   T, c0->key_base, fa, nk, lay, fm_sub, c0->fused_spin_limit, c0->d_dbg);
-            }
-        } else {
-            hipLaunchKernelGGL(hml_m_compact_scan_summary, dim3(n_groups, ny), dim3(256), 0, s, d_cs, T);
-            hipLaunchKernelGGL(hml_m_compact_scatter, dim3(n_groups, ny), dim3(256), 0, s, d_cs, T);
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_m_stats_emission<KK>), dim3(gB, ny), dim3(256), 0, s, d_cs, with_gsc, lay);
-        }
-        const uint64_t chunks = ((uint64_t)hint + L - 1) / L;
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_m_forward<KK>), dim3((unsigned)grid_for(chunks, 256, 16, 1 << 20), ny), dim3(256), 0, s, d_cs, with_gsc, L, lay);
-        const uint64_t bch = ((uint64_t)hint + HML_BWD_CHUNK - 1) / HML_BWD_CHUNK;
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_m_backward_maps<KK>), dim3((unsigned)grid_for((bch + 1) / 2 * 64, 256, 16, 1 << 18), ny), dim3(256), 0, s, d_cs, with_gsc, L, lay);   // (a wavefront per two chunks)
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_m_backward_chain<KK>), dim3(1, ny), dim3(1024), 0, s, d_cs, with_gsc, L, lay);
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_m_counts<KK>), dim3(HML_REDUCE_GROUPS, ny), dim3(256), 0, s, d_cs);
-        if (record && rec_mask) hipLaunchKernelGGL(hml_m_record, dim3(gB, ny), dim3(256), 0, s, d_cs, rec_mask);
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_m_params<KK>), dim3(1, ny), dim3(1024), 0, s, d_cs);
-        KLAUNCH_CHECK();
-        if (record) {
-            bool any_cb = false;
-            for (int k = 0; k < n; ++k) any_cb = any_cb || cs[k]->cb;
-            if (any_cb) {
-                HIPCHK(hipStreamSynchronize(s));
-                for (int k = 0; k < n; ++k) {
-                    if (int r = check_device_error(cs[k])) return r;
-                    if (cs[k]->cb) cs[k]->cb(cs[k], i, cs[k]->cb_user);
-                }
-            }
-        }
-    }
-    *done = iterations;
-    return 0;
-}
-
-#endif   // HML_IN_K
-
-#if HML_IN_CORE   // ---- (core) the rest of the C ABI
 extern "C" int hml_iterate_many(hml_ctx* const* cs, int n, char method, uint64_t iterations, uint64_t thinning) {
     if (!cs || n < 1) return set_err(HML_ERR_ARG, "no contexts");
     for (int i = 0; i < n; ++i) if (!cs[i] || !cs[i]->model_set) return set_err(HML_ERR_ARG, "model not set");
@@ -2061,40 +1293,7 @@ int hml_synth_depth(float* x, int16_t* states, uint64_t T, double depth, double 
 
 }  // extern "C"
 
-#endif   // HML_IN_CORE
 
-// ------------------------------------------------------------------------------------------------
-// The K-dependent part behind its table (one per object: -DHML_TU_K=k; a development build: -DHML_ONLY_K=k; else all).
-#if HML_IN_K
-// (the tables are not `const`: the device pass of the compiler takes a constant with constant initialisers for a device
-// constant as well and then looks for the host functions it points to; a plain host variable is only parsed there - which is
-// what instantiates the kernels that sweep_k<K> launches)
-#define HML_DEFINE_KTAB(KK)                                                                                                        \
-    static void hml_kt_params_##KK(hml_ctx* c, int mode) {                                                                         \
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_params<KK>), dim3(1), dim3(1024), 0, c->stream, c->d_mdl, c->d_partial, mode);    \
-    }                                                                                                                              \
-    static void hml_kt_compat_draw_##KK(hml_ctx* c, int mode) {                                                                    \
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_compat_draw<KK>), dim3(1), dim3(64), 0, c->stream, c->d_mdl, (hml_mt_state*)c->d_mt, mode); \
-    }                                                                                                                              \
-    static void hml_kt_derive_##KK(hml_ctx* c) {                                                                                   \
-        if (c->compat) hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_compat_derive<KK>), dim3(1), dim3(64), 0, c->stream, c->d_mdl);     \
-        else hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_derive<KK>), dim3(1), dim3(64), 0, c->stream, c->d_mdl);                     \
-    }                                                                                                                              \
-    extern hml_ktab hml_ktab_##KK;                                                                                                 \
-    hml_ktab hml_ktab_##KK = {&sweep_k<KK>, &iterate_many_k<KK>, &hml_kt_params_##KK, &hml_kt_compat_draw_##KK, &hml_kt_derive_##KK};
-#if defined(HML_TU_K)
-#define HML_DEFINE_KTAB_(K) HML_DEFINE_KTAB(K)
-HML_DEFINE_KTAB_(HML_TU_K)
-#elif defined(HML_ONLY_K)
-#define HML_DEFINE_KTAB_(K) HML_DEFINE_KTAB(K)
-HML_DEFINE_KTAB_(HML_ONLY_K)
-#else
-HML_DEFINE_KTAB(2) HML_DEFINE_KTAB(3) HML_DEFINE_KTAB(4) HML_DEFINE_KTAB(5) HML_DEFINE_KTAB(6) HML_DEFINE_KTAB(7) HML_DEFINE_KTAB(8) HML_DEFINE_KTAB(9)
-HML_DEFINE_KTAB(10) HML_DEFINE_KTAB(11) HML_DEFINE_KTAB(12) HML_DEFINE_KTAB(13) HML_DEFINE_KTAB(14) HML_DEFINE_KTAB(15) HML_DEFINE_KTAB(16)
-#endif
-#endif   // HML_IN_K
-
-#if HML_IN_CORE
 #if defined(HML_ONLY_K)
 #define HML_DECLARE_KTAB_(K) extern hml_ktab hml_ktab_##K; static const hml_ktab* ktab(int k) { return k == K ? &hml_ktab_##K : nullptr; }
 #define HML_DECLARE_KTAB(K) HML_DECLARE_KTAB_(K)
@@ -2109,4 +1308,3 @@ static const hml_ktab* ktab(int k) {
     return (k >= 2 && k <= 16) ? tabs[k] : nullptr;
 }
 #endif
-#endif   // HML_IN_CORE

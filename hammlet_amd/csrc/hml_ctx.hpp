@@ -89,6 +89,8 @@ struct hml_ctx {
     uint32_t tre_tuned_L = 0, tre_tuned_hint = 0;
     int tre_tune_step = -1;        // >= 0 while measuring: candidate step % n, pass step / n
     float tre_tune_ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    uint32_t tre_cand[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // the candidate lengths of the measurement under way (frozen when it starts:
+    int tre_cand_n = 0;                               // the list depends on the drifting block count)
     uint64_t tre_dense_sweeps = 0; // fused-trellis sweeps of this chain so far
     uint32_t graph_tre_L = 0;      // chunk length of the captured sweep
     int tre_slots = 0;             // wavefronts of hml_k_trellis_rows the device holds at once (0: not asked yet, -1: unknown)

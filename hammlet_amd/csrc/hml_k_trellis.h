@@ -131,7 +131,9 @@ HML_KERNEL __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(K <= 6 ? 4 :
     __shared__ float gtab[HML_TRE_GTAB * K];
     const uint32_t B = mdl_ro->B;
     const int lane = threadIdx.x;
-    if (blockDim.x != 64u) __builtin_trap();   // one wavefront per workgroup: the phases below rely on its in-order LDS traffic
+    // one wavefront per workgroup: the phases below hand data to each other through LDS and rely on the in-order LDS traffic
+    // of ONE wavefront (no barriers).  __launch_bounds__ only bounds the shape; another one is reported, not run.
+    if (blockDim.x != 64u) { if (threadIdx.x == 0) hml_raise(mdl, HML_DEVERR_LAUNCH_GEOMETRY, (float)blockDim.x); return; }
     hml_emit_params<K> p;
     hml_emit_load<K>(p, mdl_ro, 0);
     const uint32_t Wt = hml_tre_warmup(mdl_ro);
@@ -423,6 +425,8 @@ HML_KERNEL __launch_bounds__(64) void hml_k_trellis_refit(const float2* __restri
         if (list_is_a) mdl->fwd_mismatch2 = 0u; else mdl->fwd_mismatch = 0u;
     }
     if (n == 0u) return;
+    // (one wavefront per workgroup, like hml_k_trellis_tile: sm_e / sm_m are exchanged without barriers)
+    if (blockDim.x != 64u) { if (threadIdx.x == 0) hml_raise(mdl, HML_DEVERR_LAUNCH_GEOMETRY, (float)blockDim.x); return; }
     const int lane = threadIdx.x;
     hml_emit_params<K> p;
     hml_emit_load<K>(p, mdl, 0);

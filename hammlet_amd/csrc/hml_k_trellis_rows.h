@@ -39,9 +39,6 @@
 #define HML_TR2_WPE 3       // wavefronts per SIMD the register allocation aims at (up to 8 states)
 #endif
 #define HML_TR2_WAVES 4     // wavefronts per workgroup
-#ifndef HML_TR2_SKIP
-#define HML_TR2_SKIP 0      // development only: bit mask of row stages replaced by a trivial stand-in (timing experiments; results are then wrong)
-#endif
 template <int K>
 struct hml_tr2 {
     static constexpr int SLOTW = (K <= 8) ? 3 : 4;              // words per block in the tile: {N, then the map} {high half of a 64-bit map} Sx Sxx
@@ -373,15 +370,13 @@ void hml_k_trellis_rows(const float2* __restrict__ ia, const uint32_t* __restric
                     const int off = rel0 + sr;
                     have[k] = fc < C && off >= -(int)Wt && ((off < 0) ? cf >= (uint32_t)(-off) : (uint32_t)off < B - cf);
                     const uint32_t bb = have[k] ? cf + (uint32_t)off : 0u;
-                    if (HML_TR2_SKIP & 64) { st[k] = bb; en[k] = bb + 1u; } else {
                     st[k] = starts[bb];
-                    en[k] = starts[bb + 1u]; }
+                    en[k] = starts[bb + 1u];
                 }
                 float2 a[R / 2], z[R / 2];
 #pragma unroll
                 for (int k = 0; k < R / 2; ++k) {
-                    if (HML_TR2_SKIP & 64) { a[k] = make_float2(1.0f + 0.001f * (float)(st[k] & 255u), 2.0f); z[k] = make_float2(0.5f, 0.25f); } else {
-                    a[k] = ia[st[k]]; z[k] = ia[en[k]]; }
+                    a[k] = ia[st[k]]; z[k] = ia[en[k]];
                 }
 #pragma unroll
                 for (int k = 0; k < R / 2; ++k) {
@@ -415,8 +410,7 @@ void hml_k_trellis_rows(const float2* __restrict__ ia, const uint32_t* __restric
                 for (int r = r_first; r < R; ++r) {
                     const uint32_t b = b0 + (uint32_t)r;
                     double u = u_odd;
-                    if (HML_TR2_SKIP & 16) { u = 0.37 + 1e-9 * (double)(b & 1023); }
-                    else if (rel0 >= 0 && (r & 1) == 0) {   // blocks 2m, 2m + 1 share Philox block m (D1)
+                    if (rel0 >= 0 && (r & 1) == 0) {   // blocks 2m, 2m + 1 share Philox block m (D1)
                         // (the key words pass through an empty statement: left alone the compiler keeps the ten round keys of
                         // the schedule - two adds each - in twenty scalar registers across the loop, which it does not have)
                         hml_key kk = key;
@@ -428,10 +422,6 @@ void hml_k_trellis_rows(const float2* __restrict__ ia, const uint32_t* __restric
                     const float sx = hml_u2f(mine[r * SLOTW + SX]), sq = hml_u2f(mine[r * SLOTW + SX + 1]);
                     const float N = (float)nb;
                     float E[K], e[K];
-                    if (HML_TR2_SKIP & 1) {
-#pragma unroll
-                        for (int s = 0; s < K; ++s) E[s] = sx * (0.001f * (float)(s + 1)) - sq;
-                    } else
                     if (__builtin_expect(hml_tr2_energies<K>(p, self, sx, sq, N, E), 0)) hml_tr2_energies_literal<K>(mdl_ro, mdl, self, sx, sq, N, E);
                     // std::max in state order from numeric_limits<float>::lowest() (ForwardBackward.hpp:78-81) is the largest term
                     // unless one is a NaN (which the comparison chain lets through and then forgets); v_max3 skips NaNs, and the
@@ -442,10 +432,6 @@ void hml_k_trellis_rows(const float2* __restrict__ ia, const uint32_t* __restric
                     float xs[K], xsum = 0.0f;
 #pragma unroll
                     for (int s = 0; s < K; ++s) { xs[s] = E[s] - maxE; xsum += xs[s]; }   // every term <= 0 or NaN: the sum is a NaN only if a term is
-                    if (HML_TR2_SKIP & 2) {
-#pragma unroll
-                        for (int s = 0; s < K; ++s) e[s] = 1.0f + 0.01f * xs[s];
-                    } else
                     if (__builtin_expect(xsum != xsum, 0)) {
                         maxE = -3.40282346638528859812e+38f;
 #pragma unroll
@@ -457,10 +443,6 @@ void hml_k_trellis_rows(const float2* __restrict__ ia, const uint32_t* __restric
                         for (int s = 0; s < K; ++s) e[s] = hml_tr2_expf_nonpos(xs[s], etab);
                     }
                     bool fb = false;
-                    if (HML_TR2_SKIP & 4) {
-#pragma unroll
-                        for (int s = 0; s < K; ++s) alpha[s] = 0.5f * alpha[s] + 0.1f * e[s];
-                    } else
                     {
                         if (!SHARE || __ballot(!pred_ok) != 0ull) hml_tr2_predict<K>(cx, alpha, pred);   // (the same values where pred_ok holds)
                         fb = hml_tr2_step<K>(cx, alpha, e, pred);
@@ -492,8 +474,7 @@ void hml_k_trellis_rows(const float2* __restrict__ ia, const uint32_t* __restric
                         }
                         bool unsure = false;
                         map_t cm;
-                        if (HML_TR2_SKIP & 8) cm = (map_t)(hml_f2u(row[0]) ^ hml_f2u(row[1]) ^ hml_f2u((float)u)) & (map_t)0x11111u;
-                        else {
+                        {
                             float total[K];
                             cm = hml_tr2_maps<K>(row, cx.A, (float)u, unsure, total);
                             if (SHARE && !rescaled) {
@@ -506,7 +487,6 @@ void hml_k_trellis_rows(const float2* __restrict__ ia, const uint32_t* __restric
                         uint32_t* const w = tile + lane * PITCH + r * SLOTW;
                         w[0] = (uint32_t)cm;
                         if (SLOTW == 4) w[1] = (uint32_t)(cm >> 32);
-                        if (HML_TR2_SKIP & 32) cmap ^= cm; else
                         cmap = hml_tr2_compose<K>(cmap, cm);
                     }
                 }
@@ -534,9 +514,8 @@ void hml_k_trellis_rows(const float2* __restrict__ ia, const uint32_t* __restric
                         const uint32_t* const w = tile + c * PITCH + sr * SLOTW;
                         unsigned long long cm = w[0];
                         if (SLOTW == 4) cm |= (unsigned long long)w[1] << 32;
-                        if (HML_TR2_SKIP & 128) { if (cm == 0x12345678u && w[SX] == 77u) bstat[b] = make_float2(0.0f, 0.0f); } else {
                         bstat[b] = make_float2(hml_u2f(w[SX]), hml_u2f(w[SX + 1]));
-                        hml_tre_store_cand<K>(cand, (uint32_t)b + 1u, cm); }
+                        hml_tre_store_cand<K>(cand, (uint32_t)b + 1u, cm);
                     }
                 }
                 hml_wave_lds_fence();

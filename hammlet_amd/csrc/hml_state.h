@@ -43,7 +43,8 @@ enum {
     HML_DEVERR_MEAN_NOT_FINITE = 8,   // Observation.hpp:148-160
     HML_DEVERR_VAR_NOT_FINITE = 9,
     HML_DEVERR_VAR_NOT_POSITIVE = 10,
-    HML_DEVERR_TOO_MANY_RECORDS = 11
+    HML_DEVERR_TOO_MANY_RECORDS = 11,
+    HML_DEVERR_LAUNCH_GEOMETRY = 12   // a kernel that relies on one wavefront per workgroup was launched with another shape (a host bug)
 };
 
 #define HML_MAX_D 4            // data dimensions (K = P^D <= 16 with P >= 2)

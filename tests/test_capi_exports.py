@@ -30,12 +30,12 @@ def test_library_exports_every_declared_symbol():
 
 def test_library_holds_the_sweep_of_every_number_of_states():
     """hammlet_amd/build.py links sixteen objects: the C ABI and, per number of states 2 ... 16, the sweep behind its table of
-    function pointers (csrc/hml_capi.hip: -DHML_TU_CORE / -DHML_TU_K=k) - one table per K must be there, and the objects of the
+    function pointers (csrc/hml_capi.hip once, csrc/hml_sweep.hip with -DHML_TU_K=k) - one table per K must be there, and the objects of the
     build must be the ones the layout names (a stale single-object build would define the C ABI twice or not at all)."""
     from hammlet_amd import build
     build.build_library()
     objs = [o for _, o, _ in build._objects()]
-    assert "hml_capi.o" in objs and all("hml_capi_k%d.o" % k in objs for k in range(2, 17))
+    assert "hml_capi.o" in objs and all("hml_sweep_k%d.o" % k in objs for k in range(2, 17))
     lib = ctypes.CDLL(build.LIB_PATH)
     for k in range(2, 17):
         tab = (ctypes.c_void_p * 5).in_dll(lib, "hml_ktab_%d" % k)
