@@ -26,7 +26,9 @@
 #define HML_FM_MAX_CHAINS 8      // chains per launch (more: the host launches groups of eight)
 #define HML_FM_LIST 128          // starts per wavefront and chain kept in LDS (further ones go through the chain's staging array)
 #ifndef HML_FM_MIN_WAVES
-#define HML_FM_MIN_WAVES 6       // wavefronts per SIMD the register allocation aims at (three workgroups per CU: a tile per 2^17 positions at 10^8)
+#define HML_FM_MIN_WAVES 4       // wavefronts per SIMD the register allocation aims at: 91 VGPRs, no scratch, two workgroups per CU (tiles of 2^18
+                                 // positions at 10^8).  6 (three workgroups per CU, tiles of 2^17) spills 13 registers and is as fast: 0.179-0.181
+                                 // against 0.178 ms per round of eight chains
 #endif
 
 // what the kernel needs of one chain
@@ -55,38 +57,50 @@ struct hml_fm_params {
     hml_tr2_params<K> fast;   // 2 mu, 1 / (2 var), logN, logA (0 without self-transitions)
     hml_emit_lds<K> plain;    // mu, var, logN, logA, 1 / (2 var)
 };
+// e_s = expf(E_s - max E) of one block (K <= 6: registers)
+template <int K>
+__device__ __forceinline__ void hml_fm_terms(const hml_fm_params<K>& l, bool self, hml_model* mdl, float sx, float sq, float N, const uint64_t* exp_tab,
+                                             float (&e)[K]) {
+    float E[K];
+    if (__builtin_expect(hml_tr2_energies<K>(l.fast, self, sx, sq, N, E), 0)) hml_tr2_energies_literal<K>(mdl, mdl, self, sx, sq, N, E);
+    // std::max in state order from numeric_limits<float>::lowest() (ForwardBackward.hpp:78-81) is the largest term unless
+    // one is a NaN (which the comparison chain lets through and then forgets); v_max3 skips NaNs, and the NaN shows in
+    // the sum below, where the chain is then walked literally
+    float maxE = -3.40282346638528859812e+38f;
+#pragma unroll
+    for (int s = 0; s < K; ++s) maxE = __builtin_fmaxf(maxE, E[s]);
+    float xs[K], xsum = 0.0f;
+#pragma unroll
+    for (int s = 0; s < K; ++s) { xs[s] = E[s] - maxE; xsum += xs[s]; }   // every term <= 0 or NaN: the sum is a NaN only if a term is
+    if (__builtin_expect(xsum != xsum, 0)) {
+        maxE = -3.40282346638528859812e+38f;
+#pragma unroll
+        for (int s = 0; s < K; ++s) maxE = (E[s] < maxE) ? maxE : E[s];
+#pragma unroll
+        for (int s = 0; s < K; ++s) e[s] = hml_expf_tab(E[s] - maxE, exp_tab);
+    } else {
+#pragma unroll
+        for (int s = 0; s < K; ++s) e[s] = hml_tr2_expf_nonpos(xs[s], exp_tab);
+    }
+}
+template <int K>
+__device__ __forceinline__ void hml_fm_store(const hml_fm_params<K>& l, bool self, uint32_t b, float N, const float (&e)[K], float* __restrict__ em,
+                                             float* __restrict__ gsc, const hml_layout lay, const uint64_t* exp_tab) {
+#pragma unroll
+    for (int s = 0; s < K; ++s) {
+        em[hml_bk(lay, b, K, s)] = e[s];
+        if (gsc) gsc[hml_bk(lay, b, K, s)] = self ? hml_expf_tab((N - 1.0f) * l.plain.logA[s], exp_tab) : 1.0f;
+    }
+}
 template <int K>
 __device__ __forceinline__ void hml_fm_emit(const hml_fm_params<K>& l, bool self, hml_model* mdl, uint32_t b, float sx, float sq, float N,
                                             float* __restrict__ em, float* __restrict__ gsc, const hml_layout lay, const uint64_t* exp_tab) {
     if constexpr (K > 6) {
         hml_emit_block_looped<K>(l.plain, mdl, self, b, sx, sq, N, em, gsc, nullptr, 0, lay, exp_tab);
     } else {
-        float E[K], e[K];
-        if (__builtin_expect(hml_tr2_energies<K>(l.fast, self, sx, sq, N, E), 0)) hml_tr2_energies_literal<K>(mdl, mdl, self, sx, sq, N, E);
-        // std::max in state order from numeric_limits<float>::lowest() (ForwardBackward.hpp:78-81) is the largest term unless
-        // one is a NaN (which the comparison chain lets through and then forgets); v_max3 skips NaNs, and the NaN shows in
-        // the sum below, where the chain is then walked literally
-        float maxE = -3.40282346638528859812e+38f;
-#pragma unroll
-        for (int s = 0; s < K; ++s) maxE = __builtin_fmaxf(maxE, E[s]);
-        float xs[K], xsum = 0.0f;
-#pragma unroll
-        for (int s = 0; s < K; ++s) { xs[s] = E[s] - maxE; xsum += xs[s]; }   // every term <= 0 or NaN: the sum is a NaN only if a term is
-        if (__builtin_expect(xsum != xsum, 0)) {
-            maxE = -3.40282346638528859812e+38f;
-#pragma unroll
-            for (int s = 0; s < K; ++s) maxE = (E[s] < maxE) ? maxE : E[s];
-#pragma unroll
-            for (int s = 0; s < K; ++s) e[s] = hml_expf_tab(E[s] - maxE, exp_tab);
-        } else {
-#pragma unroll
-            for (int s = 0; s < K; ++s) e[s] = hml_tr2_expf_nonpos(xs[s], exp_tab);
-        }
-#pragma unroll
-        for (int s = 0; s < K; ++s) {
-            em[hml_bk(lay, b, K, s)] = e[s];
-            if (gsc) gsc[hml_bk(lay, b, K, s)] = self ? hml_expf_tab((N - 1.0f) * l.plain.logA[s], exp_tab) : 1.0f;
-        }
+        float e[K];
+        hml_fm_terms<K>(l, self, mdl, sx, sq, N, exp_tab, e);
+        hml_fm_store<K>(l, self, b, N, e, em, gsc, lay, exp_tab);
     }
 }
 
@@ -360,6 +374,9 @@ HML_KERNEL __launch_bounds__(HML_FUSED_WAVES * 64, HML_FM_MIN_WAVES) void hml_m_
     it1 = it0;
     if (j0 < total_items) { locate(j0, it0); request(it0, false); }
     if (j1 < total_items) { locate(j1, it1); request(it1, false); }
+    // (Measured and rejected, round 4: COMPUTING the first item's terms during the wait as well - only their stores need the
+    // block's index.  The extra live registers spill at six wavefronts per SIMD, 0.201-0.206 against 0.179-0.181 ms per round of
+    // eight chains; at four per SIMD it is a wash, 0.1761 against 0.1778.)
     if (dbg && threadIdx.x == 0) dbg[blockIdx.x * 8 + 2] = wall_clock64();
 
     // ---------------- offsets: per chain the sum of the words of all earlier tiles and the last start before this tile.

@@ -42,6 +42,10 @@ for rep in range(reps):
         for t in ths: t.join()
     t1 = time.perf_counter()
     times.append(t1 - t0)
+    if os.environ.get("SHOW_W"):
+        st = [ch.stats() for ch in chains]
+        print("   rep %d: %.4f ms | warm-up rows %s | refits %s" % (rep, 1e3 * (t1 - t0) / n, [s["forward_warmup"] for s in st],
+                                                               [s["forward_refits"] - a["forward_refits"] for s, a in zip(st, s0)]))
     blocks_all.append(sum(ch.stats()["block_updates"] - s["block_updates"] for ch, s in zip(chains, s0)))
 i = min(range(reps), key=lambda k: times[k])
 dt, blocks = times[i], blocks_all[i]
