@@ -22,7 +22,7 @@ class HmlError(RuntimeError):
 class HmlStats(C.Structure):
     _fields_ = [("sweeps", C.c_uint64), ("block_updates", C.c_uint64), ("uniform_fallbacks", C.c_uint64),
                 ("forward_refits", C.c_uint64), ("forward_serial", C.c_uint64), ("forward_warmup", C.c_uint64),
-                ("fused_fallbacks", C.c_uint64)]
+                ("fused_fallbacks", C.c_uint64), ("buffer_growths", C.c_uint64), ("block_capacity", C.c_uint64)]
 
 
 RECORD_CB = C.CFUNCTYPE(None, C.c_void_p, C.c_uint64, C.c_void_p)

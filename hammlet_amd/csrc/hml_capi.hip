@@ -120,8 +120,8 @@ static int create_inner(hml_ctx* c, void* stream) {
     else { HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)); c->own_stream = true; }
     HIPCHK(hipMalloc(&c->d_mdl, sizeof(hml_model)));
     HIPCHK(hipMemsetAsync(c->d_mdl, 0, sizeof(hml_model), c->stream));
-    HIPCHK(hipHostMalloc(&c->h_B, 2 * sizeof(uint32_t), hipHostMallocMapped));
-    c->h_B[0] = 0; c->h_B[1] = 0;
+    HIPCHK(hipHostMalloc(&c->h_B, 4 * sizeof(uint32_t), hipHostMallocMapped));
+    c->h_B[0] = 0; c->h_B[1] = 0; c->h_B[2] = 0; c->h_B[3] = 0;
     HIPCHK(hipHostGetDevicePointer((void**)&c->d_hB, c->h_B, 0));
     return 0;
 }
@@ -159,6 +159,7 @@ int hml_create(hml_ctx** out, int device, uint64_t seed, uint32_t chain_id, void
     if (const char* e = getenv("HML_COMPAT")) c->compat = atoi(e) != 0;   // option "compat" for unmodified callers (`hammlet -compat`)
     if (const char* e = getenv("HML_TRELLIS_TUNE")) c->tre_autotune = atoi(e) != 0;
     if (const char* e = getenv("HML_FUSED_SPIN_LIMIT")) c->fused_spin_limit = (uint32_t)strtoul(e, nullptr, 10);
+    if (const char* e = getenv("HML_MAX_BLOCKS")) c->cap_opt = strtoull(e, nullptr, 10);   // option "max_blocks" (tests: a tiny capacity exercises the growth everywhere)
     if (device < 64) g_live_ctx[device].fetch_add(1);
     *out = c;
     return 0;
@@ -182,12 +183,14 @@ static void trace_release(hml_ctx* c) {
 }
 static bool trace_shared(const hml_ctx* c) { return c->trace && c->trace->refs.load() > 1; }
 
-// the buffers hml_set_model allocates
-static void free_sweep_buffers(hml_ctx* c) {
+// the buffers hml_set_model allocates (keep_engine: growing the buffers of a running chain - the reference-compatible
+// mode's mt19937 state lives on)
+static void free_sweep_buffers(hml_ctx* c, bool keep_engine = false) {
     void** ptrs[] = {(void**)&c->d_em, (void**)&c->d_gsc, (void**)&c->d_rows, (void**)&c->d_entry, (void**)&c->d_exitA, (void**)&c->d_redo, (void**)&c->d_touched,
                      (void**)&c->d_fb, (void**)&c->d_smap, (void**)&c->d_cmap, (void**)&c->d_scmap, (void**)&c->d_super, (void**)&c->d_bentry2, (void**)&c->d_bentry,
-                     (void**)&c->d_q, (void**)&c->d_partial, (void**)&c->d_redo2, (void**)&c->d_tre_bitmap, (void**)&c->d_tre_ckpt, (void**)&c->d_mt, (void**)&c->d_crows};
+                     (void**)&c->d_q, (void**)&c->d_partial, (void**)&c->d_redo2, (void**)&c->d_tre_bitmap, (void**)&c->d_tre_ckpt, (void**)&c->d_crows};
     for (void** p : ptrs) if (*p) { hipFree(*p); *p = nullptr; }
+    if (!keep_engine && c->d_mt) { hipFree(c->d_mt); c->d_mt = nullptr; }
 }
 
 static void free_all(hml_ctx* c) {
@@ -245,7 +248,7 @@ static int alloc_block_buffers(hml_ctx* c) {
     c->n_spans = (uint32_t)((T + HML_SPAN - 1) / HML_SPAN);
     HIPCHK(hipMalloc(&c->d_stage, (uint64_t)c->n_spans * HML_SPAN * sizeof(uint16_t)));
     HIPCHK(hipMalloc(&c->d_span_count, c->n_spans * sizeof(uint32_t)));
-    HIPCHK(hipMalloc(&c->d_starts, (T + 1) * sizeof(uint32_t)));
+    HIPCHK(hipMalloc(&c->d_starts, (c->cap + 1) * sizeof(uint32_t)));
     HIPCHK(hipMalloc(&c->d_coarse1, ((c->n_spans + HML_GROUP_SPANS - 1) / HML_GROUP_SPANS + 1u) * sizeof(uint32_t)));
     {
         const uint64_t n_tiles = (T + HML_FUSED_SUB_POSITIONS - 1) / HML_FUSED_SUB_POSITIONS;   // (tiles of one batch: the most there can be)
@@ -253,8 +256,24 @@ static int alloc_block_buffers(hml_ctx* c) {
         HIPCHK(hipMemsetAsync(c->d_group_word, 0, (n_tiles + 1) * sizeof(unsigned long long), c->stream));
         if (getenv("HML_FUSED_DEBUG")) { HIPCHK(hipMalloc(&c->d_dbg, 4096 * 8 * 8)); HIPCHK(hipMemset(c->d_dbg, 0, 4096 * 8 * 8)); }
     }
-    HIPCHK(hipMalloc(&c->d_bstat, T * (uint64_t)c->D * sizeof(float2)));
+    HIPCHK(hipMalloc(&c->d_bstat, c->cap * (uint64_t)c->D * sizeof(float2)));   // (D > 1: cap = T, the planes lie T apart)
+    // the capacity the enumeration kernels respect (they run before there is a model: auto prior, explicit thresholds)
+    const uint32_t cap32 = (uint32_t)c->cap;
+    HIPCHK(hipMemcpyAsync(&c->d_mdl->cap, &cap32, sizeof cap32, hipMemcpyHostToDevice, c->stream));
     return 0;
+}
+
+// the block capacity of a context whose observations are being loaded (`attached`: to another context's construction)
+static void choose_capacity(hml_ctx* c, bool attached) {
+    const uint64_t T = c->T;
+    uint64_t cap = T;
+    if (c->D == 1) {
+        if (c->cap_opt) cap = c->cap_opt;
+        // a further chain on a GPU (hml_attach_observations): room for the strongly compressed regime (up to 2^22 blocks a sweep,
+        // or a sixteenth of the positions) instead of the worst case - it grows if a sweep needs more
+        else if (attached) cap = std::max<uint64_t>(1ull << 20, T / 16);
+    }
+    c->cap = std::min<uint64_t>(std::max<uint64_t>(cap, 64), T);
 }
 
 // d_x[d], h_x[d]: the observations of dimension d (T values each), on the device and on the host
@@ -340,6 +359,7 @@ static int build_from_device_x(hml_ctx* c, const float* const* d_x, const float*
             KLAUNCH_CHECK();
         }
     }
+    choose_capacity(c, false);
     if (int r = alloc_block_buffers(c)) return r;
     HIPCHK(hipStreamSynchronize(c->stream));
     c->trace = new hml_trace();
@@ -431,6 +451,7 @@ int hml_attach_observations(hml_ctx* c, hml_ctx* src) {
     c->trace = src->trace;
     c->trace->refs.fetch_add(1);
     c->d_w = src->d_w; c->d_summary = src->d_summary; c->d_coeff = src->d_coeff; c->d_ia = src->d_ia;
+    choose_capacity(c, true);
     if (int r = alloc_block_buffers(c)) { trace_release(c); return r; }
     HIPCHK(hipStreamSynchronize(c->stream));
     c->loaded = true;
@@ -473,11 +494,26 @@ int hml_set_weights(hml_ctx* c, const float* w, uint64_t T) {
 }  // extern "C"
 
 extern "C" {
+}  // extern "C"
+static int grow_capacity(hml_ctx* c, uint64_t needed);
+// an enumeration at an explicit threshold (with block statistics), waited for; a context with a reduced block capacity
+// grows until the blocks fit (hml_state.h)
+static int enumerate_blocks_sync(hml_ctx* c, float threshold) {
+    if (int r = settle_if_limited(c)) return r;   // (sweeps still under way come first)
+    for (int round = 0; round < 64; ++round) {
+        if (int r = launch_compact(c, true, threshold)) return r;
+        HIPCHK(hipStreamSynchronize(c->stream));
+        if (!chain_halted(c)) return 0;
+        if (int r = grow_capacity(c, c->h_B[2])) return r;
+    }
+    return set_err(HML_ERR_HIP, "internal error: the block capacity did not settle");
+}
+extern "C" {
+
 int hml_create_blocks(hml_ctx* c, float threshold) {
     if (!c || !c->loaded) return set_err(HML_ERR_ARG, "no observations loaded");
     if (int r = ctx_bind(c)) return r;
-    if (int r = launch_compact(c, true, threshold)) return r;
-    HIPCHK(hipStreamSynchronize(c->stream));
+    if (int r = enumerate_blocks_sync(c, threshold)) return r;
     refresh_hint(c);
     c->blocks_valid = false;   // an explicit threshold is not the model's threshold
     return 0;
@@ -488,8 +524,7 @@ int hml_autoprior(hml_ctx* c, float s2, float p, float out4[4]) {
     if (int r = ctx_bind(c)) return r;
     // y.createBlocks( sqrt(2*log((double)T)) * noiseStdev )   (AutoPriors.hpp:95-96)
     const float thr0 = (float)(std::sqrt(2 * std::log((double)c->T)) * c->sigma);
-    if (int r = launch_compact(c, true, thr0)) return r;
-    HIPCHK(hipStreamSynchronize(c->stream));
+    if (int r = enumerate_blocks_sync(c, thr0)) return r;
     refresh_hint(c);
     const uint32_t B = *c->h_B;
     std::vector<uint32_t> st(B + 1);
@@ -497,7 +532,7 @@ int hml_autoprior(hml_ctx* c, float s2, float p, float out4[4]) {
     std::vector<float2> bs((size_t)B * D);
     HIPCHK(hipMemcpy(st.data(), c->d_starts, (B + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost));
     for (int d = 0; d < D; ++d)
-        HIPCHK(hipMemcpy(bs.data() + (size_t)d * B, c->d_bstat + (uint64_t)d * c->T, B * sizeof(float2), hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(bs.data() + (size_t)d * B, c->d_bstat + (uint64_t)d * c->cap, B * sizeof(float2), hipMemcpyDeviceToHost));   // (D > 1: cap = T)
     // block means in block order, every dimension of a block in turn (AutoPriors.hpp:100-104), float accumulation
     // (SufficientStatistics<Normal>::addObs); N = nrBlocks * nrDim (AutoPriors.hpp:105)
     float muSum = 0, muSq = 0;
@@ -531,6 +566,129 @@ int hml_autoprior(hml_ctx* c, float s2, float p, float out4[4]) {
     return 0;
 }
 
+}  // extern "C"
+
+// the per-block sweep buffers, sized by the context's block capacity (hml_ctx.hpp; c->K set)
+static int alloc_sweep_buffers(hml_ctx* c) {
+    const int K = c->K;
+    const uint64_t cap = c->cap;
+    const int minL = std::min(std::min(c->fwdL, c->fwdL_dense), c->fwdL_many);
+    const uint64_t maxChunks = (cap + minL - 1) / minL + 1;   // per-chunk arrays serve either geometry
+    uint64_t plane = 0;   // floats in one chunk-transposed [L][K][cstride] array
+    auto layout = [&](int L, hml_layout& lay) {
+        int sh = 0; while ((1 << sh) < L) ++sh;
+        lay.lshift = (uint32_t)sh;
+        lay.cstride = (uint32_t)(((cap + L - 1) / L + 1 + 63) / 64 * 64);
+        plane = std::max(plane, (uint64_t)L * K * lay.cstride);
+    };
+    layout(c->fwdL, c->lay);
+    layout(c->fwdL_dense, c->lay_dense);
+    layout(c->fwdL_many, c->lay_many);
+    HIPCHK(hipMalloc(&c->d_em, plane * sizeof(float)));
+    HIPCHK(hipMalloc(&c->d_gsc, plane * sizeof(float)));
+    HIPCHK(hipMalloc(&c->d_rows, plane * sizeof(float)));
+    HIPCHK(hipMalloc(&c->d_entry, maxChunks * K * sizeof(float)));
+    HIPCHK(hipMalloc(&c->d_exitA, maxChunks * K * sizeof(float)));
+    HIPCHK(hipMalloc(&c->d_fb, maxChunks * sizeof(uint32_t)));
+    HIPCHK(hipMalloc(&c->d_smap, (cap + 2) * sizeof(unsigned long long)));
+    // per-chunk arrays serve the backward chunks of 64 rows and the fused trellis path's forward chunks of 16 or 32
+    const uint64_t bchunks = (cap + 15) / 16 + 1;
+    HIPCHK(hipMalloc(&c->d_cmap, bchunks * sizeof(unsigned long long)));
+    HIPCHK(hipMalloc(&c->d_bentry, bchunks));
+    HIPCHK(hipMalloc(&c->d_scmap, bchunks * sizeof(unsigned long long)));
+    HIPCHK(hipMalloc(&c->d_super, (bchunks / 64 + 2) * sizeof(unsigned long long)));
+    HIPCHK(hipMalloc(&c->d_bentry2, bchunks / 64 + 2));
+    HIPCHK(hipMalloc(&c->d_redo, bchunks * sizeof(uint32_t)));
+    HIPCHK(hipMemsetAsync(c->d_redo, 0, bchunks * sizeof(uint32_t), c->stream));
+    HIPCHK(hipMalloc(&c->d_touched, bchunks * sizeof(uint32_t)));
+    HIPCHK(hipMemsetAsync(c->d_touched, 0, bchunks * sizeof(uint32_t), c->stream));
+    HIPCHK(hipMalloc(&c->d_redo2, bchunks * sizeof(uint32_t)));
+    HIPCHK(hipMalloc(&c->d_tre_bitmap, (bchunks / 32 + 2) * sizeof(uint32_t)));
+    // (checkpoints of the fused trellis path: (L / 64 - 1) x ceil(B / L) <= B / 64 + 16 vectors of K + 1 words)
+    HIPCHK(hipMalloc(&c->d_tre_ckpt, (cap / 64 + 64) * (uint64_t)(K + 1) * sizeof(uint32_t)));
+    HIPCHK(hipMalloc(&c->d_q, cap * sizeof(int16_t)));
+    HIPCHK(hipMalloc(&c->d_partial, (uint64_t)HML_REDUCE_GROUPS * K * 2 * sizeof(double)));
+    HIPCHK(hipMemsetAsync(c->d_partial, 0, (uint64_t)HML_REDUCE_GROUPS * K * 2 * sizeof(double), c->stream));
+    if (c->compat) HIPCHK(hipMalloc(&c->d_crows, (cap + 1) * K * sizeof(float)));   // the reference-compatible mode's plain (B + 1) x K trellis
+    return 0;
+}
+
+// More room for blocks: the per-block buffers are released and allocated again for at least `needed` blocks (half as many
+// again, at least twice the old capacity, at most T).  Nothing in them outlives a sweep except a static block structure, which
+// the next sweep enumerates again.  The stream is idle.
+static int grow_capacity(hml_ctx* c, uint64_t needed) {
+    const uint64_t cap = std::min<uint64_t>(c->T, std::max<uint64_t>(needed + needed / 2 + 1024, 2 * c->cap));
+    if (c->graph_exec) { hipGraphExecDestroy(c->graph_exec); c->graph_exec = nullptr; }
+    void** blocks[] = {(void**)&c->d_starts, (void**)&c->d_bstat};
+    for (void** q : blocks) if (*q) { hipFree(*q); *q = nullptr; }
+    free_sweep_buffers(c, /*keep_engine*/ true);
+    if (c->d_eprobe) { hipFree(c->d_eprobe); c->d_eprobe = nullptr; }
+    if (c->d_aprobe) { hipFree(c->d_aprobe); c->d_aprobe = nullptr; }
+    c->cap = cap;
+    HIPCHK(hipMalloc(&c->d_starts, (cap + 1) * sizeof(uint32_t)));
+    HIPCHK(hipMalloc(&c->d_bstat, cap * (uint64_t)c->D * sizeof(float2)));
+    if (c->model_set) {
+        if (int r = alloc_sweep_buffers(c)) return r;
+        if (c->probes) {
+            HIPCHK(hipMalloc(&c->d_eprobe, c->cap * c->K * sizeof(float)));
+            HIPCHK(hipMalloc(&c->d_aprobe, (c->cap + 1) * c->K * sizeof(float)));
+        }
+    }
+    const uint32_t words[2] = {(uint32_t)cap, 0u};   // hml_model: cap, halted (adjacent)
+    static_assert(offsetof(hml_model, halted) == offsetof(hml_model, cap) + sizeof(uint32_t), "cap and halted are written together");
+    HIPCHK(hipMemcpyAsync(&c->d_mdl->cap, words, sizeof words, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    c->h_B[2] = 0u;
+    c->blocks_valid = false;
+    c->hint_stale = false;      // (h_B[0] holds the count the halted enumeration found)
+    c->grown++;
+    return 0;
+}
+
+static int sweep_dispatch(hml_ctx* c, char method, bool record);
+
+// The stream is idle and no sweep was left behind: a chain whose enumeration found more blocks than its buffers hold (it halts
+// on the device, hml_state.h) gets larger buffers, and the sweeps it skipped - everything enqueued since the model's sweep
+// counter stopped - run again, in order, with their recording flags.  Same results as with room from the start: a halted sweep
+// changes nothing but scratch.
+int hml_settle(hml_ctx* c) {
+    for (int round = 0; round < 64; ++round) {
+        HIPCHK(hipStreamSynchronize(c->stream));
+        if (!chain_halted(c)) { c->sweep_log.clear(); c->log_base = c->requested; return 0; }
+        const uint64_t needed = c->h_B[2];
+        if (c->cap >= c->T) return set_err(HML_ERR_HIP, "internal error: a chain with full block capacity halted");
+        std::vector<uint8_t> pending;
+        if (c->model_set) {
+            hml_model m;
+            if (int r = fetch_model(c, &m)) return r;
+            // (the log starts at log_base sweeps; what the counter says beyond that ran, the rest did not)
+            const uint64_t ran = m.sweeps >= c->log_base ? m.sweeps - c->log_base : 0;
+            if (ran < c->sweep_log.size()) pending.assign(c->sweep_log.begin() + ran, c->sweep_log.end());
+            c->log_base = m.sweeps;
+        }
+        if (int r = grow_capacity(c, needed)) return r;
+        // the log now holds exactly the sweeps that have to run (again): the model's counter tells how far they got
+        c->sweep_log = pending;
+        bool halted_again = false;
+        for (size_t i = 0; i < pending.size() && !halted_again; ++i) {
+            const char method = (pending[i] & 1) ? HML_METHOD_MIXTURE : HML_METHOD_FB;
+            const bool record = (pending[i] & 2) != 0;
+            if (int r = sweep_dispatch(c, method, record)) return r;
+            if (record && c->cb) {   // a recorded sweep the caller wants to see: it happens now (or, halted again, in the next round)
+                HIPCHK(hipStreamSynchronize(c->stream));
+                halted_again = chain_halted(c);
+                if (!halted_again) {
+                    if (int r = check_device_error(c)) return r;
+                    c->cb(c, (uint64_t)i, c->cb_user);
+                }
+            }
+        }
+    }
+    return set_err(HML_ERR_HIP, "internal error: the block capacity did not settle");
+}
+
+extern "C" {
+
 // ---------------------------------------------------------------------------------------- model
 int hml_set_model(hml_ctx* c, int K, const float nig4[4], float a_off, float a_diag, float pi_alpha, int self_trans) {
     if (!c || !c->loaded) return set_err(HML_ERR_ARG, "no observations loaded");
@@ -554,57 +712,13 @@ int hml_set_model(hml_ctx* c, int K, const float nig4[4], float a_off, float a_d
     free_sweep_buffers(c);   // (what an earlier call that failed half-way left behind)
     c->K = K;
     const uint64_t T = c->T;
-    const uint64_t layChunks = (T + c->fwdL - 1) / c->fwdL + 1;
-    const int minL = std::min(std::min(c->fwdL, c->fwdL_dense), c->fwdL_many);
-    const uint64_t maxChunks = (T + minL - 1) / minL + 1;   // per-chunk arrays serve either geometry
-    {
-        int sh = 0; while ((1 << sh) < c->fwdL) ++sh;
-        c->lay.lshift = (uint32_t)sh;
-        c->lay.cstride = (uint32_t)((layChunks + 63) / 64 * 64);
-    }
-    uint64_t plane = (uint64_t)c->fwdL * K * c->lay.cstride;   // floats in one chunk-transposed [L][K][cstride] array
-    {
-        int sh = 0; while ((1 << sh) < c->fwdL_dense) ++sh;
-        c->lay_dense.lshift = (uint32_t)sh;
-        c->lay_dense.cstride = (uint32_t)(((T + c->fwdL_dense - 1) / c->fwdL_dense + 1 + 63) / 64 * 64);
-        plane = std::max(plane, (uint64_t)c->fwdL_dense * K * c->lay_dense.cstride);
-    }
-    {
-        int sh = 0; while ((1 << sh) < c->fwdL_many) ++sh;
-        c->lay_many.lshift = (uint32_t)sh;
-        c->lay_many.cstride = (uint32_t)(((T + c->fwdL_many - 1) / c->fwdL_many + 1 + 63) / 64 * 64);
-        plane = std::max(plane, (uint64_t)c->fwdL_many * K * c->lay_many.cstride);
-    }
-    HIPCHK(hipMalloc(&c->d_em, plane * sizeof(float)));
-    HIPCHK(hipMalloc(&c->d_gsc, plane * sizeof(float)));
-    HIPCHK(hipMalloc(&c->d_rows, plane * sizeof(float)));
-    HIPCHK(hipMalloc(&c->d_entry, maxChunks * K * sizeof(float)));
-    HIPCHK(hipMalloc(&c->d_exitA, maxChunks * K * sizeof(float)));
-    HIPCHK(hipMalloc(&c->d_fb, maxChunks * sizeof(uint32_t)));
-    HIPCHK(hipMalloc(&c->d_smap, (T + 2) * sizeof(unsigned long long)));
-    // per-chunk arrays serve the backward chunks of 64 rows and the fused trellis path's forward chunks of 16 or 32
-    const uint64_t bchunks = (T + 15) / 16 + 1;
-    HIPCHK(hipMalloc(&c->d_cmap, bchunks * sizeof(unsigned long long)));
-    HIPCHK(hipMalloc(&c->d_bentry, bchunks));
-    HIPCHK(hipMalloc(&c->d_scmap, bchunks * sizeof(unsigned long long)));
-    HIPCHK(hipMalloc(&c->d_super, (bchunks / 64 + 2) * sizeof(unsigned long long)));
-    HIPCHK(hipMalloc(&c->d_bentry2, bchunks / 64 + 2));
-    HIPCHK(hipMalloc(&c->d_redo, bchunks * sizeof(uint32_t)));
-    HIPCHK(hipMemsetAsync(c->d_redo, 0, bchunks * sizeof(uint32_t), c->stream));
-    HIPCHK(hipMalloc(&c->d_touched, bchunks * sizeof(uint32_t)));
-    HIPCHK(hipMemsetAsync(c->d_touched, 0, bchunks * sizeof(uint32_t), c->stream));
-    HIPCHK(hipMalloc(&c->d_redo2, bchunks * sizeof(uint32_t)));
-    HIPCHK(hipMalloc(&c->d_tre_bitmap, (bchunks / 32 + 2) * sizeof(uint32_t)));
-    // (checkpoints of the fused trellis path: (L / 64 - 1) x ceil(B / L) <= T / 64 + 16 vectors of K + 1 words)
-    HIPCHK(hipMalloc(&c->d_tre_ckpt, (T / 64 + 64) * (uint64_t)(K + 1) * sizeof(uint32_t)));
-    HIPCHK(hipMalloc(&c->d_q, T * sizeof(int16_t)));
-    HIPCHK(hipMalloc(&c->d_partial, (uint64_t)HML_REDUCE_GROUPS * K * 2 * sizeof(double)));
-    HIPCHK(hipMemsetAsync(c->d_partial, 0, (uint64_t)HML_REDUCE_GROUPS * K * 2 * sizeof(double), c->stream));
+    if (int r = alloc_sweep_buffers(c)) return r;
 
     hml_model m;
     memset(&m, 0, sizeof m);
     m.K = K; m.self_trans = self_trans ? 1 : 0; m.dynamic = 1; m.T = (uint32_t)T;
     m.D = c->D; m.P = c->P > 0 ? c->P : K; m.stat_stride = T;
+    m.cap = (uint32_t)c->cap;
     for (int st = 0; st < K; ++st) {   // reversed P-ary digits (Mapping.hpp:92-103)
         int nn = st;
         for (int d = 0; d < HML_MAX_D; ++d) { m.map[st][d] = (uint8_t)(d < c->D ? nn % m.P : 0); nn /= m.P; }
@@ -642,7 +756,6 @@ int hml_set_model(hml_ctx* c, int K, const float nig4[4], float a_off, float a_d
         hml_mt_seed(&h, c->seed + (uint64_t)c->chain);
         HIPCHK(hipMalloc(&c->d_mt, sizeof(hml_mt_state)));
         HIPCHK(hipMemcpyAsync(c->d_mt, &h, sizeof h, hipMemcpyHostToDevice, c->stream));
-        HIPCHK(hipMalloc(&c->d_crows, (T + 1) * K * sizeof(float)));
         HIPCHK(hipStreamSynchronize(c->stream));
         kt->compat_draw(c, 2);
         KLAUNCH_CHECK();
@@ -658,6 +771,7 @@ int hml_set_model(hml_ctx* c, int K, const float nig4[4], float a_off, float a_d
 int hml_sample_prior(hml_ctx* c) {
     if (!c || !c->model_set) return set_err(HML_ERR_ARG, "model not set");
     if (int r = ctx_bind(c)) return r;
+    if (int r = settle_if_limited(c)) return r;
     if (c->compat) {
         HML_KTAB(c->K, kt); kt->compat_draw(c, 1);
     } else { HML_KTAB(c->K, kt); kt->params(c, 1); }
@@ -674,6 +788,7 @@ HML_KERNEL __launch_bounds__(64) void hml_k_set_self_trans(hml_model* mdl, int o
 int hml_set_self_transitions(hml_ctx* c, int on) {
     if (!c || !c->model_set) return set_err(HML_ERR_ARG, "model not set");
     if (int r = ctx_bind(c)) return r;
+    if (int r = settle_if_limited(c)) return r;
     hipLaunchKernelGGL(hml_k_set_self_trans, dim3(1), dim3(64), 0, c->stream, c->d_mdl, on ? 1 : 0);
     KLAUNCH_CHECK();
     if (c->graph_exec) { hipGraphExecDestroy(c->graph_exec); c->graph_exec = nullptr; }
@@ -683,6 +798,7 @@ int hml_set_self_transitions(hml_ctx* c, int on) {
 int hml_set_static_blocks(hml_ctx* c) {
     if (!c || !c->model_set) return set_err(HML_ERR_ARG, "model not set");
     if (int r = ctx_bind(c)) return r;
+    if (int r = settle_if_limited(c)) return r;
     hipLaunchKernelGGL(hml_k_set_dynamic, dim3(1), dim3(64), 0, c->stream, c->d_mdl, 0, 1);
     KLAUNCH_CHECK();
     c->dynamic = false;
@@ -694,6 +810,7 @@ int hml_set_static_blocks(hml_ctx* c) {
 int hml_set_dynamic(hml_ctx* c, int on) {
     if (!c || !c->model_set) return set_err(HML_ERR_ARG, "model not set");
     if (int r = ctx_bind(c)) return r;
+    if (int r = settle_if_limited(c)) return r;
     hipLaunchKernelGGL(hml_k_set_dynamic, dim3(1), dim3(64), 0, c->stream, c->d_mdl, on ? 1 : 0, on ? 1 : 0);
     KLAUNCH_CHECK();
     c->dynamic = on != 0;
@@ -711,9 +828,10 @@ int hml_set_recording(hml_ctx* c, int marginals, hml_record_cb cb, void* user) {
 int hml_enable_probes(hml_ctx* c, int on) {
     if (!c || !c->model_set) return set_err(HML_ERR_ARG, "model not set");
     if (int r = ctx_bind(c)) return r;
+    if (int r = settle_if_limited(c)) return r;
     if (on && !c->d_eprobe) {
-        HIPCHK(hipMalloc(&c->d_eprobe, c->T * c->K * sizeof(float)));
-        HIPCHK(hipMalloc(&c->d_aprobe, (c->T + 1) * c->K * sizeof(float)));
+        HIPCHK(hipMalloc(&c->d_eprobe, c->cap * c->K * sizeof(float)));
+        HIPCHK(hipMalloc(&c->d_aprobe, (c->cap + 1) * c->K * sizeof(float)));
     }
     c->probes = on != 0;
     return 0;
@@ -740,6 +858,8 @@ int hml_iterate(hml_ctx* c, char method, uint64_t iterations, uint64_t thinning)
         return set_err(HML_ERR_ARG, "the marginals of this context are pooled (common labels, several chains): further sweeps cannot be recorded into them");
     for (uint64_t i = 0; i < iterations; ++i) {
         const bool record = thinning > 0 && ((i + 1) % thinning == 0);
+        // a chain with a reduced block capacity that halted (hml_state.h): larger buffers, the skipped sweeps again - then on
+        if (chain_halted(c)) { if (int r = hml_settle(c)) return r; }
         refresh_hint(c);
         const bool tre_path = c->tre_fused && c->D == 1 && method == HML_METHOD_FB && c->B_hint >= c->dense_min_blocks;
         if (c->use_graph && !c->compat && !record && !c->profiling && !c->probes && (c->dynamic || c->blocks_valid) &&
@@ -774,14 +894,17 @@ int hml_iterate(hml_ctx* c, char method, uint64_t iterations, uint64_t thinning)
                 c->graph_dense = c->B_hint >= c->dense_min_blocks;
             }
             if (c->graph_exec) {
+                log_sweep(c, method, false);
                 HIPCHK(hipGraphLaunch(c->graph_exec, c->stream));
                 if (tre_path) c->tre_dense_sweeps++;
                 continue;
             }
         }
+        log_sweep(c, method, record);
         if (int r = sweep_dispatch(c, method, record)) return r;
         if (record && c->cb) {
             HIPCHK(hipStreamSynchronize(c->stream));
+            if (chain_halted(c)) { if (int r = hml_settle(c)) return r; continue; }   // (runs the sweep again and calls back)
             if (int r = check_device_error(c)) return r;
             c->cb(c, i, c->cb_user);
         }
@@ -796,28 +919,40 @@ extern "C" int hml_iterate_many(hml_ctx* const* cs, int n, char method, uint64_t
     for (int i = 0; i < n; ++i) if (!cs[i] || !cs[i]->model_set) return set_err(HML_ERR_ARG, "model not set");
     if (method != HML_METHOD_FB && method != HML_METHOD_MIXTURE) return set_err(HML_ERR_ARG, std::string("Unknown sampling type ") + method + "!");
     uint64_t done = 0;
-    if (many_eligible(cs, n, method)) {
+    while (done < iterations && many_eligible(cs, n, method)) {
         if (int r = ctx_bind(cs[0])) return r;
-        // everything the chains have enqueued on their own streams comes first; a block count that predates the current
-        // parameters is refreshed chain by chain (sweep_k's first-sweep rule)
+        // everything the chains have enqueued on their own streams comes first (a chain with a reduced block capacity catches up
+        // on what it skipped: hml_settle); a block count that predates the current parameters is refreshed chain by chain
+        // (sweep_k's first-sweep rule)
         for (int i = 0; i < n; ++i) {
             hml_ctx* c = cs[i];
+            if (int r = settle_if_limited(c)) return r;
             if (c->hint_stale) { launch_compact_pair(c, 0, 0.0f); KLAUNCH_CHECK(); }
             HIPCHK(hipStreamSynchronize(c->stream));
             c->hint_stale = false;
             if (c->graph_exec) { hipGraphExecDestroy(c->graph_exec); c->graph_exec = nullptr; }
         }
         int r = 0;
-        { HML_KTAB(cs[0]->K, kt); r = kt->iterate_many(cs, n, 0, iterations, thinning, &done); }
+        uint64_t reached = done;
+        { HML_KTAB(cs[0]->K, kt); r = kt->iterate_many(cs, n, done, iterations, thinning, &reached); }
         if (r) return r;
         // the other chains' streams continue behind the batch
         hipEvent_t ev = ev_get(cs[0]);
         HIPCHK(hipEventRecord(ev, cs[0]->stream));
         for (int i = 1; i < n; ++i) HIPCHK(hipStreamWaitEvent(cs[i]->stream, ev, 0));
         cs[0]->ev_pool.push_back(ev);
-        if (done == iterations) return 0;
+        if (reached == iterations) return 0;
         HIPCHK(hipStreamSynchronize(cs[0]->stream));
+        // the batch stopped early: a chain halted (its blocks outgrew its buffers - the loop's first step lets it catch up, then
+        // the batch goes on) or left the strongly compressed regime (chain by chain from here)
+        bool halted = false;
+        for (int i = 0; i < n; ++i) halted = halted || chain_halted(cs[i]);
+        const bool progress = reached > done;
+        done = reached;
+        if (!halted && !progress) break;
+        if (!halted) { bool sparse = true; for (int i = 0; i < n; ++i) sparse = sparse && many_sparse(cs[i]); if (!sparse) break; }
     }
+    for (int i = 0; i < n; ++i) if (int r = settle_if_limited(cs[i])) return r;
     // not batched (different shapes or devices, mixture sweeps, weakly compressed or reference-compatible chains): sweep by
     // sweep in turn, so that recorded sweeps stay aligned across the chains
     for (uint64_t i = done; i < iterations; ++i) {
@@ -826,9 +961,12 @@ extern "C" int hml_iterate_many(hml_ctx* const* cs, int n, char method, uint64_t
             hml_ctx* c = cs[k];
             if (int r = ctx_bind(c)) return r;
             if (record && c->rec_marginals && c->pooled) return set_err(HML_ERR_ARG, "the marginals of a context are pooled (common labels, several chains): further sweeps cannot be recorded into them");
+            if (chain_halted(c)) { if (int r = hml_settle(c)) return r; }
+            log_sweep(c, method, record);
             if (int r = sweep_dispatch(c, method, record)) return r;
             if (record && c->cb) {
                 HIPCHK(hipStreamSynchronize(c->stream));
+                if (chain_halted(c)) { if (int r = hml_settle(c)) return r; continue; }   // (runs the sweep again and calls back)
                 if (int r = check_device_error(c)) return r;
                 c->cb(c, i, c->cb_user);
             }
@@ -845,6 +983,12 @@ int hml_set_option(hml_ctx* c, const char* name, int value) {
         if (c->loaded) return set_err(HML_ERR_ARG, "weight_keys must be set before the observations are loaded");
         c->use_keys = value != 0;
         c->summary_always = value == 2;
+        return 0;
+    }
+    if (std::string(name) == "max_blocks") {   // block capacity of the per-block buffers (hml_ctx.hpp)
+        if (c->loaded) return set_err(HML_ERR_ARG, "max_blocks must be set before the observations are loaded");
+        if (value < 0) return set_err(HML_ERR_ARG, "max_blocks: a number of blocks, or 0 for the default");
+        c->cap_opt = (uint64_t)value;
         return 0;
     }
     if (std::string(name) == "fused_blocks") {
@@ -869,7 +1013,7 @@ int hml_set_option(hml_ctx* c, const char* name, int value) {
 int hml_sync(hml_ctx* c) {
     if (!c) return set_err(HML_ERR_ARG, "null context");
     if (int r = ctx_bind(c)) return r;
-    HIPCHK(hipStreamSynchronize(c->stream));
+    if (int r = hml_settle(c)) return r;   // (synchronises; a halted chain grows and catches up)
     if (c->d_dbg && getenv("HML_FUSED_DEBUG") && atoi(getenv("HML_FUSED_DEBUG")) == 2) {
         // the many-chain block kernel's stamps (8 words per workgroup): start | phase A done | first gathers requested | offsets known | end
         std::vector<unsigned long long> h(4096 * 8);
@@ -908,8 +1052,8 @@ int hml_sync(hml_ctx* c) {
 }
 
 // ---------------------------------------------------------------------------------------- probes
-#define NEED_MODEL() if (!c || !c->model_set) return set_err(HML_ERR_ARG, "model not set"); if (int r_ = ctx_bind(c)) return r_
-#define NEED_LOADED() if (!c || !c->loaded) return set_err(HML_ERR_ARG, "no observations loaded"); if (int r_ = ctx_bind(c)) return r_
+#define NEED_MODEL() if (!c || !c->model_set) return set_err(HML_ERR_ARG, "model not set"); if (int r_ = ctx_bind(c)) return r_; if (int r_ = settle_if_limited(c)) return r_
+#define NEED_LOADED() if (!c || !c->loaded) return set_err(HML_ERR_ARG, "no observations loaded"); if (int r_ = ctx_bind(c)) return r_; if (int r_ = settle_if_limited(c)) return r_
 
 static int current_B(hml_ctx* c, uint32_t* B) {
     HIPCHK(hipMemcpyAsync(c->h_B, &c->d_mdl->B, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
@@ -1232,6 +1376,7 @@ int hml_get_stats(hml_ctx* c, hml_stats* out) {
     out->forward_refits = m.forward_refits; out->forward_serial = m.forward_serial;
     out->forward_warmup = m.fwd_W;
     out->fused_fallbacks = m.fused_fallbacks;
+    out->buffer_growths = c->grown; out->block_capacity = c->cap;
     return 0;
 }
 

@@ -206,6 +206,15 @@ static int launch_compact(hml_ctx* c, bool use_override, float thr) {
     return 0;
 }
 
+// capacity-limited contexts (hml_ctx.hpp): every enqueued sweep is noted, so that sweeps a halted chain skipped can be run again
+static inline bool cap_limited(const hml_ctx* c) { return c->cap != 0 && c->cap < c->T; }
+static inline bool chain_halted(const hml_ctx* c) { return cap_limited(c) && ((volatile uint32_t*)c->h_B)[2] != 0u; }
+static inline void log_sweep(hml_ctx* c, char method, bool record) {
+    c->requested++;
+    if (cap_limited(c)) c->sweep_log.push_back((uint8_t)((method == HML_METHOD_MIXTURE ? 1 : 0) | (record ? 2 : 0)));
+}
+static inline int settle_if_limited(hml_ctx* c) { return cap_limited(c) ? hml_settle(c) : 0; }
+
 static void refresh_hint(hml_ctx* c) {
     const uint32_t b = *(volatile uint32_t*)c->h_B;
     if (b) c->B_hint = b + b / 4 + 1024;

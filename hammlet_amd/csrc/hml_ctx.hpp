@@ -108,8 +108,19 @@ struct hml_ctx {
     int32_t* d_diff = nullptr;
     uint32_t* d_boundary = nullptr;
     hml_model* d_mdl = nullptr;
-    uint32_t* h_B = nullptr;        // pinned + mapped, two words: [0] the block count of the latest enumeration (grid sizing hint),
-                                    // [1] set by the fused block kernel when a bounded wait expired
+    uint32_t* h_B = nullptr;        // pinned + mapped, four words: [0] the block count of the latest enumeration (grid sizing hint),
+                                    // [1] set by the fused block kernel when a bounded wait expired, [2] the chain is HALTED: the number of
+                                    // blocks an enumeration found beyond the capacity of the per-block buffers (hml_state.h)
+    // Block capacity of the per-block buffers (0 until the observations are loaded; T = the worst case, every position a block).
+    // Less for a context with option "max_blocks" and, by default, for a context ATTACHED to another one's observations; a sweep
+    // that needs more halts the chain on the device, and the host grows the buffers and runs the missing sweeps again
+    // (hml_settle) - `sweep_log` holds what was enqueued since the last point at which the stream was known to be idle.
+    uint64_t cap = 0;
+    uint64_t cap_opt = 0;           // option "max_blocks" / HML_MAX_BLOCKS (0: the default of the context's kind)
+    std::vector<uint8_t> sweep_log; // per enqueued sweep: bit 0 mixture, bit 1 recorded
+    unsigned long long log_base = 0;   // the model's sweep counter when the log started (= sweeps requested up to then)
+    unsigned long long requested = 0;  // sweeps requested of this chain so far (its sweep counter once everything has run)
+    uint64_t grown = 0;             // times the buffers were grown (hml_stats)
     uint32_t* d_hB = nullptr;       // device view of h_B
     uint32_t B_hint = 0;
     bool hint_stale = true;         // the hint predates the current parameters (new model, prior draw, mode switch)
@@ -156,6 +167,7 @@ struct hml_ctx {
 int hml_ctx_bind(hml_ctx* c);                         // hipSetDevice(ctx's device)
 int hml_ctx_fetch_model(hml_ctx* c, hml_model* out);  // synchronising copy of the device-resident model
 int hml_ctx_ensure_marginal_buffers(hml_ctx* c);
+int hml_settle(hml_ctx* c);                           // stream idle, no halted sweep left behind (block capacity, above)
 // marginal segments on the device: starts d_seg[M] and count differences at the starts d_g[M * K] (caller frees both)
 int hml_ctx_gather_marginal_segments(hml_ctx* c, uint64_t* M, uint32_t** d_seg, int32_t** d_g);
 

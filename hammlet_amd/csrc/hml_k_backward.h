@@ -908,6 +908,7 @@ HML_KERNEL __launch_bounds__(256) void hml_k_counts_dense(int16_t* __restrict__ 
 __device__ __forceinline__ void hml_b_record(const int16_t* __restrict__ q, const uint32_t* __restrict__ starts,
                                                     hml_model* __restrict__ mdl, int32_t* __restrict__ diff,
                                                     uint32_t* __restrict__ boundary) {
+    if (mdl->halted != 0u) return;   // (hml_state.h: the sweep did not happen)
     const uint32_t B = mdl->B;
     const uint64_t T1 = (uint64_t)mdl->T + 1u;
     const uint32_t stride = gridDim.x * blockDim.x;

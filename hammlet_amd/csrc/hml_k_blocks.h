@@ -322,6 +322,7 @@ __device__ __forceinline__ void hml_b_compact_scatter(const uint16_t* __restrict
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const uint32_t g = blockIdx.x;
     const uint32_t first = g * HML_GROUP_SPANS;
+    const uint32_t cap = mdl->cap;
     uint32_t acc = 0u;
     for (uint32_t i = threadIdx.x; i < g; i += 256u) acc += group_total[i];
     // lane l of every wavefront holds the count of span l of the group
@@ -348,14 +349,17 @@ __device__ __forceinline__ void hml_b_compact_scatter(const uint16_t* __restrict
         const bool is_last = (span == n_spans - 1u);
         const uint32_t base = span * (uint32_t)HML_SPAN;
         const uint16_t* __restrict__ in = stage + (uint64_t)base;
-        for (uint32_t i = lane; i < cnt; i += 64) starts[off + i] = base + (uint32_t)in[i];
+        for (uint32_t i = lane; i < cnt; i += 64) if (off + i < cap) starts[off + i] = base + (uint32_t)in[i];   // (cap: hml_state.h, "block capacity")
         if (is_last && lane == 0) {
             const uint32_t B = off + cnt;
-            mdl->B = B;
-            hml_warmup_for_many_blocks(mdl, B);
-            starts[B] = T;
-            // host-mapped word: lets the host size later grids without a copy in the stream
-            if (host_B) __hip_atomic_store(host_B, B, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            if (B > cap) hml_halt(mdl, B, host_B);
+            else {
+                mdl->B = B;
+                hml_warmup_for_many_blocks(mdl, B);
+                starts[B] = T;
+                // host-mapped word: lets the host size later grids without a copy in the stream
+                if (host_B) __hip_atomic_store(host_B, B, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
         }
     }
 }
@@ -436,6 +440,7 @@ HML_KERNEL __launch_bounds__(256) void hml_k_compact_scatter_bits(const unsigned
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const uint32_t g = blockIdx.x;
     const uint32_t first = g * HML_GROUP_SPANS;
+    const uint32_t cap = mdl->cap;
     uint32_t acc = 0u;
     for (uint32_t i = threadIdx.x; i < g; i += 256u) acc += group_total[i];
     const uint32_t cnt_l = ((uint32_t)lane < HML_GROUP_SPANS && first + (uint32_t)lane < n_spans) ? span_count[first + (uint32_t)lane] : 0u;
@@ -483,16 +488,19 @@ HML_KERNEL __launch_bounds__(256) void hml_k_compact_scatter_bits(const unsigned
             for (int j = 0; j < 4; ++j)
                 if ((m[j] >> lane) & 1ull) mybuf[pos++] = t0 + (uint32_t)j;
             hml_wave_lds_order();
-            for (uint32_t i = (uint32_t)lane; i < n_it; i += 64u) starts[off + running + i] = mybuf[i];
+            for (uint32_t i = (uint32_t)lane; i < n_it; i += 64u) if (off + running + i < cap) starts[off + running + i] = mybuf[i];
             hml_wave_lds_order();
             running += n_it;
         }
         if (span == n_spans - 1u && lane == 0) {
             const uint32_t B = off + cnt;
-            mdl->B = B;
-            hml_warmup_for_many_blocks(mdl, B);
-            starts[B] = T;
-            if (host_B) __hip_atomic_store(host_B, B, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            if (B > cap) hml_halt(mdl, B, host_B);
+            else {
+                mdl->B = B;
+                hml_warmup_for_many_blocks(mdl, B);
+                starts[B] = T;
+                if (host_B) __hip_atomic_store(host_B, B, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
         }
     }
 }

@@ -119,6 +119,7 @@ HML_KERNEL __launch_bounds__(HML_FUSED_WAVES * 64, 6) void hml_k_blocks_fused(co
     uint16_t* listed = listed_all[wave];
     uint16_t* masks = mask_all[wave];
     const float thr = mdl_ro->thr;
+    const uint32_t cap = mdl_ro->cap;
 
     // ---------------- phase A
     uint32_t total = 0u, last1 = 0u;
@@ -330,6 +331,7 @@ HML_KERNEL __launch_bounds__(HML_FUSED_WAVES * 64, 6) void hml_k_blocks_fused(co
                 }
             }
             gathered = false;
+            if (b > cap) continue;   // beyond the chain's block capacity (hml_state.h): the last workgroup halts the chain below
             starts[b] = t;   // (item wg_total of the last workgroup: starts[B] = T)
             if (t == 0u) continue;   // no block ends at position 0
             bstat[b - 1u] = make_float2(sx, sq);
@@ -343,6 +345,7 @@ HML_KERNEL __launch_bounds__(HML_FUSED_WAVES * 64, 6) void hml_k_blocks_fused(co
     // the block count
     if (last_wg && threadIdx.x == 0) {
         const uint32_t Bn = before_group + wg_total;
+        if (Bn > cap) { hml_halt(mdl, Bn, host_words); return; }
         mdl->B = Bn;
         hml_warmup_for_many_blocks(mdl, Bn);
         // host-mapped word: lets the host size later grids without a copy in the stream

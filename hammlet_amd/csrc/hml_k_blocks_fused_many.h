@@ -41,6 +41,7 @@ struct hml_fm_chain {
     float* em;
     float* gsc;           // nullptr: no plane of rescale factors (late_rescale)
     uint32_t* host_words;
+    hml_layout lay;       // the chain's chunk-transposed layout (its stride follows its own block capacity)
 };
 struct hml_fm_args {
     hml_fm_chain c[HML_FM_MAX_CHAINS];
@@ -107,7 +108,7 @@ __device__ __forceinline__ void hml_fm_emit(const hml_fm_params<K>& l, bool self
 template <int K>
 HML_KERNEL __launch_bounds__(HML_FUSED_WAVES * 64, HML_FM_MIN_WAVES) void hml_m_blocks_fused(const uint8_t* __restrict__ summary, const float* __restrict__ w,
                                                                              const float2* __restrict__ ia, uint32_t T, int32_t base,
-                                                                             const hml_fm_args args, int n, const hml_layout lay,
+                                                                             const hml_fm_args args, int n,
                                                                              uint32_t n_sub, uint32_t spin_limit, unsigned long long* __restrict__ dbg) {
     // dbg (HML_FUSED_DEBUG): wall-clock stamps of the workgroup's phases, 8 words per workgroup (printed by hml_sync)
     if (dbg && threadIdx.x == 0) dbg[blockIdx.x * 8 + 0] = wall_clock64();
@@ -126,6 +127,7 @@ HML_KERNEL __launch_bounds__(HML_FUSED_WAVES * 64, HML_FM_MIN_WAVES) void hml_m_
     __shared__ uint64_t sm_exp_tab[32];
     __shared__ hml_fm_params<K> sm_emit[NC];
     __shared__ int s_self[NC];
+    __shared__ uint32_t s_cap[NC];   // block capacity of the chain's buffers (hml_state.h)
     __shared__ hml_fm_chain s_ch[NC];
     if (threadIdx.x < 32u) sm_exp_tab[threadIdx.x] = HML_EXP2F_TAB[threadIdx.x];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -134,7 +136,7 @@ HML_KERNEL __launch_bounds__(HML_FUSED_WAVES * 64, HML_FM_MIN_WAVES) void hml_m_
         const hml_model* m = args.c[c].mdl;
         hml_emit_lds_fill<K>(sm_emit[c].plain, m, lane);
         hml_tr2_params_fill<K>(sm_emit[c].fast, m, lane);
-        if (lane == 0) { s_thr[c] = m->thr; s_gen[c] = hml_fused_generation(m); s_self[c] = m->self_trans; s_ch[c] = args.c[c]; }
+        if (lane == 0) { s_thr[c] = m->thr; s_gen[c] = hml_fused_generation(m); s_self[c] = m->self_trans; s_cap[c] = m->cap; s_ch[c] = args.c[c]; }
     }
     if (lane == 0) for (int c = 0; c < n; ++c) { wave_total[c][wave] = 0u; wave_last[c][wave] = 0u; }
     __syncthreads();
@@ -358,6 +360,7 @@ HML_KERNEL __launch_bounds__(HML_FUSED_WAVES * 64, HML_FM_MIN_WAVES) void hml_m_
     auto finish = [&](const item_t& it) {
         const hml_fm_chain& ch = s_ch[it.c];
         const uint32_t b = s_before[it.c] + it.k;
+        if (b > s_cap[it.c]) return;   // beyond the chain's block capacity: the chain is halted where its block count is set
         ch.starts[b] = it.t;   // (the end marker of the last workgroup: starts[B] = T)
         if (it.t == 0u) return;
         float sx, sq;
@@ -365,7 +368,7 @@ HML_KERNEL __launch_bounds__(HML_FUSED_WAVES * 64, HML_FM_MIN_WAVES) void hml_m_
         hml_tr2_stats(it.prev, it.t, make_float2(it.ax, it.ay), make_float2(it.zx, it.zy), sx, sq, inside);
         if (inside) hml_block_stats_one(ia, it.prev, it.t, sx, sq);   // a cell boundary of the integral array inside the block
         ch.bstat[b - 1u] = make_float2(sx, sq);
-        hml_fm_emit<K>(sm_emit[it.c], s_self[it.c] != 0, ch.mdl, b - 1u, sx, sq, (float)(it.t - it.prev), ch.em, ch.gsc, lay, sm_exp_tab);
+        hml_fm_emit<K>(sm_emit[it.c], s_self[it.c] != 0, ch.mdl, b - 1u, sx, sq, (float)(it.t - it.prev), ch.em, ch.gsc, ch.lay, sm_exp_tab);
     };
     // ---------------- first round: this thread's first two items - their gathers travel during the wait for the offsets
     item_t it0, it1;
@@ -433,9 +436,12 @@ HML_KERNEL __launch_bounds__(HML_FUSED_WAVES * 64, HML_FM_MIN_WAVES) void hml_m_
             // the block count
             if (last_wg) {
                 const uint32_t Bn = acc + (s_item0[c + 1] - s_item0[c] - 1u);
-                s_ch[c].mdl->B = Bn;
-                hml_warmup_for_many_blocks(s_ch[c].mdl, Bn);
-                if (s_ch[c].host_words) __hip_atomic_store(s_ch[c].host_words, Bn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                if (Bn > s_cap[c]) hml_halt(s_ch[c].mdl, Bn, s_ch[c].host_words);
+                else {
+                    s_ch[c].mdl->B = Bn;
+                    hml_warmup_for_many_blocks(s_ch[c].mdl, Bn);
+                    if (s_ch[c].host_words) __hip_atomic_store(s_ch[c].host_words, Bn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                }
             }
         }
     }

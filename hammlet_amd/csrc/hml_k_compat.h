@@ -157,6 +157,7 @@ HML_KERNEL __launch_bounds__(64) void hml_k_compat_sweep(hml_model* __restrict__
     __shared__ unsigned long long s_trans[K * K], s_occ[K], s_n[K];
     __shared__ float s_ps[K], s_pq[K], s_es[K], s_eq[K];   // KahanAggregator per state: positive sums and their error terms
     __shared__ float s_w[K], s_logA[K], s_logN[K];
+    if (mdl->halted != 0u) return;   // (hml_state.h: the sweep's blocks did not fit the chain's buffers; the host grows them and sweeps again)
     for (int i = threadIdx.x; i < HML_MT_N; i += 64) lmt[i] = mts->mt[i];
     __syncthreads();
     if (threadIdx.x != 0) return;

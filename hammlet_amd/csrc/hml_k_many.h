@@ -35,6 +35,7 @@ struct hml_chain_dev {
     double* partial;
     int32_t* diff;
     uint32_t* boundary;
+    hml_layout lay;   // the chain's own chunk-transposed layout (its stride follows ITS block capacity, hml_ctx.hpp)
 };
 
 HML_KERNEL __launch_bounds__(256) void hml_m_compact_scan_summary(const hml_chain_dev* __restrict__ cs, uint32_t T) {
@@ -46,25 +47,25 @@ HML_KERNEL __launch_bounds__(256) void hml_m_compact_scatter(const hml_chain_dev
     hml_b_compact_scatter(c.stage, c.span_count, c.coarse1, c.n_spans, T, c.mdl, c.starts, c.host_B);
 }
 template <int K>
-HML_KERNEL __launch_bounds__(256) void hml_m_stats_emission(const hml_chain_dev* __restrict__ cs, int with_gsc, const hml_layout lay) {
+HML_KERNEL __launch_bounds__(256) void hml_m_stats_emission(const hml_chain_dev* __restrict__ cs, int with_gsc) {
     const hml_chain_dev& c = cs[blockIdx.y];
-    hml_b_stats_emission<K>(c.ia, c.starts, c.mdl, c.bstat, c.em, with_gsc ? c.gsc : nullptr, nullptr, 0, lay);
+    hml_b_stats_emission<K>(c.ia, c.starts, c.mdl, c.bstat, c.em, with_gsc ? c.gsc : nullptr, nullptr, 0, c.lay);
 }
 template <int K>
-HML_KERNEL __launch_bounds__(256) void hml_m_forward(const hml_chain_dev* __restrict__ cs, int with_gsc, int L, const hml_layout lay) {
+HML_KERNEL __launch_bounds__(256) void hml_m_forward(const hml_chain_dev* __restrict__ cs, int with_gsc, int L) {
     const hml_chain_dev& c = cs[blockIdx.y];
-    hml_b_forward<K>(c.em, with_gsc ? c.gsc : nullptr, c.mdl, c.rows, nullptr, c.entry, c.exitv, c.fb, L, lay);
+    hml_b_forward<K>(c.em, with_gsc ? c.gsc : nullptr, c.mdl, c.rows, nullptr, c.entry, c.exitv, c.fb, L, c.lay);
 }
 template <int K>
-HML_KERNEL __launch_bounds__(256) void hml_m_backward_maps(const hml_chain_dev* __restrict__ cs, int with_gsc, int L, const hml_layout lay) {
+HML_KERNEL __launch_bounds__(256) void hml_m_backward_maps(const hml_chain_dev* __restrict__ cs, int with_gsc, int L) {
     const hml_chain_dev& c = cs[blockIdx.y];
-    hml_b_backward_maps2<K>(c.rows, c.mdl, c.smap, c.cmap, lay, c.entry, c.exitv, c.redo, L, with_gsc ? nullptr : c.starts, c.mdl);   // (two rows per lane)
+    hml_b_backward_maps2<K>(c.rows, c.mdl, c.smap, c.cmap, c.lay, c.entry, c.exitv, c.redo, L, with_gsc ? nullptr : c.starts, c.mdl);   // (two rows per lane)
 }
 template <int K>
-HML_KERNEL __launch_bounds__(1024) void hml_m_backward_chain(const hml_chain_dev* __restrict__ cs, int with_gsc, int L, const hml_layout lay) {
+HML_KERNEL __launch_bounds__(1024) void hml_m_backward_chain(const hml_chain_dev* __restrict__ cs, int with_gsc, int L) {
     const hml_chain_dev& c = cs[blockIdx.y];
     hml_b_backward_chain<K>(c.cmap, c.mdl, c.bentry, c.em, with_gsc ? c.gsc : nullptr, c.rows, nullptr, c.entry, c.exitv, c.fb, c.redo, c.touched,
-                            c.smap, L, lay, 3, 0, with_gsc ? nullptr : c.starts);
+                            c.smap, L, c.lay, 3, 0, with_gsc ? nullptr : c.starts);
 }
 template <int K>
 HML_KERNEL __launch_bounds__(256) void hml_m_counts(const hml_chain_dev* __restrict__ cs) {

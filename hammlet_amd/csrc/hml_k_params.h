@@ -72,6 +72,8 @@ __device__ __forceinline__ void hml_b_params(hml_model* __restrict__ mdl, const 
     __shared__ unsigned long long s_trans[K * K];
     __shared__ unsigned long long s_occ[K];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // a halted chain (the sweep's enumeration found more blocks than its buffers hold, hml_state.h): the sweep did not happen
+    if (mode == 0 && mdl->halted != 0u) return;   // workgroup-uniform, before any barrier
     if (tid == 0) mdl->dbg_t[0] = wall_clock64();
     __shared__ float s_var[K], s_logN[K];
     const int P = mdl->P, D = mdl->D;

@@ -80,6 +80,15 @@ struct hml_model {
     // ---- block structure ----
     uint32_t B;                  // number of blocks
     uint32_t n_spans;
+    // Block capacity of the chain's per-block buffers (starts, statistics, emission terms, trellis, maps, states): T for an
+    // ordinary context (the worst case: every position a block), less for a context that was given less (option "max_blocks";
+    // chains attached to another chain's observations by default: eight chains of 10^8 positions would otherwise reserve 80 GB
+    // for 2 10^5 blocks each).  An enumeration that finds MORE blocks writes nothing beyond the capacity, leaves B = 0 - every
+    // kernel of the sweep then finds nothing to do - and HALTS the chain: `halted` = the number of blocks it found; the
+    // parameter and recording kernels return at once while it is set, so the chain's state stays that of the last completed
+    // sweep.  The host grows the buffers and runs the missing sweeps again (hml_capi.hip: hml_settle) - same results.
+    uint32_t cap;
+    uint32_t halted;
     // ---- per-sweep accumulators (zeroed by the parameter kernel) ----
     unsigned long long trans[HML_CNT_SPLIT][HML_MAX_K * HML_MAX_K];
     unsigned long long occ[HML_CNT_SPLIT][HML_MAX_K];
@@ -114,6 +123,15 @@ struct hml_model {
 };
 
 #if defined(__HIPCC__)
+// the enumeration found `found` > cap blocks (host_words: the context's host-mapped words [block count, fused-kernel trouble, halted])
+__device__ __forceinline__ void hml_halt(hml_model* mdl, uint32_t found, uint32_t* host_words) {
+    mdl->B = 0u;
+    mdl->halted = found;
+    if (host_words) {
+        __hip_atomic_store(host_words, found, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);       // (the grids and buffers the next attempt needs)
+        __hip_atomic_store(host_words + 2, found, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
 // A young chain over millions of blocks (weakly compressed input: each block carries little evidence, the filter forgets
 // slowly) starts its forward pass with four times the usual warm-up instead of finding that level through repairs:
 // on C5 the first ten sweeps cost 203 ms each (3.6e5 refits) until the adaptation had raised W from 24 to 96.

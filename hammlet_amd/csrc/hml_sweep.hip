@@ -307,7 +307,6 @@ static int iterate_many_k(hml_ctx* const* cs, int n, uint64_t first, uint64_t it
     hipStream_t s = c0->stream;
     const uint32_t T = (uint32_t)c0->T;
     const int L = c0->fwdL_many;
-    const hml_layout lay = c0->lay_many;
     const int with_gsc = c0->late_rescale ? 0 : 1;
     const uint32_t n_groups = (c0->n_spans + HML_GROUP_SPANS - 1) / HML_GROUP_SPANS;
     const bool records = thinning > 0 && thinning <= iterations;
@@ -328,7 +327,7 @@ static int iterate_many_k(hml_ctx* const* cs, int n, uint64_t first, uint64_t it
         d.stage = c->d_stage; d.span_count = c->d_span_count; d.coarse1 = c->d_coarse1; d.starts = c->d_starts; d.host_B = c->d_hB;
         d.bstat = c->d_bstat; d.mdl = c->d_mdl; d.em = c->d_em; d.gsc = c->d_gsc; d.rows = c->d_rows; d.entry = c->d_entry; d.exitv = c->d_exitA;
         d.fb = c->d_fb; d.redo = c->d_redo; d.touched = c->d_touched; d.smap = c->d_smap; d.cmap = c->d_cmap; d.bentry = c->d_bentry;
-        d.q = c->d_q; d.partial = c->d_partial; d.diff = c->d_diff; d.boundary = c->d_boundary;
+        d.q = c->d_q; d.partial = c->d_partial; d.diff = c->d_diff; d.boundary = c->d_boundary; d.lay = c->lay_many;
     }
     if (c0->many_cap < n) {
         if (c0->d_many) HIPCHK(hipFree(c0->d_many));
@@ -362,12 +361,14 @@ static int iterate_many_k(hml_ctx* const* cs, int n, uint64_t first, uint64_t it
         else { fm_sub = (uint32_t)m; fm_wg = (uint32_t)((c0->T + m * HML_FUSED_SUB_POSITIONS - 1) / (m * HML_FUSED_SUB_POSITIONS)); }
     }
     for (uint64_t i = first; i < iterations; ++i) {
-        for (int k = 0; k < n; ++k) if (!many_sparse(cs[k])) { *done = i; return 0; }   // a chain left the strongly compressed regime: the caller goes on one by one
+        // a chain left the strongly compressed regime, or halted because its blocks outgrew its buffers (hml_state.h): back to the caller
+        for (int k = 0; k < n; ++k) if (!many_sparse(cs[k]) || chain_halted(cs[k])) { *done = i; return 0; }
         const bool record = thinning > 0 && ((i + 1) % thinning == 0);
         uint32_t hint = 0;
         for (int k = 0; k < n; ++k) hint = std::max(hint, cs[k]->B_hint ? cs[k]->B_hint : (uint32_t)std::min<uint64_t>(T, 1u << 20));
         const unsigned ny = (unsigned)n;
         const unsigned gB = (unsigned)grid_for(hint, 256, 64, 16384);
+        for (int k = 0; k < n; ++k) log_sweep(cs[k], HML_METHOD_FB, record);
         // (a bounded wait of the block kernel expired - somebody else is using the GPU: the scan + scatter launches from here on)
         if (fm) for (int k = 0; k < n; ++k) if (cs[k]->h_B[1] && !cs[k]->fused_keep) fm = false;
         if (fm) {
@@ -379,21 +380,21 @@ static int iterate_many_k(hml_ctx* const* cs, int n, uint64_t first, uint64_t it
                     hml_ctx* c = cs[k0 + k];
                     hml_fm_chain& f = fa.c[k];
                     f.mdl = c->d_mdl; f.group_word = c->d_group_word; f.stage = c->d_stage; f.starts = c->d_starts; f.bstat = c->d_bstat;
-                    f.em = c->d_em; f.gsc = with_gsc ? c->d_gsc : nullptr; f.host_words = c->d_hB;
+                    f.em = c->d_em; f.gsc = with_gsc ? c->d_gsc : nullptr; f.host_words = c->d_hB; f.lay = c->lay_many;
                 }
                 hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_m_blocks_fused<KK>), dim3(fm_wg), dim3(HML_FUSED_WAVES * 64), 0, s, c0->d_summary, c0->d_w, c0->d_ia,
-                                   T, c0->key_base, fa, nk, lay, fm_sub, c0->fused_spin_limit, c0->d_dbg);
+                                   T, c0->key_base, fa, nk, fm_sub, c0->fused_spin_limit, c0->d_dbg);
             }
         } else {
             hipLaunchKernelGGL(hml_m_compact_scan_summary, dim3(n_groups, ny), dim3(256), 0, s, d_cs, T);
             hipLaunchKernelGGL(hml_m_compact_scatter, dim3(n_groups, ny), dim3(256), 0, s, d_cs, T);
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_m_stats_emission<KK>), dim3(gB, ny), dim3(256), 0, s, d_cs, with_gsc, lay);
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_m_stats_emission<KK>), dim3(gB, ny), dim3(256), 0, s, d_cs, with_gsc);
         }
         const uint64_t chunks = ((uint64_t)hint + L - 1) / L;
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_m_forward<KK>), dim3((unsigned)grid_for(chunks, 256, 16, 1 << 20), ny), dim3(256), 0, s, d_cs, with_gsc, L, lay);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_m_forward<KK>), dim3((unsigned)grid_for(chunks, 256, 16, 1 << 20), ny), dim3(256), 0, s, d_cs, with_gsc, L);
         const uint64_t bch = ((uint64_t)hint + HML_BWD_CHUNK - 1) / HML_BWD_CHUNK;
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_m_backward_maps<KK>), dim3((unsigned)grid_for((bch + 1) / 2 * 64, 256, 16, 1 << 18), ny), dim3(256), 0, s, d_cs, with_gsc, L, lay);   // (a wavefront per two chunks)
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_m_backward_chain<KK>), dim3(1, ny), dim3(1024), 0, s, d_cs, with_gsc, L, lay);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_m_backward_maps<KK>), dim3((unsigned)grid_for((bch + 1) / 2 * 64, 256, 16, 1 << 18), ny), dim3(256), 0, s, d_cs, with_gsc, L);   // (a wavefront per two chunks)
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_m_backward_chain<KK>), dim3(1, ny), dim3(1024), 0, s, d_cs, with_gsc, L);
         hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_m_counts<KK>), dim3(HML_REDUCE_GROUPS, ny), dim3(256), 0, s, d_cs);
         if (record && rec_mask) hipLaunchKernelGGL(hml_m_record, dim3(gB, ny), dim3(256), 0, s, d_cs, rec_mask);
         hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_m_params<KK>), dim3(1, ny), dim3(1024), 0, s, d_cs);
@@ -405,7 +406,7 @@ static int iterate_many_k(hml_ctx* const* cs, int n, uint64_t first, uint64_t it
                 HIPCHK(hipStreamSynchronize(s));
                 for (int k = 0; k < n; ++k) {
                     if (int r = check_device_error(cs[k])) return r;
-                    if (cs[k]->cb) cs[k]->cb(cs[k], i, cs[k]->cb_user);
+                    if (cs[k]->cb && !chain_halted(cs[k])) cs[k]->cb(cs[k], i, cs[k]->cb_user);   // (a halted chain calls back when it catches up: hml_settle)
                 }
             }
         }

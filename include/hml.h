@@ -154,6 +154,12 @@ int hml_set_recording(hml_ctx* ctx, int marginals, hml_record_cb cb, void* user)
  * below 24 positions per block stream the floats instead); 2: the summary at any compression; 0: always stream all T
  * float weights.  Same block structures every way (exact). */
 int hml_set_option(hml_ctx* ctx, const char* name, int value);
+/* "max_blocks" (before the observations are loaded; univariate models): the BLOCK CAPACITY of the context's per-block buffers
+ * (block starts, statistics, emission terms, trellis rows, maps, states) - by default T, the worst case of every position a
+ * block (about 100 bytes per position: 10 GB at 10^8 positions and 5 states), and max(2^20, T / 16) for a context attached
+ * to another one's observations (hml_attach_observations).  A sweep whose enumeration finds more blocks writes nothing beyond
+ * the capacity and halts the chain on the device; the host then allocates larger buffers and runs the missing sweeps again,
+ * with the same results (hml_stats.buffer_growths counts how often).  0: the default.  Environment: HML_MAX_BLOCKS. */
 /* "fused_blocks" (any time), 1 (default): dynamic sweeps take the fused block kernel (block scan + block statistics +
  * emission terms in one launch; its workgroups hand block offsets to each other inside the launch, with a bounded
  * wait: when the GPU is shared and a wait expires the waiting workgroup computes the missing word itself, and the chain
@@ -288,6 +294,8 @@ typedef struct {
     uint64_t forward_serial;    /* chunks finished by the sequential fallback              */
     uint64_t forward_warmup;     /* current (adaptive) warm-up length of the speculative forward pass */
     uint64_t fused_fallbacks;    /* tile words of the fused block kernel computed by a waiting workgroup (bounded wait expired) */
+    uint64_t buffer_growths;     /* times the per-block buffers were grown (option "max_blocks", attached contexts) */
+    uint64_t block_capacity;     /* blocks per sweep the per-block buffers hold at present */
 } hml_stats;
 int hml_get_stats(hml_ctx* ctx, hml_stats* out);
 

@@ -12,3 +12,12 @@ pytestmark = pytest.mark.gpu
 
 def test_bounded_fuzz_against_the_checker(hml):
     assert fuzz(hml, 300, 20261004) == 300
+
+
+def test_bounded_fuzz_with_a_tiny_block_capacity(hml, monkeypatch):
+    """The same differential run with every chain's per-block buffers sized for 64 blocks (HML_MAX_BLOCKS): enumerations that
+    find more halt the chain on the device, the host grows the buffers and runs the skipped sweeps again (hml_settle) -
+    at every kind of call (auto prior, explicit thresholds, static structures, prior draws, mixture / FB sweeps, both forward
+    geometries) the results must be those of a chain with room from the start, i.e. the checker's."""
+    monkeypatch.setenv("HML_MAX_BLOCKS", "64")
+    assert fuzz(hml, 150, 4) == 150

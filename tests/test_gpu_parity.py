@@ -524,6 +524,81 @@ def test_attached_chains_batched_through_the_many_chain_block_kernel(hml, monkey
         g.close()
 
 
+@pytest.mark.parametrize("n_chains,attached", [(1, False), (4, False), (5, True)])
+def test_block_capacity_grows_without_changing_the_chain(hml, n_chains, attached):
+    """Option max_blocks (hml_state.h "block capacity"): per-block buffers for 64 blocks where the sweeps need hundreds and,
+    after a prior re-draw, thousands.  The enumeration that finds more blocks than fit halts the chain on the device; the host
+    allocates larger buffers and runs the skipped sweeps again - alone (hml_iterate), batched (hml_iterate_many: the other
+    chains of the batch go on meanwhile) and batched over a shared construction - and every chain stays, bit for bit, the
+    chain the checker runs; recorded sweeps and their callbacks keep their order."""
+    K, T = 5, 300_000
+    x = ol.trace(T, K, 12)
+    pairs, seen = [], []
+    for chain in range(n_chains):
+        o = ol.OracleChain(K=K, seed=9, chain=chain, rng=ol.RNG_CTR, math=ol.MATH_DEV, reduce=ol.REDUCE_DEV)
+        o.load(x)
+        g = hml.Chain(device=0, seed=9, chain_id=chain)
+        g.set_option("max_blocks", 64)
+        if attached and chain > 0:
+            g.attach(pairs[0][1])
+        else:
+            g.load(x)
+        setup_model(o, g, K)
+        o.token("F")
+        g.sample_prior()
+        o.set_record(marginals=True)
+        seen.append([])
+        g.set_recording(marginals=True, callback=(lambda ch, sweep, log=seen[-1]: log.append(int(ch.stats()["sweeps"]))))
+        pairs.append((o, g))
+    gs = [g for _, g in pairs]
+    recorded = 0
+    for method, iters, thin in (("F", 14, 0), ("F", 8, 4), ("P", 0, 0), ("F", 9, 3), ("M", 3, 1), ("F", 4, 1)):
+        if method == "P":
+            for o, g in pairs:
+                o.token("P")
+                o.token("F")
+                g.sample_prior()
+            continue
+        for o, _ in pairs:
+            o.iterate(method, iters, thin)
+        if n_chains == 1:
+            gs[0].iterate(method, iters, thin)
+        else:
+            hml.iterate_many(gs, method, iters, thin)
+        recorded += iters // thin if thin else 0
+        for chain, (o, g) in enumerate(pairs):
+            g.sync()
+            compare_state(o, g, what="chain %d" % chain)
+    for (o, g), log in zip(pairs, seen):
+        st = g.stats()
+        assert st["sweeps"] == 14 + 8 + 9 + 3 + 4 and st["buffer_growths"] >= 2 and 64 < st["block_capacity"] < T
+        seg, cnt = g.marginals_rle()
+        assert hml.marginals_text(seg, cnt) == o.text("marginals")
+        # one callback per recorded sweep, in order, each after exactly the sweeps before it
+        assert log == [14 + 4, 14 + 8, 22 + 3, 22 + 6, 22 + 9, 32, 33, 34, 35, 36, 37, 38], log
+    for g in gs:
+        g.close()
+
+
+def test_attached_chains_start_with_a_reduced_block_capacity(hml):
+    """a context attached to another one's observations reserves room for max(2^20, T / 16) blocks per sweep instead of T - and
+    the source, like every ordinary context, for the worst case"""
+    T = 20_000_000
+    x = ol.trace(T, 3, 2)
+    a = hml.Chain(device=0, seed=1)
+    a.load(x)
+    a.set_model(3, a.autoprior())
+    b = hml.Chain(device=0, seed=1, chain_id=1)
+    b.attach(a)
+    b.set_model(3, b.autoprior())
+    assert a.stats()["block_capacity"] == T and b.stats()["block_capacity"] == max(1 << 20, T // 16)
+    a.sample_prior(); b.sample_prior()
+    hml.iterate_many([a, b], "F", 5, 0)
+    a.sync(); b.sync()
+    assert b.stats()["buffer_growths"] == 0 and b.stats()["sweeps"] == 5
+    a.close(); b.close()
+
+
 def test_attach_observations_argument_checks(hml):
     x = ol.trace(20_000, 3, 1)
     a = hml.Chain(device=0, seed=1)
