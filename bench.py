@@ -40,9 +40,10 @@ PMC_FILES = {"c3_1e8_k5_dynamic": PMC_FILE, "c3u": "profiles/round4_pmc_hbm_traf
              "c5_2.5e8_depth_k5": "profiles/round4_pmc_hbm_traffic_c5.json", "c4_1e8_k10": "profiles/round4_pmc_hbm_traffic_c4.json"}
 DENSE_KERNEL = "hml_k_trellis_rows"   # first pass over the trellis of a weakly compressed sweep (hml_k_trellis_rows.h)
 MIN_BRACKETS = 32                     # launches of the roofline kernel that are bracketed by events, whatever --steps is
-LEG_MIN_STEPS = 200                   # every auxiliary leg times at least this many sweeps, whatever --steps is (the headline keeps
+LEG_MIN_STEPS = 1000                  # every auxiliary leg times at least this many sweeps, whatever --steps is (the headline keeps
                                       # the driver's --steps): a 20-sweep leg is a 1-2 ms region in which thread start-up and the first
-                                      # launches dominate (round 3's driver line showed three chains at 0.4x one chain that way)
+                                      # launches dominate (round 3's driver line showed three chains at 0.4x one chain that way), and
+                                      # with 200 the threaded chain legs still read 20-40 % low (18 ms regions); 1000 sweeps cost < 0.2 s a leg
 
 
 def family_kernels(K):
@@ -490,6 +491,7 @@ def main():
                                "note": "sweeps 64..1064 of the headline's chain: the settled rate (the headline at the driver's --steps 20 --warmup 5 "
                                        "times sweeps 5..25 of a fresh chain)"}
         ch.set_recording(marginals=True)
+        ch.iterate("F", 10, 10)   # (the first recorded sweep allocates and clears the marginals' difference arrays - 2 GB, 45 ms: outside the timed region)
         ch.sync()
         r0 = ch.stats()
         barrier()

@@ -5,7 +5,7 @@
 #   3. two separate --pmc passes (FETCH_SIZE, WRITE_SIZE) of the compressed legs, and of the dense regime (tools/time_dense.py c3u)
 # Everything lands under gpurun_out/<tag>/; tools/pmc_summary.py + tools/kstats.py turn it into the files kept in profiles/.
 set -e
-TAG=${1:-r3}
+TAG=${1:-r4}
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/$TAG
 if [ "${2:-all}" != "2" ]; then rm -rf $O; fi
@@ -17,17 +17,20 @@ PART=${2:-all}
 if [ "$PART" != "2" ]; then
 echo "== bench (driver settings)"; python3 $R/bench.py --steps 20 --warmup 5 > $O/bench_driver.json 2> $O/bench_driver.err
 echo "== bench (defaults)";        python3 $R/bench.py > $O/bench_default.json 2> $O/bench_default.err
-echo "== kernel stats";  rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o run -- python3 $R/bench.py --no-cpu-baseline > $O/bench_under_rocprof.json 2> $O/stats.err
-echo "== pmc fetch";     rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o run -- python3 $R/bench.py --steps 200 --warmup 50 --no-cpu-baseline --no-uncompressed-leg > $O/pmc_fetch.json 2> $O/pmc_fetch.err
-echo "== pmc write";     rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o run -- python3 $R/bench.py --steps 200 --warmup 50 --no-cpu-baseline --no-uncompressed-leg > $O/pmc_write.json 2> $O/pmc_write.err
+echo "== kernel stats";  rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o run -- python3 $R/bench.py --no-cpu-baseline --no-config-legs > $O/bench_under_rocprof.json 2> $O/stats.err
+echo "== pmc fetch";     rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o run -- python3 $R/bench.py --steps 200 --warmup 50 --no-cpu-baseline --no-uncompressed-leg --no-config-legs > $O/pmc_fetch.json 2> $O/pmc_fetch.err
+echo "== pmc write";     rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o run -- python3 $R/bench.py --steps 200 --warmup 50 --no-cpu-baseline --no-uncompressed-leg --no-config-legs > $O/pmc_write.json 2> $O/pmc_write.err
+echo "== c4 pmc fetch";  rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/c4_fetch -o run -- python3 $R/bench.py --workload c4_1e8_k10 --steps 200 --warmup 64 --no-cpu-baseline --no-stream-leg --no-two-chain-leg > $O/c4_fetch.json 2> $O/c4_fetch.err
+echo "== c4 pmc write";  rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/c4_write -o run -- python3 $R/bench.py --workload c4_1e8_k10 --steps 200 --warmup 64 --no-cpu-baseline --no-stream-leg --no-two-chain-leg > $O/c4_write.json 2> $O/c4_write.err
 fi
 if [ "$PART" = "1" ]; then
 cd $R
-python3 tools/pmc_summary.py $O/pmc_fetch $O/pmc_write $O/pmc_hbm_traffic.json "rocprofv3 --pmc <COUNTER> --output-format csv -- python3 bench.py --steps 200 --warmup 50 --no-cpu-baseline --no-uncompressed-leg" > /dev/null
+python3 tools/pmc_summary.py $O/pmc_fetch $O/pmc_write $O/pmc_hbm_traffic.json "rocprofv3 --pmc <COUNTER> --output-format csv -- python3 bench.py --steps 200 --warmup 50 --no-cpu-baseline --no-uncompressed-leg --no-config-legs" > /dev/null
+python3 tools/pmc_summary.py $O/c4_fetch $O/c4_write $O/pmc_hbm_traffic_c4.json "rocprofv3 --pmc <COUNTER> --output-format csv -- python3 bench.py --workload c4_1e8_k10 --steps 200 --warmup 64 --no-cpu-baseline --no-stream-leg --no-two-chain-leg" > /dev/null
 python3 tools/kstats.py $O/stats > $O/kernel_stats_c3_bench.txt
 find $O/stats -name '*kernel_stats.csv' -exec cp {} $O/stats_kernel_stats.csv \;
 rm -rf $O/stats
-find $O/pmc_fetch $O/pmc_write -name '*.csv' -size +8M -delete
+find $O/pmc_fetch $O/pmc_write $O/c4_fetch $O/c4_write -name '*.csv' -size +8M -delete
 cat $O/bench_driver.json; head -14 $O/kernel_stats_c3_bench.txt 2>/dev/null || true
 exit 0
 fi
