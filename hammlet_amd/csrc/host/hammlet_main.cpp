@@ -99,9 +99,17 @@ public:
         mCv.wait(lock, [&] { return mReleased; });
         return mOk;
     }
-    void abandon() {
+    // a host thread that drives several chains: all of them arrive, one wait
+    bool arrive(const vector<int>& indices, const vector<hml_ctx*>& ctxs) {
+        std::unique_lock<std::mutex> lock(mMutex);
+        for (size_t k = 0; k < indices.size(); ++k) mCtx[indices[k]] = ctxs[k];
+        mCv.notify_all();
+        mCv.wait(lock, [&] { return mReleased; });
+        return mOk;
+    }
+    void abandon(int n = 1) {
         std::lock_guard<std::mutex> lock(mMutex);
-        ++mAbandoned;
+        mAbandoned += n;
         mCv.notify_all();
     }
     // main side
@@ -121,150 +129,153 @@ public:
     }
 };
 
-// Chains of `-chains N` that share a GPU share the construction of the observations (weights, summary, integral arrays -
-// hml_attach_observations): the first chain of a device builds it and applies the weight multiplier, the others attach to
-// it, and the builder goes on only when all of them have (its context must be alive while they attach).
-class DeviceTraces {
-    std::mutex mMutex;
-    std::condition_variable mCv;
-    std::map<int, hml_ctx*> mSource;
-    std::map<int, int> mPending;
-    std::map<int, bool> mFailed;
-
-public:
-    void expect(int device) { ++mPending[device]; }   // (before the threads start)
-    void publish(int device, hml_ctx* ctx) {
-        std::unique_lock<std::mutex> lock(mMutex);
-        mSource[device] = ctx;
-        mCv.notify_all();
-        mCv.wait(lock, [&] { return mPending[device] <= 0; });
-    }
-    void fail(int device) {
-        std::lock_guard<std::mutex> lock(mMutex);
-        mFailed[device] = true;
-        mCv.notify_all();
-    }
-    hml_ctx* waitForSource(int device) {
-        std::unique_lock<std::mutex> lock(mMutex);
-        mCv.wait(lock, [&] { return mSource.count(device) != 0 || mFailed[device]; });
-        if (!mSource.count(device)) throw std::runtime_error("The chain that loads the observations on this device failed!");
-        return mSource[device];
-    }
-    void attached(int device) {
-        std::lock_guard<std::mutex> lock(mMutex);
-        --mPending[device];
-        mCv.notify_all();
-    }
-};
-
 // One chain from its device context to its output files.  `index` > 0 (chains of `-chains N` beyond the first): the
 // per-sweep side files carry the infix "chainK." and the (pooled) marginals are left to chain 0.
-// `traces` (chains sharing GPUs): `builds` = this chain builds its device's construction, else it attaches to it.
-static void runChain(const Job& job, vector<real_t>& inputValues, bool steal, int device, uint32_t chainId, int index, bool verbose,
-                     Rendezvous* rendezvous, DeviceTraces* traces = nullptr, bool builds = true) {
-    // an attaching chain reports to the builder of its device whatever happens to it (the builder waits for all of them)
-    struct Attaching {
-        DeviceTraces* t; int d; bool open;
-        void close() { if (open) { open = false; t->attached(d); } }
-        ~Attaching() { close(); }
-    } attaching{traces, device, traces != nullptr && !builds};
-    inputDevice() = device;
-    rng_t RNG(job.seed, device, chainId);
-    Transitions<DirichletVector> A(job.nrStates, RNG);
-    Initial<Dirichlet> pi(job.nrStates, RNG);
-    TransitionHyperParam<DirichletParamVector> tau_A(job.nrStates, job.trans, job.selfTrans);
-    InitialHyperParam<DirichletParam> tau_pi(job.nrStates, job.initialAlpha);
-    Mapping mapping(job.nrDataDim, job.thetaParams.size(), combinations);
-
-    const string prefix = index == 0 ? job.opref : job.opref + "chain" + std::to_string(index) + ".";
-    Records records(job.T, prefix, job.osuff, job.nrStates);
-    auto wants = [&](const char* o) { return job.outputs.at(o); };
-    records.setRecordStateSequence(wants("sequences"), job.overwrite);
-    records.setRecordTheta(wants("parameters"), job.overwrite);
-    records.setRecordBlocks(wants("blocks"), job.overwrite);
-    records.setRecordCompression(wants("compression"), job.overwrite);
-    records.setRecordSegments(wants("segments"), job.overwrite);
-    if (index == 0) {
-        records.setRecordMarginals(wants("marginals"), job.overwrite);
-        records.setRecordMaxSegmentation(wants("maxsegmentation"), job.overwrite);
-    } else {
-        records.setRecordMarginals(false);
-        records.setAccumulateMarginals(wants("marginals") || wants("maxsegmentation"));   // for the pool
-    }
-
-    typedef Statistics<IntegralArray, Normal> S;
-    typedef Blocks<BreakpointArray> B;
-    // upload + maxlet transform + weights + integral array (GPU); a lone chain takes the vector, several share it
-    std::unique_ptr<S> iaHolder;
-    if (traces && !builds) {
-        iaHolder.reset(new S(traces->waitForSource(device), job.T, job.nrDataDim, S::attachInput));
-        attaching.close();
-    } else {
-        try {
-            iaHolder.reset(steal ? new S(inputValues, job.nrDataDim) : new S(static_cast<const vector<real_t>&>(inputValues), job.nrDataDim, S::keepInput));
-        } catch (...) {
-            if (traces) traces->fail(device);
-            throw;
-        }
-    }
-    S& ia = *iaHolder;
-    B waveletBlocks(ia);
-    if (!(traces && !builds)) {
-        try {
-            if (job.weightMultiplier != 1) waveletBlocks.scaleWeights(job.weightMultiplier);   // (the attached chains find the weights scaled)
-        } catch (...) {
-            if (traces) traces->fail(device);
-            throw;
-        }
-        if (traces) traces->publish(device, RNG.ctx());
-    }
-    Emissions<S, B> y(ia, waveletBlocks);
-    records.attach(y.ctx());
-
-    vector<vector<real_t>> thetaParams = job.thetaParams;
-    const double stdEstimate = ia.noiseEstimate();
-    thetaParams[0] = autoPrior(thetaParams[0][0], thetaParams[0][1], y, stdEstimate);
-    for (auto& p : thetaParams) p = thetaParams[0];
-    ThetaHyperParam<NormalInverseGammaParam> tau_theta(thetaParams);
-    Theta<NormalInverseGamma> theta(tau_theta, tau_A, tau_pi, job.useSelfTrans, RNG);
-
-    // the scheme (reference main.cpp:383-452): a pending prior draw happens when the next token starts, whatever it is
+// `source` (chains sharing a GPU): the context whose construction this chain attaches to (nullptr: it builds its own).
+typedef Statistics<IntegralArray, Normal> StatsT;
+typedef Blocks<BreakpointArray> BlocksT;
+struct ChainRun {
+    const Job& job;
+    int index;
+    bool verbose;
+    rng_t RNG;
+    Transitions<DirichletVector> A;
+    Initial<Dirichlet> pi;
+    TransitionHyperParam<DirichletParamVector> tau_A;
+    InitialHyperParam<DirichletParam> tau_pi;
+    Mapping mapping;
+    Records records;
+    std::unique_ptr<StatsT> ia;
+    std::unique_ptr<BlocksT> waveletBlocks;
+    std::unique_ptr<Emissions<StatsT, BlocksT>> y;
+    std::unique_ptr<ThetaHyperParam<NormalInverseGammaParam>> tau_theta;
+    std::unique_ptr<Theta<NormalInverseGamma>> theta;
     bool samplePrior = true, dynamic = true;
-    if (verbose) cout << "Setting block structure to dynamic" << endl << flush;
-    for (const Step& st : job.scheme) {
+
+    ChainRun(const Job& job_, vector<real_t>& inputValues, bool steal, int device, uint32_t chainId, int index_, bool verbose_, hml_ctx* source)
+        : job(job_), index(index_), verbose(verbose_), RNG((inputDevice() = device, job_.seed), device, chainId), A(job_.nrStates, RNG), pi(job_.nrStates, RNG),
+          tau_A(job_.nrStates, job_.trans, job_.selfTrans), tau_pi(job_.nrStates, job_.initialAlpha),
+          mapping(job_.nrDataDim, job_.thetaParams.size(), combinations),
+          records(job_.T, index_ == 0 ? job_.opref : job_.opref + "chain" + std::to_string(index_) + ".", job_.osuff, job_.nrStates) {
+        auto wants = [&](const char* o) { return job.outputs.at(o); };
+        records.setRecordStateSequence(wants("sequences"), job.overwrite);
+        records.setRecordTheta(wants("parameters"), job.overwrite);
+        records.setRecordBlocks(wants("blocks"), job.overwrite);
+        records.setRecordCompression(wants("compression"), job.overwrite);
+        records.setRecordSegments(wants("segments"), job.overwrite);
+        if (index == 0) {
+            records.setRecordMarginals(wants("marginals"), job.overwrite);
+            records.setRecordMaxSegmentation(wants("maxsegmentation"), job.overwrite);
+        } else {
+            records.setRecordMarginals(false);
+            records.setAccumulateMarginals(wants("marginals") || wants("maxsegmentation"));   // for the pool
+        }
+        // upload + maxlet transform + weights + integral array (GPU); a lone chain takes the vector, several share it - and
+        // chains that share a GPU share the construction itself
+        if (source) ia.reset(new StatsT(source, job.T, job.nrDataDim, StatsT::attachInput));
+        else ia.reset(steal ? new StatsT(inputValues, job.nrDataDim) : new StatsT(static_cast<const vector<real_t>&>(inputValues), job.nrDataDim, StatsT::keepInput));
+        waveletBlocks.reset(new BlocksT(*ia));
+        if (!source && job.weightMultiplier != 1) waveletBlocks->scaleWeights(job.weightMultiplier);   // (attached chains find the weights scaled)
+    }
+    // the rest of the set-up (after the construction is complete: an attaching chain may read it from now on)
+    void model() {
+        y.reset(new Emissions<StatsT, BlocksT>(*ia, *waveletBlocks));
+        records.attach(y->ctx());
+        vector<vector<real_t>> thetaParams = job.thetaParams;
+        const double stdEstimate = ia->noiseEstimate();
+        thetaParams[0] = autoPrior(thetaParams[0][0], thetaParams[0][1], *y, stdEstimate);
+        for (auto& p : thetaParams) p = thetaParams[0];
+        tau_theta.reset(new ThetaHyperParam<NormalInverseGammaParam>(thetaParams));
+        theta.reset(new Theta<NormalInverseGamma>(*tau_theta, tau_A, tau_pi, job.useSelfTrans, RNG));
+        if (verbose) cout << "Setting block structure to dynamic" << endl << flush;
+    }
+    // a token of the scheme up to (not including) the sweeps of "F" / "M" (reference main.cpp:383-452): a pending prior draw
+    // happens when the next token starts, whatever it is.  Returns true when sweeps are to follow.
+    bool token(const Step& st) {
         if (samplePrior) {
             if (verbose) cout << "Sampling prior" << endl << flush;
             hml_check(hml_sample_prior(RNG.ctx()));
             samplePrior = false;
         }
-        if (st.method == "P") { samplePrior = true; continue; }
+        if (st.method == "P") { samplePrior = true; return false; }
         if (st.method == "S") {
             if (verbose) cout << "Setting block structure to static" << endl << flush;
-            y.createBlocks(theta);
+            y->createBlocks(*theta);
             dynamic = false;
-            continue;
+            return false;
         }
         if (st.method == "D") {
             if (verbose) cout << "Setting block structure to dynamic" << endl << flush;
             dynamic = true;   // (sampleHMM switches the device back to per-sweep recompression)
-            continue;
+            return false;
         }
         if (st.incomplete) throw std::runtime_error("Incomplete command line for -i!");
+        if (st.method != "F" && st.method != "M") throw std::runtime_error("Unknown sampling type " + st.method + "!");
+        if (verbose) cout << (st.method == "F" ? "Sampling Forward-Backward" : "Sampling mixture") << endl << flush;
+        return true;
+    }
+    void sweeps(const Step& st) {
         if (st.method == "F") {
-            if (verbose) cout << "Sampling Forward-Backward" << endl << flush;
             StateSequence<ForwardBackward> q(RNG);
-            sampleHMM(y, q, theta, tau_theta, A, tau_A, pi, tau_pi, mapping, st.iterations, st.thinning, records, dynamic, job.useSelfTrans);
-        } else if (st.method == "M") {
-            if (verbose) cout << "Sampling mixture" << endl << flush;
-            StateSequence<Mixture> q(RNG);
-            sampleHMM(y, q, theta, tau_theta, A, tau_A, pi, tau_pi, mapping, st.iterations, st.thinning, records, dynamic, job.useSelfTrans);
+            sampleHMM(*y, q, *theta, *tau_theta, A, tau_A, pi, tau_pi, mapping, st.iterations, st.thinning, records, dynamic, job.useSelfTrans);
         } else {
-            throw std::runtime_error("Unknown sampling type " + st.method + "!");
+            StateSequence<Mixture> q(RNG);
+            sampleHMM(*y, q, *theta, *tau_theta, A, tau_A, pi, tau_pi, mapping, st.iterations, st.thinning, records, dynamic, job.useSelfTrans);
         }
     }
-    hml_check(hml_sync(RNG.ctx()));
-    if (rendezvous && !rendezvous->arrive(index, RNG.ctx())) records.discardMarginals();   // pooling failed elsewhere
-    records.close();
+};
+
+static void runChain(const Job& job, vector<real_t>& inputValues, bool steal, int device, uint32_t chainId, int index, bool verbose,
+                     Rendezvous* rendezvous) {
+    ChainRun run(job, inputValues, steal, device, chainId, index, verbose, nullptr);
+    run.model();
+    for (const Step& st : job.scheme)
+        if (run.token(st)) run.sweeps(st);
+    hml_check(hml_sync(run.RNG.ctx()));
+    if (rendezvous && !rendezvous->arrive(index, run.RNG.ctx())) run.records.discardMarginals();   // pooling failed elsewhere
+    run.records.close();
+}
+
+// The chains of `-chains N` that share ONE GPU, driven by one host thread in lockstep: the first builds the construction of the
+// observations, the others attach to it (hml_attach_observations), and the sweeps of a scheme token run through
+// hml_iterate_many - one set of launches for all of them where they are batched (include/hml.h).  Same files per chain as
+// chain by chain.  indices[k] = the chain's index in the run (its Philox sub-key is `chain` + index).
+static void runDeviceGroup(const Job& job, vector<real_t>& inputValues, int device, uint32_t chain, const vector<int>& indices, bool verbose,
+                           Rendezvous* rendezvous) {
+    vector<std::unique_ptr<ChainRun>> runs;
+    for (size_t k = 0; k < indices.size(); ++k) {
+        runs.emplace_back(new ChainRun(job, inputValues, /*steal*/ false, device, chain + (uint32_t)indices[k], indices[k], verbose && indices[k] == 0,
+                                       k == 0 ? nullptr : runs[0]->RNG.ctx()));
+        runs.back()->model();
+    }
+    for (const Step& st : job.scheme) {
+        bool sweeps = false;
+        for (auto& r : runs) sweeps = r->token(st) || sweeps;
+        if (!sweeps) continue;
+        const size_t n = runs.size();
+        vector<Emissions<StatsT, BlocksT>*> ys(n);
+        vector<Theta<NormalInverseGamma>*> thetas(n);
+        vector<TransitionHyperParam<DirichletParamVector>*> tauAs(n);
+        vector<InitialHyperParam<DirichletParam>*> tauPis(n);
+        vector<Records*> recs(n);
+        for (size_t k = 0; k < n; ++k) { ys[k] = runs[k]->y.get(); thetas[k] = runs[k]->theta.get(); tauAs[k] = &runs[k]->tau_A; tauPis[k] = &runs[k]->tau_pi; recs[k] = &runs[k]->records; }
+        const bool dynamic = runs[0]->dynamic;
+        if (st.method == "F") {
+            vector<std::unique_ptr<StateSequence<ForwardBackward>>> qs;
+            vector<StateSequence<ForwardBackward>*> qp(n);
+            for (size_t k = 0; k < n; ++k) { qs.emplace_back(new StateSequence<ForwardBackward>(runs[k]->RNG)); qp[k] = qs.back().get(); }
+            sampleHMMMany(ys, qp, thetas, tauAs, tauPis, st.iterations, st.thinning, recs, dynamic, job.useSelfTrans);
+        } else {
+            vector<std::unique_ptr<StateSequence<Mixture>>> qs;
+            vector<StateSequence<Mixture>*> qp(n);
+            for (size_t k = 0; k < n; ++k) { qs.emplace_back(new StateSequence<Mixture>(runs[k]->RNG)); qp[k] = qs.back().get(); }
+            sampleHMMMany(ys, qp, thetas, tauAs, tauPis, st.iterations, st.thinning, recs, dynamic, job.useSelfTrans);
+        }
+    }
+    vector<hml_ctx*> ctxs;
+    for (auto& r : runs) { hml_check(hml_sync(r->RNG.ctx())); ctxs.push_back(r->RNG.ctx()); }
+    const bool pooled = !rendezvous || rendezvous->arrive(indices, ctxs);
+    for (auto& r : runs) { if (!pooled) r->records.discardMarginals(); r->records.close(); }
 }
 
 int main(int argc, const char* argv[]) {
@@ -455,19 +466,27 @@ int main(int argc, const char* argv[]) {
             int nDev = 1;
             hml_check(hml_device_count(&nDev));
             Rendezvous rv(nrChains);
-            DeviceTraces traces;   // chains beyond the first of a device attach to its construction
-            for (int k = nDev; k < nrChains; ++k) traces.expect((device + k) % nDev);
+            // chain k lives on GPU (device + k) mod #GPUs; the chains of one GPU are driven by ONE host thread in lockstep and
+            // share the construction of the observations
+            std::map<int, vector<int>> byDevice;
+            for (int k = 0; k < nrChains; ++k) byDevice[(device + k) % nDev].push_back(k);
             vector<std::thread> threads;
-            vector<std::exception_ptr> errors(nrChains);
-            for (int k = 0; k < nrChains; ++k)
-                threads.emplace_back([&, k] {
+            vector<std::exception_ptr> errors(byDevice.size());
+            size_t gi = 0;
+            for (auto& kv : byDevice) {
+                const int dev = kv.first;
+                const vector<int> idx = kv.second;
+                const size_t slot = gi++;
+                threads.emplace_back([&, dev, idx, slot] {
                     try {
-                        runChain(job, inputValues, /*steal*/ false, (device + k) % nDev, chain + (uint32_t)k, k, verbose && k == 0, &rv, &traces, /*builds*/ k < nDev);
+                        if (idx.size() == 1) runChain(job, inputValues, /*steal*/ false, dev, chain + (uint32_t)idx[0], idx[0], verbose && idx[0] == 0, &rv);
+                        else runDeviceGroup(job, inputValues, dev, chain, idx, verbose, &rv);
                     } catch (...) {
-                        errors[k] = std::current_exception();
-                        rv.abandon();
+                        errors[slot] = std::current_exception();
+                        rv.abandon((int)idx.size());
                     }
                 });
+            }
             // all chains have sampled (or one has failed): pool, then let them write their files
             vector<hml_ctx*> ctxs = rv.waitForAll();
             std::exception_ptr poolError;

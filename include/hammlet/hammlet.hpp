@@ -677,5 +677,49 @@ void sampleHMM(E& y, Q& q, TH& theta, TTH&, TA&, TTA& tau_A, TP&, TTP& tau_pi, c
     hml_check(hml_set_recording(ctx, records.recordsMarginals() ? 1 : 0, nullptr, nullptr));
 }
 
+// sampleHMM for SEVERAL chains of one GPU in lockstep (`hammlet -chains N` with more chains than GPUs): every chain is
+// prepared like sampleHMM prepares it, ONE hml_iterate_many runs `iterations` sweeps of all of them - chains over a shared
+// construction go through one set of launches (include/hml.h) - and recorded sweeps call every chain's Records in chain
+// order.  Same files per chain as sampleHMM chain by chain.  Reference: src/HMM.hpp:60-125, once per chain.
+template <typename Q, typename E, typename TH, typename TTA, typename TTP>
+void sampleHMMMany(const std::vector<E*>& ys, const std::vector<Q*>& qs, const std::vector<TH*>& thetas, const std::vector<TTA*>& tauAs,
+                   const std::vector<TTP*>& tauPis, const size_t iterations, const size_t thinning, const std::vector<Records*>& records,
+                   const bool dynamic = true, const bool useSelfTransitions = true) {
+    const size_t n = ys.size();
+    if (thinning > iterations)
+        std::cout << "[WARNING] Thinning parameter is larger than number of iterations. No data will be recorded!" << std::endl;
+    struct Hook { Records* rec; Q* q; TH* theta; };
+    std::vector<Hook> hooks(n);
+    std::vector<hml_ctx*> ctxs(n);
+    std::vector<hml_stats> before(n);
+    for (size_t k = 0; k < n; ++k) {
+        TH& theta = *thetas[k];
+        theta.device().offerTransitions(tauAs[k]->off, tauAs[k]->diag);
+        theta.device().offerInitial(tauPis[k]->alpha);
+        theta.device().setSelfTransitions(useSelfTransitions);
+        theta.device().requireModel();
+        theta.device().setDynamic(dynamic);
+        ctxs[k] = ys[k]->ctx();
+        records[k]->attach(ctxs[k]);
+        hooks[k] = Hook{records[k], qs[k], thetas[k]};
+        hml_check(hml_set_recording(ctxs[k], records[k]->recordsMarginals() ? 1 : 0,
+                                    records[k]->needsPerSweepData() ? +[](hml_ctx* c, uint64_t, void* user) {
+                                        Hook* h = static_cast<Hook*>(user);
+                                        h->rec->recordSweep(c, *h->theta);
+                                    } : (hml_record_cb) nullptr,
+                                    &hooks[k]));
+        hml_check(hml_get_stats(ctxs[k], &before[k]));
+    }
+    hml_check(hml_iterate_many(ctxs.data(), (int)n, Q::methodChar(), iterations, thinning));
+    for (size_t k = 0; k < n; ++k) {
+        hml_stats after{};
+        hml_check(hml_sync(ctxs[k]));
+        hml_check(hml_get_stats(ctxs[k], &after));
+        for (uint64_t i = before[k].uniform_fallbacks; i < after.uniform_fallbacks; ++i)
+            std::cout << "[WARNING] Uniform sampling of forward variables!" << std::endl;
+        hml_check(hml_set_recording(ctxs[k], records[k]->recordsMarginals() ? 1 : 0, nullptr, nullptr));
+    }
+}
+
 }  // namespace hammlet
 #endif
