@@ -184,7 +184,9 @@ int hml_set_option(hml_ctx* ctx, const char* name, int value);
  * Chains that live on one device, have the same shape (positions, states) and are in the strongly compressed regime of a
  * univariate Forward-Backward sweep are BATCHED: every kernel of the sweep is launched once for all of them (the chain
  * is the grid's second dimension), so the host pays for one chain's launches - a single such chain is bound by latency
- * and leaves most of the GPU idle.  Everything else (other shapes or devices, mixture sweeps, weakly compressed,
+ * and leaves most of the GPU idle.  Chains that share ONE construction (hml_attach_observations) additionally take one
+ * block kernel for up to eight of them (block starts, statistics and emission terms of all chains from one pass over the
+ * shared summary / weights / integral array): eight chains of 10^8 positions and 5 states reach 2.5 times one chain's rate.  Everything else (other shapes or devices, mixture sweeps, weakly compressed,
  * multivariate or reference-compatible chains) is run chain by chain inside the same call.  A chain's results are the
  * same bit for bit as under hml_iterate; recorded sweeps call each chain's callback in chain order. */
 int hml_iterate_many(hml_ctx* const* ctxs, int n, char method, uint64_t iterations, uint64_t thinning);
