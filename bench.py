@@ -602,44 +602,49 @@ def main():
         v3, ms3 = several(3)
         out["three_chains_one_gpu"] = {"value": v3, "unit": "block-updates/s", "chains": 3, "steps": leg_steps, "ms_per_sweep_round": ms3,
                                        "note": "three host threads, three streams (private constructions, scan + scatter launches)"}
-        # eight chains attached to one construction, ONE set of launches by one host thread (hml_iterate_many; the many-chain
-        # block kernel of hml_k_blocks_fused_many.h)
-        free0 = torch.cuda.mem_get_info()[0]
-        group = []
-        mem = []
-        for r in range(8):
-            ch = hammlet_amd.Chain(device=local_rank, seed=args.seed, chain_id=r)
-            if r == 0:
-                ch.load(x)
-            else:
-                ch.attach(group[0])
-            ch.set_model(K, ch.autoprior(0.2, 0.9))
-            ch.sample_prior()
-            ch.set_recording(marginals=False)
-            ch.sync()
-            group.append(ch)
-            mem.append(free0 - torch.cuda.mem_get_info()[0])
-        hammlet_amd.iterate_many(group, "F", max(args.warmup, 64), 0)
-        for ch in group:
-            ch.sync()
-        b0 = [ch.stats()["block_updates"] for ch in group]
-        barrier()
-        t0 = time.perf_counter()
-        hammlet_amd.iterate_many(group, "F", leg_steps, 0)
-        for ch in group:
-            ch.sync()
-        barrier()
-        t1 = time.perf_counter()
-        b8 = sum(ch.stats()["block_updates"] - b for ch, b in zip(group, b0))
-        for ch in group:
-            ch.close()
-        out["eight_chains_one_gpu_batched"] = {"value": b8 / (t1 - t0), "unit": "block-updates/s", "chains": 8, "steps": leg_steps,
-                                               "ms_per_sweep_round": 1e3 * (t1 - t0) / leg_steps,
-                                               "x_one_chain": (b8 / (t1 - t0)) / out.get("steady_state", out)["value"],
-                                               "device_bytes_chain_1": mem[0], "device_bytes_per_further_chain": (mem[-1] - mem[0]) / 7.0,
-                                               "note": "eight chains attached to ONE construction (hml_attach_observations), hml_iterate_many: block starts, statistics "
-                                                       "and emission terms of all chains from one pass over the shared trace (hml_m_blocks_fused), the other kernels "
-                                                       "once for all chains (the chain is the grid's second dimension); one host thread"}
+        # eight (sixteen) chains attached to one construction, launched by one host thread (hml_iterate_many: the many-chain
+        # block kernel of hml_k_blocks_fused_many.h; two groups of chains on a stream each)
+        def attached(n_chains):
+            free0 = torch.cuda.mem_get_info()[0]
+            group = []
+            mem = []
+            for r in range(n_chains):
+                ch = hammlet_amd.Chain(device=local_rank, seed=args.seed, chain_id=r)
+                if r == 0:
+                    ch.load(x)
+                else:
+                    ch.attach(group[0])
+                ch.set_model(K, ch.autoprior(0.2, 0.9))
+                ch.sample_prior()
+                ch.set_recording(marginals=False)
+                ch.sync()
+                group.append(ch)
+                mem.append(free0 - torch.cuda.mem_get_info()[0])
+            hammlet_amd.iterate_many(group, "F", max(args.warmup, 64), 0)
+            for ch in group:
+                ch.sync()
+            b0 = [ch.stats()["block_updates"] for ch in group]
+            barrier()
+            t0 = time.perf_counter()
+            hammlet_amd.iterate_many(group, "F", leg_steps, 0)
+            for ch in group:
+                ch.sync()
+            barrier()
+            t1 = time.perf_counter()
+            bn = sum(ch.stats()["block_updates"] - b for ch, b in zip(group, b0))
+            for ch in group:
+                ch.close()
+            return {"value": bn / (t1 - t0), "unit": "block-updates/s", "chains": n_chains, "steps": leg_steps,
+                    "ms_per_sweep_round": 1e3 * (t1 - t0) / leg_steps,
+                    "x_one_chain": (bn / (t1 - t0)) / out.get("steady_state", out)["value"],
+                    "device_bytes_chain_1": mem[0], "device_bytes_per_further_chain": (mem[-1] - mem[0]) / (n_chains - 1.0)}
+        out["eight_chains_one_gpu_batched"] = attached(8)
+        out["eight_chains_one_gpu_batched"]["note"] = (
+            "eight chains attached to ONE construction (hml_attach_observations), hml_iterate_many: block starts, statistics "
+            "and emission terms of a group's chains from one pass over the shared trace (hml_m_blocks_fused), the other kernels "
+            "once per group (the chain is the grid's second dimension); one host thread, two groups of four chains on a stream each")
+        out["sixteen_chains_one_gpu_batched"] = attached(16)
+        out["sixteen_chains_one_gpu_batched"]["note"] = "as above, two groups of eight chains"
 
     def dense_leg(xd, Kd, scale, pmc_key, shared_sums, n_timed):
         """a weakly compressed chain (millions of blocks per sweep: the fused trellis path, hml_k_trellis_rows.h): 64 burn-in

@@ -338,6 +338,17 @@ static int iterate_many_k(hml_ctx* const* cs, int n, uint64_t first, uint64_t it
     HIPCHK(hipMemcpyAsync(c0->d_many, h.data(), n * sizeof(hml_chain_dev), hipMemcpyHostToDevice, s));
     HIPCHK(hipStreamSynchronize(s));   // (the staging vector goes out of scope below)
     const hml_chain_dev* d_cs = (const hml_chain_dev*)c0->d_many;
+    // The batch runs as G GROUPS of chains, each on a stream of its own (its first chain's), enqueued by this one host thread: a
+    // group's latency-bound stretches - the one-workgroup kernels, the block kernel's hand-off, launch boundaries - are filled by
+    // the other group's throughput-bound kernels (round 4, config 3, ms per round of sweeps: 2 chains 0.078 against 0.082, 4: 0.106 /
+    // 0.126, 8: 0.158 / 0.174, 16: 0.259 / 0.307).  More than two groups lose again: the block kernel's pass over the summary and
+    // the weights does not depend on the number of chains and is repeated per group, on tiles that grow with the number of grids
+    // that have to be resident together (8 chains in 4 groups: 0.236).  HML_MANY_GROUPS overrides.
+    int G = n >= 2 ? 2 : 1;
+    if (const char* e = getenv("HML_MANY_GROUPS")) G = std::max(1, std::min(std::min(atoi(e), 4), n));
+    struct Grp { int first, count; hipStream_t s; };
+    std::vector<Grp> grp(G);
+    for (int g = 0; g < G; ++g) { grp[g].first = (int)((int64_t)g * n / G); grp[g].count = (int)((int64_t)(g + 1) * n / G) - grp[g].first; grp[g].s = cs[grp[g].first]->stream; }
     // Chains attached to ONE trace (hml_attach_observations) take the many-chain block kernel: block starts, statistics and
     // emission terms of every chain from one pass over the shared summary / weights / integral array (hml_k_blocks_fused_many.h).
     // Its workgroups wait for lower-numbered ones inside the launch, so the whole grid must be resident - the tile grows
@@ -356,54 +367,76 @@ static int iterate_many_k(hml_ctx* const* cs, int n, uint64_t first, uint64_t it
             if (const char* e = getenv("HML_FUSED_MANY_SLOTS")) c0->fm_slots = atoi(e);   // (tests: force larger tiles)
         }
         const uint64_t batches = (c0->T + HML_FUSED_SUB_POSITIONS - 1) / HML_FUSED_SUB_POSITIONS;
-        const uint64_t m = c0->fm_slots > 0 ? (batches + (uint64_t)c0->fm_slots - 1) / (uint64_t)c0->fm_slots : HML_FUSED_MAX_SUB + 1;
+        // The block kernels of the G groups run side by side, and other contexts of the device that are not in this batch may be
+        // running a batch of their own at the same time (another host thread): every launch takes its SHARE of the workgroup
+        // slots, so that all these grids are resident together.
+        const int live = c0->device < 64 ? g_live_ctx[c0->device].load() : n;
+        const int sharers = G * std::max(1, (live + n - 1) / n);
+        const int64_t slots = c0->fm_slots > 0 ? std::max<int64_t>(1, c0->fm_slots / sharers) : 0;
+        const uint64_t m = slots > 0 ? (batches + (uint64_t)slots - 1) / (uint64_t)slots : HML_FUSED_MAX_SUB + 1;
         if (m > HML_FUSED_MAX_SUB) fm = false;
         else { fm_sub = (uint32_t)m; fm_wg = (uint32_t)((c0->T + m * HML_FUSED_SUB_POSITIONS - 1) / (m * HML_FUSED_SUB_POSITIONS)); }
     }
+    // every chain's own stream goes on behind its group's (also on the early ways out)
+    auto join = [&](bool wait) -> int {
+        for (int g = 0; g < G; ++g) {
+            if (wait) { HIPCHK(hipStreamSynchronize(grp[g].s)); continue; }
+            hipEvent_t ev = ev_get(c0);
+            HIPCHK(hipEventRecord(ev, grp[g].s));
+            for (int k = grp[g].first; k < grp[g].first + grp[g].count; ++k) if (cs[k]->stream != grp[g].s) HIPCHK(hipStreamWaitEvent(cs[k]->stream, ev, 0));
+            c0->ev_pool.push_back(ev);
+        }
+        return 0;
+    };
     for (uint64_t i = first; i < iterations; ++i) {
         // a chain left the strongly compressed regime, or halted because its blocks outgrew its buffers (hml_state.h): back to the caller
-        for (int k = 0; k < n; ++k) if (!many_sparse(cs[k]) || chain_halted(cs[k])) { *done = i; return 0; }
+        for (int k = 0; k < n; ++k) if (!many_sparse(cs[k]) || chain_halted(cs[k])) { *done = i; return join(true); }
         const bool record = thinning > 0 && ((i + 1) % thinning == 0);
-        uint32_t hint = 0;
-        for (int k = 0; k < n; ++k) hint = std::max(hint, cs[k]->B_hint ? cs[k]->B_hint : (uint32_t)std::min<uint64_t>(T, 1u << 20));
-        const unsigned ny = (unsigned)n;
-        const unsigned gB = (unsigned)grid_for(hint, 256, 64, 16384);
         for (int k = 0; k < n; ++k) log_sweep(cs[k], HML_METHOD_FB, record);
         // (a bounded wait of the block kernel expired - somebody else is using the GPU: the scan + scatter launches from here on)
         if (fm) for (int k = 0; k < n; ++k) if (cs[k]->h_B[1] && !cs[k]->fused_keep) fm = false;
-        if (fm) {
-            for (int k0 = 0; k0 < n; k0 += HML_FM_MAX_CHAINS) {
-                const int nk = std::min(n - k0, (int)HML_FM_MAX_CHAINS);
-                hml_fm_args fa;
-                memset(&fa, 0, sizeof fa);
-                for (int k = 0; k < nk; ++k) {
-                    hml_ctx* c = cs[k0 + k];
-                    hml_fm_chain& f = fa.c[k];
-                    f.mdl = c->d_mdl; f.group_word = c->d_group_word; f.stage = c->d_stage; f.starts = c->d_starts; f.bstat = c->d_bstat;
-                    f.em = c->d_em; f.gsc = with_gsc ? c->d_gsc : nullptr; f.host_words = c->d_hB; f.lay = c->lay_many;
+        for (int g = 0; g < G; ++g) {
+            const int g0 = grp[g].first, gn = grp[g].count;
+            hipStream_t s = grp[g].s;
+            const hml_chain_dev* d_g = d_cs + g0;
+            uint32_t hint = 0;
+            for (int k = g0; k < g0 + gn; ++k) hint = std::max(hint, cs[k]->B_hint ? cs[k]->B_hint : (uint32_t)std::min<uint64_t>(T, 1u << 20));
+            const unsigned ny = (unsigned)gn;
+            const unsigned gB = (unsigned)grid_for(hint, 256, 64, 16384);
+            if (fm) {
+                for (int k0 = g0; k0 < g0 + gn; k0 += HML_FM_MAX_CHAINS) {
+                    const int nk = std::min(g0 + gn - k0, (int)HML_FM_MAX_CHAINS);
+                    hml_fm_args fa;
+                    memset(&fa, 0, sizeof fa);
+                    for (int k = 0; k < nk; ++k) {
+                        hml_ctx* c = cs[k0 + k];
+                        hml_fm_chain& f = fa.c[k];
+                        f.mdl = c->d_mdl; f.group_word = c->d_group_word; f.stage = c->d_stage; f.starts = c->d_starts; f.bstat = c->d_bstat;
+                        f.em = c->d_em; f.gsc = with_gsc ? c->d_gsc : nullptr; f.host_words = c->d_hB; f.lay = c->lay_many;
+                    }
+                    hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_m_blocks_fused<KK>), dim3(fm_wg), dim3(HML_FUSED_WAVES * 64), 0, s, c0->d_summary, c0->d_w, c0->d_ia,
+                                       T, c0->key_base, fa, nk, fm_sub, c0->fused_spin_limit, g == 0 ? c0->d_dbg : nullptr);
                 }
-                hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_m_blocks_fused<KK>), dim3(fm_wg), dim3(HML_FUSED_WAVES * 64), 0, s, c0->d_summary, c0->d_w, c0->d_ia,
-                                   T, c0->key_base, fa, nk, fm_sub, c0->fused_spin_limit, c0->d_dbg);
+            } else {
+                hipLaunchKernelGGL(hml_m_compact_scan_summary, dim3(n_groups, ny), dim3(256), 0, s, d_g, T);
+                hipLaunchKernelGGL(hml_m_compact_scatter, dim3(n_groups, ny), dim3(256), 0, s, d_g, T);
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_m_stats_emission<KK>), dim3(gB, ny), dim3(256), 0, s, d_g, with_gsc);
             }
-        } else {
-            hipLaunchKernelGGL(hml_m_compact_scan_summary, dim3(n_groups, ny), dim3(256), 0, s, d_cs, T);
-            hipLaunchKernelGGL(hml_m_compact_scatter, dim3(n_groups, ny), dim3(256), 0, s, d_cs, T);
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_m_stats_emission<KK>), dim3(gB, ny), dim3(256), 0, s, d_cs, with_gsc);
+            const uint64_t chunks = ((uint64_t)hint + L - 1) / L;
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_m_forward<KK>), dim3((unsigned)grid_for(chunks, 256, 16, 1 << 20), ny), dim3(256), 0, s, d_g, with_gsc, L);
+            const uint64_t bch = ((uint64_t)hint + HML_BWD_CHUNK - 1) / HML_BWD_CHUNK;
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_m_backward_maps<KK>), dim3((unsigned)grid_for((bch + 1) / 2 * 64, 256, 16, 1 << 18), ny), dim3(256), 0, s, d_g, with_gsc, L);   // (a wavefront per two chunks)
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_m_backward_chain<KK>), dim3(1, ny), dim3(1024), 0, s, d_g, with_gsc, L);
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_m_counts<KK>), dim3(HML_REDUCE_GROUPS, ny), dim3(256), 0, s, d_g);
+            if (record && (rec_mask >> g0)) hipLaunchKernelGGL(hml_m_record, dim3(gB, ny), dim3(256), 0, s, d_g, rec_mask >> g0);
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_m_params<KK>), dim3(1, ny), dim3(1024), 0, s, d_g);
         }
-        const uint64_t chunks = ((uint64_t)hint + L - 1) / L;
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_m_forward<KK>), dim3((unsigned)grid_for(chunks, 256, 16, 1 << 20), ny), dim3(256), 0, s, d_cs, with_gsc, L);
-        const uint64_t bch = ((uint64_t)hint + HML_BWD_CHUNK - 1) / HML_BWD_CHUNK;
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_m_backward_maps<KK>), dim3((unsigned)grid_for((bch + 1) / 2 * 64, 256, 16, 1 << 18), ny), dim3(256), 0, s, d_cs, with_gsc, L);   // (a wavefront per two chunks)
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_m_backward_chain<KK>), dim3(1, ny), dim3(1024), 0, s, d_cs, with_gsc, L);
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_m_counts<KK>), dim3(HML_REDUCE_GROUPS, ny), dim3(256), 0, s, d_cs);
-        if (record && rec_mask) hipLaunchKernelGGL(hml_m_record, dim3(gB, ny), dim3(256), 0, s, d_cs, rec_mask);
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_m_params<KK>), dim3(1, ny), dim3(1024), 0, s, d_cs);
         KLAUNCH_CHECK();
         if (record) {
             bool any_cb = false;
             for (int k = 0; k < n; ++k) any_cb = any_cb || cs[k]->cb;
             if (any_cb) {
-                HIPCHK(hipStreamSynchronize(s));
+                if (int r = join(true)) return r;
                 for (int k = 0; k < n; ++k) {
                     if (int r = check_device_error(cs[k])) return r;
                     if (cs[k]->cb && !chain_halted(cs[k])) cs[k]->cb(cs[k], i, cs[k]->cb_user);   // (a halted chain calls back when it catches up: hml_settle)
@@ -411,6 +444,7 @@ static int iterate_many_k(hml_ctx* const* cs, int n, uint64_t first, uint64_t it
             }
         }
     }
+    if (int r = join(false)) return r;
     *done = iterations;
     return 0;
 }

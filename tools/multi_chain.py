@@ -14,7 +14,7 @@ x = hammlet_amd.synth_gauss(T, K, levels, sigma, dwell, data_seed, nthreads=8)
 chains = []
 for r in range(R):
     ch = hammlet_amd.Chain(device=0, seed=1, chain_id=r)
-    if mode == "attached" and r > 0:
+    if mode in ("attached", "attached2") and r > 0:
         ch.attach(chains[0])
     else:
         ch.load(x)
@@ -25,7 +25,8 @@ for r in range(R):
     chains.append(ch)
 for ch in chains:
     ch.sync()
-reps = int(os.environ.get("REPS", "5")) if mode in ("many", "attached") else 1
+reps = int(os.environ.get("REPS", "5")) if mode in ("many", "attached", "attached2") else 1
+GROUPS = int(os.environ.get("GROUPS", "2"))
 times, blocks_all = [], []
 for rep in range(reps):
     s0 = [ch.stats() for ch in chains]
@@ -37,6 +38,14 @@ for rep in range(reps):
     if mode in ("many", "attached"):
         hammlet_amd.iterate_many(chains, "F", n, 0)
         for ch in chains: ch.sync()
+    elif mode == "attached2":   # GROUPS host threads, each batching its share of the chains (all attached to chain 0's construction)
+        def run_group(g):
+            hammlet_amd.iterate_many(g, "F", n, 0)
+            for ch in g: ch.sync()
+        gs = [chains[i::GROUPS] for i in range(GROUPS)]
+        tg = [threading.Thread(target=run_group, args=(g,)) for g in gs]
+        for t in tg: t.start()
+        for t in tg: t.join()
     else:
         for t in ths: t.start()
         for t in ths: t.join()
