@@ -11,15 +11,17 @@ from tests import oracle_lib as ol
 from tests.test_gpu_parity import run_both
 
 ENV_KEYS = ("HML_DENSE_MIN_BLOCKS", "HML_FWD_CHUNK_DENSE", "HML_TRELLIS_FUSED", "HML_TRELLIS_L", "HML_TRELLIS_ROWS", "HML_TRELLIS_CKPT",
-            "HML_STAGE_BITS", "HML_FWD_WARMUP", "HML_LATE_RESCALE", "HML_FWD_CHUNK")
+            "HML_STAGE_BITS", "HML_FWD_WARMUP", "HML_LATE_RESCALE", "HML_FWD_CHUNK",
+            "HML_MANY_GROUPS", "HML_FUSED_MANY_SLOTS", "HML_MAX_BLOCKS", "HML_FWD_CHUNK_MANY")
 
 
-def fuzz(hml, n_cfg, seed, log=None):
+def fuzz(hml, n_cfg, seed, log=None, many=False):
     """n_cfg random configurations; returns the number that ran identical (all, or an AssertionError names the first
-    that differs).  The environment switches it sets are restored afterwards."""
+    that differs).  The environment switches it sets are restored afterwards.  many: several chains through
+    hml_iterate_many (_fuzz_many) instead of one through hml_iterate."""
     saved = {k: os.environ.get(k) for k in ENV_KEYS}
     try:
-        return _fuzz(hml, n_cfg, seed, log or (lambda *a, **k: None))
+        return (_fuzz_many if many else _fuzz)(hml, n_cfg, seed, log or (lambda *a, **k: None))
     finally:
         for k, v in saved.items():
             if v is None:
@@ -106,4 +108,104 @@ def _fuzz(hml, n_cfg, seed, log):
         assert ok, desc
         g.close(); o.close()
 
+    return n_cfg
+
+
+def _setenv(name, value):
+    if value is None:
+        os.environ.pop(name, None)
+    else:
+        os.environ[name] = str(value)
+
+
+def _fuzz_many(hml, n_cfg, seed, log):
+    """Several chains of one trace through hml_iterate_many - attached to one construction (hml_attach_observations: the
+    many-chain block kernel) or with private ones, in 1-4 groups of chains, tiles of several batches, tiny block capacities,
+    weakly compressed chains that leave the batch - each against the checker's chain of the same (seed, chain) run alone."""
+    rng = np.random.default_rng(seed)
+    bits = lambda a: np.ascontiguousarray(a, np.float32).view(np.uint32)
+    t_start = time.time()
+    for it in range(n_cfg):
+        K = int(rng.choice([2, 3, 4, 5, 5, 6, 8, 10, 13, 16]))
+        T = int(rng.choice([1000, 4097, 30000, 65537, 120000, 300000]))
+        if K > 8:
+            T = min(T, 120000)
+        n = int(rng.integers(2, 11))
+        attached = bool(rng.random() < 0.75)
+        mult = float(rng.choice([1.0, 1.0, 1.5]))
+        self_trans = bool(rng.random() < 0.8)
+        kw = dict(t_off=float(rng.choice([0.5, 0.1, 1.0])), t_diag=float(rng.choice([0.5, 10.0])), pi_alpha=float(rng.choice([0.5, 2.0])),
+                  e_var=float(rng.choice([0.2, 0.1])), e_p=float(rng.choice([0.9, 0.8])), self_trans=self_trans, weight_mult=mult)
+        env = {"HML_MANY_GROUPS": rng.choice([None, None, 1, 2, 3, 4]), "HML_FUSED_MANY_SLOTS": rng.choice([None, None, None, 2, 5]),
+               "HML_MAX_BLOCKS": rng.choice([None, None, 64]), "HML_FWD_CHUNK_MANY": rng.choice([None, None, 4, 16]),
+               "HML_DENSE_MIN_BLOCKS": rng.choice([1 << 22, 1 << 22, 1 << 22, 400]), "HML_LATE_RESCALE": rng.choice([1, 1, 0]),
+               "HML_FWD_WARMUP": rng.choice([None, None, 4, 8])}
+        for k, v in env.items():
+            _setenv(k, v)
+        seed_c = int(rng.integers(0, 1 << 30))
+        x = ol.synth_depth(T, seed=int(rng.integers(1, 100))) if rng.random() < 0.15 else ol.trace(T, min(K, 5), int(rng.integers(1, 1000)))
+        scheme = []
+        for _ in range(int(rng.integers(1, 5))):
+            tok = rng.choice(["F", "F", "F", "M", "S", "D", "P"])
+            scheme.append((str(tok), int(rng.integers(1, 9)), int(rng.integers(0, 3))) if tok in ("F", "M") else str(tok))
+        if not isinstance(scheme[-1], tuple):
+            scheme.append(("F", int(rng.integers(1, 5)), 1))
+        pairs = []
+        weights_key = int(rng.choice([1, 1, 2, 0]))
+        for chain in range(n):
+            o = ol.OracleChain(K=K, seed=seed_c, chain=chain, rng=ol.RNG_CTR, math=ol.MATH_DEV, reduce=ol.REDUCE_DEV, **kw)
+            g = hml.Chain(device=0, seed=seed_c, chain_id=chain)
+            o.load(x)
+            g.set_option("weight_keys", weights_key)
+            if attached and chain > 0:
+                g.attach(pairs[0][1])
+            else:
+                g.load(x)
+                if mult != 1.0:
+                    g.scale_weights(mult)
+            po = o.autoprior()
+            pg = g.autoprior(kw["e_var"], kw["e_p"])
+            assert np.array_equal(bits(po), bits(pg)), ("autoprior", it, chain)
+            o.init_model()
+            g.set_model(K, pg, kw["t_off"], kw["t_diag"], kw["pi_alpha"], self_trans)
+            o.set_record(marginals=True)
+            pairs.append((o, g))
+        gs = [g for _, g in pairs]
+        pending = True
+        for tok in scheme:
+            if pending:
+                for g in gs:
+                    g.sample_prior()
+                pending = False
+            if tok in ("P", "S", "D"):
+                for o, g in pairs:
+                    o.token(tok)
+                    if tok == "S":
+                        g.set_static_blocks()
+                    elif tok == "D":
+                        g.set_dynamic(True)
+                pending = tok == "P"
+            else:
+                m, iters, thin = tok
+                for o, _ in pairs:
+                    o.iterate(m, iters, thin)
+                hml.iterate_many(gs, m, iters, thin)
+        ok = True
+        for chain, (o, g) in enumerate(pairs):
+            g.sync()
+            Ao, pio = o.transitions()
+            Ag, pig = g.transitions()
+            ok = ok and (np.array_equal(o.blocks(), g.blocks()) and np.array_equal(o.states(), g.states()) and np.array_equal(bits(o.theta()), bits(g.theta()))
+                         and np.array_equal(bits(Ao), bits(Ag)) and np.array_equal(bits(pio), bits(pig))
+                         and hml.marginals_text(*g.marginals_rle()) == o.text("marginals"))
+            if not ok:
+                break
+        B = len(gs[0].blocks()) - 1
+        desc = "%3d %s T=%d K=%d chains=%d attached=%d mult=%g self=%d env=%s scheme=%s  B=%d  %.0f s" % (
+            it, "ok " if ok else "DIFF (chain %d)" % chain, T, K, n, attached, mult, self_trans,
+            {k[4:]: (None if v is None else int(v)) for k, v in env.items()}, scheme, B, time.time() - t_start)
+        log(desc)
+        assert ok, desc
+        for o, g in reversed(pairs):   # (attached contexts before their source - either order is allowed)
+            g.close(); o.close()
     return n_cfg

@@ -2,7 +2,7 @@
 tools/fuzz_parity.py were builder-run only): 300 random configurations at a fixed seed - sizes around the structural
 edges, 2-16 states, 1-3 data dimensions, random schemes of M / F / S / D / P tokens, priors, weight multipliers, read-depth
 input, every switchable kernel path - GPU against the checker in device mode after each: blocks, state sequences,
-parameter bits, marginals text.  About 20 seconds."""
+parameter bits, marginals text; then 100 configurations of several chains through hml_iterate_many.  About 45 seconds."""
 import pytest
 
 from tests.fuzz_util import fuzz
@@ -21,3 +21,12 @@ def test_bounded_fuzz_with_a_tiny_block_capacity(hml, monkeypatch):
     geometries) the results must be those of a chain with room from the start, i.e. the checker's."""
     monkeypatch.setenv("HML_MAX_BLOCKS", "64")
     assert fuzz(hml, 150, 4) == 150
+
+
+def test_bounded_fuzz_of_batched_chains(hml):
+    """Round 4's sweep of several chains: 2-10 chains of one trace through hml_iterate_many - attached to one construction
+    (hml_attach_observations, the many-chain block kernel hml_m_blocks_fused) or with private ones, in 1-4 groups of
+    chains on separate streams, tiles of several batches, block capacities of 64, weakly compressed chains that leave the
+    batch, static block structures, prior draws between the calls - every chain against the checker's chain of the same
+    (seed, chain) run alone: blocks, state sequences, parameter and transition bits, marginals text."""
+    assert fuzz(hml, 100, 20261005, many=True) == 100
