@@ -378,7 +378,7 @@ int hml_set_dimensions(hml_ctx* c, int D, int P) {
     if (D > HML_MAX_D) return set_err(HML_ERR_ARG, "at most 4 data dimensions are supported");
     if (P > 0) {   // P = 0: taken from hml_set_model's number of states (K = P^D)
         long k = 1;
-        for (int d = 0; d < D; ++d) { k *= P; if (k > HML_MAX_K) return set_err(HML_ERR_ARG, "number of states must be in [2,16]"); }
+        for (int d = 0; d < D; ++d) { k *= P; if (k > HML_CAP_K) return set_err(HML_ERR_ARG, "number of states must be in [2,16] (up to 64 in the reference-compatible mode: option \"compat\")"); }   // (hml_set_model checks against the mode)
         if (k <= 1) return set_err(HML_ERR_MODEL, "Requested parameters would yield an HMM with less than 2 states!");
     }
     c->D = D; c->P = P;
@@ -572,6 +572,13 @@ int hml_autoprior(hml_ctx* c, float s2, float p, float out4[4]) {
 static int alloc_sweep_buffers(hml_ctx* c) {
     const int K = c->K;
     const uint64_t cap = c->cap;
+    if (c->compat) {   // the reference-compatible mode (hml_k_compat.h): plain emission terms [b][s], a plain (B + 1) x K trellis, the states
+        HIPCHK(hipMalloc(&c->d_em, cap * K * sizeof(float)));
+        HIPCHK(hipMalloc(&c->d_gsc, cap * K * sizeof(float)));
+        HIPCHK(hipMalloc(&c->d_crows, (cap + 1) * K * sizeof(float)));
+        HIPCHK(hipMalloc(&c->d_q, cap * sizeof(int16_t)));
+        return 0;
+    }
     const int minL = std::min(std::min(c->fwdL, c->fwdL_dense), c->fwdL_many);
     const uint64_t maxChunks = (cap + minL - 1) / minL + 1;   // per-chunk arrays serve either geometry
     uint64_t plane = 0;   // floats in one chunk-transposed [L][K][cstride] array
@@ -609,7 +616,6 @@ static int alloc_sweep_buffers(hml_ctx* c) {
     HIPCHK(hipMalloc(&c->d_q, cap * sizeof(int16_t)));
     HIPCHK(hipMalloc(&c->d_partial, (uint64_t)HML_REDUCE_GROUPS * K * 2 * sizeof(double)));
     HIPCHK(hipMemsetAsync(c->d_partial, 0, (uint64_t)HML_REDUCE_GROUPS * K * 2 * sizeof(double), c->stream));
-    if (c->compat) HIPCHK(hipMalloc(&c->d_crows, (cap + 1) * K * sizeof(float)));   // the reference-compatible mode's plain (B + 1) x K trellis
     return 0;
 }
 
@@ -693,7 +699,8 @@ extern "C" {
 int hml_set_model(hml_ctx* c, int K, const float nig4[4], float a_off, float a_diag, float pi_alpha, int self_trans) {
     if (!c || !c->loaded) return set_err(HML_ERR_ARG, "no observations loaded");
     if (K < 2) return set_err(HML_ERR_MODEL, "Requested parameters would yield an HMM with less than 2 states!");
-    if (K > HML_MAX_K) return set_err(HML_ERR_ARG, "number of states must be in [2,16]");
+    if (K > (c->compat ? HML_CAP_K : HML_MAX_K))
+        return set_err(HML_ERR_ARG, c->compat ? "number of states must be in [2,64]" : "number of states must be in [2,16] (up to 64 in the reference-compatible mode: option \"compat\")");
     if (c->model_set) return set_err(HML_ERR_ARG, "model already set");
     if (c->D > 1 && c->P == 0) {   // the number of parameters follows from K = P^D
         for (int pp = 2; pp <= K; ++pp) { long k = 1; for (int d = 0; d < c->D; ++d) k *= pp; if (k == K) { c->P = pp; break; } if (k > K) break; }
@@ -707,7 +714,8 @@ int hml_set_model(hml_ctx* c, int K, const float nig4[4], float a_off, float a_d
     if (!(nig4[0] > 0)) return set_err(HML_ERR_MODEL, "Alpha (" + std::to_string(nig4[0]) + ") must be positive!");
     if (!(nig4[1] > 0)) return set_err(HML_ERR_MODEL, "Beta (" + std::to_string(nig4[1]) + ") must be positive!");
     if (!(nig4[3] > 0)) return set_err(HML_ERR_MODEL, "Nu (" + std::to_string(nig4[3]) + ")must be positive!");
-    HML_KTAB(K, kt);   // (before anything is allocated: a development build knows one K only)
+    const hml_ktab* kt = nullptr;   // (before anything is allocated: a development build knows one K only; the reference-compatible mode takes K at run time)
+    if (!c->compat) { kt = ktab(K); if (!kt) return set_err(HML_ERR_ARG, "number of states must be in [2,16]"); }
     if (int r = ctx_bind(c)) return r;
     free_sweep_buffers(c);   // (what an earlier call that failed half-way left behind)
     c->K = K;
@@ -757,7 +765,7 @@ int hml_set_model(hml_ctx* c, int K, const float nig4[4], float a_off, float a_d
         HIPCHK(hipMalloc(&c->d_mt, sizeof(hml_mt_state)));
         HIPCHK(hipMemcpyAsync(c->d_mt, &h, sizeof h, hipMemcpyHostToDevice, c->stream));
         HIPCHK(hipStreamSynchronize(c->stream));
-        kt->compat_draw(c, 2);
+        hipLaunchKernelGGL(hml_k_compat_draw, dim3(1), dim3(64), 0, c->stream, c->d_mdl, (hml_mt_state*)c->d_mt, 2);
         KLAUNCH_CHECK();
         c->model_set = true;
         return 0;
@@ -773,7 +781,7 @@ int hml_sample_prior(hml_ctx* c) {
     if (int r = ctx_bind(c)) return r;
     if (int r = settle_if_limited(c)) return r;
     if (c->compat) {
-        HML_KTAB(c->K, kt); kt->compat_draw(c, 1);
+        hipLaunchKernelGGL(hml_k_compat_draw, dim3(1), dim3(64), 0, c->stream, c->d_mdl, (hml_mt_state*)c->d_mt, 1);
     } else { HML_KTAB(c->K, kt); kt->params(c, 1); }
     KLAUNCH_CHECK();
     if (c->dynamic) c->blocks_valid = false;
@@ -842,7 +850,51 @@ int hml_enable_probes(hml_ctx* c, int on) {
 
 int hml_ctx_ensure_marginal_buffers(hml_ctx* c) { return ensure_marginal_buffers(c); }
 
+// A sweep of the reference-compatible mode (hml_k_compat.h): block starts and block statistics by the default path's
+// kernels, the order-dependent part in the reference's order (the number of states is a run-time value there), the
+// marginals by hml_k_record.
+static int sweep_compat(hml_ctx* c, char method, bool record) {
+    hipStream_t s = c->stream;
+    if (c->dynamic || !c->blocks_valid) {
+        if (int r = launch_compact(c, false, 0.0f)) return r;   // starts, block count, block statistics at the model's threshold
+        if (!c->dynamic) c->blocks_valid = true;
+    }
+    refresh_hint(c);
+    const uint32_t hint = c->B_hint ? c->B_hint : (uint32_t)std::min<uint64_t>(c->T, 1u << 20);
+    const int mix = method == HML_METHOD_MIXTURE ? 1 : 0;
+    hml_mt_state* const mt = (hml_mt_state*)c->d_mt;
+    hipLaunchKernelGGL(hml_k_compat_emission, dim3(grid_for(hint, 256, 64, 16384)), dim3(256), 0, s, c->d_mdl, c->d_starts, c->d_bstat, c->d_em, c->d_gsc, mix,
+                       c->probes ? c->d_eprobe : nullptr);
+    if (mix) hipLaunchKernelGGL(hml_k_compat_mixture, dim3(1), dim3(64), 0, s, c->d_mdl, mt, c->d_em, c->d_q);
+    else {
+        float* const aprobe = c->probes ? c->d_aprobe : nullptr;
+        // (up to 16 states: the number of states as a compile-time value - A in registers, loops unrolled; beyond: the model's value)
+#define HML_COMPAT_FB(KC)                                                                                                                       \
+        case KC:                                                                                                                                \
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_compat_forward<KC>), dim3(1), dim3(64), 0, s, c->d_mdl, c->d_starts, c->d_em, c->d_gsc, c->d_crows, aprobe); \
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_compat_backward<KC>), dim3(1), dim3(64), 0, s, c->d_mdl, mt, c->d_crows, c->d_q);           \
+            break;
+        switch (c->K <= HML_MAX_K ? c->K : 0) {
+            HML_COMPAT_FB(2) HML_COMPAT_FB(3) HML_COMPAT_FB(4) HML_COMPAT_FB(5) HML_COMPAT_FB(6) HML_COMPAT_FB(7) HML_COMPAT_FB(8) HML_COMPAT_FB(9)
+            HML_COMPAT_FB(10) HML_COMPAT_FB(11) HML_COMPAT_FB(12) HML_COMPAT_FB(13) HML_COMPAT_FB(14) HML_COMPAT_FB(15) HML_COMPAT_FB(16)
+            default:
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_compat_forward<0>), dim3(1), dim3(64), 0, s, c->d_mdl, c->d_starts, c->d_em, c->d_gsc, c->d_crows, aprobe);
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_compat_backward<0>), dim3(1), dim3(64), 0, s, c->d_mdl, mt, c->d_crows, c->d_q);
+        }
+#undef HML_COMPAT_FB
+    }
+    hipLaunchKernelGGL(hml_k_compat_update, dim3(1), dim3(64), 0, s, c->d_mdl, mt, c->d_starts, c->d_bstat, c->d_q, mix);
+    if (record && c->rec_marginals) {
+        if (c->pooled) return set_err(HML_ERR_ARG, "the marginals of this context are pooled (common labels, several chains): further sweeps cannot be recorded into them");
+        if (int r = ensure_marginal_buffers(c)) return r;
+        hipLaunchKernelGGL(hml_k_record, dim3(grid_for(hint, 256, 64, 16384)), dim3(256), 0, s, c->d_q, c->d_starts, c->d_mdl, c->d_diff, c->d_boundary);
+    }
+    KLAUNCH_CHECK();
+    return 0;
+}
+
 static int sweep_dispatch(hml_ctx* c, char method, bool record) {
+    if (c->compat) return sweep_compat(c, method, record);
     HML_KTAB(c->K, kt);
     return kt->sweep(c, method, record);
 }
@@ -1122,7 +1174,8 @@ int hml_set_parameters(hml_ctx* c, const float* mean_var, const float* A, const 
     memcpy(m.A, A, (size_t)K * K * sizeof(float));
     memcpy(m.pi, pi, (size_t)K * sizeof(float));
     HIPCHK(hipMemcpyAsync(c->d_mdl, &m, sizeof m, hipMemcpyHostToDevice, c->stream));
-    { HML_KTAB(K, kt); kt->derive(c); }
+    if (c->compat) hipLaunchKernelGGL(hml_k_compat_derive, dim3(1), dim3(64), 0, c->stream, c->d_mdl);   // (glibc's logf)
+    else { HML_KTAB(K, kt); kt->derive(c); }
     KLAUNCH_CHECK();
     HIPCHK(hipStreamSynchronize(c->stream));
     if (c->dynamic) c->blocks_valid = false;
@@ -1274,7 +1327,8 @@ int hml_max_segmentation(hml_ctx* c, uint64_t* n_runs, uint64_t* run_len, int32_
     HIPCHK(hipMemsetAsync(d_rc + n_chunks, 0, sizeof(int32_t), c->stream));
     hipLaunchKernelGGL(hml_k_seg_partial, dim3(n_chunks), dim3(256), 0, c->stream, d_g, (uint32_t)M, K, d_cs, n_chunks);
     hipLaunchKernelGGL(hml_k_dense_chunkscan, dim3(K), dim3(1024), 0, c->stream, d_cs, n_chunks);
-    hipLaunchKernelGGL(hml_k_seg_argmax, dim3(n_chunks), dim3(256), 0, c->stream, d_g, (uint32_t)M, K, d_cs, n_chunks, d_st);
+    if (K <= HML_MAX_K) hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_seg_argmax<HML_MAX_K>), dim3(n_chunks), dim3(256), 0, c->stream, d_g, (uint32_t)M, K, d_cs, n_chunks, d_st);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_seg_argmax<HML_CAP_K>), dim3(n_chunks), dim3(256), 0, c->stream, d_g, (uint32_t)M, K, d_cs, n_chunks, d_st);
     hipLaunchKernelGGL(hml_k_seg_run_count, dim3(n_chunks), dim3(256), 0, c->stream, d_st, (uint32_t)M, d_rc);
     hipLaunchKernelGGL(hml_k_dense_chunkscan, dim3(1), dim3(1024), 0, c->stream, d_rc, n_chunks + 1u);   // d_rc[n_chunks] = total
     KLAUNCH_CHECK();
@@ -1319,10 +1373,10 @@ int hml_marginals_dense_device(hml_ctx* c, void* out_dev, const int32_t* perm) {
     int32_t *d_cs = nullptr, *d_perm = nullptr;
     HIPCHK(hipMalloc(&d_cs, (uint64_t)K * n_chunks * sizeof(int32_t)));
     if (perm) {
-        uint32_t seen = 0u;
+        uint64_t seen = 0u;
         for (int k = 0; k < K; ++k) {
             if (perm[k] < 0 || perm[k] >= K || ((seen >> perm[k]) & 1u)) { hipFree(d_cs); return set_err(HML_ERR_ARG, "perm is not a permutation of the K states"); }
-            seen |= 1u << perm[k];
+            seen |= (uint64_t)1 << perm[k];
         }
         HIPCHK(hipMalloc(&d_perm, K * sizeof(int32_t)));
         HIPCHK(hipMemcpyAsync(d_perm, perm, K * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));

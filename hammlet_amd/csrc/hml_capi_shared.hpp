@@ -51,8 +51,7 @@ struct hml_ktab {
     int (*sweep)(hml_ctx* c, char method, bool record);
     int (*iterate_many)(hml_ctx* const* cs, int n, uint64_t first, uint64_t iterations, uint64_t thinning, uint64_t* done);
     void (*params)(hml_ctx* c, int mode);        // hml_k_params<K>: 1 = draw from the priors, 2 = Theta's constructor draw
-    void (*compat_draw)(hml_ctx* c, int mode);   // hml_k_compat_draw<K> (reference-compatible chains)
-    void (*derive)(hml_ctx* c);                  // hml_k_derive<K>; reference-compatible chains: hml_k_compat_derive<K> (glibc's logf)
+    void (*derive)(hml_ctx* c);                  // hml_k_derive<K>
 };
 
 // Live contexts per device.  The fused block kernel hands block offsets from workgroup to workgroup inside one launch
@@ -144,11 +143,14 @@ static int fetch_model(hml_ctx* c, hml_model* out) {
 }
 
 static int check_device_error(hml_ctx* c) {
-    hml_model m;
-    if (int r = fetch_model(c, &m)) return r;
-    if (m.err_code != 0) {
+    // (the two error words only: the model is 100 KB since its arrays hold HML_CAP_K states)
+    struct { uint32_t code; float value; } e;
+    static_assert(offsetof(hml_model, err_value) == offsetof(hml_model, err_code) + sizeof(uint32_t), "err_code and err_value are read together");
+    HIPCHK(hipMemcpyAsync(&e, &c->d_mdl->err_code, sizeof e, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (e.code != 0) {
         char buf[256];
-        return set_err(HML_ERR_MODEL, deverr_text(m.err_code, m.err_value, buf, sizeof buf));
+        return set_err(HML_ERR_MODEL, deverr_text(e.code, e.value, buf, sizeof buf));
     }
     return 0;
 }

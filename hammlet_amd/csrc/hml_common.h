@@ -24,7 +24,8 @@
 #define HML_CELLSIZE 65535u
 
 // Maximum number of states the device kernels are compiled for.
-#define HML_MAX_K 16
+#define HML_MAX_K 16            // states of the default path (register-resident kernels instantiated for 2 .. 16; 4-bit packed maps)
+#define HML_CAP_K 64            // states the model's arrays hold: the reference-compatible mode takes K at run time, a lane per state
 
 HML_HD uint32_t hml_f2u(float f) { return __builtin_bit_cast(uint32_t, f); }
 HML_HD float hml_u2f(uint32_t u) { return __builtin_bit_cast(float, u); }

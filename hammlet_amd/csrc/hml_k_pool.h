@@ -21,7 +21,7 @@ HML_KERNEL __launch_bounds__(256) void hml_k_pool_export(const int32_t* __restri
     const uint64_t n = (uint64_t)(K + 1) * T1;
     int32_t* __restrict__ tail = payload + n;
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    uint32_t seen = 0u;   // wave-uniform: rows this wavefront has flagged as used already
+    unsigned long long seen = 0ull;   // wave-uniform: rows this wavefront has flagged as used already
     for (uint64_t i0 = (uint64_t)blockIdx.x * blockDim.x; i0 < n; i0 += stride) {   // workgroup-uniform trip count
         const uint64_t i = i0 + threadIdx.x;
         int32_t v = 0;
@@ -40,9 +40,9 @@ HML_KERNEL __launch_bounds__(256) void hml_k_pool_export(const int32_t* __restri
         unsigned long long m = __ballot(nz);
         while (m != 0ull) {   // wave-uniform; one trip unless the wavefront straddles two rows
             const int r0 = __builtin_amdgcn_readlane(r, __ffsll((long long)m) - 1);
-            if (!((seen >> r0) & 1u)) {
+            if (!((seen >> r0) & 1ull)) {
                 if ((threadIdx.x & 63u) == 0u) atomicOr(reinterpret_cast<unsigned int*>(tail + 1 + r0), 1u);
-                seen |= 1u << r0;
+                seen |= 1ull << r0;
             }
             nz = nz && r != r0;
             m = __ballot(nz);

@@ -15,7 +15,7 @@
 // phase 1: per chunk of 256 segments, the column sums of g -> chunk_sum[s * n_chunks + chunk]
 HML_KERNEL __launch_bounds__(256) void hml_k_seg_partial(const int32_t* __restrict__ g, uint32_t M, int K,
                                                          int32_t* __restrict__ chunk_sum, uint32_t n_chunks) {
-    __shared__ int32_t red[4][HML_MAX_K];
+    __shared__ int32_t red[4][HML_CAP_K];
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int s = 0; s < K; ++s) {
@@ -31,15 +31,17 @@ HML_KERNEL __launch_bounds__(256) void hml_k_seg_partial(const int32_t* __restri
 
 // phase 3 (phase 2 is hml_k_dense_chunkscan over the K rows of chunk_sum): running counts of every segment and
 // their arg-max -> seg_state[i]
+// (KM: the most states the running counts are kept for - HML_MAX_K, or HML_CAP_K for the reference-compatible mode's larger models)
+template <int KM>
 HML_KERNEL __launch_bounds__(256) void hml_k_seg_argmax(const int32_t* __restrict__ g, uint32_t M, int K,
                                                         const int32_t* __restrict__ chunk_base, uint32_t n_chunks,
                                                         int16_t* __restrict__ seg_state) {
-    __shared__ int32_t wsum[4][HML_MAX_K];
+    __shared__ int32_t wsum[4][KM];
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    int32_t incl[HML_MAX_K];
+    int32_t incl[KM];
 #pragma unroll
-    for (int s = 0; s < HML_MAX_K; ++s) {
+    for (int s = 0; s < KM; ++s) {
         if (s < K) {
             int32_t v = i < M ? g[(uint64_t)i * K + s] : 0;
 #pragma unroll
@@ -55,7 +57,7 @@ HML_KERNEL __launch_bounds__(256) void hml_k_seg_argmax(const int32_t* __restric
     int best = 0;
     int32_t best_count = 0;
 #pragma unroll
-    for (int s = 0; s < HML_MAX_K; ++s) {
+    for (int s = 0; s < KM; ++s) {
         if (s < K) {
             int32_t c = chunk_base[(uint64_t)s * n_chunks + blockIdx.x] + incl[s];
             for (int w2 = 0; w2 < wave; ++w2) c += wsum[w2][s];

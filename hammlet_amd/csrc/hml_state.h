@@ -47,7 +47,7 @@ enum {
     HML_DEVERR_LAUNCH_GEOMETRY = 12   // a kernel that relies on one wavefront per workgroup was launched with another shape (a host bug)
 };
 
-#define HML_MAX_D 4            // data dimensions (K = P^D <= 16 with P >= 2)
+#define HML_MAX_D 4            // data dimensions (K = P^D <= 16 with P >= 2; up to 64 in the reference-compatible mode)
 
 struct hml_model {
     // ---- configuration ----
@@ -55,8 +55,8 @@ struct hml_model {
     // multivariate / shared parameters ("-s C P D", reference src/Mapping.hpp:53-137): K = P^D states over D interleaved
     // data dimensions; state s uses parameter map[s][d] = (s / P^d) % P for dimension d.  D = 1: P = K, map[s][0] = s.
     int32_t D, P;
-    uint8_t map[HML_MAX_K][HML_MAX_D];
-    float logNs[HML_MAX_K];      // theta.logNormalizer(state): sum over the state's parameters (Theta.hpp:148-158)
+    uint8_t map[HML_CAP_K][HML_MAX_D];
+    float logNs[HML_CAP_K];      // theta.logNormalizer(state): sum over the state's parameters (Theta.hpp:148-158)
     uint64_t stat_stride;        // elements between the per-dimension planes of the integral array / block statistics
     int32_t self_trans;
     int32_t dynamic;
@@ -65,18 +65,18 @@ struct hml_model {
     float a_off, a_diag, pi_alpha;
     hml_key key;
     // ---- current parameters ----
-    float mu[HML_MAX_K], var[HML_MAX_K], sd[HML_MAX_K];
-    double rvar2[HML_MAX_K];     // 1 / (2 var): the emission kernels multiply by it instead of dividing (hml_inner_product)
-    float logN[HML_MAX_K];       // theta.logNormalizer(s)          (EFD.hpp:35-38)
-    float logA[HML_MAX_K];       // log A(s,s)                       (ForwardBackward.hpp:47-52)
-    float A[HML_MAX_K * HML_MAX_K];   // row-major, stride K
-    float pi[HML_MAX_K];
+    float mu[HML_CAP_K], var[HML_CAP_K], sd[HML_CAP_K];
+    double rvar2[HML_CAP_K];     // 1 / (2 var): the emission kernels multiply by it instead of dividing (hml_inner_product)
+    float logN[HML_CAP_K];       // theta.logNormalizer(s)          (EFD.hpp:35-38)
+    float logA[HML_CAP_K];       // log A(s,s)                       (ForwardBackward.hpp:47-52)
+    float A[HML_CAP_K * HML_CAP_K];   // row-major, stride K
+    float pi[HML_CAP_K];
     float thr;                   // current wavelet threshold
     float thr_theta;             // threshold implied by the current theta (createBlocks(theta))
     // ---- posteriors (reset to the priors after every draw) ----
-    float nig_post[HML_MAX_K][4];
-    float dirA[HML_MAX_K * HML_MAX_K];
-    float dirPi[HML_MAX_K];
+    float nig_post[HML_CAP_K][4];
+    float dirA[HML_CAP_K * HML_CAP_K];
+    float dirPi[HML_CAP_K];
     // ---- block structure ----
     uint32_t B;                  // number of blocks
     uint32_t n_spans;
@@ -90,12 +90,12 @@ struct hml_model {
     uint32_t cap;
     uint32_t halted;
     // ---- per-sweep accumulators (zeroed by the parameter kernel) ----
-    unsigned long long trans[HML_CNT_SPLIT][HML_MAX_K * HML_MAX_K];
+    unsigned long long trans[HML_CNT_SPLIT][HML_MAX_K * HML_MAX_K];   // (default path only)
     unsigned long long occ[HML_CNT_SPLIT][HML_MAX_K];
     // copies of the last sweep's sufficient statistics (probe)
-    unsigned long long last_trans[HML_MAX_K * HML_MAX_K];
-    unsigned long long last_occ[HML_MAX_K];
-    float last_sum[HML_MAX_K], last_sumsq[HML_MAX_K];
+    unsigned long long last_trans[HML_CAP_K * HML_CAP_K];
+    unsigned long long last_occ[HML_CAP_K];
+    float last_sum[HML_CAP_K], last_sumsq[HML_CAP_K];
     // ---- counters ----
     unsigned long long epoch;
     unsigned long long sweeps, block_updates, uniform_fallbacks, forward_refits, forward_serial;

@@ -30,31 +30,8 @@ static bool fused_geometry(hml_ctx* c, uint32_t* n_sub, uint32_t* n_wg) {
 }
 
 
-// A sweep of the reference-compatible mode (hml_k_compat.h): block starts and block statistics by the default path's
-// kernels, everything order-dependent by one lane in the reference's order, the marginals by hml_k_record.
-template <int KK>
-static int sweep_compat(hml_ctx* c, char method, bool record) {
-    hipStream_t s = c->stream;
-    if (c->dynamic || !c->blocks_valid) {
-        if (int r = launch_compact(c, false, 0.0f)) return r;   // starts, block count, block statistics at the model's threshold
-        if (!c->dynamic) c->blocks_valid = true;
-    }
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_compat_sweep<KK>), dim3(1), dim3(64), 0, s, c->d_mdl, (hml_mt_state*)c->d_mt, c->d_starts, c->d_bstat,
-                       c->d_crows, c->d_q, method == HML_METHOD_MIXTURE ? 1 : 0, c->probes ? c->d_eprobe : nullptr, c->probes ? c->d_aprobe : nullptr);
-    if (record && c->rec_marginals) {
-        if (c->pooled) return set_err(HML_ERR_ARG, "the marginals of this context are pooled (common labels, several chains): further sweeps cannot be recorded into them");
-        if (int r = ensure_marginal_buffers(c)) return r;
-        refresh_hint(c);
-        const uint32_t hint = c->B_hint ? c->B_hint : (uint32_t)std::min<uint64_t>(c->T, 1u << 20);
-        hipLaunchKernelGGL(hml_k_record, dim3(grid_for(hint, 256, 64, 16384)), dim3(256), 0, s, c->d_q, c->d_starts, c->d_mdl, c->d_diff, c->d_boundary);
-    }
-    KLAUNCH_CHECK();
-    return 0;
-}
-
 template <int KK>
 static int sweep_k(hml_ctx* c, char method, bool record) {
-    if (c->compat) return sweep_compat<KK>(c, method, record);
     hipStream_t s = c->stream;
     const bool mix = (method == HML_METHOD_MIXTURE);
     const uint32_t T = (uint32_t)c->T;
@@ -460,15 +437,11 @@ static int iterate_many_k(hml_ctx* const* cs, int n, uint64_t first, uint64_t it
     static void hml_kt_params_##KK(hml_ctx* c, int mode) {                                                                         \
         hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_params<KK>), dim3(1), dim3(1024), 0, c->stream, c->d_mdl, c->d_partial, mode);    \
     }                                                                                                                              \
-    static void hml_kt_compat_draw_##KK(hml_ctx* c, int mode) {                                                                    \
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_compat_draw<KK>), dim3(1), dim3(64), 0, c->stream, c->d_mdl, (hml_mt_state*)c->d_mt, mode); \
-    }                                                                                                                              \
     static void hml_kt_derive_##KK(hml_ctx* c) {                                                                                   \
-        if (c->compat) hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_compat_derive<KK>), dim3(1), dim3(64), 0, c->stream, c->d_mdl);     \
-        else hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_derive<KK>), dim3(1), dim3(64), 0, c->stream, c->d_mdl);                     \
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_derive<KK>), dim3(1), dim3(64), 0, c->stream, c->d_mdl);                          \
     }                                                                                                                              \
     extern hml_ktab hml_ktab_##KK;                                                                                                 \
-    hml_ktab hml_ktab_##KK = {&sweep_k<KK>, &iterate_many_k<KK>, &hml_kt_params_##KK, &hml_kt_compat_draw_##KK, &hml_kt_derive_##KK};
+    hml_ktab hml_ktab_##KK = {&sweep_k<KK>, &iterate_many_k<KK>, &hml_kt_params_##KK, &hml_kt_derive_##KK};
 #if defined(HML_TU_K)
 #define HML_DEFINE_KTAB_(K) HML_DEFINE_KTAB(K)
 HML_DEFINE_KTAB_(HML_TU_K)

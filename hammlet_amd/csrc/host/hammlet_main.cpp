@@ -347,6 +347,12 @@ int main(int argc, const char* argv[]) {
         }
         Mapping mapping(nrDataDim, nrParams, combinations);
         const size_t nrStates = mapping.nrStates();
+        // more than 16 states: the library's default path is compiled for 2 .. 16; its reference-compatible mode takes any number
+        // up to 64 (the reference's own chain, see -compat), so such a model runs there
+        if (nrStates > 16 && !args.isSet("-compat")) {
+            setenv("HML_COMPAT", "1", 1);
+            if (verbose) cout << "More than 16 states: running in the reference-compatible mode (-compat)." << endl;
+        }
 
         // first token = off-diagonal, second = diagonal (reference main.cpp:144-149)
         const real_t trans = args.parse<real_t>("-t", 0);

@@ -51,6 +51,12 @@ CASES = {
     "mv_c32_mixed": (30000, 3, 52, "-s C 3 2 -R 6 -i M 20 1 S P F 30 2 D F 10 1", ["marginals", "sequences", "parameters", "compression"]),
     "mv_c23": (20000, 2, 53, "-s C 2 3 -R 7 -i F 30 1", ["marginals", "parameters", "blocks"]),
     "mv_c42_no_self": (70000, 4, 54, "-s C 4 2 -R 8 -S -m 1.3 -i F 20 2", ["marginals", "parameters", "compression"]),
+    # more than 16 states (round 4: the reference takes any -s K, main.cpp:112-136; the GPU library runs such models in its
+    # reference-compatible mode, hml_k_compat.h)
+    "k20_many_states": (60000, 6, 61, "-s 20 -R 12 -i F 30 1", ["marginals", "sequences", "parameters", "blocks"]),
+    "k40_mixed_scheme": (30000, 5, 62, "-s 40 -R 13 -t 0.2 2 -i M 10 1 S P F 15 2 D F 5 1", ["marginals", "parameters", "compression"]),
+    "mv_c52_25_states": (40000, 5, 63, "-s C 5 2 -R 14 -i F 20 1", ["marginals", "parameters", "compression"]),
+    "k64_most_states": (20000, 4, 64, "-s 64 -R 15 -i F 12 1", ["marginals", "parameters"]),
 }
 
 

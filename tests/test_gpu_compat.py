@@ -76,11 +76,15 @@ def test_quotient_by_reciprocal(hml):
     (100000, 3, 1, [("F", 30, 1)]),
     (20000, 4, 3, [("M", 20, 5), ("D",), ("F", 25, 2), ("P",), ("M", 6, 1), ("S",), ("F", 12, 1)]),
     (70000, 5, 8, [("F", 12, 3)]),
+    # more than 16 states (round 4): the mode takes the number of states at run time, up to 64
+    (50000, 17, 9, [("F", 10, 1)]),
+    (30000, 33, 10, [("M", 6, 2), ("S",), ("F", 8, 1), ("P",), ("D",), ("F", 5, 1)]),
+    (20000, 64, 11, [("F", 6, 1)]),
 ])
 def test_compat_chain_is_the_reference_chain(hml, T, K, seed, scheme):
     """through the C ABI: block structure, state sequence, parameter bits, transition matrix, counts and marginals of a
     compat chain equal those of the checker in REFERENCE mode (sequential mt19937, libm, Kahan sums, size_t += float)"""
-    x = ol.trace(T, K, seed)
+    x = ol.trace(T, min(K, 6), seed)
     o = ol.OracleChain(K=K, seed=seed, rng=ol.RNG_MT, math=ol.MATH_LIBM, reduce=ol.REDUCE_REF)
     o.load(x)
     o.autoprior()
@@ -117,6 +121,7 @@ def test_compat_chain_is_the_reference_chain(hml, T, K, seed, scheme):
 
 
 @pytest.mark.parametrize("P,D,T,seed,scheme", [
+    (6, 2, 20000, 8, [("F", 8, 1)]),   # 36 states
     (2, 2, 30000, 5, [("F", 20, 1)]),
     (3, 2, 20000, 6, [("M", 10, 1), ("S",), ("P",), ("F", 12, 2), ("D",), ("F", 6, 1)]),
     (2, 3, 20000, 7, [("F", 10, 1)]),
