@@ -156,6 +156,7 @@ int hml_create(hml_ctx** out, int device, uint64_t seed, uint32_t chain_id, void
     if (const char* e = getenv("HML_STAGE_BITS")) c->stage_bits = atoi(e) != 0;
     if (const char* e = getenv("HML_TRELLIS_ROWS")) c->tre_rows = atoi(e) != 0;   // 0: round 2's first pass (hml_k_trellis_tile) for comparison
     if (const char* e = getenv("HML_LATE_RESCALE")) c->late_rescale = atoi(e) != 0;
+    if (const char* e = getenv("HML_PARAMS_SPREAD")) c->params_spread = atoi(e) != 0;
     if (const char* e = getenv("HML_COMPAT")) c->compat = atoi(e) != 0;   // option "compat" for unmodified callers (`hammlet -compat`)
     if (const char* e = getenv("HML_TRELLIS_TUNE")) c->tre_autotune = atoi(e) != 0;
     if (const char* e = getenv("HML_FUSED_SPIN_LIMIT")) c->fused_spin_limit = (uint32_t)strtoul(e, nullptr, 10);
@@ -614,8 +615,10 @@ static int alloc_sweep_buffers(hml_ctx* c) {
     // (checkpoints of the fused trellis path: (L / 64 - 1) x ceil(B / L) <= B / 64 + 16 vectors of K + 1 words)
     HIPCHK(hipMalloc(&c->d_tre_ckpt, (cap / 64 + 64) * (uint64_t)(K + 1) * sizeof(uint32_t)));
     HIPCHK(hipMalloc(&c->d_q, cap * sizeof(int16_t)));
-    HIPCHK(hipMalloc(&c->d_partial, (uint64_t)HML_REDUCE_GROUPS * K * 2 * sizeof(double)));
-    HIPCHK(hipMemsetAsync(c->d_partial, 0, (uint64_t)HML_REDUCE_GROUPS * K * 2 * sizeof(double), c->stream));
+    // (the count pass's group partials [2 K][1024] and, behind them, the first level of their tree [16][2 K]: hml_k_params.h)
+    const uint64_t n_partial = ((uint64_t)HML_REDUCE_GROUPS + HML_PARAMS_TREE_WGS) * K * 2;
+    HIPCHK(hipMalloc(&c->d_partial, n_partial * sizeof(double)));
+    HIPCHK(hipMemsetAsync(c->d_partial, 0, n_partial * sizeof(double), c->stream));
     return 0;
 }
 
@@ -719,6 +722,9 @@ int hml_set_model(hml_ctx* c, int K, const float nig4[4], float a_off, float a_d
     if (int r = ctx_bind(c)) return r;
     free_sweep_buffers(c);   // (what an earlier call that failed half-way left behind)
     c->K = K;
+    // the parameter kernel's tree over 16 workgroups (hml_k_params.h) from 8 states: it reads 2 K x 8 KB of group partials -
+    // config 4's sweep (10 states) 0.0938 -> 0.0869 ms, config 3's (5 states) unchanged either way
+    if (!getenv("HML_PARAMS_SPREAD")) c->params_spread = K >= 8;
     const uint64_t T = c->T;
     if (int r = alloc_sweep_buffers(c)) return r;
 

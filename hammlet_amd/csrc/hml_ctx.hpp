@@ -105,6 +105,7 @@ struct hml_ctx {
     uint8_t *d_bentry = nullptr, *d_bentry2 = nullptr;
     int16_t* d_q = nullptr;
     double* d_partial = nullptr;
+    bool params_spread = false;    // single-chain sweeps: the parameter kernel's tree over 16 workgroups (hml_k_params.h; HML_PARAMS_SPREAD)
     int32_t* d_diff = nullptr;
     uint32_t* d_boundary = nullptr;
     hml_model* d_mdl = nullptr;

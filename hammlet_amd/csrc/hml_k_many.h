@@ -81,7 +81,7 @@ HML_KERNEL __launch_bounds__(256) void hml_m_record(const hml_chain_dev* __restr
 template <int K>
 HML_KERNEL __launch_bounds__(1024) void hml_m_params(const hml_chain_dev* __restrict__ cs) {
     const hml_chain_dev& c = cs[blockIdx.y];
-    hml_b_params<K>(c.mdl, c.partial, 0);
+    hml_b_params<K, true>(c.mdl, c.partial, 0, (int)blockIdx.x, (int)gridDim.x);
 }
 
 #endif

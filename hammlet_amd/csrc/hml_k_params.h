@@ -2,6 +2,8 @@
 #ifndef HML_K_PARAMS_H
 #define HML_K_PARAMS_H
 
+#include <type_traits>
+
 #include "hml_dist.h"
 #include "hml_k_backward.h"
 #include "hml_state.h"
@@ -62,10 +64,21 @@ HML_KERNEL __launch_bounds__(64) void hml_k_set_dynamic(hml_model* mdl, int on, 
 // One workgroup of 1024: wavefront 0 draws theta, wavefront 1 pi, wavefronts 2.. the K*K entries
 // of A, every variate from its own Philox sub-stream.
 // ------------------------------------------------------------------------------------------
-template <int K>
-__device__ __forceinline__ void hml_b_params(hml_model* __restrict__ mdl, const double* __restrict__ partial,
-                                                     int mode) {
+// SPREAD (round 4; mode 0 only, launched with gridDim.x = HML_PARAMS_TREE_WGS = 16): the first level of the count pass's tree
+// - 1024 group partials per statistic, pairwise inside each run of 64 - is spread over sixteen workgroups.  Workgroup w reduces
+// groups 64 w .. 64 w + 63 of every statistic (the pairwise tree that wavefront w of the one-workgroup form runs) and leaves
+// 2 K doubles behind the group partials; its last wavefront - which draws nothing - takes a ticket while the others draw, and
+// the workgroup that arrives last of the sixteen is the one that goes on: it reads 16 x 2 K doubles instead of 1024 x 2 K
+// through one compute unit's memory pipeline (160 KB at K = 10: the tree was 7 us of a 14 us kernel; several chains at once
+// stretch it further).  Every workgroup makes the draws that depend on the counts only - nothing outside the workgroup is
+// written before the ticket is known - so none of this lies on the path of the one that goes on.  Same summation tree, same
+// bits (D3 fixes the order, not who adds).  Config 4's sweep (10 states) 0.0938 -> 0.0869 ms, eight chains of config 3 0.161 ->
+// 0.154 ms per round; config 3's single chain gains nothing (0.0557 / 0.0564) and keeps the one-workgroup form.
+template <int K, bool SPREAD>
+__device__ __forceinline__ void hml_b_params(hml_model* __restrict__ mdl, typename std::conditional<SPREAD, double, const double>::type* __restrict__ partial,
+                                                     int mode, int leaf, int nleaf) {
     __shared__ double wp[16][K][2];
+    __shared__ uint32_t s_last;
     __shared__ float fin[K][2];
     __shared__ float graw[K * K];
     __shared__ float praw[K];
@@ -84,7 +97,9 @@ __device__ __forceinline__ void hml_b_params(hml_model* __restrict__ mdl, const 
     if (wave == 0 && lane < P) { hyp0 = mdl->nig_post[lane][0]; hyp1 = mdl->nig_post[lane][1]; hyp2 = mdl->nig_post[lane][2]; hyp3 = mdl->nig_post[lane][3]; }
     if (wave == 1 && lane < K) hyp0 = mdl->dirPi[lane];
     if (tid >= 128 && tid < 128 + K * K) hyp0 = mdl->dirA[tid - 128];
-    // gather the split integer accumulators
+    // gather the split integer accumulators (SPREAD: every workgroup reads them, the one that goes on resets them - below, once it
+    // knows it is the one; each workgroup has read them before it takes its ticket)
+    unsigned long long acc_total = 0ull;
     if (tid >= 128 && tid < 128 + K * K) {
         const int e = tid - 128;
         unsigned long long v[HML_CNT_SPLIT];
@@ -92,9 +107,10 @@ __device__ __forceinline__ void hml_b_params(hml_model* __restrict__ mdl, const 
         for (int sp = 0; sp < HML_CNT_SPLIT; ++sp) v[sp] = mdl->trans[sp][e];   // all loads in flight together
         unsigned long long t = 0ull;
 #pragma unroll
-        for (int sp = 0; sp < HML_CNT_SPLIT; ++sp) { t += v[sp]; mdl->trans[sp][e] = 0ull; }
+        for (int sp = 0; sp < HML_CNT_SPLIT; ++sp) { t += v[sp]; if (!SPREAD) mdl->trans[sp][e] = 0ull; }
         s_trans[e] = t;
-        mdl->last_trans[e] = t;
+        if (!SPREAD) mdl->last_trans[e] = t;
+        acc_total = t;
     }
     if (tid >= 512 && tid < 512 + K) {
         const int k = tid - 512;
@@ -103,9 +119,18 @@ __device__ __forceinline__ void hml_b_params(hml_model* __restrict__ mdl, const 
         for (int sp = 0; sp < HML_CNT_SPLIT; ++sp) v[sp] = mdl->occ[sp][k];
         unsigned long long t = 0ull;
 #pragma unroll
-        for (int sp = 0; sp < HML_CNT_SPLIT; ++sp) { t += v[sp]; mdl->occ[sp][k] = 0ull; }
+        for (int sp = 0; sp < HML_CNT_SPLIT; ++sp) { t += v[sp]; if (!SPREAD) mdl->occ[sp][k] = 0ull; }
         s_occ[k] = t;
-        mdl->last_occ[k] = t;
+        if (!SPREAD) mdl->last_occ[k] = t;
+        acc_total = t;
+    }
+    // SPREAD: this workgroup's share of the tree's first level - wavefront v takes statistics v, v + 16 - left behind the group partials
+    typename std::conditional<SPREAD, double, const double>::type* const level1 = partial + (uint64_t)HML_REDUCE_GROUPS * 2 * K;   // [16][2 K]
+    if constexpr (SPREAD) {
+        for (int idx = wave; idx < 2 * K; idx += 16) {
+            const double r = hml_wave_tree_f64(partial[(uint64_t)idx * HML_REDUCE_GROUPS + 64u * (uint32_t)leaf + (uint32_t)lane]);
+            if (lane == 0) __hip_atomic_store(reinterpret_cast<unsigned long long*>(level1) + leaf * 2 * K + idx, hml_d2u(r), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
     // this thread's group partials of the count pass (the tree below), requested behind the counts - which the first draws
     // wait for - and travelling while those draws run
@@ -118,16 +143,41 @@ __device__ __forceinline__ void hml_b_params(hml_model* __restrict__ mdl, const 
     double part_s[K], part_q[K], part2_s[K], part2_q[K];
 #pragma unroll
     for (int s = 0; s < K; ++s) {
-        part_s[s] = (mode == 0 && !draws) ? partial[(uint64_t)(s * 2 + 0) * HML_REDUCE_GROUPS + tid] : 0.0;
-        part_q[s] = (mode == 0 && !draws) ? partial[(uint64_t)(s * 2 + 1) * HML_REDUCE_GROUPS + tid] : 0.0;
-        part2_s[s] = (mode == 0 && mirror >= 0) ? partial[(uint64_t)(s * 2 + 0) * HML_REDUCE_GROUPS + (mirror * 64 + lane)] : 0.0;
-        part2_q[s] = (mode == 0 && mirror >= 0) ? partial[(uint64_t)(s * 2 + 1) * HML_REDUCE_GROUPS + (mirror * 64 + lane)] : 0.0;
+        part_s[s] = (!SPREAD && mode == 0 && !draws) ? partial[(uint64_t)(s * 2 + 0) * HML_REDUCE_GROUPS + tid] : 0.0;
+        part_q[s] = (!SPREAD && mode == 0 && !draws) ? partial[(uint64_t)(s * 2 + 1) * HML_REDUCE_GROUPS + tid] : 0.0;
+        part2_s[s] = (!SPREAD && mode == 0 && mirror >= 0) ? partial[(uint64_t)(s * 2 + 0) * HML_REDUCE_GROUPS + (mirror * 64 + lane)] : 0.0;
+        part2_q[s] = (!SPREAD && mode == 0 && mirror >= 0) ? partial[(uint64_t)(s * 2 + 1) * HML_REDUCE_GROUPS + (mirror * 64 + lane)] : 0.0;
     }
 
     // s_occ / s_trans (LDS) must be visible to the drawing lanes; the group partials requested above may keep travelling:
     // a barrier that waits for LDS traffic only (__syncthreads would also wait for every outstanding global load)
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if (SPREAD) __syncthreads();   // (this workgroup's first-level sums are on their way before its ticket is taken)
+    else asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     if (tid == 0) mdl->dbg_t[1] = wall_clock64();
+    if constexpr (SPREAD) {
+        // the ticket, by the last wavefront (it draws nothing) while the others draw
+        static_assert(NDRAW <= 8, "wavefronts 8 (occupancies) and 15 (ticket) draw nothing");
+        if (wave == 15) {
+            uint32_t last = 0u;
+            if (lane == 0) {
+                __threadfence();   // this workgroup's sums before its ticket
+                const uint32_t t = atomicAdd(&mdl->params_ticket, 1u);
+                last = ((t + 1u) % (uint32_t)nleaf == 0u) ? 1u : 0u;
+                s_last = last;
+            }
+            last = (uint32_t)__builtin_amdgcn_readfirstlane((int)last);
+            if (last != 0u) {   // wave-uniform: fetch the first-level sums of all sixteen
+                __threadfence();
+                if (lane < 2 * K) {
+                    unsigned long long raw[16];
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) raw[i] = __hip_atomic_load(reinterpret_cast<unsigned long long*>(level1) + i * 2 * K + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) wp[i][lane >> 1][lane & 1] = hml_u2d(raw[i]);
+                }
+            }
+        }
+    }
 
     // ---- the draws that need the COUNTS only, ahead of the sums: the gamma rejection loop depends on its shape parameter
     // alone (hml_gamma_core_f32), the normal variate on nothing; scale and location follow behind the tree.  Same
@@ -167,16 +217,32 @@ __device__ __forceinline__ void hml_b_params(hml_model* __restrict__ mdl, const 
     }
     if (tid == 128) mdl->dbg_t[4] = wall_clock64();
 
+    if constexpr (SPREAD) {
+        __syncthreads();   // the ticket's outcome and, in the workgroup that goes on, the first-level sums
+        if (s_last == 0u) return;   // workgroup-uniform; nothing outside the workgroup was written so far
+        if (tid >= 128 && tid < 128 + K * K) {
+            const int e = tid - 128;
+#pragma unroll
+            for (int sp = 0; sp < HML_CNT_SPLIT; ++sp) mdl->trans[sp][e] = 0ull;
+            mdl->last_trans[e] = acc_total;
+        }
+        if (tid >= 512 && tid < 512 + K) {
+            const int k = tid - 512;
+#pragma unroll
+            for (int sp = 0; sp < HML_CNT_SPLIT; ++sp) mdl->occ[sp][k] = 0ull;
+            mdl->last_occ[k] = acc_total;
+        }
+    }
     if (mode == 0) {
         // finish the fixed tree over the 1024 group partials: pairwise inside each wavefront ...
-        if (!draws) {   // wave-uniform
+        if (!SPREAD && !draws) {   // wave-uniform
 #pragma unroll
             for (int s = 0; s < K; ++s) {
                 const double a = hml_wave_tree_f64(part_s[s]), d = hml_wave_tree_f64(part_q[s]);
                 if (lane == 0) { wp[wave][s][0] = a; wp[wave][s][1] = d; }
             }
         }
-        if (mirror >= 0) {
+        if (!SPREAD && mirror >= 0) {
 #pragma unroll
             for (int s = 0; s < K; ++s) {
                 const double a = hml_wave_tree_f64(part2_s[s]), d = hml_wave_tree_f64(part2_q[s]);
@@ -351,7 +417,13 @@ __device__ __forceinline__ void hml_b_params(hml_model* __restrict__ mdl, const 
 template <int K>
 HML_KERNEL __launch_bounds__(1024) void hml_k_params(hml_model* __restrict__ mdl, const double* __restrict__ partial,
                                                      int mode) {
-    hml_b_params<K>(mdl, partial, mode);
+    hml_b_params<K, false>(mdl, partial, mode, 0, 1);
+}
+// ... with the tree's first level spread over HML_PARAMS_TREE_WGS workgroups (mode 0)
+#define HML_PARAMS_TREE_WGS 16
+template <int K>
+HML_KERNEL __launch_bounds__(1024) void hml_k_params_spread(hml_model* __restrict__ mdl, double* __restrict__ partial) {
+    hml_b_params<K, true>(mdl, partial, 0, (int)blockIdx.x, (int)gridDim.x);
 }
 
 

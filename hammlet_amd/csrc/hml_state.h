@@ -119,6 +119,7 @@ struct hml_model {
     uint32_t tre_hi_shift, tre_lo_shift;   // ... the warm-up grows above B >> hi refits per sweep and shrinks below B >> lo
     uint32_t tre_W_floor, tre_floor_age;   // ... and does not shrink below the length that last let the refits explode (forgotten slowly)
     unsigned long long fwd_refits_seen, fwd_serial_seen;
+    uint32_t params_ticket;      // arrivals of the parameter kernel's workgroups (hml_k_params.h: the last of every 16 goes on)
     unsigned long long dbg_t[12];   // wall_clock64 stamps of the parameter kernel's stages (printed by hml_sync with HML_PARAMS_DEBUG)
 };
 

@@ -271,7 +271,8 @@ static int sweep_k(hml_ctx* c, char method, bool record) {
     }
     {
         ProfScope ps(c, "params");
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_params<KK>), dim3(1), dim3(1024), 0, s, c->d_mdl, c->d_partial, 0);
+        if (c->params_spread) hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_params_spread<KK>), dim3(HML_PARAMS_TREE_WGS), dim3(1024), 0, s, c->d_mdl, c->d_partial);
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_params<KK>), dim3(1), dim3(1024), 0, s, c->d_mdl, c->d_partial, 0);
     }
     KLAUNCH_CHECK();
     return 0;
@@ -406,7 +407,7 @@ static int iterate_many_k(hml_ctx* const* cs, int n, uint64_t first, uint64_t it
             hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_m_backward_chain<KK>), dim3(1, ny), dim3(1024), 0, s, d_g, with_gsc, L);
             hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_m_counts<KK>), dim3(HML_REDUCE_GROUPS, ny), dim3(256), 0, s, d_g);
             if (record && (rec_mask >> g0)) hipLaunchKernelGGL(hml_m_record, dim3(gB, ny), dim3(256), 0, s, d_g, rec_mask >> g0);
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_m_params<KK>), dim3(1, ny), dim3(1024), 0, s, d_g);
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_m_params<KK>), dim3(HML_PARAMS_TREE_WGS, ny), dim3(1024), 0, s, d_g);
         }
         KLAUNCH_CHECK();
         if (record) {
