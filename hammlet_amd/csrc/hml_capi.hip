@@ -157,6 +157,8 @@ int hml_create(hml_ctx** out, int device, uint64_t seed, uint32_t chain_id, void
     if (const char* e = getenv("HML_TRELLIS_ROWS")) c->tre_rows = atoi(e) != 0;   // 0: round 2's first pass (hml_k_trellis_tile) for comparison
     if (const char* e = getenv("HML_LATE_RESCALE")) c->late_rescale = atoi(e) != 0;
     if (const char* e = getenv("HML_PARAMS_SPREAD")) c->params_spread = atoi(e) != 0;
+    if (const char* e = getenv("HML_COMPAT_CHUNKS")) c->compat_chunks = atoi(e);   // (1: the sequential form; > 1: that many chunks)
+    if (const char* e = getenv("HML_COMPAT_WARMUP")) c->compat_warmup = atoi(e);   // (tests: a warm-up too short to forget the start)
     if (const char* e = getenv("HML_COMPAT")) c->compat = atoi(e) != 0;   // option "compat" for unmodified callers (`hammlet -compat`)
     if (const char* e = getenv("HML_TRELLIS_TUNE")) c->tre_autotune = atoi(e) != 0;
     if (const char* e = getenv("HML_FUSED_SPIN_LIMIT")) c->fused_spin_limit = (uint32_t)strtoul(e, nullptr, 10);
@@ -189,7 +191,7 @@ static bool trace_shared(const hml_ctx* c) { return c->trace && c->trace->refs.l
 static void free_sweep_buffers(hml_ctx* c, bool keep_engine = false) {
     void** ptrs[] = {(void**)&c->d_em, (void**)&c->d_gsc, (void**)&c->d_rows, (void**)&c->d_entry, (void**)&c->d_exitA, (void**)&c->d_redo, (void**)&c->d_touched,
                      (void**)&c->d_fb, (void**)&c->d_smap, (void**)&c->d_cmap, (void**)&c->d_scmap, (void**)&c->d_super, (void**)&c->d_bentry2, (void**)&c->d_bentry,
-                     (void**)&c->d_q, (void**)&c->d_partial, (void**)&c->d_redo2, (void**)&c->d_tre_bitmap, (void**)&c->d_tre_ckpt, (void**)&c->d_crows};
+                     (void**)&c->d_q, (void**)&c->d_partial, (void**)&c->d_redo2, (void**)&c->d_tre_bitmap, (void**)&c->d_tre_ckpt, (void**)&c->d_crows, (void**)&c->d_cchunk, (void**)&c->d_cdraws, (void**)&c->d_clists};
     for (void** p : ptrs) if (*p) { hipFree(*p); *p = nullptr; }
     if (!keep_engine && c->d_mt) { hipFree(c->d_mt); c->d_mt = nullptr; }
 }
@@ -577,6 +579,12 @@ static int alloc_sweep_buffers(hml_ctx* c) {
         HIPCHK(hipMalloc(&c->d_em, cap * K * sizeof(float)));
         HIPCHK(hipMalloc(&c->d_gsc, cap * K * sizeof(float)));
         HIPCHK(hipMalloc(&c->d_crows, (cap + 1) * K * sizeof(float)));
+        // chunks of the filter and of the backward draws (hml_compat_chunks), the engine's outputs of a sweep (two per block)
+        HIPCHK(hipMalloc(&c->d_cchunk, (uint64_t)HML_COMPAT_MAX_CHUNKS * (2 * K * sizeof(float) + 3 * sizeof(uint32_t))));
+        HIPCHK(hipMalloc(&c->d_cdraws, 2 * cap * sizeof(uint32_t)));
+        // the count pass's lists by state (hml_compat_lists): statistics, sizes, per-tile counts, flags
+        HIPCHK(hipMalloc(&c->d_clists, cap * sizeof(float4) + (uint64_t)HML_CAP_K * HML_CAP_K * sizeof(unsigned long long) +
+                                        ((cap + HML_COMPAT_PART_TILE - 1) / HML_COMPAT_PART_TILE) * K * sizeof(uint32_t) + (HML_CAP_K + 1) * sizeof(uint32_t) + 64));
         HIPCHK(hipMalloc(&c->d_q, cap * sizeof(int16_t)));
         return 0;
     }
@@ -874,22 +882,58 @@ static int sweep_compat(hml_ctx* c, char method, bool record) {
     if (mix) hipLaunchKernelGGL(hml_k_compat_mixture, dim3(1), dim3(64), 0, s, c->d_mdl, mt, c->d_em, c->d_q);
     else {
         float* const aprobe = c->probes ? c->d_aprobe : nullptr;
+        // filter and backward draws in chunks with a wavefront each, then one wavefront that checks the chunks in order
+        // (hml_k_compat.h); one chunk - the sequential form - for short sweeps and when the rows are probed
+        uint32_t C = 1u;
+        if (!c->probes && c->compat_chunks > 1) C = std::min<uint32_t>((uint32_t)c->compat_chunks, HML_COMPAT_MAX_CHUNKS);   // (tests: any sweep in that many chunks)
+        else if (!c->probes && c->compat_chunks == 0 && hint >= 8192u) C = std::min<uint32_t>(1024u, hint / 128u);
+        hml_compat_chunks ch;
+        char* base = (char*)c->d_cchunk;
+        ch.entry = (float*)base; base += (uint64_t)HML_COMPAT_MAX_CHUNKS * c->K * sizeof(float);
+        ch.exitv = (float*)base; base += (uint64_t)HML_COMPAT_MAX_CHUNKS * c->K * sizeof(float);
+        ch.nfb = (uint32_t*)base; base += (uint64_t)HML_COMPAT_MAX_CHUNKS * sizeof(uint32_t);
+        ch.in_state = (int32_t*)base; base += (uint64_t)HML_COMPAT_MAX_CHUNKS * sizeof(int32_t);
+        ch.out_state = (int32_t*)base;
+        ch.W = c->compat_warmup > 0 ? (uint32_t)c->compat_warmup : c->compat_warmup < 0 ? 0u : (c->K <= 16 ? 64u : 128u);   // (< 0: none - tests)
+        hipLaunchKernelGGL(hml_k_compat_draws, dim3(1), dim3(64), 0, s, c->d_mdl, mt, c->d_cdraws, 2u);
         // (up to 16 states: the number of states as a compile-time value - A in registers, loops unrolled; beyond: the model's value)
 #define HML_COMPAT_FB(KC)                                                                                                                       \
         case KC:                                                                                                                                \
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_compat_forward<KC>), dim3(1), dim3(64), 0, s, c->d_mdl, c->d_starts, c->d_em, c->d_gsc, c->d_crows, aprobe); \
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_compat_backward<KC>), dim3(1), dim3(64), 0, s, c->d_mdl, mt, c->d_crows, c->d_q);           \
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_compat_forward<KC>), dim3(C), dim3(64), 0, s, c->d_mdl, c->d_em, c->d_gsc, c->d_crows, aprobe, ch); \
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_compat_forward_check<KC>), dim3(1), dim3(64), 0, s, c->d_mdl, c->d_em, c->d_gsc, c->d_crows, ch, C); \
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_compat_backward<KC>), dim3(C), dim3(64), 0, s, c->d_mdl, c->d_crows, c->d_cdraws, c->d_q, ch);  \
+            if (C > 1u) hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_compat_backward_check<KC>), dim3(1), dim3(64), 0, s, c->d_mdl, c->d_crows, c->d_cdraws, c->d_q, ch, C); \
             break;
         switch (c->K <= HML_MAX_K ? c->K : 0) {
             HML_COMPAT_FB(2) HML_COMPAT_FB(3) HML_COMPAT_FB(4) HML_COMPAT_FB(5) HML_COMPAT_FB(6) HML_COMPAT_FB(7) HML_COMPAT_FB(8) HML_COMPAT_FB(9)
             HML_COMPAT_FB(10) HML_COMPAT_FB(11) HML_COMPAT_FB(12) HML_COMPAT_FB(13) HML_COMPAT_FB(14) HML_COMPAT_FB(15) HML_COMPAT_FB(16)
             default:
-                hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_compat_forward<0>), dim3(1), dim3(64), 0, s, c->d_mdl, c->d_starts, c->d_em, c->d_gsc, c->d_crows, aprobe);
-                hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_compat_backward<0>), dim3(1), dim3(64), 0, s, c->d_mdl, mt, c->d_crows, c->d_q);
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_compat_forward<0>), dim3(C), dim3(64), 0, s, c->d_mdl, c->d_em, c->d_gsc, c->d_crows, aprobe, ch);
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_compat_forward_check<0>), dim3(1), dim3(64), 0, s, c->d_mdl, c->d_em, c->d_gsc, c->d_crows, ch, C);
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_compat_backward<0>), dim3(C), dim3(64), 0, s, c->d_mdl, c->d_crows, c->d_cdraws, c->d_q, ch);
+                if (C > 1u) hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_compat_backward_check<0>), dim3(1), dim3(64), 0, s, c->d_mdl, c->d_crows, c->d_cdraws, c->d_q, ch, C);
         }
 #undef HML_COMPAT_FB
     }
-    hipLaunchKernelGGL(hml_k_compat_update, dim3(1), dim3(64), 0, s, c->d_mdl, mt, c->d_starts, c->d_bstat, c->d_q, mix);
+    // the count pass: by state (partition, then one wavefront over all lists) for long univariate sweeps, in block order otherwise
+    hml_compat_lists pl;
+    {
+        const uint64_t tiles = (c->cap + HML_COMPAT_PART_TILE - 1) / HML_COMPAT_PART_TILE;
+        char* base = (char*)c->d_clists;
+        pl.item = (float4*)base; base += c->cap * sizeof(float4);
+        pl.offdiag = (unsigned long long*)base; base += (uint64_t)HML_CAP_K * HML_CAP_K * sizeof(unsigned long long);
+        pl.tile_count = (uint32_t*)base; base += tiles * c->K * sizeof(uint32_t);
+        pl.state_off = (uint32_t*)base;
+    }
+    const int by_state = (c->D == 1 && (c->compat_chunks > 1 || (c->compat_chunks == 0 && hint >= 8192u))) ? 1 : 0;
+    if (by_state) {
+        const unsigned tiles_now = (unsigned)(((uint64_t)hint + hint / 8 + HML_COMPAT_PART_TILE) / HML_COMPAT_PART_TILE);   // (kernels find B themselves; tiles beyond it return)
+        const unsigned tg = std::min<uint64_t>(std::max(1u, tiles_now), (c->cap + HML_COMPAT_PART_TILE - 1) / HML_COMPAT_PART_TILE);
+        hipLaunchKernelGGL(hml_k_compat_part_count, dim3(tg), dim3(256), 0, s, c->d_mdl, c->d_q, pl);
+        hipLaunchKernelGGL(hml_k_compat_part_scan, dim3(1), dim3(64), 0, s, c->d_mdl, pl);
+        hipLaunchKernelGGL(hml_k_compat_part_scatter, dim3(tg), dim3(256), 0, s, c->d_mdl, c->d_q, c->d_starts, c->d_bstat, pl);
+    }
+    hipLaunchKernelGGL(hml_k_compat_update, dim3(1), dim3(64), 0, s, c->d_mdl, mt, c->d_starts, c->d_bstat, c->d_q, mix, pl, by_state);
     if (record && c->rec_marginals) {
         if (c->pooled) return set_err(HML_ERR_ARG, "the marginals of this context are pooled (common labels, several chains): further sweeps cannot be recorded into them");
         if (int r = ensure_marginal_buffers(c)) return r;

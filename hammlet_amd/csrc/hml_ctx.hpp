@@ -156,6 +156,11 @@ struct hml_ctx {
     bool compat = false;           // option "compat": sweeps exactly as the reference computes them (hml_k_compat.h)
     void* d_mt = nullptr;          // its engine (hml_mt_state)
     float* d_crows = nullptr;      // its trellis, (T + 1) x K
+    void* d_cchunk = nullptr;      // chunks of its filter / backward draws (hml_compat_chunks, hml_k_compat.h)
+    uint32_t* d_cdraws = nullptr;  // the engine's outputs of a sweep's categorical draws
+    void* d_clists = nullptr;      // its count pass's lists by state (hml_compat_lists)
+    int compat_chunks = 0;         // 0: chosen from the block count; 1: the sequential form (HML_COMPAT_CHUNKS)
+    int compat_warmup = 0;         // blocks a chunk runs ahead of its first; 0: 64 (128 beyond 16 states) (HML_COMPAT_WARMUP)
     bool pooled = false;           // the marginals are a pooled payload (hml_pool_install): common labels, counts of several chains
     std::vector<int32_t> pool_perm;   // perm[pooled label] = this chain's label, from the export that preceded the pooling
     int profiling = 0;             // 0 off, 1 dominant kernel only (blocks_compact, every 32nd launch), 2 every kernel family

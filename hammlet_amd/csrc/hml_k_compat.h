@@ -162,6 +162,7 @@ HML_KERNEL __launch_bounds__(64) void hml_k_compat_draw(hml_model* __restrict__ 
 //                           draws: one lane, its blocks staged through LDS by all.
 // ------------------------------------------------------------------------------------------------------------------------
 #define HML_COMPAT_TILE 1024   // floats staged per tile: min(64, 1024 / K) blocks
+#define HML_COMPAT_MAX_CHUNKS 2048
 
 __device__ __forceinline__ float hml_lane_f32(float v, int i) {   // (i wave-uniform)
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), i));
@@ -289,39 +290,41 @@ HML_KERNEL __launch_bounds__(256) void hml_k_compat_emission(hml_model* __restri
     }
 }
 
-// StateSequence<ForwardBackward>::sample's filter (ForwardBackward.hpp:86-123).  rows: (B + 1) x K floats, row 0 = pi; row t
-// as the backward pass reads it - rescaled by A(s, s)^(N_t - 1) (:115-119) - except the last.  KC: the number of states as
-// a compile-time value (2 .. 16: A's column in registers, loops unrolled) or 0 = the model's value (A in LDS).
+// ---- filter and backward draws in CHUNKS (round 4).  Both recursions forget where they started: a chunk of L blocks is run by
+// its own wavefront from a guessed start W blocks earlier (the filter: a flat row; the backward draws: state 0 - all chains of
+// draws share the uniforms, so paths from different states coalesce), and is RIGHT exactly if the value it reached at its first
+// block equals, bit for bit, what the chunk before it left there.  A second launch of one wavefront walks the chunks in order,
+// compares, and runs the rare chunk that was wrong again from the right value (then the next comparison uses what it left).
+// The first chunk starts from the true value, so by induction every stored row / state is the sequential one.  One chunk
+// (gridDim.x = 1) is the sequential form: probes, short sweeps.
+struct hml_compat_chunks {
+    float* entry;        // [C][K] filter: the row a chunk reached at its first block (from its warm-up)
+    float* exitv;        // [C][K] ... and the unscaled row it left behind its last block
+    uint32_t* nfb;       // [C] uniform fallbacks inside the chunk's own blocks
+    int32_t* in_state;   // [C] backward draws: the state above the chunk's first row (from its warm-up)
+    int32_t* out_state;  // [C] ... and the state of its last row
+    uint32_t W;          // warm-up, blocks
+};
+// blocks per chunk of a launch of C chunks over B blocks
+__device__ __forceinline__ uint32_t hml_compat_chunk_len(uint32_t B, uint32_t C) { const uint32_t L = (B + C - 1u) / C; return L < 64u ? 64u : L; }
+
+// StateSequence<ForwardBackward>::sample's filter (ForwardBackward.hpp:86-123) over blocks [b_begin, b_end), rows stored from
+// block b_store on.  rows: (B + 1) x K floats, row 0 = pi; row t = b + 1 in the form the backward pass reads it - rescaled by
+// A(s, s)^(N_b - 1) (:115-119: the reference rescales a row once the next one exists; the same product) - except the last.
+// prev: the row before block b_begin (in), behind block b_end - 1 (out, unscaled); entry_out: the row before block b_store.
+// KC: the number of states as a compile-time value (2 .. 16: A's column in registers, loops unrolled) or 0 = the model's
+// value (A in LDS).
 template <int KC>
-HML_KERNEL __launch_bounds__(64) void hml_k_compat_forward(hml_model* __restrict__ mdl, const uint32_t* __restrict__ starts,
-                                                           const float* __restrict__ em, const float* __restrict__ g,
-                                                           float* __restrict__ rows, float* __restrict__ aprobe) {
-    __shared__ float sA[KC ? 1 : HML_CAP_K * HML_CAP_K];   // row-major: lane j reads A(i, j)
-    __shared__ float tile[HML_COMPAT_TILE], tile_g[HML_COMPAT_TILE];
-    if (mdl->halted != 0u) return;
-    const int lane = threadIdx.x;
-    const int K = KC ? KC : mdl->K;
-    const uint32_t B = mdl->B;
-    const bool self = mdl->self_trans != 0;
+__device__ __forceinline__ void hml_compat_forward_range(int K, uint32_t B, bool self, const float* __restrict__ em, const float* __restrict__ g,
+                                                         float* __restrict__ rows, float* __restrict__ aprobe, const float (&acol)[KC ? KC : 1],
+                                                         const float* sA, float* tile, float* tile_g, uint32_t b_begin, uint32_t b_store, uint32_t b_end,
+                                                         float& prev, float* entry_out, uint32_t& nfb, int lane) {
     const bool act = lane < K;
-    float acol[KC ? KC : 1];
-    if (KC) {
-#pragma unroll
-        for (int i = 0; i < (KC ? KC : 1); ++i) acol[i] = act ? mdl->A[i * K + lane] : 0.0f;
-    } else {
-        for (int i = lane; i < K * K; i += 64) sA[i] = mdl->A[i];
-    }
-    float prev = act ? mdl->pi[lane] : 0.0f;
-    if (act) { rows[lane] = prev; if (aprobe) aprobe[lane] = prev; }
-    // the factor of row 0: a "block" of size 1 before the first (prevN = 1, ForwardBackward.hpp:107)
-    float gprev = (act && self) ? hml_glibc_expf((1.0f - 1.0f) * mdl->logA[lane]) : 1.0f;
     const uint32_t TB = (uint32_t)((HML_COMPAT_TILE / K) < 64 ? (HML_COMPAT_TILE / K) : 64);
-    hml_compat_fence();
-    unsigned long long nfb = 0ull;
     constexpr int NREG = HML_COMPAT_TILE / 64;
     float nxt[NREG], nxt_g[NREG];
     auto fetch = [&](uint32_t b0) {   // a tile's emission terms and factors into registers (they travel during the tile before)
-        const uint32_t nb = (b0 < B) ? ((B - b0 < TB) ? B - b0 : TB) : 0u;
+        const uint32_t nb = (b0 < b_end) ? ((b_end - b0 < TB) ? b_end - b0 : TB) : 0u;
 #pragma unroll
         for (int r = 0; r < NREG; ++r) {
             const uint32_t i = (uint32_t)r * 64u + (uint32_t)lane;
@@ -330,19 +333,22 @@ HML_KERNEL __launch_bounds__(64) void hml_k_compat_forward(hml_model* __restrict
             nxt_g[r] = (in && self) ? g[(uint64_t)b0 * K + i] : 1.0f;
         }
     };
-    fetch(0u);
-    for (uint32_t b0 = 0; b0 < B; b0 += TB) {
-        const uint32_t nb = (B - b0 < TB) ? B - b0 : TB;
+    fetch(b_begin);
+    for (uint32_t b0 = b_begin; b0 < b_end; b0 += TB) {
+        const uint32_t nb = (b_end - b0 < TB) ? b_end - b0 : TB;
+        hml_compat_fence();
 #pragma unroll
         for (int r = 0; r < NREG; ++r) { tile[r * 64 + lane] = nxt[r]; tile_g[r * 64 + lane] = nxt_g[r]; }
         hml_compat_fence();
         fetch(b0 + TB);
         float e_nx = act ? tile[lane] : 0.0f, g_nx = act ? tile_g[lane] : 1.0f;   // (one block ahead of the filter)
         for (uint32_t r = 0; r < nb; ++r) {
-            const uint64_t t = (uint64_t)b0 + r + 1u;
+            const uint32_t b = b0 + r;
+            const uint64_t t = (uint64_t)b + 1u;
             float f = e_nx;
             const float gcur = g_nx;
             if (r + 1u < nb) { e_nx = act ? tile[(r + 1u) * (uint32_t)K + (uint32_t)lane] : 0.0f; g_nx = act ? tile_g[(r + 1u) * (uint32_t)K + (uint32_t)lane] : 1.0f; }
+            if (b == b_store && entry_out && act) entry_out[lane] = prev;
             float tt = 0.0f;
             if (KC) {
 #pragma unroll
@@ -360,36 +366,226 @@ HML_KERNEL __launch_bounds__(64) void hml_k_compat_forward(hml_model* __restrict
             }
             float fw;
             if (Z != 0.0f) fw = f / Z;
-            else { nfb++; fw = (float)(1.0 / (double)(float)K); }
-            if (act) {
+            else { if (b >= b_store) nfb++; fw = (float)(1.0 / (double)(float)K); }
+            if (act && b >= b_store) {
                 if (aprobe) aprobe[t * K + lane] = fw;
-                if (self) rows[(t - 1u) * K + lane] = prev * gprev;   // :115-119
-                rows[t * K + lane] = fw;
+                rows[t * K + lane] = (self && t < (uint64_t)B) ? fw * gcur : fw;
             }
             prev = act ? fw : 0.0f;
-            gprev = gcur;
         }
-        hml_compat_fence();
     }
-    if (lane == 0) mdl->uniform_fallbacks += nfb;
 }
 
-// ... and its backward draws (ForwardBackward.hpp:133-162; Trellis::sample, Trellis.hpp:61-66): the last row, then rows
-// B-1 .. 1 with weights rows[t][i] * A(i, q_{t+1}), two engine outputs per draw
 template <int KC>
-HML_KERNEL __launch_bounds__(64) void hml_k_compat_backward(hml_model* __restrict__ mdl, hml_mt_state* __restrict__ mts,
-                                                            const float* __restrict__ rows, int16_t* __restrict__ q) {
+HML_KERNEL __launch_bounds__(64) void hml_k_compat_forward(hml_model* __restrict__ mdl, const float* __restrict__ em, const float* __restrict__ g,
+                                                           float* __restrict__ rows, float* __restrict__ aprobe, const hml_compat_chunks ch) {
+    __shared__ float sA[KC ? 1 : HML_CAP_K * HML_CAP_K];   // row-major: lane j reads A(i, j)
+    __shared__ float tile[HML_COMPAT_TILE], tile_g[HML_COMPAT_TILE];
+    if (mdl->halted != 0u) return;
+    const int lane = threadIdx.x;
+    const int K = KC ? KC : mdl->K;
+    const uint32_t B = mdl->B;
+    const uint32_t C = gridDim.x, c = blockIdx.x, L = hml_compat_chunk_len(B, C);
+    const uint32_t lo = c * L;
+    if (lo >= B) return;
+    const uint32_t hi = (lo + L < B) ? lo + L : B;
+    const bool self = mdl->self_trans != 0;
+    const bool act = lane < K;
+    float acol[KC ? KC : 1];
+    if (KC) {
+#pragma unroll
+        for (int i = 0; i < (KC ? KC : 1); ++i) acol[i] = act ? mdl->A[i * K + lane] : 0.0f;
+    } else {
+        for (int i = lane; i < K * K; i += 64) sA[i] = mdl->A[i];
+    }
+    const uint32_t ws = (lo > ch.W) ? lo - ch.W : 0u;
+    float prev = act ? ((ws == 0u) ? mdl->pi[lane] : (float)(1.0 / (double)(float)K)) : 0.0f;
+    if (c == 0u && act) {
+        if (aprobe) aprobe[lane] = prev;
+        // row 0 with the factor of a "block" of size 1 before the first (prevN = 1, ForwardBackward.hpp:107)
+        rows[lane] = self ? prev * hml_glibc_expf((1.0f - 1.0f) * mdl->logA[lane]) : prev;
+    }
+    uint32_t nfb = 0u;
+    hml_compat_forward_range<KC>(K, B, self, em, g, rows, aprobe, acol, sA, tile, tile_g, ws, lo, hi, prev, ch.entry + (uint64_t)c * K, nfb, lane);
+    if (act) ch.exitv[(uint64_t)c * K + lane] = prev;
+    if (lane == 0) ch.nfb[c] = nfb;
+}
+
+// the filter's chunks in order: a chunk whose first row is not what the chunk before it left runs again from that row
+template <int KC>
+HML_KERNEL __launch_bounds__(64) void hml_k_compat_forward_check(hml_model* __restrict__ mdl, const float* __restrict__ em, const float* __restrict__ g,
+                                                                 float* __restrict__ rows, const hml_compat_chunks ch, uint32_t C) {
+    __shared__ float sA[KC ? 1 : HML_CAP_K * HML_CAP_K];
+    __shared__ float tile[HML_COMPAT_TILE], tile_g[HML_COMPAT_TILE];
+    if (mdl->halted != 0u) return;
+    const int lane = threadIdx.x;
+    const int K = KC ? KC : mdl->K;
+    const uint32_t B = mdl->B;
+    const uint32_t L = hml_compat_chunk_len(B, C);
+    const uint32_t n_chunks = (B + L - 1u) / L;
+    const bool self = mdl->self_trans != 0;
+    const bool act = lane < K;
+    float acol[KC ? KC : 1];
+    if (KC) {
+#pragma unroll
+        for (int i = 0; i < (KC ? KC : 1); ++i) acol[i] = act ? mdl->A[i * K + lane] : 0.0f;
+    } else {
+        for (int i = lane; i < K * K; i += 64) sA[i] = mdl->A[i];
+    }
+    hml_compat_fence();
+    unsigned long long total_nfb = 0ull, redone = 0ull;
+    for (uint32_t c0 = 0; c0 < n_chunks; c0 += 64u) {
+        // lane l: is chunk c0 + l consistent with the chunk before it?  (what a chunk that runs again leaves is compared below)
+        const uint32_t cl = c0 + (uint32_t)lane;
+        bool bad = false;
+        if (cl < n_chunks && cl > 0u && cl * L > ch.W)   // (a chunk whose warm-up reaches block 0 started from pi: exact)
+            for (int s = 0; s < K; ++s) bad = bad || (hml_f2u(ch.entry[(uint64_t)cl * K + s]) != hml_f2u(ch.exitv[(uint64_t)(cl - 1u) * K + s]));
+        total_nfb += (cl < n_chunks) ? (unsigned long long)ch.nfb[cl] : 0ull;
+        unsigned long long todo = __ballot(bad);
+        while (todo != 0ull) {   // wave-uniform
+            const uint32_t c = c0 + (uint32_t)(__ffsll((long long)todo) - 1);
+            todo &= todo - 1ull;
+            // chunks c, c + 1, ... until one leaves what its successor started from
+            for (uint32_t cc = c; cc < n_chunks; ++cc) {
+                const uint32_t lo = cc * L, hi = (lo + L < B) ? lo + L : B;
+                float prev = act ? ch.exitv[(uint64_t)(cc - 1u) * K + lane] : 0.0f;
+                uint32_t nfb = 0u;
+                const uint32_t old_nfb = ch.nfb[cc];
+                hml_compat_forward_range<KC>(K, B, self, em, g, rows, nullptr, acol, sA, tile, tile_g, lo, lo, hi, prev, nullptr, nfb, lane);
+                if (act) ch.exitv[(uint64_t)cc * K + lane] = prev;
+                if (lane == 0) ch.nfb[cc] = nfb;
+                total_nfb += (lane == 0) ? (unsigned long long)nfb - (unsigned long long)old_nfb : 0ull;
+                redone++;
+                if (cc + 1u >= n_chunks) break;
+                if (cc + 1u - c0 < 64u) todo &= ~(1ull << (cc + 1u - c0));   // (the successor is compared right here)
+                const float nx = act ? ch.entry[(uint64_t)(cc + 1u) * K + lane] : 0.0f;
+                const bool exact_next = (cc + 1u) * L <= ch.W;
+                if (exact_next || __ballot(act && hml_f2u(nx) != hml_f2u(prev)) == 0ull) break;
+            }
+        }
+    }
+    // (lane 0 holds its chunks' share plus the corrections; the others their chunks' share)
+    for (int m = 32; m >= 1; m >>= 1) total_nfb += __shfl_xor(total_nfb, m);
+    if (lane == 0) { mdl->uniform_fallbacks += total_nfb; mdl->forward_refits += redone; }
+}
+
+// the engine's next n outputs -> out[0 .. n): the uniforms of a sweep's categorical draws do not depend on the data
+HML_KERNEL __launch_bounds__(64) void hml_k_compat_draws(hml_model* __restrict__ mdl, hml_mt_state* __restrict__ mts, uint32_t* __restrict__ out, uint32_t per_block) {
     __shared__ uint32_t lmt[HML_MT_N];
+    __shared__ uint32_t buf[HML_MT_N];
+    if (mdl->halted != 0u) return;
+    const int lane = threadIdx.x;
+    const uint64_t n = (uint64_t)mdl->B * per_block;
+    for (int i = lane; i < HML_MT_N; i += 64) lmt[i] = mts->mt[i];
+    uint32_t idx = mts->idx;
+    hml_compat_fence();
+    for (uint64_t o = 0; o < n; ) {
+        const uint32_t m = (n - o < (uint64_t)HML_MT_N) ? (uint32_t)(n - o) : (uint32_t)HML_MT_N;
+        hml_mt_fill_wave(lmt, idx, buf, m, lane);
+        for (uint32_t k = (uint32_t)lane; k < m; k += 64u) out[o + k] = buf[k];
+        hml_compat_fence();
+        o += m;
+    }
+    for (int i = lane; i < HML_MT_N; i += 64) mts->mt[i] = lmt[i];
+    if (lane == 0) mts->idx = idx;
+}
+
+// StateSequence<ForwardBackward>::sample's backward draws (ForwardBackward.hpp:133-162; Trellis::sample, Trellis.hpp:61-66) over
+// rows t_begin, t_begin - 1, ..., t_end + 1 (row B: the weights are the row itself; below: rows[t][i] * A(i, q_{t+1})), the states
+// stored from row t_store down.  j: the state above row t_begin (in), of row t_end + 1 (out).  draws: two engine outputs per row, row
+// t at 2 (B - t).  Returns false if a weight was negative (the caller runs the rows again where it may raise: ForwardBackward.hpp:147-149).
+template <int KC, bool RAISE>
+__device__ __forceinline__ bool hml_compat_backward_range(hml_model* mdl, int K, uint32_t B, const float* __restrict__ rows, const uint32_t* __restrict__ draws,
+                                                          int16_t* __restrict__ q, const float (&arow)[KC ? KC : 1], const float* sAT, float* tile, uint32_t* tile_d,
+                                                          int16_t* tile_q, uint32_t t_begin, uint32_t t_store, uint32_t t_end, int& j, int* in_out, int lane) {
+    const bool act = lane < K;
+    const uint32_t TB = (uint32_t)((HML_COMPAT_TILE / K) < 64 ? (HML_COMPAT_TILE / K) : 64);
+    constexpr int NREG = HML_COMPAT_TILE / 64;
+    bool clean = true;
+    float nxt[NREG];
+    uint32_t nxt_d[2];
+    auto fetch = [&](uint32_t hi) {   // rows lo + 1 .. hi and their outputs into registers
+        const uint32_t span = hi > t_end ? hi - t_end : 0u;
+        const uint32_t nb = span < TB ? span : TB;
+        const uint32_t lo = hi - nb;
+#pragma unroll
+        for (int r = 0; r < NREG; ++r) {
+            const uint32_t i = (uint32_t)r * 64u + (uint32_t)lane;
+            nxt[r] = (i < nb * (uint32_t)K) ? rows[(uint64_t)(lo + 1u) * K + i] : 0.0f;
+        }
+        // outputs of rows hi, hi - 1, ...: 2 (B - hi) + k, k < 2 nb (lane: k = lane, lane + 64)
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const uint32_t k = (uint32_t)r * 64u + (uint32_t)lane;
+            nxt_d[r] = (k < 2u * nb) ? draws[2ull * (B - hi) + k] : 0u;
+        }
+    };
+    fetch(t_begin);
+    for (uint32_t hi = t_begin; hi > t_end; ) {
+        const uint32_t nb = (hi - t_end) < TB ? (hi - t_end) : TB;
+        const uint32_t lo = hi - nb;
+        hml_compat_fence();
+#pragma unroll
+        for (int r = 0; r < NREG; ++r) tile[r * 64 + lane] = nxt[r];
+        tile_d[lane] = nxt_d[0]; tile_d[64 + lane] = nxt_d[1];
+        hml_compat_fence();
+        fetch(lo);
+        float row_nx = act ? tile[(nb - 1u) * (uint32_t)K + (uint32_t)lane] : 0.0f;   // (one row ahead of the draws)
+        uint32_t d0 = tile_d[0], d1 = tile_d[1];
+        for (uint32_t r = 0; r < nb; ++r) {
+            const uint32_t t = hi - r;
+            const float row = row_nx;
+            const double u = hml_canonical_f64(d0, d1);
+            if (r + 1u < nb) { row_nx = act ? tile[(nb - 2u - r) * (uint32_t)K + (uint32_t)lane] : 0.0f; d0 = tile_d[2u * r + 2u]; d1 = tile_d[2u * r + 3u]; }
+            if (t == t_store && in_out && lane == 0) *in_out = j;
+            float w;
+            if (t == B) w = act ? row : 0.0f;   // (the last row: no check, like Trellis::sample)
+            else {
+                float a;
+                if (KC) {
+                    a = arow[0];
+#pragma unroll
+                    for (int jj = 1; jj < (KC ? KC : 1); ++jj) a = (j == jj) ? arow[jj] : a;
+                } else a = sAT[j * K + lane];
+                w = act ? row * a : 0.0f;
+                const unsigned long long neg = __ballot(w < 0.0f);
+                if (neg != 0ull) {   // ForwardBackward.hpp:147-149 (the first negative weight in state order is the one reported)
+                    clean = false;
+                    if (RAISE) {
+                        const int first = __ffsll((long long)neg) - 1;
+                        if (lane == first) hml_raise(mdl, HML_DEVERR_NEG_BACKWARD, w);
+                        hml_compat_fence();
+                        if (w < 0.0f && lane != first) hml_raise(mdl, HML_DEVERR_NEG_BACKWARD, w);
+                    }
+                }
+            }
+            j = hml_compat_categorical_wave<KC>(w, K, u, lane);
+            if (lane == 0) tile_q[r] = (int16_t)j;
+        }
+        hml_compat_fence();
+        // q[t - 1] of row t = hi - lane, rows from t_store down
+        if ((uint32_t)lane < nb && hi - (uint32_t)lane <= t_store) q[hi - 1u - (uint32_t)lane] = tile_q[lane];
+        hi = lo;
+    }
+    return clean;
+}
+
+template <int KC>
+HML_KERNEL __launch_bounds__(64) void hml_k_compat_backward(hml_model* __restrict__ mdl, const float* __restrict__ rows, const uint32_t* __restrict__ draws,
+                                                            int16_t* __restrict__ q, const hml_compat_chunks ch) {
     __shared__ float sAT[KC ? 1 : HML_CAP_K * HML_CAP_K];   // transposed: lane i reads A(i, j) at [j * K + i]
     __shared__ float tile[HML_COMPAT_TILE];
-    __shared__ uint32_t draws[128];
+    __shared__ uint32_t tile_d[128];
     __shared__ int16_t tile_q[64];
     if (mdl->halted != 0u) return;
     const int lane = threadIdx.x;
     const int K = KC ? KC : mdl->K;
     const uint32_t B = mdl->B;
+    const uint32_t C = gridDim.x, c = blockIdx.x, L = hml_compat_chunk_len(B, C);
+    if (c * L >= B) return;
+    const uint32_t hi = B - c * L;                                   // rows hi .. lo + 1 (chunk 0 holds row B)
+    const uint32_t lo = (hi > L) ? hi - L : 0u;
     const bool act = lane < K;
-    for (int i = lane; i < HML_MT_N; i += 64) lmt[i] = mts->mt[i];
     float arow[KC ? KC : 1];   // A(lane, j)
     if (KC) {
 #pragma unroll
@@ -397,66 +593,70 @@ HML_KERNEL __launch_bounds__(64) void hml_k_compat_backward(hml_model* __restric
     } else {
         for (int idx = lane; idx < K * K; idx += 64) { const int i = idx / K, j = idx - i * K; sAT[j * K + i] = mdl->A[idx]; }
     }
-    const uint32_t TB = (uint32_t)((HML_COMPAT_TILE / K) < 64 ? (HML_COMPAT_TILE / K) : 64);
-    uint32_t idx = mts->idx;
+    const uint32_t tw = (hi + ch.W < B) ? hi + ch.W : B;   // (tw = B: the chain of draws from its true start)
+    int j = 0, in_state = -1;
+    const bool single = (C == 1u);
+    bool clean;
+    if (single) clean = hml_compat_backward_range<KC, true>(mdl, K, B, rows, draws, q, arow, sAT, tile, tile_d, tile_q, tw, hi, lo, j, &in_state, lane);
+    else clean = hml_compat_backward_range<KC, false>(mdl, K, B, rows, draws, q, arow, sAT, tile, tile_d, tile_q, tw, hi, lo, j, &in_state, lane);
+    if (lane == 0) {
+        ch.out_state[c] = j;
+        // (a chunk that met a negative weight is run again by the checking launch, which raises; -2 never equals a state)
+        ch.in_state[c] = clean ? ((tw == B) ? -1 : in_state) : -2;
+    }
+}
+// the chunks of the backward draws from the top: a chunk that started from another state than the chunk above it ended in (or met
+// a negative weight) runs again from that state
+template <int KC>
+HML_KERNEL __launch_bounds__(64) void hml_k_compat_backward_check(hml_model* __restrict__ mdl, const float* __restrict__ rows, const uint32_t* __restrict__ draws,
+                                                                  int16_t* __restrict__ q, const hml_compat_chunks ch, uint32_t C) {
+    __shared__ float sAT[KC ? 1 : HML_CAP_K * HML_CAP_K];
+    __shared__ float tile[HML_COMPAT_TILE];
+    __shared__ uint32_t tile_d[128];
+    __shared__ int16_t tile_q[64];
+    if (mdl->halted != 0u) return;
+    const int lane = threadIdx.x;
+    const int K = KC ? KC : mdl->K;
+    const uint32_t B = mdl->B;
+    const uint32_t L = hml_compat_chunk_len(B, C);
+    const uint32_t n_chunks = (B + L - 1u) / L;
+    const bool act = lane < K;
+    float arow[KC ? KC : 1];
+    if (KC) {
+#pragma unroll
+        for (int j = 0; j < (KC ? KC : 1); ++j) arow[j] = act ? mdl->A[lane * K + j] : 0.0f;
+    } else {
+        for (int idx = lane; idx < K * K; idx += 64) { const int i = idx / K, j = idx - i * K; sAT[j * K + i] = mdl->A[idx]; }
+    }
     hml_compat_fence();
-    int j = 0;
-    {
-        hml_mt_fill_wave(lmt, idx, draws, 2u, lane);
-        const float w = act ? rows[(uint64_t)B * K + lane] : 0.0f;
-        j = hml_compat_categorical_wave<KC>(w, K, hml_canonical_f64(draws[0], draws[1]), lane);
-        if (lane == 0) q[B - 1u] = (int16_t)j;
-        hml_compat_fence();
-    }
-    constexpr int NREG = HML_COMPAT_TILE / 64;
-    float nxt[NREG];
-    auto fetch = [&](uint32_t hi) {   // rows lo + 1 .. hi into registers
-        const uint32_t nb = hi < TB ? hi : TB;
-        const uint32_t lo = hi - nb;
-#pragma unroll
-        for (int r = 0; r < NREG; ++r) {
-            const uint32_t i = (uint32_t)r * 64u + (uint32_t)lane;
-            nxt[r] = (i < nb * (uint32_t)K) ? rows[(uint64_t)(lo + 1u) * K + i] : 0.0f;
+    unsigned long long redone = 0ull;
+    for (uint32_t c0 = 0; c0 < n_chunks; c0 += 64u) {
+        const uint32_t cl = c0 + (uint32_t)lane;
+        bool bad = false;
+        if (cl < n_chunks && cl > 0u) {
+            const int in = ch.in_state[cl];
+            bad = (in == -2) || (in >= 0 && in != ch.out_state[cl - 1u]);
         }
-    };
-    fetch(B - 1u);
-    for (uint32_t hi = B - 1u; hi > 0u; ) {   // rows lo + 1 .. hi, taken downwards
-        const uint32_t nb = hi < TB ? hi : TB;
-        const uint32_t lo = hi - nb;
-#pragma unroll
-        for (int r = 0; r < NREG; ++r) tile[r * 64 + lane] = nxt[r];
-        hml_mt_fill_wave(lmt, idx, draws, 2u * nb, lane);   // (fences)
-        fetch(lo);
-        float row_nx = act ? tile[(nb - 1u) * (uint32_t)K + (uint32_t)lane] : 0.0f;   // (one row ahead of the draws)
-        uint32_t d0 = draws[0], d1 = draws[1];
-        for (uint32_t r = 0; r < nb; ++r) {
-            const float row = row_nx;
-            const double u = hml_canonical_f64(d0, d1);
-            if (r + 1u < nb) { row_nx = act ? tile[(nb - 2u - r) * (uint32_t)K + (uint32_t)lane] : 0.0f; d0 = draws[2u * r + 2u]; d1 = draws[2u * r + 3u]; }
-            float a;
-            if (KC) {
-                a = arow[0];
-#pragma unroll
-                for (int jj = 1; jj < (KC ? KC : 1); ++jj) a = (j == jj) ? arow[jj] : a;
-            } else a = sAT[j * K + lane];
-            const float w = act ? row * a : 0.0f;
-            const unsigned long long neg = __ballot(w < 0.0f);
-            if (neg != 0ull) {   // ForwardBackward.hpp:147-149 (the first negative weight in state order is the one reported)
-                const int first = __ffsll((long long)neg) - 1;
-                if (lane == first) hml_raise(mdl, HML_DEVERR_NEG_BACKWARD, w);
+        unsigned long long todo = __ballot(bad);
+        while (todo != 0ull) {   // wave-uniform
+            const uint32_t c = c0 + (uint32_t)(__ffsll((long long)todo) - 1);
+            todo &= todo - 1ull;
+            for (uint32_t cc = c; cc < n_chunks; ++cc) {
+                const uint32_t hi = B - cc * L, lo = (hi > L) ? hi - L : 0u;
+                int j = ch.out_state[cc - 1u];
+                hml_compat_backward_range<KC, true>(mdl, K, B, rows, draws, q, arow, sAT, tile, tile_d, tile_q, hi, hi, lo, j, nullptr, lane);
                 hml_compat_fence();
-                if (w < 0.0f && lane != first) hml_raise(mdl, HML_DEVERR_NEG_BACKWARD, w);
+                if (lane == 0) ch.out_state[cc] = j;
+                hml_compat_fence();
+                redone++;
+                if (cc + 1u >= n_chunks) break;
+                if (cc + 1u - c0 < 64u) todo &= ~(1ull << (cc + 1u - c0));   // (the successor is compared right here)
+                const int in = ch.in_state[cc + 1u];
+                if (in == -1 || in == j) break;
             }
-            j = hml_compat_categorical_wave<KC>(w, K, u, lane);
-            if (lane == 0) tile_q[r] = (int16_t)j;
         }
-        hml_compat_fence();
-        if ((uint32_t)lane < nb) q[hi - 1u - (uint32_t)lane] = tile_q[lane];   // q[t - 1] of row t = hi - lane
-        hml_compat_fence();
-        hi = lo;
     }
-    for (int i = lane; i < HML_MT_N; i += 64) mts->mt[i] = lmt[i];
-    if (lane == 0) mts->idx = idx;
+    if (lane == 0) mdl->forward_refits += redone;   // (the statistic counts chunks of either pass that ran again)
 }
 
 // StateSequence<Mixture>::sample's draws (Mixture.hpp:90-112): one per block in block order, no transitions
@@ -484,6 +684,103 @@ HML_KERNEL __launch_bounds__(64) void hml_k_compat_mixture(hml_model* __restrict
     if (lane == 0) mts->idx = idx;
 }
 
+// ---- the count pass by STATE (round 4; univariate models).  What the reference accumulates in block order is, per state, a chain
+// of its own - the Kahan sums of the state's parameter, its occupancy and its diagonal transition count (the two that go through a
+// float) only ever see the blocks of that state, in block order; the off-diagonal transition counts are exact increments.  So the
+// blocks are PARTITIONED by state, stably (per tile of 4096 blocks a histogram, a scan over the tiles, a ranked scatter), and one
+// wavefront walks all lists at once, lane s its own: max_s(blocks of state s) steps instead of B.
+#define HML_COMPAT_PART_TILE 4096
+struct hml_compat_lists {
+    uint32_t* tile_count;   // [tiles][K] blocks of state s in the tile, then their exclusive prefix over the tiles
+    uint32_t* state_off;    // [K + 1] first list position of state s
+    unsigned long long* offdiag;   // [K * K] transitions between different states
+    float4* item;           // [B] per list position: the block's statistics (Sx, Sxx), its size, and whether the block before it has
+                            // the same state (prev_0 = 0, ForwardBackward.hpp:172) - 16 bytes, one load
+};
+HML_KERNEL __launch_bounds__(256) void hml_k_compat_part_count(const hml_model* __restrict__ mdl, const int16_t* __restrict__ q, const hml_compat_lists pl) {
+    __shared__ uint32_t h[HML_CAP_K];
+    if (mdl->halted != 0u) return;
+    const int K = mdl->K;
+    const uint32_t B = mdl->B;
+    if (blockIdx.x == 0) for (int i = threadIdx.x; i < K * K; i += 256) pl.offdiag[i] = 0ull;
+    // (the grid is sized from an earlier sweep's block count: tiles are dealt round robin, whatever B is)
+    for (uint32_t tile = blockIdx.x; (uint64_t)tile * HML_COMPAT_PART_TILE < B; tile += gridDim.x) {   // workgroup-uniform
+        const uint32_t b0 = tile * (uint32_t)HML_COMPAT_PART_TILE;
+        if (threadIdx.x < (unsigned)K) h[threadIdx.x] = 0u;
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < (uint32_t)HML_COMPAT_PART_TILE && b0 + i < B; i += 256u) atomicAdd(&h[q[b0 + i]], 1u);
+        __syncthreads();
+        if (threadIdx.x < (unsigned)K) pl.tile_count[(uint64_t)tile * K + threadIdx.x] = h[threadIdx.x];
+        __syncthreads();
+    }
+}
+HML_KERNEL __launch_bounds__(64) void hml_k_compat_part_scan(const hml_model* __restrict__ mdl, const hml_compat_lists pl) {
+    if (mdl->halted != 0u) return;
+    const int K = mdl->K, lane = threadIdx.x;
+    const uint32_t B = mdl->B;
+    const uint32_t tiles = (B + HML_COMPAT_PART_TILE - 1u) / HML_COMPAT_PART_TILE;
+    uint32_t run = 0u;
+    if (lane < K) {
+        uint32_t nxt = pl.tile_count[lane];
+        for (uint32_t t = 0; t < tiles; ++t) {
+            const uint32_t v = nxt;
+            if (t + 1u < tiles) nxt = pl.tile_count[(uint64_t)(t + 1u) * K + lane];
+            pl.tile_count[(uint64_t)t * K + lane] = run;
+            run += v;
+        }
+    }
+    // first list position of every state: exclusive prefix of the totals over the states
+    uint32_t incl = run;
+    for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(incl, d); if (lane >= d) incl += o; }
+    if (lane < K) pl.state_off[lane] = incl - run;
+    if (lane == K - 1) pl.state_off[K] = incl;
+}
+HML_KERNEL __launch_bounds__(256) void hml_k_compat_part_scatter(const hml_model* __restrict__ mdl, const int16_t* __restrict__ q, const uint32_t* __restrict__ starts,
+                                                                 const float2* __restrict__ bstat, const hml_compat_lists pl) {
+    __shared__ uint32_t cnt[HML_CAP_K], pw[4][HML_CAP_K];
+    if (mdl->halted != 0u) return;
+    const int K = mdl->K;
+    const uint32_t B = mdl->B;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (uint32_t tile = blockIdx.x; (uint64_t)tile * HML_COMPAT_PART_TILE < B; tile += gridDim.x) {   // workgroup-uniform
+    const uint32_t b0 = tile * (uint32_t)HML_COMPAT_PART_TILE;
+    __syncthreads();
+    if (threadIdx.x < (unsigned)K) cnt[threadIdx.x] = pl.state_off[threadIdx.x] + pl.tile_count[(uint64_t)tile * K + threadIdx.x];
+    for (int i = threadIdx.x; i < 4 * HML_CAP_K; i += 256) (&pw[0][0])[i] = 0u;
+    __syncthreads();
+    for (uint32_t step = 0; step < (uint32_t)HML_COMPAT_PART_TILE / 256u; ++step) {   // workgroup-uniform trip count
+        const uint32_t b = b0 + step * 256u + threadIdx.x;
+        const bool in = b < B;
+        const int s = in ? (int)q[b] : -1;
+        const int prev = (in && b > 0u) ? (int)q[b - 1u] : 0;
+        // rank among the wavefront's blocks of the same state, in block order
+        uint32_t rank = 0u;
+        unsigned long long left = __ballot(in);
+        while (left != 0ull) {   // wave-uniform: one trip per state present
+            const int leader = __builtin_amdgcn_readlane(s, __ffsll((long long)left) - 1);
+            const unsigned long long m = __ballot(s == leader);
+            if (s == leader) rank = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+            if (lane == 0) pw[wave][leader] = (uint32_t)__popcll(m);
+            left &= ~m;
+        }
+        __syncthreads();
+        if (in) {
+            uint32_t pos = cnt[s] + rank;
+            for (int w2 = 0; w2 < wave; ++w2) pos += pw[w2][s];
+            const float2 st = bstat[b];
+            pl.item[pos] = make_float4(st.x, st.y, hml_u2f(starts[b + 1u] - starts[b]), hml_u2f(prev == s ? 1u : 0u));
+            if (prev != s) atomicAdd(&pl.offdiag[prev * K + s], 1ull);
+        }
+        __syncthreads();
+        if (threadIdx.x < (unsigned)K) {
+            cnt[threadIdx.x] += pw[0][threadIdx.x] + pw[1][threadIdx.x] + pw[2][threadIdx.x] + pw[3][threadIdx.x];
+            pw[0][threadIdx.x] = 0u; pw[1][threadIdx.x] = 0u; pw[2][threadIdx.x] = 0u; pw[3][threadIdx.x] = 0u;
+        }
+        __syncthreads();
+    }
+    }
+}
+
 // count pass in block order (ForwardBackward.hpp:170-200 / Mixture.hpp:113-141), conjugate updates (Conjugate.hpp:121-168,
 // 178-205), theta, pi, A (HMM.hpp:111-115), derived values.  The aggregators live in registers, lane = parameter (Kahan sums,
 // term counts) or state (occupancy, the diagonal transition count - the two that go through a float); a block's state, size and
@@ -491,7 +788,7 @@ HML_KERNEL __launch_bounds__(64) void hml_k_compat_mixture(hml_model* __restrict
 // off-diagonal transition counts are plain integer increments in LDS.
 HML_KERNEL __launch_bounds__(64) void hml_k_compat_update(hml_model* __restrict__ mdl, hml_mt_state* __restrict__ mts,
                                                           const uint32_t* __restrict__ starts, const float2* __restrict__ bstat,
-                                                          const int16_t* __restrict__ q, int method) {
+                                                          const int16_t* __restrict__ q, int method, const hml_compat_lists pl, int by_state) {
     __shared__ uint32_t lmt[HML_MT_N];
     __shared__ unsigned long long s_trans[HML_CAP_K * HML_CAP_K], s_occ[HML_CAP_K], s_n[HML_CAP_K];
     __shared__ float s_ps[HML_CAP_K], s_pq[HML_CAP_K];
@@ -521,6 +818,46 @@ HML_KERNEL __launch_bounds__(64) void hml_k_compat_update(hml_model* __restrict_
 #pragma unroll
         for (int d = 0; d < HML_MAX_D; ++d) r_st[d] = (in && d < D) ? bstat[(uint64_t)d * dstride + b] : make_float2(0.0f, 0.0f);
     };
+    if (by_state) {
+        // the lists of hml_k_compat_part_scatter: lane s walks the blocks of state s in block order, 16 entries in flight
+        const uint32_t off = (lane < K) ? pl.state_off[lane] : 0u;
+        const uint32_t cnt = (lane < K) ? pl.state_off[lane + 1] - off : 0u;
+        uint32_t longest = cnt;
+        for (int m = 32; m >= 1; m >>= 1) { const uint32_t o = (uint32_t)__shfl_xor((int)longest, m); longest = o > longest ? o : longest; }
+        constexpr int NB = 16;
+        float4 bi[2][NB];
+        auto fetch_list = [&](uint32_t base, int set) {
+#pragma unroll
+            for (int k = 0; k < NB; ++k) bi[set][k] = (base + (uint32_t)k < cnt) ? pl.item[off + base + k] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        };
+        auto walk = [&](uint32_t base, int set) {
+#pragma unroll
+            for (int k = 0; k < NB; ++k) {
+                if (base + (uint32_t)k < cnt) {
+                    const uint32_t n = hml_f2u(bi[set][k].z);
+                    if (method == 1) { occ += (double)n; diag += (double)(n - 1u); }
+                    else {
+                        const float N = (float)n;   // size_t += float: the sum goes through a float
+                        diag = (double)((float)diag + (N - 1.0f));
+                        occ = (double)((float)occ + N);
+                    }
+                    if (hml_f2u(bi[set][k].w) != 0u) diag += 1.0;
+                    const float sx = bi[set][k].x, sq = bi[set][k].y;
+                    { const float y = sx - es, t = ps + y; es = (t - ps) - y; ps = t; }
+                    { const float y = sq - eq, t = pq + y; eq = (t - pq) - y; pq = t; }
+                    n_terms += n;
+                }
+            }
+        };
+        fetch_list(0u, 0);
+        for (uint32_t base = 0; base < longest; base += 2u * NB) {   // wave-uniform
+            fetch_list(base + NB, 1);
+            walk(base, 0);
+            fetch_list(base + 2u * NB, 0);
+            walk(base + NB, 1);
+        }
+        for (int i = lane; i < K * K; i += 64) if (i / K != i % K) s_trans[i] = pl.offdiag[i];
+    } else {
     fetch(0u);
     for (uint32_t b0 = 0; b0 < B; b0 += 64u) {
         const uint32_t nb = (B - b0 < 64u) ? B - b0 : 64u;
@@ -565,6 +902,7 @@ HML_KERNEL __launch_bounds__(64) void hml_k_compat_update(hml_model* __restrict_
             }
             prevs = s;
         }
+    }
     }
     hml_compat_fence();
     if (lane < K) { s_trans[lane * K + lane] = (unsigned long long)diag; s_occ[lane] = (unsigned long long)occ; s_n[lane] = n_terms; s_ps[lane] = ps; s_pq[lane] = pq; }

@@ -81,9 +81,17 @@ def test_quotient_by_reciprocal(hml):
     (30000, 33, 10, [("M", 6, 2), ("S",), ("F", 8, 1), ("P",), ("D",), ("F", 5, 1)]),
     (20000, 64, 11, [("F", 6, 1)]),
 ])
-def test_compat_chain_is_the_reference_chain(hml, T, K, seed, scheme):
+@pytest.mark.parametrize("chunks,warmup", [(None, None), (37, -1), (200, 3), (1, None)])
+def test_compat_chain_is_the_reference_chain(hml, monkeypatch, T, K, seed, scheme, chunks, warmup):
     """through the C ABI: block structure, state sequence, parameter bits, transition matrix, counts and marginals of a
-    compat chain equal those of the checker in REFERENCE mode (sequential mt19937, libm, Kahan sums, size_t += float)"""
+    compat chain equal those of the checker in REFERENCE mode (sequential mt19937, libm, Kahan sums, size_t += float).
+    Round 4: filter and backward draws run in chunks that are checked against each other, the count pass by state
+    (hml_k_compat.h): the default geometry; 37 chunks without any warm-up - every chunk starts from a flat row / state 0, so
+    chunks ARE wrong and run again (the statistic says so) - and 200 with 3 blocks of it; one chunk, the sequential form."""
+    if chunks is not None:
+        monkeypatch.setenv("HML_COMPAT_CHUNKS", str(chunks))
+    if warmup is not None:
+        monkeypatch.setenv("HML_COMPAT_WARMUP", str(warmup))
     x = ol.trace(T, min(K, 6), seed)
     o = ol.OracleChain(K=K, seed=seed, rng=ol.RNG_MT, math=ol.MATH_LIBM, reduce=ol.REDUCE_REF)
     o.load(x)
@@ -118,6 +126,8 @@ def test_compat_chain_is_the_reference_chain(hml, T, K, seed, scheme):
             assert np.array_equal(bits(Ao), bits(Ag)) and np.array_equal(bits(pio), bits(pig))
     seg, cnt = g.marginals_rle()
     assert hml.marginals_text(seg, cnt) == o.text("marginals")
+    if warmup == -1:
+        assert g.stats()["forward_refits"] > 0   # chunks were wrong and ran again
 
 
 @pytest.mark.parametrize("P,D,T,seed,scheme", [
@@ -169,12 +179,16 @@ def test_compat_multivariate_chain_is_the_reference_chain(hml, P, D, T, seed, sc
     assert hml.marginals_text(seg, cnt) == o.text("marginals")
 
 
+@pytest.mark.parametrize("chunks", [None, "50:-1"])
 @pytest.mark.parametrize("case", sorted(MANIFEST))
-def test_cli_compat_writes_the_reference_binarys_files(case):
+def test_cli_compat_writes_the_reference_binarys_files(case, chunks, monkeypatch):
     """`hammlet -compat` with the flags of a golden run against the files the UNMODIFIED REFERENCE BINARY wrote for them
     (tests/golden/<case>/, oracle/_ref/hammlet in the build container): byte for byte, from the GPU - all 19 runs: the
     15 univariate ones and (round 4) the four multivariate / shared-parameter runs `-s C P D` (reference
     src/Mapping.hpp:53-137, src/EFD.hpp:83-93, src/StateSequence/ForwardBackward.hpp:189-207)."""
+    if chunks is not None:   # every sweep in 50 chunks without warm-up: chunks that start wrong run again
+        monkeypatch.setenv("HML_COMPAT_CHUNKS", chunks.split(":")[0])
+        monkeypatch.setenv("HML_COMPAT_WARMUP", chunks.split(":")[1])
     m = MANIFEST[case]
     x = ol.trace(m["T"], m["trace_levels"], m["data_seed"])
     if m.get("dims", 1) > 1:   # dimension d = the generator with data seed + d, interleaved by position (tests/test_oracle_golden.py)
