@@ -12,10 +12,10 @@
 //   D3  per-state sums of the block statistics by one float Kahan aggregator in block order (ForwardBackward.hpp:189-192,
 //       KahanAggregator.hpp:26-45);
 //   D4  transition and occupancy counts as `size_t += float` (ForwardBackward.hpp:183-187: they round above 2^24).
-// The order-dependent part - filter, backward draws, count pass, conjugate updates, parameter draws - is one lane of one
-// wavefront walking the blocks (this mode is for traces up to ~10^6 positions; the default path is the fast one); block
-// enumeration, block statistics and the marginals use the same kernels as the default path (integer-exact there).
-// Models over several data dimensions ("-s C P D") since round 4.
+// The order-dependent part - filter, backward draws, count pass, conjugate updates, parameter draws - keeps the reference's
+// arithmetic and order but not its one thread (round 4, below: a lane per state, chunks that are checked against each other,
+// the count pass by state); block enumeration, block statistics and the marginals use the same kernels as the default path
+// (integer-exact there).  Models over several data dimensions ("-s C P D") and 2 .. 64 states.
 #ifndef HML_K_COMPAT_H
 #define HML_K_COMPAT_H
 
@@ -145,21 +145,22 @@ HML_KERNEL __launch_bounds__(64) void hml_k_compat_draw(hml_model* __restrict__ 
 }
 
 // ------------------------------------------------------------------------------------------------------------------------
-// One sweep (sampleHMM's body, HMM.hpp:99-121) over the blocks the launches before it enumerated, in four launches (round 4;
-// rounds 3 had one lane walk the whole sweep: 3.9 us per block at config 3 - a chain of dependent memory round trips -
-// seven times slower than the reference on one CPU core).  The number of states is a run-time value here (up to
-// HML_CAP_K = 64: one lane per state), so the mode also serves models the default path's register-resident kernels do not
-// instantiate (K > 16).  Everything is the reference's arithmetic in the reference's order:
+// One sweep (sampleHMM's body, HMM.hpp:99-121) over the blocks the launches before it enumerated (round 4; round 3 had one
+// lane walk the whole sweep: 3.9 us per block at config 3 - a chain of dependent memory round trips - seven times slower than
+// the reference on one CPU core).  The number of states is a run-time value here (up to HML_CAP_K = 64: one lane per state), so
+// the mode also serves models the default path's register-resident kernels do not instantiate (K > 16).  Everything is the
+// reference's arithmetic in the reference's order:
 //   hml_k_compat_emission   the blocks' emission terms, a lane per block (independent between blocks: EFD.hpp:23-38,83-93,
 //                           ForwardBackward.hpp:67-84 / Mixture.hpp:54-77);
-//   hml_k_compat_forward / _backward   filter and backward draws by ONE wavefront, lane j = state j: the K sums over the predecessors run
-//                           side by side (each lane its own, i = 0 .. K-1 in order), the row sum Z and the categorical's double
-//                           sums are taken serially over the lanes in index order (v_readlane), blocks staged through LDS 64 at a
-//                           time; the engine's outputs are tempered a tile ahead (they do not depend on the data) and its twist
-//                           runs on all lanes;
+//   hml_k_compat_draws      the engine's outputs of the sweep's categorical draws, ahead of them (they do not depend on the data);
+//   hml_k_compat_forward / _backward (+ _check)   filter and backward draws, a wavefront per CHUNK of blocks, lane j = state j: the K
+//                           sums over the predecessors run side by side (each lane its own, i = 0 .. K-1 in order), the row sum Z
+//                           and the categorical's double sums are taken serially over the lanes in index order (v_readlane); chunks
+//                           start from a guess some blocks early and are checked against each other (see "in CHUNKS" below);
 //   hml_k_compat_mixture    Mixture.hpp:90-112: a lane per block, the draws in block order;
-//   hml_k_compat_update     count pass in block order (float Kahan sums, `size_t += float` counts), conjugate updates, parameter
-//                           draws: one lane, its blocks staged through LDS by all.
+//   hml_k_compat_part_*, hml_k_compat_update   count pass (float Kahan sums, `size_t += float` counts) by state over stably
+//                           partitioned lists - or in block order: one lane, its blocks staged by all - conjugate updates, parameter
+//                           draws.
 // ------------------------------------------------------------------------------------------------------------------------
 #define HML_COMPAT_TILE 1024   // floats staged per tile: min(64, 1024 / K) blocks
 #define HML_COMPAT_MAX_CHUNKS 2048
