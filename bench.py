@@ -552,6 +552,31 @@ def main():
         ch.close()
         del x2
         chain = None
+        # the reference-compatible mode on the headline's trace (option "compat": the reference's own mt19937 stream, libm
+        # arithmetic, Kahan sums and size_t += float counts - its chain, bit for bit): a bounded sample of sweeps
+        ch = hammlet_amd.Chain(device=local_rank, seed=args.seed, chain_id=rank)
+        ch.set_option("compat", 1)
+        ch.load(x)
+        ch.set_model(K, ch.autoprior(0.2, 0.9))
+        ch.sample_prior()
+        ch.set_recording(marginals=False)
+        ch.iterate("F", 4, 0)
+        ch.sync()
+        c0 = ch.stats()
+        barrier()
+        t0 = time.perf_counter()
+        ch.iterate("F", 24, 0)
+        ch.sync()
+        barrier()
+        t1 = time.perf_counter()
+        c1 = ch.stats()
+        ch.close()
+        out["reference_compatible"] = {"value": (c1["block_updates"] - c0["block_updates"]) / (t1 - t0), "unit": "block-updates/s", "steps": 24,
+                                       "ms_per_step": 1e3 * (t1 - t0) / 24, "blocks_per_sweep": (c1["block_updates"] - c0["block_updates"]) / 24,
+                                       "chunks_rerun": c1["forward_refits"] - c0["forward_refits"],
+                                       "note": "option compat = 1: the sweeps the reference's single thread computes, bit for bit (cpu_baseline.reference_binary "
+                                               "times that thread on this trace); filter and backward draws in chunks that are checked against each other, "
+                                               "count pass by state (hml_k_compat.h)"}
 
     # third leg: several independent chains of the same workload on ONE GPU (chain-parallel inside the GPU: a single chain is
     # latency-bound and leaves most of the machine idle).  Two / three chains each on its own stream and host thread; eight
