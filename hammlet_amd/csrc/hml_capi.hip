@@ -933,7 +933,7 @@ static int sweep_compat(hml_ctx* c, char method, bool record) {
         hipLaunchKernelGGL(hml_k_compat_part_scan, dim3(1), dim3(64), 0, s, c->d_mdl, pl);
         hipLaunchKernelGGL(hml_k_compat_part_scatter, dim3(tg), dim3(256), 0, s, c->d_mdl, c->d_q, c->d_starts, c->d_bstat, pl);
     }
-    hipLaunchKernelGGL(hml_k_compat_update, dim3(1), dim3(64), 0, s, c->d_mdl, mt, c->d_starts, c->d_bstat, c->d_q, mix, pl, by_state);
+    hipLaunchKernelGGL(hml_k_compat_update, dim3(1), dim3(by_state ? 256 : 64), 0, s, c->d_mdl, mt, c->d_starts, c->d_bstat, c->d_q, mix, pl, by_state);
     if (record && c->rec_marginals) {
         if (c->pooled) return set_err(HML_ERR_ARG, "the marginals of this context are pooled (common labels, several chains): further sweeps cannot be recorded into them");
         if (int r = ensure_marginal_buffers(c)) return r;

@@ -787,7 +787,7 @@ HML_KERNEL __launch_bounds__(256) void hml_k_compat_part_scatter(const hml_model
 // term counts) or state (occupancy, the diagonal transition count - the two that go through a float); a block's state, size and
 // statistics reach all lanes as scalars (v_readlane from the lane that loaded them), the lane concerned takes them.  The
 // off-diagonal transition counts are plain integer increments in LDS.
-HML_KERNEL __launch_bounds__(64) void hml_k_compat_update(hml_model* __restrict__ mdl, hml_mt_state* __restrict__ mts,
+HML_KERNEL __launch_bounds__(256) void hml_k_compat_update(hml_model* __restrict__ mdl, hml_mt_state* __restrict__ mts,
                                                           const uint32_t* __restrict__ starts, const float2* __restrict__ bstat,
                                                           const int16_t* __restrict__ q, int method, const hml_compat_lists pl, int by_state) {
     __shared__ uint32_t lmt[HML_MT_N];
@@ -795,14 +795,17 @@ HML_KERNEL __launch_bounds__(64) void hml_k_compat_update(hml_model* __restrict_
     __shared__ float s_ps[HML_CAP_K], s_pq[HML_CAP_K];
     __shared__ uint8_t s_map[HML_CAP_K][HML_MAX_D];
     if (mdl->halted != 0u) return;
-    const int lane = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;   // (64 threads in block order, 256 by state)
     const int K = mdl->K, P = mdl->P, D = mdl->D;
     const uint32_t B = mdl->B;
     const uint64_t dstride = mdl->stat_stride;        // block statistics: one plane per dimension
-    for (int i = lane; i < HML_MT_N; i += 64) lmt[i] = mts->mt[i];
-    for (int i = lane; i < K * K; i += 64) s_trans[i] = 0ull;
-    if (lane < K) for (int d = 0; d < HML_MAX_D; ++d) s_map[lane][d] = mdl->map[lane][d];
-    hml_compat_fence();
+    if (wave == 0) {
+        for (int i = lane; i < HML_MT_N; i += 64) lmt[i] = mts->mt[i];
+        for (int i = lane; i < K * K; i += 64) s_trans[i] = 0ull;
+        if (lane < K) for (int d = 0; d < HML_MAX_D; ++d) s_map[lane][d] = mdl->map[lane][d];
+    }
+    if (by_state) __syncthreads();
+    else hml_compat_fence();
     // lane = parameter: KahanAggregator (positive sum and its error term) of Sx and Sxx, number of terms; lane = state: occupancy, A(s, s)'s count
     float ps = 0.0f, pq = 0.0f, es = 0.0f, eq = 0.0f;
     // (occupancy and diagonal count as doubles: integers below 2^53 are exact there, and float <-> double conversions are one
@@ -820,7 +823,9 @@ HML_KERNEL __launch_bounds__(64) void hml_k_compat_update(hml_model* __restrict_
         for (int d = 0; d < HML_MAX_D; ++d) r_st[d] = (in && d < D) ? bstat[(uint64_t)d * dstride + b] : make_float2(0.0f, 0.0f);
     };
     if (by_state) {
-        // the lists of hml_k_compat_part_scatter: lane s walks the blocks of state s in block order, 16 entries in flight
+        // the lists of hml_k_compat_part_scatter: lane s walks the blocks of state s in block order, 16 entries in flight - and the
+        // four chains that a state's blocks feed (Kahan sum of Sx, of Sxx, diagonal count, occupancy) are independent of each
+        // other: FOUR wavefronts (the launch has 256 threads in this mode), each walks all lists for one of them
         const uint32_t off = (lane < K) ? pl.state_off[lane] : 0u;
         const uint32_t cnt = (lane < K) ? pl.state_off[lane + 1] - off : 0u;
         uint32_t longest = cnt;
@@ -831,33 +836,43 @@ HML_KERNEL __launch_bounds__(64) void hml_k_compat_update(hml_model* __restrict_
 #pragma unroll
             for (int k = 0; k < NB; ++k) bi[set][k] = (base + (uint32_t)k < cnt) ? pl.item[off + base + k] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         };
-        auto walk = [&](uint32_t base, int set) {
+        auto run = [&](auto step) {
+            fetch_list(0u, 0);
+            for (uint32_t base = 0; base < longest; base += 2u * NB) {   // wave-uniform
+                fetch_list(base + NB, 1);
 #pragma unroll
-            for (int k = 0; k < NB; ++k) {
-                if (base + (uint32_t)k < cnt) {
-                    const uint32_t n = hml_f2u(bi[set][k].z);
-                    if (method == 1) { occ += (double)n; diag += (double)(n - 1u); }
-                    else {
-                        const float N = (float)n;   // size_t += float: the sum goes through a float
-                        diag = (double)((float)diag + (N - 1.0f));
-                        occ = (double)((float)occ + N);
-                    }
-                    if (hml_f2u(bi[set][k].w) != 0u) diag += 1.0;
-                    const float sx = bi[set][k].x, sq = bi[set][k].y;
-                    { const float y = sx - es, t = ps + y; es = (t - ps) - y; ps = t; }
-                    { const float y = sq - eq, t = pq + y; eq = (t - pq) - y; pq = t; }
-                    n_terms += n;
-                }
+                for (int k = 0; k < NB; ++k) if (base + (uint32_t)k < cnt) step(bi[0][k]);
+                fetch_list(base + 2u * NB, 0);
+#pragma unroll
+                for (int k = 0; k < NB; ++k) if (base + NB + (uint32_t)k < cnt) step(bi[1][k]);
             }
         };
-        fetch_list(0u, 0);
-        for (uint32_t base = 0; base < longest; base += 2u * NB) {   // wave-uniform
-            fetch_list(base + NB, 1);
-            walk(base, 0);
-            fetch_list(base + 2u * NB, 0);
-            walk(base + NB, 1);
+        if (wave == 0) {
+            run([&](const float4& it) { const float y = it.x - es, t = ps + y; es = (t - ps) - y; ps = t; });
+            if (lane < K) s_ps[lane] = ps;
+        } else if (wave == 1) {
+            run([&](const float4& it) { const float y = it.y - eq, t = pq + y; eq = (t - pq) - y; pq = t; });
+            if (lane < K) s_pq[lane] = pq;
+        } else if (wave == 2) {
+            run([&](const float4& it) {
+                const uint32_t n = hml_f2u(it.z);
+                if (method == 1) diag += (double)(n - 1u);
+                else diag = (double)((float)diag + ((float)n - 1.0f));   // size_t += float: the sum goes through a float
+                if (hml_f2u(it.w) != 0u) diag += 1.0;
+            });
+            if (lane < K) s_trans[lane * K + lane] = (unsigned long long)diag;
+        } else {
+            run([&](const float4& it) {
+                const uint32_t n = hml_f2u(it.z);
+                if (method == 1) occ += (double)n;
+                else occ = (double)((float)occ + (float)n);
+                n_terms += n;
+            });
+            if (lane < K) { s_occ[lane] = (unsigned long long)occ; s_n[lane] = n_terms; }
         }
-        for (int i = lane; i < K * K; i += 64) if (i / K != i % K) s_trans[i] = pl.offdiag[i];
+        for (int i = tid; i < K * K; i += 256) if (i / K != i % K) s_trans[i] = pl.offdiag[i];
+        __syncthreads();
+        if (tid != 0) return;
     } else {
     fetch(0u);
     for (uint32_t b0 = 0; b0 < B; b0 += 64u) {
@@ -905,10 +920,12 @@ HML_KERNEL __launch_bounds__(64) void hml_k_compat_update(hml_model* __restrict_
         }
     }
     }
-    hml_compat_fence();
-    if (lane < K) { s_trans[lane * K + lane] = (unsigned long long)diag; s_occ[lane] = (unsigned long long)occ; s_n[lane] = n_terms; s_ps[lane] = ps; s_pq[lane] = pq; }
-    hml_compat_fence();
-    if (lane != 0) return;
+    if (!by_state) {
+        hml_compat_fence();
+        if (lane < K) { s_trans[lane * K + lane] = (unsigned long long)diag; s_occ[lane] = (unsigned long long)occ; s_n[lane] = n_terms; s_ps[lane] = ps; s_pq[lane] = pq; }
+        hml_compat_fence();
+        if (lane != 0) return;
+    }
     hml_mt_src src{lmt, mts->idx};
     // ---- conjugate updates
     for (int k = 0; k < K; ++k) mdl->last_occ[k] = s_occ[k];
