@@ -560,8 +560,8 @@ def main():
         ch.set_model(K, ch.autoprior(0.2, 0.9))
         ch.sample_prior()
         ch.set_recording(marginals=False)
-        ch.iterate("F", 4, 0)
-        ch.sync()
+        ch.iterate("F", 64, 0)     # (a settled chain, like the steady_state leg: the count pass walks the states' lists side by side,
+        ch.sync()                  #  and a young chain has nearly all blocks in one state)
         c0 = ch.stats()
         barrier()
         t0 = time.perf_counter()

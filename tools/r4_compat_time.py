@@ -1,4 +1,4 @@
-"""Time of a sweep of the reference-compatible mode (option "compat"): python tools/r4_compat_time.py [workload] [sweeps]"""
+"""Time of a sweep of the reference-compatible mode (option "compat"): python tools/r4_compat_time.py [workload] [sweeps]   (BURNIN=n sweeps first)"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench, hammlet_amd
@@ -12,7 +12,7 @@ ch.load(x)
 ch.set_model(K, ch.autoprior(0.2, 0.9))
 ch.sample_prior()
 ch.set_recording(marginals=False)
-ch.iterate("F", 2, 0); ch.sync()
+ch.iterate("F", int(os.environ.get("BURNIN", "2")), 0); ch.sync()
 b0 = ch.stats()["block_updates"]
 t0 = time.perf_counter()
 ch.iterate("F", n, 0); ch.sync()
