@@ -81,13 +81,16 @@ def test_quotient_by_reciprocal(hml):
     (30000, 33, 10, [("M", 6, 2), ("S",), ("F", 8, 1), ("P",), ("D",), ("F", 5, 1)]),
     (20000, 64, 11, [("F", 6, 1)]),
 ])
-@pytest.mark.parametrize("chunks,warmup", [(None, None), (37, -1), (200, 3), (1, None)])
+@pytest.mark.parametrize("chunks,warmup", [(None, None), (37, -1), (200, 3), (1, None), ("cap64", -1)])
 def test_compat_chain_is_the_reference_chain(hml, monkeypatch, T, K, seed, scheme, chunks, warmup):
     """through the C ABI: block structure, state sequence, parameter bits, transition matrix, counts and marginals of a
     compat chain equal those of the checker in REFERENCE mode (sequential mt19937, libm, Kahan sums, size_t += float).
     Round 4: filter and backward draws run in chunks that are checked against each other, the count pass by state
     (hml_k_compat.h): the default geometry; 37 chunks without any warm-up - every chunk starts from a flat row / state 0, so
     chunks ARE wrong and run again (the statistic says so) - and 200 with 3 blocks of it; one chunk, the sequential form."""
+    if chunks == "cap64":   # ... and per-block buffers for 64 blocks: the chain halts, the host grows them and sweeps again (hml_settle) -
+        monkeypatch.setenv("HML_MAX_BLOCKS", "64")   # the engine's outputs of a halted sweep must not be consumed
+        chunks = 29
     if chunks is not None:
         monkeypatch.setenv("HML_COMPAT_CHUNKS", str(chunks))
     if warmup is not None:
