@@ -12,16 +12,20 @@ from tests.test_gpu_parity import run_both
 
 ENV_KEYS = ("HML_DENSE_MIN_BLOCKS", "HML_FWD_CHUNK_DENSE", "HML_TRELLIS_FUSED", "HML_TRELLIS_L", "HML_TRELLIS_ROWS", "HML_TRELLIS_CKPT",
             "HML_STAGE_BITS", "HML_FWD_WARMUP", "HML_LATE_RESCALE", "HML_FWD_CHUNK",
-            "HML_MANY_GROUPS", "HML_FUSED_MANY_SLOTS", "HML_MAX_BLOCKS", "HML_FWD_CHUNK_MANY")
+            "HML_MANY_GROUPS", "HML_FUSED_MANY_SLOTS", "HML_MAX_BLOCKS", "HML_FWD_CHUNK_MANY", "HML_COMPAT_CHUNKS", "HML_COMPAT_WARMUP")
 
 
-def fuzz(hml, n_cfg, seed, log=None, many=False):
+def fuzz(hml, n_cfg, seed, log=None, many=False, compat=False):
     """n_cfg random configurations; returns the number that ran identical (all, or an AssertionError names the first
     that differs).  The environment switches it sets are restored afterwards.  many: several chains through
-    hml_iterate_many (_fuzz_many) instead of one through hml_iterate."""
+    hml_iterate_many (_fuzz_many) instead of one through hml_iterate.  compat: the reference-compatible mode against the
+    checker's REFERENCE mode (mt19937, libm, Kahan sums, size_t += float) - up to 64 states, chunk geometries that force
+    wrong chunks."""
     saved = {k: os.environ.get(k) for k in ENV_KEYS}
     try:
-        return (_fuzz_many if many else _fuzz)(hml, n_cfg, seed, log or (lambda *a, **k: None))
+        if many:
+            return _fuzz_many(hml, n_cfg, seed, log or (lambda *a, **k: None))
+        return _fuzz(hml, n_cfg, seed, log or (lambda *a, **k: None), compat=compat)
     finally:
         for k, v in saved.items():
             if v is None:
@@ -30,7 +34,7 @@ def fuzz(hml, n_cfg, seed, log=None, many=False):
                 os.environ[k] = v
 
 
-def _fuzz(hml, n_cfg, seed, log):
+def _fuzz(hml, n_cfg, seed, log, compat=False):
     rng = np.random.default_rng(seed)
     bits = lambda a: np.ascontiguousarray(a, np.float32).view(np.uint32)
     t_start = time.time()
@@ -39,8 +43,10 @@ def _fuzz(hml, n_cfg, seed, log):
         D = int(rng.choice([1, 1, 1, 2, 2, 3]))
         if D == 1:
             P = None; K = int(rng.integers(2, 17))
+            if compat and rng.random() < 0.3:
+                K = int(rng.choice([17, 20, 31, 32, 33, 48, 64]))
         else:
-            P = int(rng.choice([2, 3, 4] if D == 2 else [2])); K = P ** D
+            P = int(rng.choice(([2, 3, 4, 5, 7] if compat else [2, 3, 4]) if D == 2 else ([2, 3] if compat else [2]))); K = P ** D
         T = int(rng.choice([17, 1000, 4097, 30000, 65535, 65537, 120000, 300000]))
         if K > 8 or D > 1:
             T = min(T, 120000)
@@ -62,6 +68,11 @@ def _fuzz(hml, n_cfg, seed, log):
         else: os.environ.pop("HML_FWD_WARMUP", None)
         os.environ["HML_LATE_RESCALE"] = str(int(rng.choice([1, 1, 0])))
         os.environ["HML_FWD_CHUNK"] = str(int(rng.choice([4, 4, 1, 2, 8])))
+        if compat:   # chunks of the filter / backward draws: the default, the sequential form, many chunks with hardly any warm-up
+            _setenv("HML_COMPAT_CHUNKS", rng.choice([None, None, 1, 7, 60, 500]))
+            _setenv("HML_COMPAT_WARMUP", rng.choice([None, None, -1, 1, 4]))
+            if K > 16:
+                T = min(T, 65537)
         seed = int(rng.integers(0, 1 << 30))
         levels = min(K if D == 1 else P, 5)
         if rng.random() < 0.2 and D == 1:
@@ -74,8 +85,13 @@ def _fuzz(hml, n_cfg, seed, log):
             scheme.append((str(tok), int(rng.integers(1, 9)), int(rng.integers(0, 3))) if tok in ("F", "M") else str(tok))
         if not isinstance(scheme[-1], tuple):   # the probes (blocks, states) describe the last SWEEP; end with one
             scheme.append(("F", int(rng.integers(1, 5)), 1))
-        o = ol.OracleChain(K=K, seed=seed, rng=ol.RNG_CTR, math=ol.MATH_DEV, reduce=ol.REDUCE_DEV, **kw)
+        if compat:
+            o = ol.OracleChain(K=K, seed=seed, rng=ol.RNG_MT, math=ol.MATH_LIBM, reduce=ol.REDUCE_REF, **kw)
+        else:
+            o = ol.OracleChain(K=K, seed=seed, rng=ol.RNG_CTR, math=ol.MATH_DEV, reduce=ol.REDUCE_DEV, **kw)
         g = hml.Chain(device=0, seed=seed)
+        if compat:
+            g.set_option("compat", 1)
         if D > 1:
             o.set_dimensions(D, P); g.set_dimensions(D, P)
         g.set_option("weight_keys", int(rng.choice([1, 1, 2, 0])))

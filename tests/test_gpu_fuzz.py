@@ -30,3 +30,12 @@ def test_bounded_fuzz_of_batched_chains(hml):
     batch, static block structures, prior draws between the calls - every chain against the checker's chain of the same
     (seed, chain) run alone: blocks, state sequences, parameter and transition bits, marginals text."""
     assert fuzz(hml, 100, 20261005, many=True) == 100
+
+
+def test_bounded_fuzz_of_the_reference_compatible_mode(hml):
+    """The reference-compatible mode (option "compat", hml_k_compat.h) against the checker's REFERENCE mode - sequential mt19937,
+    libm arithmetic, Kahan sums, size_t += float counts, i.e. the reference binary's own chain (the checker in that mode is pinned
+    on the binary's files, tests/test_oracle_golden.py) - on 120 random configurations: 2-64 states, 1-3 data dimensions, random
+    schemes, weakly compressed input, and chunk geometries of the filter / backward draws from the sequential form to hundreds of
+    chunks without warm-up, where chunks start wrong and run again."""
+    assert fuzz(hml, 120, 20261006, compat=True) == 120
