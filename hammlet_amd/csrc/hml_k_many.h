@@ -38,6 +38,12 @@ struct hml_chain_dev {
     hml_layout lay;   // the chain's own chunk-transposed layout (its stride follows ITS block capacity, hml_ctx.hpp)
 };
 
+// The chains of one launch as a KERNEL ARGUMENT (up to eight; round 4): the pointers come with the launch instead of through one
+// more dependent load from an array in device memory - the first of the six or seven memory round trips that these short kernels
+// consist of, and beside another group's kernels every one of them takes three times as long.
+#define HML_MANY_ARG_CHAINS 8
+struct hml_many_args { hml_chain_dev c[HML_MANY_ARG_CHAINS]; };
+
 HML_KERNEL __launch_bounds__(256) void hml_m_compact_scan_summary(const hml_chain_dev* __restrict__ cs, uint32_t T) {
     const hml_chain_dev& c = cs[blockIdx.y];
     hml_b_compact_scan_summary(c.summary, c.w, T, c.mdl, 0.0f, 0, c.key_base, c.stage, c.span_count, c.coarse1);
@@ -52,35 +58,35 @@ HML_KERNEL __launch_bounds__(256) void hml_m_stats_emission(const hml_chain_dev*
     hml_b_stats_emission<K>(c.ia, c.starts, c.mdl, c.bstat, c.em, with_gsc ? c.gsc : nullptr, nullptr, 0, c.lay);
 }
 template <int K>
-HML_KERNEL __launch_bounds__(256) void hml_m_forward(const hml_chain_dev* __restrict__ cs, int with_gsc, int L) {
-    const hml_chain_dev& c = cs[blockIdx.y];
+HML_KERNEL __launch_bounds__(256) void hml_m_forward(const hml_many_args a, int with_gsc, int L) {
+    const hml_chain_dev& c = a.c[blockIdx.y];
     hml_b_forward<K>(c.em, with_gsc ? c.gsc : nullptr, c.mdl, c.rows, nullptr, c.entry, c.exitv, c.fb, L, c.lay);
 }
 template <int K>
-HML_KERNEL __launch_bounds__(256) void hml_m_backward_maps(const hml_chain_dev* __restrict__ cs, int with_gsc, int L) {
-    const hml_chain_dev& c = cs[blockIdx.y];
+HML_KERNEL __launch_bounds__(256) void hml_m_backward_maps(const hml_many_args a, int with_gsc, int L) {
+    const hml_chain_dev& c = a.c[blockIdx.y];
     hml_b_backward_maps2<K>(c.rows, c.mdl, c.smap, c.cmap, c.lay, c.entry, c.exitv, c.redo, L, with_gsc ? nullptr : c.starts, c.mdl);   // (two rows per lane)
 }
 template <int K>
-HML_KERNEL __launch_bounds__(1024) void hml_m_backward_chain(const hml_chain_dev* __restrict__ cs, int with_gsc, int L) {
-    const hml_chain_dev& c = cs[blockIdx.y];
+HML_KERNEL __launch_bounds__(1024) void hml_m_backward_chain(const hml_many_args a, int with_gsc, int L) {
+    const hml_chain_dev& c = a.c[blockIdx.y];
     hml_b_backward_chain<K>(c.cmap, c.mdl, c.bentry, c.em, with_gsc ? c.gsc : nullptr, c.rows, nullptr, c.entry, c.exitv, c.fb, c.redo, c.touched,
                             c.smap, L, c.lay, 3, 0, with_gsc ? nullptr : c.starts);
 }
 template <int K>
-HML_KERNEL __launch_bounds__(256) void hml_m_counts(const hml_chain_dev* __restrict__ cs) {
-    const hml_chain_dev& c = cs[blockIdx.y];
+HML_KERNEL __launch_bounds__(256) void hml_m_counts(const hml_many_args a) {
+    const hml_chain_dev& c = a.c[blockIdx.y];
     hml_b_counts<K, true, false>(c.q, c.starts, c.bstat, c.mdl, c.partial, c.smap, c.bentry);
 }
 // (only the chains whose bit is set record this sweep: a chain may have its marginals switched off)
-HML_KERNEL __launch_bounds__(256) void hml_m_record(const hml_chain_dev* __restrict__ cs, unsigned long long chains_recording) {
+HML_KERNEL __launch_bounds__(256) void hml_m_record(const hml_many_args a, unsigned long long chains_recording) {
     if (!((chains_recording >> blockIdx.y) & 1ull)) return;
-    const hml_chain_dev& c = cs[blockIdx.y];
+    const hml_chain_dev& c = a.c[blockIdx.y];
     hml_b_record(c.q, c.starts, c.mdl, c.diff, c.boundary);
 }
 template <int K>
-HML_KERNEL __launch_bounds__(1024) void hml_m_params(const hml_chain_dev* __restrict__ cs) {
-    const hml_chain_dev& c = cs[blockIdx.y];
+HML_KERNEL __launch_bounds__(1024) void hml_m_params(const hml_many_args a) {
+    const hml_chain_dev& c = a.c[blockIdx.y];
     hml_b_params<K, true>(c.mdl, c.partial, 0, (int)blockIdx.x, (int)gridDim.x);
 }
 

@@ -401,13 +401,21 @@ static int iterate_many_k(hml_ctx* const* cs, int n, uint64_t first, uint64_t it
                 hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_m_stats_emission<KK>), dim3(gB, ny), dim3(256), 0, s, d_g, with_gsc);
             }
             const uint64_t chunks = ((uint64_t)hint + L - 1) / L;
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_m_forward<KK>), dim3((unsigned)grid_for(chunks, 256, 16, 1 << 20), ny), dim3(256), 0, s, d_g, with_gsc, L);
             const uint64_t bch = ((uint64_t)hint + HML_BWD_CHUNK - 1) / HML_BWD_CHUNK;
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_m_backward_maps<KK>), dim3((unsigned)grid_for((bch + 1) / 2 * 64, 256, 16, 1 << 18), ny), dim3(256), 0, s, d_g, with_gsc, L);   // (a wavefront per two chunks)
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_m_backward_chain<KK>), dim3(1, ny), dim3(1024), 0, s, d_g, with_gsc, L);
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_m_counts<KK>), dim3(HML_REDUCE_GROUPS, ny), dim3(256), 0, s, d_g);
-            if (record && (rec_mask >> g0)) hipLaunchKernelGGL(hml_m_record, dim3(gB, ny), dim3(256), 0, s, d_g, rec_mask >> g0);
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_m_params<KK>), dim3(HML_PARAMS_TREE_WGS, ny), dim3(1024), 0, s, d_g);
+            // the chains' pointers travel as a kernel argument, eight chains to a launch (hml_many_args)
+            for (int k0 = g0; k0 < g0 + gn; k0 += HML_MANY_ARG_CHAINS) {
+                const int nk = std::min(g0 + gn - k0, (int)HML_MANY_ARG_CHAINS);
+                hml_many_args ma;
+                memset(&ma, 0, sizeof ma);
+                for (int k = 0; k < nk; ++k) ma.c[k] = h[k0 + k];
+                const unsigned nyk = (unsigned)nk;
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_m_forward<KK>), dim3((unsigned)grid_for(chunks, 256, 16, 1 << 20), nyk), dim3(256), 0, s, ma, with_gsc, L);
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_m_backward_maps<KK>), dim3((unsigned)grid_for((bch + 1) / 2 * 64, 256, 16, 1 << 18), nyk), dim3(256), 0, s, ma, with_gsc, L);   // (a wavefront per two chunks)
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_m_backward_chain<KK>), dim3(1, nyk), dim3(1024), 0, s, ma, with_gsc, L);
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_m_counts<KK>), dim3(HML_REDUCE_GROUPS, nyk), dim3(256), 0, s, ma);
+                if (record && (rec_mask >> k0)) hipLaunchKernelGGL(hml_m_record, dim3(gB, nyk), dim3(256), 0, s, ma, rec_mask >> k0);
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_m_params<KK>), dim3(HML_PARAMS_TREE_WGS, nyk), dim3(1024), 0, s, ma);
+            }
         }
         KLAUNCH_CHECK();
         if (record) {
