@@ -131,6 +131,23 @@ HML_KERNEL __launch_bounds__(HML_FUSED_WAVES * 64, HML_FM_MIN_WAVES) void hml_m_
     __shared__ hml_fm_chain s_ch[NC];
     if (threadIdx.x < 32u) sm_exp_tab[threadIdx.x] = HML_EXP2F_TAB[threadIdx.x];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // the first batch's summary words do not depend on the chains' parameters: requested ahead of them, so that the two round
+    // trips overlap (beside another group's kernels a round trip takes three times its idle latency)
+    const uint32_t g = blockIdx.x;
+    const uint32_t n_spans = (uint32_t)(((uint64_t)T + HML_SPAN - 1) / HML_SPAN);
+    const uint32_t eighth = n_sub * (uint32_t)HML_FUSED_WAVE_BATCH;                   // positions per wavefront
+    const uint32_t tile_positions = eighth * (uint32_t)NW;
+    const uint64_t wave_base = ((uint64_t)g * NW + (uint32_t)wave) * eighth;          // first position of this wavefront's eighth
+    auto load_batch = [&](uint32_t j, uint32_t (&gw)[HML_SUM_SPANS]) {
+        const uint32_t span0 = (uint32_t)(wave_base / HML_SPAN) + j * HML_SUM_SPANS;
+#pragma unroll
+        for (int s = 0; s < HML_SUM_SPANS; ++s)
+            gw[s] = (j < n_sub && span0 + s < n_spans)
+                        ? __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(summary) + (uint64_t)(span0 + s) * 64u + lane)
+                        : 0u;
+    };
+    uint32_t gw[HML_SUM_SPANS];
+    load_batch(0u, gw);
     // chain c's parameters (written by the parameter kernel of the sweep before) by wavefront c, c + 8, ...
     for (int c = wave; c < n; c += NW) {
         const hml_model* m = args.c[c].mdl;
@@ -142,11 +159,6 @@ HML_KERNEL __launch_bounds__(HML_FUSED_WAVES * 64, HML_FM_MIN_WAVES) void hml_m_
     __syncthreads();
     if (dbg && threadIdx.x == 0) dbg[blockIdx.x * 8 + 5] = wall_clock64();
 
-    const uint32_t g = blockIdx.x;
-    const uint32_t n_spans = (uint32_t)(((uint64_t)T + HML_SPAN - 1) / HML_SPAN);
-    const uint32_t eighth = n_sub * (uint32_t)HML_FUSED_WAVE_BATCH;                   // positions per wavefront
-    const uint32_t tile_positions = eighth * (uint32_t)NW;
-    const uint64_t wave_base = ((uint64_t)g * NW + (uint32_t)wave) * eighth;          // first position of this wavefront's eighth
     uint16_t* listed = listed_all[wave];
 
     // ---------------- phase A: the starts of every chain in this wavefront's eighth
@@ -159,16 +171,6 @@ HML_KERNEL __launch_bounds__(HML_FUSED_WAVES * 64, HML_FM_MIN_WAVES) void hml_m_
             kmin = k < kmin ? k : kmin;
         }
         const hml_swar_ge sw_ge = hml_swar_ge_make(kmin);
-        auto load_batch = [&](uint32_t j, uint32_t (&gw)[HML_SUM_SPANS]) {
-            const uint32_t span0 = (uint32_t)(wave_base / HML_SPAN) + j * HML_SUM_SPANS;
-#pragma unroll
-            for (int s = 0; s < HML_SUM_SPANS; ++s)
-                gw[s] = (j < n_sub && span0 + s < n_spans)
-                            ? __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(summary) + (uint64_t)(span0 + s) * 64u + lane)
-                            : 0u;
-        };
-        uint32_t gw[HML_SUM_SPANS];
-        load_batch(0u, gw);
         for (uint32_t j = 0; j < n_sub; ++j) {   // wave-uniform
             const uint32_t span0 = (uint32_t)(wave_base / HML_SPAN) + j * HML_SUM_SPANS;
             if (span0 >= n_spans) break;
