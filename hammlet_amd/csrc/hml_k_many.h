@@ -38,11 +38,12 @@ struct hml_chain_dev {
     hml_layout lay;   // the chain's own chunk-transposed layout (its stride follows ITS block capacity, hml_ctx.hpp)
 };
 
-// The chains of one launch as a KERNEL ARGUMENT (up to eight; round 4): the pointers come with the launch instead of through one
+// The chains of one launch as a KERNEL ARGUMENT (up to sixteen: 3.7 of the 4 KB a launch may carry; round 4): the pointers come with the launch instead of through one
 // more dependent load from an array in device memory - the first of the six or seven memory round trips that these short kernels
 // consist of, and beside another group's kernels every one of them takes three times as long.
-#define HML_MANY_ARG_CHAINS 8
+#define HML_MANY_ARG_CHAINS 16
 struct hml_many_args { hml_chain_dev c[HML_MANY_ARG_CHAINS]; };
+static_assert(sizeof(hml_many_args) + 64 <= 4096, "kernel arguments of the batched kernels");
 
 HML_KERNEL __launch_bounds__(256) void hml_m_compact_scan_summary(const hml_chain_dev* __restrict__ cs, uint32_t T) {
     const hml_chain_dev& c = cs[blockIdx.y];

@@ -402,7 +402,7 @@ static int iterate_many_k(hml_ctx* const* cs, int n, uint64_t first, uint64_t it
             }
             const uint64_t chunks = ((uint64_t)hint + L - 1) / L;
             const uint64_t bch = ((uint64_t)hint + HML_BWD_CHUNK - 1) / HML_BWD_CHUNK;
-            // the chains' pointers travel as a kernel argument, eight chains to a launch (hml_many_args)
+            // the chains' pointers travel as a kernel argument, up to sixteen chains to a launch (hml_many_args)
             for (int k0 = g0; k0 < g0 + gn; k0 += HML_MANY_ARG_CHAINS) {
                 const int nk = std::min(g0 + gn - k0, (int)HML_MANY_ARG_CHAINS);
                 hml_many_args ma;
