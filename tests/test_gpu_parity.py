@@ -461,7 +461,7 @@ def test_batched_chains_are_the_chains_run_alone(hml, K, n_chains):
 @pytest.mark.parametrize("K,n_chains,T,slots,spin,groups", [(5, 8, 300_000, None, None, None), (3, 2, 300_000, None, None, None), (10, 3, 200_000, None, None, None),
                                                             (5, 9, 140_000, None, None, None), (4, 3, 1_200_000, 3, None, None), (5, 4, 300_000, None, 0, None),
                                                             (16, 2, 70_000, None, None, None), (5, 7, 200_000, None, None, 1), (5, 7, 200_000, None, None, 3),
-                                                            (4, 5, 150_000, None, None, 4), (5, 18, 100_000, None, None, 2)])
+                                                            (4, 5, 150_000, None, None, 4), (5, 18, 100_000, None, None, 2), (3, 36, 40_000, None, None, 2), (5, 17, 60_000, None, None, 1)])
 def test_attached_chains_batched_through_the_many_chain_block_kernel(hml, monkeypatch, K, n_chains, T, slots, spin, groups):
     """hml_attach_observations + hml_iterate_many: chains that share ONE construction (weights, summary, integral array)
     take hml_m_blocks_fused (hml_k_blocks_fused_many.h) - block starts, block statistics and emission terms of all chains
@@ -469,7 +469,8 @@ def test_attached_chains_batched_through_the_many_chain_block_kernel(hml, monkey
     eight chains (one launch), nine (two launches), many states (parameters from LDS), tiles of several batches (slots = 3
     forces n_sub > 1), every tile word computed by the waiting workgroup (spin limit 0), integral-array cells crossed.
     The batch runs as groups of chains on streams of their own (two by default; HML_MANY_GROUPS): one group, three and four
-    uneven ones, and eighteen chains (groups of nine: two launches of the block kernel each)."""
+    uneven ones, eighteen chains (groups of nine: two launches of the block kernel each), and groups of eighteen and seventeen
+    chains: the other kernels take up to sixteen chains per launch (their pointers travel as a kernel argument)."""
     if groups is not None:
         monkeypatch.setenv("HML_MANY_GROUPS", str(groups))
     if slots is not None:
