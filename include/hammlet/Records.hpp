@@ -10,14 +10,18 @@
 // The marginal counts are accumulated on the device (difference arrays + boundary bitmap) and fetched in
 // run-length form at close(); the per-sweep files are appended from the device's block list and state
 // sequence after every recorded sweep.
-// Note on "segments": the reference's second column is the length of its internal count queue in the
-// middle of a rotation - an artefact of its data structure; this implementation writes the number of
-// count entries the finished structure would hold (documented as approximate in DESIGN.md).
+// Note on "segments": the reference's second column is the length of its internal count queue
+// (StateMarginals::internalSize(), src/StateMarginals.hpp:204) at the moment Records::record writes the line
+// (src/Records.hpp:208-209) - before the sweep's LAST run of equal states has been added.  The queue holds one
+// record per marginal segment - the non-zero counts in state order, an index entry before every stored state
+// whose predecessor is not stored (never before state 0), a terminator (src/StateMarginals.hpp:71-115) - so a
+// record's length is a function of the SET of states with a count: |S| + #{s in S: s > 0, s-1 not in S} + 1.
+// MarginalSegmentSets below keeps those sets (a sorted list of segment starts with a 64-bit state mask each,
+// merged with the sweep's runs in one pass) and yields the reference's two numbers exactly.
 #ifndef HAMMLET_RECORDS_HPP
 #define HAMMLET_RECORDS_HPP
 
 #include <fstream>
-#include <set>
 #include <string>
 #include <vector>
 
@@ -28,6 +32,42 @@ inline bool fileExists(const std::string& path) {
     return f.good();
 }
 
+// marginal segments as (start, set of states with a non-zero count): what the `segments` file needs and nothing more
+class MarginalSegmentSets {
+    std::vector<uint32_t> mStart{0};
+    std::vector<uint64_t> mStates{0};
+    static uint64_t recordLength(uint64_t set) {
+        return (uint64_t)__builtin_popcountll(set) + (uint64_t)__builtin_popcountll(set & ~(set << 1) & ~1ull) + 1;
+    }
+
+public:
+    size_t nrSegments() const { return mStart.size(); }
+    // one recorded sweep given as runs of equal state (start of run r, its state; the last run ends at T).  Returns the
+    // length of the reference's count queue when all runs but the last have been added.
+    uint64_t addSweep(const std::vector<uint32_t>& runStart, const std::vector<int16_t>& runState, uint64_t T) {
+        const size_t R = runStart.size(), M = mStart.size();
+        std::vector<uint32_t> start;
+        std::vector<uint64_t> states;
+        start.reserve(M + R);
+        states.reserve(M + R);
+        uint64_t queued = 0;
+        size_t r = 0, m = 0;
+        for (uint64_t pos = 0; pos < T;) {
+            const uint64_t nextRun = r + 1 < R ? runStart[r + 1] : T, nextSeg = m + 1 < M ? mStart[m + 1] : T;
+            const uint64_t with = mStates[m] | (1ull << runState[r]);
+            start.push_back((uint32_t)pos);
+            states.push_back(with);
+            queued += recordLength(pos < runStart[R - 1] ? with : mStates[m]);
+            pos = nextRun < nextSeg ? nextRun : nextSeg;
+            r += pos == nextRun;
+            m += pos == nextSeg;
+        }
+        mStart.swap(start);
+        mStates.swap(states);
+        return queued;
+    }
+};
+
 class Records {
     const size_t mSize;
     std::string mPrefix, mSuffix;
@@ -36,7 +76,7 @@ class Records {
          mRecordTheta = false, mRecordSegments = false, mRecordMaxSeg = false, mAccumulate = false;
     std::ofstream mMarginalsFile, mSequenceFile, mBlocksFile, mThetaFile, mCompressionsFile, mSegmentFile, mMaxSegFile;
     bool mClosed = false;
-    std::set<uint32_t> mBoundaries;   // only maintained when the segments file is requested
+    MarginalSegmentSets mSegmentSets;   // only maintained when the segments file is requested
 
     void setRecordX(std::ofstream& file, const std::string& type, bool& member, bool flag, bool overwrite) {
         member = flag;
@@ -85,12 +125,14 @@ public:
         hml_check(hml_get_states(ctx, q.data()));
         bool firstSeg = true;
         size_t segStart = 0;
+        std::vector<uint32_t> runStart;
+        std::vector<int16_t> runState;
         for (size_t b = 0; b < B; ++b) {
             if (mRecordBlocks) mBlocksFile << (b ? "\t" : "") << (starts[b + 1] - starts[b]);
             const bool last = (b + 1 == B);
             if (last || q[b + 1] != q[b]) {
                 if (mRecordSequences) mSequenceFile << (firstSeg ? "" : "\t") << (starts[b + 1] - starts[segStart]) << ":" << (size_t)q[b];
-                if (mRecordSegments) mBoundaries.insert(starts[segStart]);
+                if (mRecordSegments) { runStart.push_back(starts[segStart]); runState.push_back(q[b]); }
                 firstSeg = false;
                 segStart = b + 1;
             }
@@ -98,7 +140,16 @@ public:
         if (mRecordBlocks) mBlocksFile << "\n";
         if (mRecordSequences) mSequenceFile << "\n";
         if (mRecordCompression) mCompressionsFile << ((double)mSize) / ((double)B) << std::endl;
-        if (mRecordSegments) mSegmentFile << mBoundaries.size() << "\t" << mBoundaries.size() * 2 << std::endl;
+        if (mRecordSegments) {
+            // (the reference adds to its marginals only when they are recorded, src/Records.hpp:176,212: otherwise one
+            // empty record)
+            if (recordsMarginals()) {
+                const uint64_t queued = mSegmentSets.addSweep(runStart, runState, mSize);
+                mSegmentFile << mSegmentSets.nrSegments() << "\t" << queued << std::endl;
+            } else {
+                mSegmentFile << 1 << "\t" << 1 << std::endl;
+            }
+        }
     }
     // ... and Records::record(theta) (src/Records.hpp:196-203): the parameters line of the sweep
     template <typename ThetaT>

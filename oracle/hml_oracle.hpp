@@ -135,8 +135,11 @@ public:
     uint64_t total_blocks = 0;     // sum of B over sweeps
 
     // recording
-    bool rec_marginals = true, rec_sequences = false, rec_blocks = false, rec_params = false, rec_compression = false;
-    std::string out_sequences, out_blocks, out_params, out_compression;
+    bool rec_marginals = true, rec_sequences = false, rec_blocks = false, rec_params = false, rec_compression = false,
+         rec_segments = false;
+    std::string out_sequences, out_blocks, out_params, out_compression, out_segments;
+    // `segments` file (Records.hpp:208-209): marginal segments as sorted starts + the set of states with a non-zero count
+    std::vector<uint64_t> mseg_start{0}, mseg_states{0};
     std::vector<int32_t> diff;        // K * (T+1) difference array
     std::vector<uint8_t> boundary;    // T bits as bytes
     int max_state_recorded = -1;
@@ -830,6 +833,8 @@ public:
         char buf[64];
         size_t segStart = 0;
         bool firstSeg = true;
+        std::vector<uint64_t> run_start;
+        std::vector<int> run_state;
         for (size_t b = 0; b < B; ++b) {
             if (rec_blocks) {
                 snprintf(buf, sizeof buf, "%s%zu", b == 0 ? "" : "\t", (size_t)(starts[b + 1] - starts[b]));
@@ -849,10 +854,12 @@ public:
                     snprintf(buf, sizeof buf, "%s%zu:%d", firstSeg ? "" : "\t", s1 - s0, st);
                     out_sequences += buf;
                 }
+                if (rec_segments && rec_marginals) { run_start.push_back(s0); run_state.push_back(st); }
                 firstSeg = false;
                 segStart = b + 1;
             }
         }
+        if (rec_segments) segments_line(run_start, run_state);
         if (rec_blocks) out_blocks += "\n";
         if (rec_sequences) out_sequences += "\n";
         if (rec_compression) {
@@ -860,6 +867,43 @@ public:
             out_compression += buf;
         }
         n_recorded++;
+    }
+    // The `segments` line of a recorded sweep (Records.hpp:208-209): StateMarginals::nrSegments() and internalSize()
+    // (StateMarginals.hpp:194-206) at the moment Records::record writes them - BEFORE the sweep's last run of equal states
+    // goes into addRecord.  StateMarginals keeps one record per marginal segment in a rotating queue: the counts of the
+    // states in ascending order, a state with a zero count left out, an index entry in front of every stored state that
+    // does not follow the one stored before it (state 0 never needs one), one terminator (StateMarginals.hpp:71-115).
+    // A record's length therefore depends only on the SET of states with a count.  At the time of writing the records of
+    // the segments before the last run's start already hold this sweep's state, the others do not yet; the last run
+    // ends at T and absorbs whole records (no split, StateMarginals.hpp:117-131), so the number of segments is final.
+    static uint64_t record_length(uint64_t states) {
+        return (uint64_t)__builtin_popcountll(states) + (uint64_t)__builtin_popcountll(states & ~(states << 1) & ~1ull) + 1;
+    }
+    void segments_line(const std::vector<uint64_t>& run_start, const std::vector<int>& run_state) {
+        char buf[64];
+        if (!rec_marginals) {   // addRecord is never called (Records.hpp:176,212): the queue stays {0}
+            out_segments += "1\t1\n";
+            return;
+        }
+        const size_t R = run_start.size(), M = mseg_start.size();
+        const uint64_t last_run = run_start[R - 1];
+        std::vector<uint64_t> ns, nm;
+        ns.reserve(M + R); nm.reserve(M + R);
+        uint64_t internal = 0;
+        size_t i = 0, j = 0;   // run i and old segment j contain the position p
+        uint64_t p = 0;
+        while (p < T) {
+            const uint64_t before = mseg_states[j], after = before | (1ull << run_state[i]);
+            ns.push_back(p); nm.push_back(after);
+            internal += record_length(p < last_run ? after : before);
+            const uint64_t e_run = i + 1 < R ? run_start[i + 1] : T, e_seg = j + 1 < M ? mseg_start[j + 1] : T;
+            p = std::min(e_run, e_seg);
+            if (p == e_run) ++i;
+            if (p == e_seg) ++j;
+        }
+        mseg_start.swap(ns); mseg_states.swap(nm);
+        snprintf(buf, sizeof buf, "%zu\t%llu\n", mseg_start.size(), (unsigned long long)internal);
+        out_segments += buf;
     }
     void append_params() {
         // Theta::str -> concat(Observation<NormalParam>::str) (Theta.hpp:215-219, Observation.hpp:205-210)

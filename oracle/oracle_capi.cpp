@@ -65,6 +65,7 @@ int orc_set_record(void* h, int marg, int seq, int blocks, int params, int compr
     o->rec_marginals = marg; o->rec_sequences = seq; o->rec_blocks = blocks; o->rec_params = params; o->rec_compression = compr;
     return 0;
 }
+int orc_set_record_segments(void* h, int on) { ((Oracle*)h)->rec_segments = on != 0; return 0; }
 int orc_set_probes(void* h, int on) { ((Oracle*)h)->keep_probes = on != 0; return 0; }
 int orc_iterate(void* h, char method, uint64_t iters, uint64_t thin) {
     ORC_TRY Oracle* o = (Oracle*)h;
@@ -130,11 +131,11 @@ void orc_get_posterior(void* h, float* nig4K, float* dirA, float* dirPi) {
 int orc_marginals_dense(void* h, int32_t* out) {
     ORC_TRY Oracle* o = (Oracle*)h; std::vector<int32_t> v; o->marginals_dense(v); memcpy(out, v.data(), v.size() * 4); ORC_END
 }
-// text outputs: which = 0 marginals, 1 sequences, 2 blocks, 3 parameters, 4 compression
+// text outputs: which = 0 marginals, 1 sequences, 2 blocks, 3 parameters, 4 compression, 5 segments
 uint64_t orc_text(void* h, int which, char* buf, uint64_t cap) {
     Oracle* o = (Oracle*)h;
     std::string s = which == 0 ? o->marginals_text() : which == 1 ? o->out_sequences : which == 2 ? o->out_blocks
-                    : which == 3 ? o->out_params : o->out_compression;
+                    : which == 3 ? o->out_params : which == 5 ? o->out_segments : o->out_compression;
     if (buf && cap >= s.size()) memcpy(buf, s.data(), s.size());
     return s.size();
 }

@@ -113,6 +113,7 @@ int main(int argc, const char* argv[]) {
         o.rec_params = has("P", "parameters");
         o.rec_blocks = has("B", "blocks");
         o.rec_compression = has("C", "compression");
+        o.rec_segments = has("G", "segments");
 
         o.load(x.data(), x.size());
         { std::vector<float>().swap(x); }
@@ -150,6 +151,7 @@ int main(int argc, const char* argv[]) {
         if (o.rec_blocks) put("blocks", o.out_blocks);
         if (o.rec_params) put("parameters", o.out_params);
         if (o.rec_compression) put("compression", o.out_compression);
+        if (o.rec_segments) put("segments", o.out_segments);
         return 0;
     } catch (std::exception& e) {
         std::cout << std::flush;

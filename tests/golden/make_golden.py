@@ -26,10 +26,10 @@ REF = os.path.join(REPO, "oracle", "_ref", "hammlet")
 
 # name -> (T, K, data_seed, flags, outputs)
 CASES = {
-    "c1_fb": (100000, 3, 1, "-s 3 -R 1 -i F 100 1", ["marginals", "sequences", "parameters", "blocks", "compression"]),
+    "c1_fb": (100000, 3, 1, "-s 3 -R 1 -i F 100 1", ["marginals", "sequences", "parameters", "blocks", "compression", "segments"]),
     "c1_default_scheme": (100000, 3, 11, "-s 3 -R 11", ["marginals"]),
     "k4_mixed_scheme": (20000, 4, 3, "-s 4 -R 3 -i M 50 5 D F 60 2 P M 10 1 S F 30 1",
-                        ["marginals", "sequences", "parameters", "compression"]),
+                        ["marginals", "sequences", "parameters", "compression", "segments"]),
     "k3_no_self_transitions": (100000, 3, 1, "-s 3 -R 5 -S -i F 50 1", ["marginals", "parameters"]),
     "k3_priors_multiplier": (100000, 3, 1, "-s 3 -R 7 -m 1.5 -t 1 10 -I 2 -e normal 0.1 0.8 -i M 20 1 F 50 1",
                              ["marginals", "parameters", "compression"]),
@@ -40,6 +40,10 @@ CASES = {
     # breakpoints at T/2, 3T/4, ...), the 65535-position integral-array cell, tiny inputs
     "t16": (16, 2, 21, "-s 2 -R 1 -i F 20 1", ["marginals", "sequences", "blocks", "parameters"]),
     "t1000": (1000, 3, 22, "-s 3 -R 2 -i M 5 1 F 20 1", ["marginals", "sequences", "blocks", "parameters"]),
+    # `-O segments` (Records.hpp:208-209: #marginal segments and the length of StateMarginals' count queue before the
+    # sweep's last run is added) - with the marginals (c1_fb, k4_mixed_scheme, k40_mixed_scheme, mv_c22 above) and
+    # WITHOUT them, where the queue never grows
+    "t1000_segments_only": (1000, 3, 22, "-s 3 -R 2 -i M 5 1 F 20 1", ["segments", "sequences"]),
     "t4096": (4096, 3, 23, "-s 3 -R 3 -i F 20 1", ["marginals", "blocks", "parameters"]),
     "t65535": (65535, 3, 24, "-s 3 -R 4 -i F 20 2", ["marginals", "blocks", "parameters"]),
     "t65536": (65536, 3, 25, "-s 3 -R 5 -i F 20 2", ["marginals", "blocks", "parameters"]),
@@ -47,14 +51,14 @@ CASES = {
     "t131071": (131071, 4, 27, "-s 4 -R 7 -i F 20 4", ["marginals", "parameters", "compression"]),
     # multivariate / shared parameters ("-s C P D": K = P^D states, D interleaved data dimensions).
     # Trace: dimension d is the univariate generator with data seed + d; the values of a position follow each other.
-    "mv_c22": (30000, 2, 51, "-s C 2 2 -R 5 -i F 50 1", ["marginals", "sequences", "parameters", "blocks", "compression"]),
+    "mv_c22": (30000, 2, 51, "-s C 2 2 -R 5 -i F 50 1", ["marginals", "sequences", "parameters", "blocks", "compression", "segments"]),
     "mv_c32_mixed": (30000, 3, 52, "-s C 3 2 -R 6 -i M 20 1 S P F 30 2 D F 10 1", ["marginals", "sequences", "parameters", "compression"]),
     "mv_c23": (20000, 2, 53, "-s C 2 3 -R 7 -i F 30 1", ["marginals", "parameters", "blocks"]),
     "mv_c42_no_self": (70000, 4, 54, "-s C 4 2 -R 8 -S -m 1.3 -i F 20 2", ["marginals", "parameters", "compression"]),
     # more than 16 states (round 4: the reference takes any -s K, main.cpp:112-136; the GPU library runs such models in its
     # reference-compatible mode, hml_k_compat.h)
     "k20_many_states": (60000, 6, 61, "-s 20 -R 12 -i F 30 1", ["marginals", "sequences", "parameters", "blocks"]),
-    "k40_mixed_scheme": (30000, 5, 62, "-s 40 -R 13 -t 0.2 2 -i M 10 1 S P F 15 2 D F 5 1", ["marginals", "parameters", "compression"]),
+    "k40_mixed_scheme": (30000, 5, 62, "-s 40 -R 13 -t 0.2 2 -i M 10 1 S P F 15 2 D F 5 1", ["marginals", "parameters", "compression", "segments"]),
     "mv_c52_25_states": (40000, 5, 63, "-s C 5 2 -R 14 -i F 20 1", ["marginals", "parameters", "compression"]),
     "k64_most_states": (20000, 4, 64, "-s 64 -R 15 -i F 12 1", ["marginals", "parameters"]),
 }

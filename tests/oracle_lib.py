@@ -37,6 +37,7 @@ def load():
     lib.orc_token.argtypes = [_P, C.c_char]
     lib.orc_set_record.argtypes = [_P] + [C.c_int] * 5
     lib.orc_set_probes.argtypes = [_P, C.c_int]
+    lib.orc_set_record_segments.argtypes = [_P, C.c_int]
     lib.orc_iterate.argtypes = [_P, C.c_char, C.c_uint64, C.c_uint64]
     lib.orc_enumerate_blocks.argtypes = [_P, C.c_float]
     for n in ("orc_T", "orc_nblocks", "orc_total_blocks", "orc_warn_uniform", "orc_n_recorded"):
@@ -168,8 +169,9 @@ class OracleChain:
     def token(self, t):
         self._chk(self.lib.orc_token(self.h, t.encode()))
 
-    def set_record(self, marginals=True, sequences=False, blocks=False, params=False, compression=False):
+    def set_record(self, marginals=True, sequences=False, blocks=False, params=False, compression=False, segments=False):
         self.lib.orc_set_record(self.h, int(marginals), int(sequences), int(blocks), int(params), int(compression))
+        self.lib.orc_set_record_segments(self.h, int(segments))
 
     def set_probes(self, on=True):
         self.lib.orc_set_probes(self.h, int(on))
@@ -259,7 +261,7 @@ class OracleChain:
         return out
 
     def text(self, which):
-        idx = {"marginals": 0, "sequences": 1, "blocks": 2, "parameters": 3, "compression": 4}[which]
+        idx = {"marginals": 0, "sequences": 1, "blocks": 2, "parameters": 3, "compression": 4, "segments": 5}[which]
         n = self.lib.orc_text(self.h, idx, None, 0)
         buf = C.create_string_buffer(n + 1)
         self.lib.orc_text(self.h, idx, buf, n)

@@ -1,5 +1,5 @@
 """End-to-end file-level parity of the `hammlet` driver (GPU) with the CPU checker's driver in device mode:
-same flags, same input, byte-identical marginals / sequences / blocks / parameters / compression files."""
+same flags, same input, byte-identical marginals / sequences / blocks / parameters / compression / segments files."""
 import os
 import subprocess
 import tempfile
@@ -13,7 +13,7 @@ pytestmark = pytest.mark.gpu
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CLI = os.path.join(REPO, "hammlet_amd", "hammlet")
 ORACLE_CLI = os.path.join(ol.ORACLE_DIR, "hammlet_oracle")
-OUTS = ["marginals", "sequences", "parameters", "blocks", "compression"]
+OUTS = ["marginals", "sequences", "parameters", "blocks", "compression", "segments"]
 
 
 def run_pair(x, flags, text_input=False):

@@ -186,9 +186,10 @@ def test_compat_multivariate_chain_is_the_reference_chain(hml, P, D, T, seed, sc
 @pytest.mark.parametrize("case", sorted(MANIFEST))
 def test_cli_compat_writes_the_reference_binarys_files(case, chunks, monkeypatch):
     """`hammlet -compat` with the flags of a golden run against the files the UNMODIFIED REFERENCE BINARY wrote for them
-    (tests/golden/<case>/, oracle/_ref/hammlet in the build container): byte for byte, from the GPU - all 19 runs: the
-    15 univariate ones and (round 4) the four multivariate / shared-parameter runs `-s C P D` (reference
-    src/Mapping.hpp:53-137, src/EFD.hpp:83-93, src/StateSequence/ForwardBackward.hpp:189-207)."""
+    (tests/golden/<case>/, oracle/_ref/hammlet in the build container): byte for byte, from the GPU - every run of the manifest: the
+    univariate ones, the four multivariate / shared-parameter runs `-s C P D` (reference src/Mapping.hpp:53-137,
+    src/EFD.hpp:83-93, src/StateSequence/ForwardBackward.hpp:189-207), the runs with 20-64 states, and (round 5) the `segments`
+    side file (src/Records.hpp:208-209, src/StateMarginals.hpp:204) of five of them."""
     if chunks is not None:   # every sweep in 50 chunks without warm-up: chunks that start wrong run again
         monkeypatch.setenv("HML_COMPAT_CHUNKS", chunks.split(":")[0])
         monkeypatch.setenv("HML_COMPAT_WARMUP", chunks.split(":")[1])
