@@ -288,7 +288,12 @@ def main():
         scan_ms, scan_n = chain.profile_get(roof_family)
         null_ms, null_n = chain.profile_get("event_null")
 
+    per_rank_ms = None
     if dist is not None:
+        mine = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        per_rank_ms = [1e3 * float(t.item()) / args.steps for t in every]
         tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
@@ -328,10 +333,16 @@ def main():
                 scan_avg_s = max(scan_raw_s - null_s, 1e-9)
         moved = traffic if traffic else phys_bytes
         traffic_raw = pmc_traffic(args.workload, DENSE_INST if dense_workload else FAMILY_KERNEL["blocks_compact"], "bytes_raw")
-        achieved = moved / scan_avg_s / 1e9
+        # `frac` is the LOWER bound: FETCH_SIZE + WRITE_SIZE as counted; `frac_upper` prices the fetches doubled (the gfx950
+        # correction of the microarchitecture guide, calibrated on wide streaming reads - this kernel gathers, so the truth lies
+        # between the two).  Without a committed profile both come from the estimate.
+        moved_raw = traffic_raw if traffic_raw else moved
+        achieved = moved_raw / scan_avg_s / 1e9
+        achieved_upper = moved / scan_avg_s / 1e9
         sweep_bytes = 4.0 * T + B_avg * (36 + 8 * K)   # SURVEY.md 8d bytes_iter
         frac = achieved / HBM_PEAK_GBS
-        assert frac <= 1.0, "a roofline fraction above 1 means the byte count is not what the kernel moves"
+        frac_upper = achieved_upper / HBM_PEAK_GBS
+        assert frac <= frac_upper <= 1.0, "a roofline fraction above 1 means the byte count is not what the kernel moves"
         out = {
             "metric": "block-updates/sec (Gibbs sweep) + HBM GB/s, 10^8 pos / 5 states",
             "value": blocks_all / elapsed,
@@ -352,11 +363,11 @@ def main():
             "roofline": {"bound": "hbm", "kernel": DENSE_KERNEL + " (emission terms + forward filter + backward candidate maps)" if dense_workload
                          else "hml_k_blocks_fused (block scan + block statistics + emission terms)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": frac,
+                         "achieved_upper": achieved_upper, "frac_upper": frac_upper,
                          "traffic": traffic, "traffic_source": PMC_FILES.get(args.workload) if traffic else None,
-                         "bytes_priced": "pmc: 2*FETCH_SIZE + WRITE_SIZE per launch" if traffic else "estimate (no committed profile)",
+                         "bytes_priced": ("frac: pmc FETCH_SIZE + WRITE_SIZE per launch as counted (lower bound); frac_upper: 2*FETCH_SIZE + "
+                                          "WRITE_SIZE (the guide's gfx950 correction; = `traffic`)") if traffic else "estimate (no committed profile)",
                          "traffic_raw": traffic_raw,
-                         "frac_raw": (traffic_raw / scan_avg_s / 1e9 / HBM_PEAK_GBS) if traffic_raw else None,
-                         "frac_raw_note": "FETCH_SIZE + WRITE_SIZE as counted (no gfx950 doubling of the fetches): the lower bound of the bytes moved",
                          "kernel_avg_us": 1e6 * scan_avg_s, "kernel_bracket_us": 1e6 * scan_raw_s,
                          "empty_bracket_us": 1e6 * null_s, "launches": scan_n, "launches_in_timed_region": brackets_timed,
                          "launches_note": "HIP events on the chain's stream; launches beyond those of the timed region come from a "
@@ -398,12 +409,14 @@ def main():
                 continue
             us = 1e3 * (ms - before[nm][0]) / dn
             tr = pmc_traffic(args.workload, fam_kernel[nm])
-            row = {"bracket_us": round(us, 2), "launches_per_sweep": round(dn / n_extra, 2), "traffic": tr}
+            tr_raw = pmc_traffic(args.workload, fam_kernel[nm], "bytes_raw")
+            row = {"bracket_us": round(us, 2), "launches_per_sweep": round(dn / n_extra, 2), "traffic": tr, "traffic_raw": tr_raw}
             net = max(us - 1e6 * null_s, 0.5)
             row["kernel_us"] = round(net, 2)
-            if tr:
-                row["frac"] = round(tr / (net * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)
-                assert row["frac"] <= 1.0
+            if tr:   # frac: counter bytes as counted (lower bound), frac_upper: fetches doubled - as in `roofline`
+                row["frac_upper"] = round(tr / (net * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)
+                row["frac"] = round((tr_raw or tr) / (net * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)
+                assert row["frac"] <= row["frac_upper"] <= 1.0
             table[fam_kernel[nm]] = row
         out["kernels"] = table
 
@@ -420,31 +433,70 @@ def main():
             fam[nm] = round(1e3 * (ms - before[nm][0]) / max(1, n - before[nm][1]), 2)
         out["kernel_us_per_sweep"] = fam
 
+    # what the other ranks cost this one: rank 0 repeats the timed region ALONE (the others wait at the barrier), so the line
+    # carries the ratio the scaling curve should show if nothing but the shared host and power budget couples the chains
+    if dist_mode:
+        if rank == 0:
+            torch.cuda.synchronize()
+            ta = time.perf_counter()
+            chain.iterate("F", args.steps, 0)
+            chain.sync()
+            alone = time.perf_counter() - ta
+            out["per_rank_ms_per_step"] = per_rank_ms
+            out["rank0_alone_ms_per_step"] = 1e3 * alone / args.steps
+            out["efficiency_vs_rank0_alone"] = alone / elapsed
+            out["efficiency_note"] = ("rank 0's time for the same number of sweeps with the other ranks idle (right after the timed region: "
+                                      "an older chain, which is if anything faster) / the slowest rank's time in the timed region")
+        barrier()
+
     # chain-parallel pooling (not timed): a few recorded sweeps, then the library's own collective - every rank joins
-    # an RCCL communicator (hml_pool_create) and hml_pool_marginals relabels, all-reduces and installs the pooled marginals
+    # an RCCL communicator (hml_pool_create) and hml_pool_marginals relabels, pools and installs the marginals.  BOTH forms of
+    # the collective run (round 5): the ranks' boundary lists through ncclAllGather (what the library picks for a strongly
+    # compressed chain) on this rank's chain, and the dense int32 [K+1][T+1] payload through ncclAllReduce(sum) - the
+    # gigabytes SURVEY.md section 5 prices - on a second chain attached to the same observations.
     if dist_mode:
         # (the headline above is complete by now: a pooling that fails - the collective has never run on more than one GPU in the
         # build's environment - is reported in the line, it does not take the line away)
         try:
             from hammlet_amd import chains
             pool = chains.make_pool(local_rank, always_broadcast=True)
-            chain.set_recording(marginals=True)
-            chain.iterate("F", 10, 5)
-            chain.sync()
-            barrier()
-            tp0 = time.perf_counter()
-            seg, cnt, _ = chains.pooled_marginals(chain, pool)
-            barrier()
-            if rank == 0:
+            second = hammlet_amd.Chain(device=local_rank, seed=args.seed + 1000, chain_id=rank)
+            second.attach(chain)
+            second.set_model(K, second.autoprior(0.2, 0.9))
+            second.sample_prior()
+            pooling = {"transport": "RCCL inside libhammlet_hip.so (hml_pool_marginals): the ranks' boundary lists through ncclAllGather when they are "
+                                    "at most an eighth of the dense int32 [K+1][T+1] payload, else that payload through ncclAllReduce(sum); "
+                                    "both forms are forced here in turn (hml_pool_set_form)",
+                       "dense_payload_bytes": 4 * ((K + 1) * (T + 1) + 1 + K), "ranks": world}
+            n_rec = 2
+            for form, name, ch in ((0, "default", chain), (1, "dense", second)):
+                ch.set_recording(marginals=True)
+                ch.iterate("F", 5 * n_rec, 5)
+                ch.sync()
+                pool.set_form(form)
+                barrier()
+                tp0 = time.perf_counter()
+                seg, cnt, _ = chains.pooled_marginals(ch, pool)
+                barrier()
+                secs = time.perf_counter() - tp0
+                # every position was recorded n_rec times by every rank: the pooled counts of every segment add up to ranks x recorded
+                rows = cnt.sum(axis=1)
+                assert int(seg.sum()) == T and int(rows.min()) == world * n_rec and int(rows.max()) == world * n_rec, \
+                    "pooled marginals: row sums %d..%d, expected ranks x recorded = %d" % (int(rows.min()), int(rows.max()), world * n_rec)
                 info, last = pool.info(), pool.last()
-                out["pooling"] = {"transport": "RCCL inside libhammlet_hip.so (hml_pool_marginals): the ranks' boundary lists through ncclAllGather when they are "
-                                               "at most an eighth of the dense int32 [K+1][T+1] payload, else that payload through ncclAllReduce(sum)",
-                                  "form": last["form"], "list_slot_segments": last["entries"],
-                                  "dense_payload_bytes": 4 * ((K + 1) * (T + 1) + 1 + K),
-                                  "rccl_version": info["rccl_version"], "all_reduce_bytes": info["last_bytes"],
-                                  "all_reduce_ms": info["last_allreduce_ms"],
-                                  "seconds_incl_export_and_install": time.perf_counter() - tp0,
-                                  "pooled_segments": int(len(seg)), "counts_per_position": int(cnt[0].sum()), "ranks": world}
+                pooling[name] = {"form": last["form"], "list_slot_segments": last["entries"], "collective_bytes": info["last_bytes"],
+                                 "collective_ms": info["last_allreduce_ms"], "seconds_incl_export_and_install": secs,
+                                 "pooled_segments": int(len(seg)), "counts_per_position": int(rows[0]),
+                                 "algbw_GBps": info["last_bytes"] / max(info["last_allreduce_ms"], 1e-6) / 1e6}
+                pooling["rccl_version"] = info["rccl_version"]
+            # (keys of the first record at the top level as well: what round 4's line carried)
+            d = pooling["default"]
+            pooling.update({"form": d["form"], "list_slot_segments": d["list_slot_segments"], "all_reduce_bytes": d["collective_bytes"],
+                            "all_reduce_ms": d["collective_ms"], "pooled_segments": d["pooled_segments"],
+                            "counts_per_position": d["counts_per_position"]})
+            if rank == 0:
+                out["pooling"] = pooling
+            second.close()
             pool.close()
         except Exception as e:
             if rank == 0:
@@ -711,9 +763,9 @@ def main():
                 if tr:
                     row["traffic"] = tr
                     row["traffic_raw"] = pmc_traffic(pmc_key, kern, "bytes_raw")
-                    row["frac"] = round(tr / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)
-                    row["frac_raw"] = round(row["traffic_raw"] / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)
-                    assert row["frac"] <= 1.0
+                    row["frac_upper"] = round(tr / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)
+                    row["frac"] = round(row["traffic_raw"] / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)
+                    assert row["frac"] <= row["frac_upper"] <= 1.0
                 dense_tab[nm] = row
         Td = ch.T
         ch.close()
@@ -773,8 +825,8 @@ def main():
                 if tr:
                     row["traffic"] = tr
                     row["traffic_raw"] = pmc_traffic("c4_1e8_k10", kern, "bytes_raw")
-                    row["frac"] = round(tr / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)
-                    row["frac_raw"] = round(row["traffic_raw"] / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)
+                    row["frac_upper"] = round(tr / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)
+                    row["frac"] = round(row["traffic_raw"] / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)
                 tab4[kern] = row
         ch.close()
         del x4
@@ -798,6 +850,36 @@ def main():
         out["cpu_baseline"] = None
 
     if rank == 0:
+        # the kernels SURVEY.md 8d and BASELINE.json's north star name, gathered into `roofline` from the legs that measured them
+        roof = out["roofline"]
+        if "float_stream" in out:   # 8d's literal roofline kernel: all T float weights streamed (bandwidth-bound; traffic = algorithmic bytes)
+            roof["float_stream_frac"] = out["float_stream"]["roofline"]["frac"]
+            roof["float_stream_kernel"] = out["float_stream"]["roofline"]["kernel"]
+
+        def fwd_row(kern, us, workload_key):
+            tr_up, tr_raw = pmc_traffic(workload_key, kern), pmc_traffic(workload_key, kern, "bytes_raw")
+            row = {"kernel": kern, "kernel_us": us, "traffic": tr_up, "traffic_raw": tr_raw}
+            if tr_raw:
+                row["frac"] = tr_raw / (us * 1e-6) / 1e9 / HBM_PEAK_GBS
+            if tr_up:
+                row["frac_upper"] = tr_up / (us * 1e-6) / 1e9 / HBM_PEAK_GBS
+            return row
+        fwd = {}
+        kf = family_kernels(K)["forward"]
+        if kf in out.get("kernels", {}):
+            fwd["strongly_compressed"] = fwd_row(kf, out["kernels"][kf]["kernel_us"], args.workload)
+            fwd["strongly_compressed"]["workload"] = args.workload
+        tr_leg = out.get("uncompressed_c3u", {}).get("kernels", {}).get("trellis")
+        if tr_leg:
+            fwd["uncompressed_c3u"] = fwd_row(tr_leg["kernels"], tr_leg["us_per_sweep"], "c3u")
+            fwd["uncompressed_c3u"]["workload"] = "c3u (the same trace, every position its own block)"
+        if dense_workload and DENSE_INST:
+            fwd["this_workload"] = {"kernel": DENSE_INST, "kernel_us": roof["kernel_avg_us"], "frac": roof["frac"], "frac_upper": roof["frac_upper"]}
+        if fwd:
+            fwd["note"] = ("the forward-trellis kernel of the north star: hml_k_forward (speculative chunked filter) where sweeps are strongly "
+                           "compressed - latency-bound - and hml_k_trellis_rows (emission terms + filter + candidate maps in one pass) where they "
+                           "are not - bound by vector issue; frac = counter bytes as counted / duration / 8 TB/s, frac_upper with the fetches doubled")
+            roof["forward_trellis"] = fwd
         print(json.dumps(out))
     if dist is not None:
         dist.barrier()

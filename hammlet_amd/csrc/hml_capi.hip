@@ -696,7 +696,9 @@ int hml_settle(hml_ctx* c) {
                 halted_again = chain_halted(c);
                 if (!halted_again) {
                     if (int r = check_device_error(c)) return r;
-                    c->cb(c, (uint64_t)i, c->cb_user);
+                    // (hml.h: the callback is told the sweep's index in its hml_iterate call, not its place in this list)
+                    const unsigned long long ordinal = c->log_base + i;
+                    c->cb(c, ordinal >= c->call_base ? (uint64_t)(ordinal - c->call_base) : 0u, c->cb_user);
                 }
             }
         }
@@ -824,7 +826,23 @@ int hml_set_static_blocks(hml_ctx* c) {
     hipLaunchKernelGGL(hml_k_set_dynamic, dim3(1), dim3(64), 0, c->stream, c->d_mdl, 0, 1);
     KLAUNCH_CHECK();
     c->dynamic = false;
-    if (int r = launch_compact(c, false, 0.0f)) return r;
+    if (!cap_limited(c)) {
+        if (int r = launch_compact(c, false, 0.0f)) return r;
+    } else {
+        // a context with a reduced block capacity (attached chains, option max_blocks): the enumeration at the model's
+        // threshold may find more blocks than the buffers hold - it then writes nothing and halts the chain.  The structure
+        // is only valid once an enumeration has fitted, so wait for it and grow like enumerate_blocks_sync (ADVICE round 4:
+        // static sweeps enqueued behind a halted enumeration ran as no-ops until the host noticed)
+        bool fitted = false;
+        for (int round = 0; round < 64 && !fitted; ++round) {
+            if (int r = launch_compact(c, false, 0.0f)) return r;
+            HIPCHK(hipStreamSynchronize(c->stream));
+            fitted = !chain_halted(c);
+            if (!fitted) { if (int r = grow_capacity(c, c->h_B[2])) return r; }
+        }
+        if (!fitted) return set_err(HML_ERR_HIP, "internal error: the block capacity did not settle");
+        refresh_hint(c);
+    }
     c->blocks_valid = true;
     return 0;
 }
@@ -956,6 +974,7 @@ int hml_iterate(hml_ctx* c, char method, uint64_t iterations, uint64_t thinning)
     if (method != HML_METHOD_FB && method != HML_METHOD_MIXTURE)
         return set_err(HML_ERR_ARG, std::string("Unknown sampling type ") + method + "!");
     if (int r = ctx_bind(c)) return r;
+    c->call_base = c->requested;
     if (thinning > 0 && thinning <= iterations && c->rec_marginals && c->pooled)   // (before anything is enqueued: a sweep is not abandoned half-way)
         return set_err(HML_ERR_ARG, "the marginals of this context are pooled (common labels, several chains): further sweeps cannot be recorded into them");
     for (uint64_t i = 0; i < iterations; ++i) {
@@ -1020,6 +1039,7 @@ extern "C" int hml_iterate_many(hml_ctx* const* cs, int n, char method, uint64_t
     if (!cs || n < 1) return set_err(HML_ERR_ARG, "no contexts");
     for (int i = 0; i < n; ++i) if (!cs[i] || !cs[i]->model_set) return set_err(HML_ERR_ARG, "model not set");
     if (method != HML_METHOD_FB && method != HML_METHOD_MIXTURE) return set_err(HML_ERR_ARG, std::string("Unknown sampling type ") + method + "!");
+    for (int i = 0; i < n; ++i) cs[i]->call_base = cs[i]->requested;
     uint64_t done = 0;
     while (done < iterations && many_eligible(cs, n, method)) {
         if (int r = ctx_bind(cs[0])) return r;
@@ -1290,26 +1310,24 @@ int hml_recorded_sweeps(hml_ctx* c, uint64_t* n) {
 static int gather_marginal_segments(hml_ctx* c, uint64_t* M_out, uint32_t** d_seg_out, int32_t** d_g_out) {
     const uint32_t T = (uint32_t)c->T;
     const int K = c->K;
-    uint32_t *d_cnt = nullptr, *d_off = nullptr, *d_seg = nullptr;
-    int32_t* d_g = nullptr;
-    HIPCHK(hipMalloc(&d_cnt, c->n_spans * sizeof(uint32_t)));
-    HIPCHK(hipMalloc(&d_off, c->n_spans * sizeof(uint32_t)));
-    hipLaunchKernelGGL(hml_k_marg_count, dim3((c->n_spans + 3) / 4), dim3(256), 0, c->stream, c->d_boundary, T, d_cnt);
+    DevBuf d_cnt, d_off, d_seg, d_g;   // (released on every early return; the two results are handed over at the end)
+    HIPCHK(hipMalloc(&d_cnt.p, c->n_spans * sizeof(uint32_t)));
+    HIPCHK(hipMalloc(&d_off.p, c->n_spans * sizeof(uint32_t)));
+    hipLaunchKernelGGL(hml_k_marg_count, dim3((c->n_spans + 3) / 4), dim3(256), 0, c->stream, c->d_boundary, T, d_cnt.as<uint32_t>());
     std::vector<uint32_t> h_cnt(c->n_spans), h_off(c->n_spans);
-    HIPCHK(hipMemcpyAsync(h_cnt.data(), d_cnt, c->n_spans * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(h_cnt.data(), d_cnt.p, c->n_spans * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     uint64_t M = 0;
     for (uint32_t i = 0; i < c->n_spans; ++i) { h_off[i] = (uint32_t)M; M += h_cnt[i]; }
-    HIPCHK(hipMemcpyAsync(d_off, h_off.data(), c->n_spans * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipMalloc(&d_seg, (M + 1) * sizeof(uint32_t)));
-    HIPCHK(hipMalloc(&d_g, M * K * sizeof(int32_t)));
-    hipLaunchKernelGGL(hml_k_marg_scatter, dim3((c->n_spans + 3) / 4), dim3(256), 0, c->stream, c->d_boundary, T, d_off, d_seg);
-    hipLaunchKernelGGL(hml_k_marg_gather, dim3(grid_for(M, 256, 1, 16384)), dim3(256), 0, c->stream, c->d_diff, T, K, d_seg,
-                       (uint32_t)M, d_g);
+    HIPCHK(hipMemcpyAsync(d_off.p, h_off.data(), c->n_spans * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMalloc(&d_seg.p, (M + 1) * sizeof(uint32_t)));
+    HIPCHK(hipMalloc(&d_g.p, std::max<uint64_t>(M, 1) * K * sizeof(int32_t)));
+    hipLaunchKernelGGL(hml_k_marg_scatter, dim3((c->n_spans + 3) / 4), dim3(256), 0, c->stream, c->d_boundary, T, d_off.as<uint32_t>(), d_seg.as<uint32_t>());
+    hipLaunchKernelGGL(hml_k_marg_gather, dim3(grid_for(M, 256, 1, 16384)), dim3(256), 0, c->stream, c->d_diff, T, K, d_seg.as<uint32_t>(),
+                       (uint32_t)M, d_g.as<int32_t>());
     KLAUNCH_CHECK();
     HIPCHK(hipStreamSynchronize(c->stream));
-    hipFree(d_cnt); hipFree(d_off);
-    *M_out = M; *d_seg_out = d_seg; *d_g_out = d_g;
+    *M_out = M; *d_seg_out = d_seg.release<uint32_t>(); *d_g_out = d_g.release<int32_t>();
     return 0;
 }
 
@@ -1330,17 +1348,15 @@ int hml_marginals_rle(hml_ctx* c, uint64_t* n_segments, int* n_columns, uint64_t
         return 0;
     }
     uint64_t M = 0;
-    uint32_t* d_seg = nullptr;
-    int32_t* d_g = nullptr;
-    if (int r = gather_marginal_segments(c, &M, &d_seg, &d_g)) return r;
+    DevBuf b_seg, b_g;
+    { uint32_t* sg = nullptr; int32_t* gg = nullptr; const int r = gather_marginal_segments(c, &M, &sg, &gg); b_seg.p = sg; b_g.p = gg; if (r) return r; }
     *n_segments = M; *n_columns = ncol;
-    if (!seg_len) { hipFree(d_seg); hipFree(d_g); return 0; }
+    if (!seg_len) return 0;
     std::vector<uint32_t> h_seg(M);
     std::vector<int32_t> h_g(M * K);
-    HIPCHK(hipMemcpyAsync(h_seg.data(), d_seg, M * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipMemcpyAsync(h_g.data(), d_g, M * K * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(h_seg.data(), b_seg.p, M * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(h_g.data(), b_g.p, M * K * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
-    hipFree(d_seg); hipFree(d_g);
     // running sums over segments: counts of a segment = sum of the differences at all boundaries up to it
     std::vector<int32_t> cur(K, 0);
     for (uint64_t i = 0; i < M; ++i) {
@@ -1365,15 +1381,16 @@ int hml_max_segmentation(hml_ctx* c, uint64_t* n_runs, uint64_t* run_len, int32_
         return 0;
     }
     uint64_t M = 0;
-    uint32_t* d_seg = nullptr;
-    int32_t* d_g = nullptr;
-    if (int r = gather_marginal_segments(c, &M, &d_seg, &d_g)) return r;
+    DevBuf b_seg, b_g, b_cs, b_rc, b_st;
+    { uint32_t* sg = nullptr; int32_t* gg = nullptr; const int r = gather_marginal_segments(c, &M, &sg, &gg); b_seg.p = sg; b_g.p = gg; if (r) return r; }
+    uint32_t* const d_seg = b_seg.as<uint32_t>();
+    int32_t* const d_g = b_g.as<int32_t>();
     const uint32_t n_chunks = (uint32_t)((M + 255) / 256);
-    int32_t *d_cs = nullptr, *d_rc = nullptr;
-    int16_t* d_st = nullptr;
-    HIPCHK(hipMalloc(&d_cs, (uint64_t)K * n_chunks * sizeof(int32_t)));
-    HIPCHK(hipMalloc(&d_rc, ((uint64_t)n_chunks + 1) * sizeof(int32_t)));
-    HIPCHK(hipMalloc(&d_st, M * sizeof(int16_t)));
+    HIPCHK(hipMalloc(&b_cs.p, (uint64_t)K * n_chunks * sizeof(int32_t)));
+    HIPCHK(hipMalloc(&b_rc.p, ((uint64_t)n_chunks + 1) * sizeof(int32_t)));
+    HIPCHK(hipMalloc(&b_st.p, M * sizeof(int16_t)));
+    int32_t *const d_cs = b_cs.as<int32_t>(), *const d_rc = b_rc.as<int32_t>();
+    int16_t* const d_st = b_st.as<int16_t>();
     HIPCHK(hipMemsetAsync(d_rc + n_chunks, 0, sizeof(int32_t), c->stream));
     hipLaunchKernelGGL(hml_k_seg_partial, dim3(n_chunks), dim3(256), 0, c->stream, d_g, (uint32_t)M, K, d_cs, n_chunks);
     hipLaunchKernelGGL(hml_k_dense_chunkscan, dim3(K), dim3(1024), 0, c->stream, d_cs, n_chunks);
@@ -1388,10 +1405,11 @@ int hml_max_segmentation(hml_ctx* c, uint64_t* n_runs, uint64_t* run_len, int32_
     *n_runs = (uint64_t)R;
     int rc = 0;
     if (run_len) {
-        uint32_t* d_rs = nullptr;
-        int16_t* d_rq = nullptr;
-        HIPCHK(hipMalloc(&d_rs, (uint64_t)R * sizeof(uint32_t)));
-        HIPCHK(hipMalloc(&d_rq, (uint64_t)R * sizeof(int16_t)));
+        DevBuf b_rs, b_rq;
+        HIPCHK(hipMalloc(&b_rs.p, (uint64_t)R * sizeof(uint32_t)));
+        HIPCHK(hipMalloc(&b_rq.p, (uint64_t)R * sizeof(int16_t)));
+        uint32_t* const d_rs = b_rs.as<uint32_t>();
+        int16_t* const d_rq = b_rq.as<int16_t>();
         hipLaunchKernelGGL(hml_k_seg_run_scatter, dim3(n_chunks), dim3(256), 0, c->stream, d_st, d_seg, (uint32_t)M, d_rc, d_rs, d_rq);
         KLAUNCH_CHECK();
         std::vector<uint32_t> h_rs(R);
@@ -1403,9 +1421,7 @@ int hml_max_segmentation(hml_ctx* c, uint64_t* n_runs, uint64_t* run_len, int32_
             run_len[r] = (uint64_t)((r + 1 < R ? h_rs[r + 1] : T) - h_rs[r]);
             if (run_state) run_state[r] = h_rq[r];
         }
-        hipFree(d_rs); hipFree(d_rq);
     }
-    hipFree(d_seg); hipFree(d_g); hipFree(d_cs); hipFree(d_rc); hipFree(d_st);
     return rc;
 }
 

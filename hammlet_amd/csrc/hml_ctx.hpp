@@ -121,6 +121,8 @@ struct hml_ctx {
     std::vector<uint8_t> sweep_log; // per enqueued sweep: bit 0 mixture, bit 1 recorded
     unsigned long long log_base = 0;   // the model's sweep counter when the log started (= sweeps requested up to then)
     unsigned long long requested = 0;  // sweeps requested of this chain so far (its sweep counter once everything has run)
+    unsigned long long call_base = 0;  // `requested` when the current hml_iterate / hml_iterate_many call began: a sweep's index in
+                                       // its call (what the recording callback is told) = its ordinal - call_base
     uint64_t grown = 0;             // times the buffers were grown (hml_stats)
     uint32_t* d_hB = nullptr;       // device view of h_B
     uint32_t B_hint = 0;

@@ -20,4 +20,15 @@ int hml_set_err(int code, const std::string& msg);
 
 #define KLAUNCH_CHECK() HIPCHK(hipGetLastError())
 
+// device memory that is released on every path out of a function (HIPCHK returns early)
+struct DevBuf {
+    void* p = nullptr;
+    DevBuf() = default;
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    template <class T> T* as() const { return static_cast<T*>(p); }
+    template <class T> T* release() { T* q = static_cast<T*>(p); p = nullptr; return q; }
+};
+
 #endif

@@ -98,11 +98,6 @@ int grid_for(uint64_t items, int per_block, int hi) {
 }
 
 // device memory and events that are released on every way out of a function
-struct DevBuf {
-    void* p = nullptr;
-    ~DevBuf() { if (p) (void)hipFree(p); }
-    template <class T> T* as() const { return static_cast<T*>(p); }
-};
 struct EventPair {
     hipEvent_t e0 = nullptr, e1 = nullptr;
     ~EventPair() { if (e0) (void)hipEventDestroy(e0); if (e1) (void)hipEventDestroy(e1); }
@@ -149,21 +144,33 @@ int install_payload(hml_ctx* c, const int32_t* payload) {
 // that left early (a failed export, a chain of another K or T) would otherwise leave the others waiting in the collective.
 // ncclMax over {status, K, -K, T's halves and their negatives, the rank's number of marginal segments (two halves)}:
 // *m_max = the largest number of segments any rank holds (what sizes the slots of the boundary-list form).
-int handshake(ncclComm_t comm, hipStream_t stream, int32_t* d_hs, int local_rc, const hml_ctx* c, uint64_t m_local = 0, uint64_t* m_max = nullptr) {
+int handshake(ncclComm_t comm, hipStream_t stream, int32_t* d_hs, int local_rc, const hml_ctx* c, uint64_t m_local = 0, uint64_t* m_max = nullptr,
+              int form = 0) {
     const int32_t tl = (int32_t)(c->T & 0x7fffffffu), th = (int32_t)(c->T >> 31);
     // (the maximum of a two-word number by ncclMax: the high half first - the low half only counts among the ranks that
     // hold the largest high half, so it travels in a second round when the high halves differ; segment counts are below
     // 2^32, their high half is one bit: send the number as 16-bit pieces whose element-wise maxima bound it from above)
     const int32_t m3 = (int32_t)((m_local >> 32) & 0xffffu), m2 = (int32_t)((m_local >> 16) & 0xffffu), m1 = (int32_t)(m_local & 0xffffu);
-    const int32_t h[12] = {local_rc ? 1 : 0, c->K, -c->K, tl, -tl, th, -th, m3, m2, m1, 0, 0};
-    HIPCHK(hipMemcpyAsync(d_hs, h, sizeof h, hipMemcpyHostToDevice, stream));
+    // the form of the collective that follows ({form, -form}: the ranks must hold the same one, or some would enter
+    // ncclAllReduce and the others ncclAllGather - ADVICE round 4)
+    const int32_t h[12] = {local_rc ? 1 : 0, c->K, -c->K, tl, -tl, th, -th, m3, m2, m1, form, -form};
+    // A HIP failure on this rank BEFORE the collective is posted must not keep it from posting: the others would wait in
+    // theirs.  It goes into the status word instead (every word 1 when even the copy fails: status 1 for everybody).
+    int hip_rc = 0;
+    if (hipMemcpyAsync(d_hs, h, sizeof h, hipMemcpyHostToDevice, stream) != hipSuccess) {
+        (void)hipGetLastError();
+        hip_rc = set_err(HML_ERR_HIP, "pooling handshake: the copy of the status words failed");
+        (void)hipMemsetD32Async((hipDeviceptr_t)d_hs, 1, 12, stream);
+    }
     NCCLCHK(rccl().AllReduce(d_hs, d_hs, 12, ncclInt32, ncclMax, comm, stream));
     int32_t g[12];
     HIPCHK(hipMemcpyAsync(g, d_hs, sizeof g, hipMemcpyDeviceToHost, stream));
     HIPCHK(hipStreamSynchronize(stream));
     if (local_rc) return local_rc;
+    if (hip_rc) return hip_rc;
     if (g[0] != 0) return set_err(HML_ERR_ARG, "pooling abandoned: another rank failed before the collective");
     if (g[1] != -g[2] || g[3] != -g[4] || g[5] != -g[6]) return set_err(HML_ERR_ARG, "pooling abandoned: the ranks' chains differ in the number of states or positions");
+    if (g[10] != -g[11]) return set_err(HML_ERR_ARG, "pooling abandoned: the ranks ask for different forms of the collective (hml_pool_set_form / HML_POOL_FORM must agree on all ranks)");
     // an upper bound of the largest count that every rank computes alike (exact when one rank holds the largest of every piece)
     if (m_max) *m_max = ((uint64_t)(uint32_t)g[7] << 32) | ((uint64_t)(uint32_t)g[8] << 16) | (uint64_t)(uint32_t)g[9];
     return 0;
@@ -261,7 +268,8 @@ int hml_pool_install(hml_ctx* c, const void* payload_dev) {
 // [K+1][T+1] int32, 2.4 GB at 10^8 positions / 5 states whatever it holds - or the ranks' boundary lists through
 // ncclAllGather, chosen when the gathered lists are at most an eighth of the dense payload (a strongly compressed chain:
 // config 3 after 100 recorded sweeps holds 23 000 segments, 0.6 MB).  Every rank takes the same decision from the same
-// handshake.  A rank that cannot go on (wrong device, no model, out of memory, a failed export) still joins the
+// handshake - which also carries the requested form (hml_pool_set_form / HML_POOL_FORM): ranks that ask for different
+// forms all return HML_ERR_ARG instead of entering different collectives.  A rank that cannot go on (wrong device, no model, out of memory, a failed export) still joins the
 // handshakes with its status, so that nobody is left inside a collective.
 int hml_pool_marginals(hml_pool* p, hml_ctx* c, int32_t* perm_out) {
     if (!p || !c) return set_err(HML_ERR_ARG, "null argument");
@@ -275,7 +283,7 @@ int hml_pool_marginals(hml_pool* p, hml_ctx* c, int32_t* perm_out) {
     DevBuf d_seg, d_g;
     if (!rc) rc = hml_ctx_ensure_marginal_buffers(c);
     if (!rc) { uint32_t* sg = nullptr; int32_t* gg = nullptr; rc = hml_ctx_gather_marginal_segments(c, &M, &sg, &gg); d_seg.p = sg; d_g.p = gg; }
-    if (int r = handshake(p->comm, p->stream, p->d_handshake, rc, c, M, &M_max)) return r;
+    if (int r = handshake(p->comm, p->stream, p->d_handshake, rc, c, M, &M_max, p->form)) return r;
     const int K = c->K;
     const uint64_t n = payload_count(c);
     const uint64_t slot = hml_pool_list_header(K) + M_max * (uint64_t)(K + 1);

@@ -273,7 +273,8 @@ int hml_pool_info(hml_pool* pool, int* rank, int* n_ranks, double* last_allreduc
  * [M, recorded sweeps, used[0..K-1]], then M x [position, relabelled deltas 0..K-1] - through ncclAllGather and adds all
  * lists into zeroed arrays (config 3 after 100 recorded sweeps: 23 000 segments, 0.6 MB per rank).  form 0 (default): the
  * lists when the gathered slots are at most an eighth of the dense payload - every rank decides alike from a handshake
- * that carries the ranks' segment counts; 1: always dense; 2: always lists.  Environment: HML_POOL_FORM.
+ * that carries the ranks' segment counts; 1: always dense; 2: always lists.  Environment: HML_POOL_FORM.  The form is part
+ * of the handshake: when the ranks hold different ones hml_pool_marginals returns HML_ERR_ARG on ALL of them.
  * hml_pool_last: the form the last call took (1 / 2) and, for the lists, the slot size in segments. */
 int hml_pool_set_form(hml_pool* pool, int form);
 int hml_pool_last(hml_pool* pool, int* form, uint64_t* entries);

@@ -84,3 +84,57 @@ def assert_within(dist, yard, what=""):
     assert d_tv <= 2 * yard["tv"] + 1e-4, (what, "state marginals", dist, yard)
     assert d_mean <= 2 * yard["mean"], (what, "posterior-mean means", dist, yard)
     assert d_var <= 2 * yard["var"], (what, "posterior-mean variances", dist, yard)
+
+
+# ---- run-length forms for full-size traces (10^8 positions: a dense [T][K] table per chain would be 4 GB) -------------------------
+def summarise_rle(seg, cnt, params):
+    """like summarise, but the per-position quantities stay per marginal segment: `ends` (cumulative segment ends), `prob_seg`
+    [M][K] relabelled by ascending posterior-mean mean, `argmax_seg` [M]"""
+    pm = params.mean(axis=0)
+    order = np.argsort(pm[:, 0], kind="stable")
+    n = cnt.sum(axis=1)
+    assert np.all(n == n[0])
+    prob_seg = cnt[:, order] / float(n[0])
+    return {"order": order, "ends": np.cumsum(seg), "prob_seg": prob_seg, "argmax_seg": prob_seg.argmax(axis=1),
+            "mean": pm[order, 0], "var": pm[order, 1], "recorded": int(n[0])}
+
+
+def distance_rle(a, b):
+    """distance() for two run-length summaries: both segmentations are refined to their common one and every piece weighs
+    in with its length"""
+    assert a["ends"][-1] == b["ends"][-1]
+    ends = np.union1d(a["ends"], b["ends"])
+    length = np.diff(np.concatenate(([0], ends))).astype(np.float64)
+    ia = np.searchsorted(a["ends"], ends, side="left")
+    ib = np.searchsorted(b["ends"], ends, side="left")
+    T = float(ends[-1])
+    d_arg = float((length * (a["argmax_seg"][ia] != b["argmax_seg"][ib])).sum() / T)
+    d_tv = float((length * 0.5 * np.abs(a["prob_seg"][ia] - b["prob_seg"][ib]).sum(axis=1)).sum() / T)
+    return (d_arg, d_tv, float(np.abs(a["mean"] - b["mean"]).max()), float((np.abs(a["var"] - b["var"]) / b["var"]).max()))
+
+
+def read_golden_text(path):
+    """a golden text file, stored plain or xz-compressed (files above 1 MB)"""
+    import lzma
+    if os.path.exists(path):
+        with open(path) as f:
+            return f.read()
+    with lzma.open(path + ".xz", "rt") as f:
+        return f.read()
+
+
+def reference_summary_rle(name, seed, K):
+    d = os.path.join(GOLDEN, name)
+    seg, cnt = parse_marginals(read_golden_text(os.path.join(d, "marginals_seed%d.csv" % seed)), K)
+    par = parse_parameters(read_golden_text(os.path.join(d, "parameters_seed%d.csv" % seed)), K)
+    return summarise_rle(seg, cnt, par)
+
+
+def yardstick_rle(case, full_refs):
+    runs = [r for r in case["reference_runs"] if r["main_mode"]]
+    m = np.asarray([r["mean"] for r in runs])
+    v = np.asarray([r["var"] for r in runs])
+    d_mean = max(float(np.abs(m[i] - m[j]).max()) for i in range(len(runs)) for j in range(i))
+    d_var = max(float((np.abs(v[i] - v[j]) / v[j]).max()) for i in range(len(runs)) for j in range(i))
+    d_arg, d_tv, _, _ = distance_rle(full_refs[0], full_refs[1])
+    return {"argmax": d_arg, "tv": d_tv, "mean": d_mean, "var": d_var}

@@ -40,3 +40,16 @@ def test_bench_multi_rank_branches_on_one_gpu():
     assert p["all_reduce_bytes"] == 4 * (2 + 5 + p["list_slot_segments"] * 6) and p["all_reduce_bytes"] * 8 <= p["dense_payload_bytes"]
     assert p["counts_per_position"] == 2                                           # two recorded sweeps (F 10 5) of one chain
     assert line["roofline"]["launches"] >= 32
+    # round 5: BOTH forms of the collective run and are checked (pooled row sums = ranks x recorded, asserted inside bench.py):
+    # the boundary lists on the rank's chain, the dense [K+1][T+1] payload through ncclAllReduce on a second, attached chain
+    assert p["default"]["form"] == "lists" and p["dense"]["form"] == "dense"
+    assert p["dense"]["collective_bytes"] == p["dense_payload_bytes"] and p["dense"]["counts_per_position"] == 2
+    assert p["dense"]["collective_ms"] > 0 and p["dense"]["algbw_GBps"] > 0
+    # per-rank times and the slowdown against rank 0 running alone
+    assert len(line["per_rank_ms_per_step"]) == 1 and line["rank0_alone_ms_per_step"] > 0
+    assert 0.3 < line["efficiency_vs_rank0_alone"] < 3.0
+    # the roofline object: frac = counter bytes as counted (lower bound) <= frac_upper (fetches doubled) <= 1; the kernel the north
+    # star names is in the parsed line
+    r = line["roofline"]
+    assert 0 < r["frac"] <= r["frac_upper"] <= 1.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    assert "forward_trellis" in r and r["forward_trellis"]["strongly_compressed"]["kernel"] == "hml_k_forward<5>"
