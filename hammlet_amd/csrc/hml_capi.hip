@@ -191,7 +191,7 @@ static bool trace_shared(const hml_ctx* c) { return c->trace && c->trace->refs.l
 static void free_sweep_buffers(hml_ctx* c, bool keep_engine = false) {
     void** ptrs[] = {(void**)&c->d_em, (void**)&c->d_gsc, (void**)&c->d_rows, (void**)&c->d_entry, (void**)&c->d_exitA, (void**)&c->d_redo, (void**)&c->d_touched,
                      (void**)&c->d_fb, (void**)&c->d_smap, (void**)&c->d_cmap, (void**)&c->d_scmap, (void**)&c->d_super, (void**)&c->d_bentry2, (void**)&c->d_bentry,
-                     (void**)&c->d_q, (void**)&c->d_partial, (void**)&c->d_redo2, (void**)&c->d_tre_bitmap, (void**)&c->d_tre_ckpt, (void**)&c->d_crows, (void**)&c->d_cchunk, (void**)&c->d_cdraws, (void**)&c->d_clists};
+                     (void**)&c->d_q, (void**)&c->d_partial, (void**)&c->d_redo2, (void**)&c->d_tre_bitmap, (void**)&c->d_tre_ckpt, (void**)&c->d_crows, (void**)&c->d_cchunk, (void**)&c->d_cdraws, (void**)&c->d_clists, (void**)&c->d_wacc};
     for (void** p : ptrs) if (*p) { hipFree(*p); *p = nullptr; }
     if (!keep_engine && c->d_mt) { hipFree(c->d_mt); c->d_mt = nullptr; }
 }
@@ -199,7 +199,7 @@ static void free_sweep_buffers(hml_ctx* c, bool keep_engine = false) {
 static void free_all(hml_ctx* c) {
     trace_release(c);
     free_sweep_buffers(c);
-    void* ptrs[] = {c->d_group_word, c->d_stage, c->d_span_count, c->d_starts, c->d_bstat, c->d_eprobe, c->d_aprobe, c->d_coarse1,
+    void* ptrs[] = {c->d_group_word, c->d_wave_total, c->d_stage, c->d_span_count, c->d_starts, c->d_bstat, c->d_eprobe, c->d_aprobe, c->d_coarse1,
                     c->d_diff, c->d_boundary, c->d_mdl, c->d_many};
     for (void* p : ptrs) if (p) hipFree(p);
     if (c->h_B) hipHostFree(c->h_B);
@@ -257,6 +257,7 @@ static int alloc_block_buffers(hml_ctx* c) {
         const uint64_t n_tiles = (T + HML_FUSED_SUB_POSITIONS - 1) / HML_FUSED_SUB_POSITIONS;   // (tiles of one batch: the most there can be)
         HIPCHK(hipMalloc(&c->d_group_word, (n_tiles + 1) * sizeof(unsigned long long)));
         HIPCHK(hipMemsetAsync(c->d_group_word, 0, (n_tiles + 1) * sizeof(unsigned long long), c->stream));
+        HIPCHK(hipMalloc(&c->d_wave_total, (n_tiles + 1) * HML_FUSED_WAVES * sizeof(uint32_t)));
         if (getenv("HML_FUSED_DEBUG")) { HIPCHK(hipMalloc(&c->d_dbg, 4096 * 8 * 8)); HIPCHK(hipMemset(c->d_dbg, 0, 4096 * 8 * 8)); }
     }
     HIPCHK(hipMalloc(&c->d_bstat, c->cap * (uint64_t)c->D * sizeof(float2)));   // (D > 1: cap = T, the planes lie T apart)
@@ -285,7 +286,7 @@ static int build_from_device_x(hml_ctx* c, const float* const* d_x, const float*
     const int D = c->D;
     {   // what an earlier load that failed half-way may have left behind
         trace_release(c);
-        void** stale[] = {(void**)&c->d_stage, (void**)&c->d_span_count, (void**)&c->d_starts, (void**)&c->d_coarse1, (void**)&c->d_group_word, (void**)&c->d_bstat};
+        void** stale[] = {(void**)&c->d_stage, (void**)&c->d_span_count, (void**)&c->d_starts, (void**)&c->d_coarse1, (void**)&c->d_group_word, (void**)&c->d_wave_total, (void**)&c->d_bstat};
         for (void** q : stale) if (*q) { hipFree(*q); *q = nullptr; }
     }
     // noise estimate (src/main.cpp:303-311): f64 accumulation, in index order, of the finest-level
@@ -381,7 +382,7 @@ int hml_set_dimensions(hml_ctx* c, int D, int P) {
     if (D > HML_MAX_D) return set_err(HML_ERR_ARG, "at most 4 data dimensions are supported");
     if (P > 0) {   // P = 0: taken from hml_set_model's number of states (K = P^D)
         long k = 1;
-        for (int d = 0; d < D; ++d) { k *= P; if (k > HML_CAP_K) return set_err(HML_ERR_ARG, "number of states must be in [2,16] (up to 64 in the reference-compatible mode: option \"compat\")"); }   // (hml_set_model checks against the mode)
+        for (int d = 0; d < D; ++d) { k *= P; if (k > HML_CAP_K) return set_err(HML_ERR_ARG, "number of states must be in [2,64]"); }
         if (k <= 1) return set_err(HML_ERR_MODEL, "Requested parameters would yield an HMM with less than 2 states!");
     }
     c->D = D; c->P = P;
@@ -445,7 +446,7 @@ int hml_attach_observations(hml_ctx* c, hml_ctx* src) {
     HIPCHK(hipStreamSynchronize(src->stream));   // (a weight multiplier still on its way)
     trace_release(c);
     {
-        void** stale[] = {(void**)&c->d_stage, (void**)&c->d_span_count, (void**)&c->d_starts, (void**)&c->d_coarse1, (void**)&c->d_group_word, (void**)&c->d_bstat};
+        void** stale[] = {(void**)&c->d_stage, (void**)&c->d_span_count, (void**)&c->d_starts, (void**)&c->d_coarse1, (void**)&c->d_group_word, (void**)&c->d_wave_total, (void**)&c->d_bstat};
         for (void** q : stale) if (*q) { hipFree(*q); *q = nullptr; }
     }
     c->T = src->T; c->D = src->D;
@@ -580,12 +581,26 @@ static int alloc_sweep_buffers(hml_ctx* c) {
         HIPCHK(hipMalloc(&c->d_gsc, cap * K * sizeof(float)));
         HIPCHK(hipMalloc(&c->d_crows, (cap + 1) * K * sizeof(float)));
         // chunks of the filter and of the backward draws (hml_compat_chunks), the engine's outputs of a sweep (two per block)
-        HIPCHK(hipMalloc(&c->d_cchunk, (uint64_t)HML_COMPAT_MAX_CHUNKS * (2 * K * sizeof(float) + 3 * sizeof(uint32_t))));
+        HIPCHK(hipMalloc(&c->d_cchunk, (uint64_t)HML_COMPAT_MAX_CHUNKS * (2 * K * sizeof(float) + 4 * sizeof(uint32_t))));
         HIPCHK(hipMalloc(&c->d_cdraws, 2 * cap * sizeof(uint32_t)));
         // the count pass's lists by state (hml_compat_lists): statistics, sizes, per-tile counts, flags
         HIPCHK(hipMalloc(&c->d_clists, cap * sizeof(float4) + (uint64_t)HML_CAP_K * HML_CAP_K * sizeof(unsigned long long) +
                                         ((cap + HML_COMPAT_PART_TILE - 1) / HML_COMPAT_PART_TILE) * K * sizeof(uint32_t) + (HML_CAP_K + 1) * sizeof(uint32_t) + 64));
         HIPCHK(hipMalloc(&c->d_q, cap * sizeof(int16_t)));
+        return 0;
+    }
+    if (c->wide) {   // more than 16 states (hml_k_wide.h): the lane-per-state kernels' plain layouts, the default path's count tree
+        HIPCHK(hipMalloc(&c->d_em, cap * K * sizeof(float)));
+        HIPCHK(hipMalloc(&c->d_gsc, cap * K * sizeof(float)));
+        HIPCHK(hipMalloc(&c->d_crows, (cap + 1) * K * sizeof(float)));
+        HIPCHK(hipMalloc(&c->d_cchunk, (uint64_t)HML_COMPAT_MAX_CHUNKS * (2 * K * sizeof(float) + 4 * sizeof(uint32_t))));
+        HIPCHK(hipMalloc(&c->d_cdraws, 2 * (cap + 1) * sizeof(uint32_t)));
+        HIPCHK(hipMalloc(&c->d_q, cap * sizeof(int16_t)));
+        const uint64_t n_partial = (uint64_t)HML_REDUCE_GROUPS * K * 2;
+        HIPCHK(hipMalloc(&c->d_partial, n_partial * sizeof(double)));
+        HIPCHK(hipMemsetAsync(c->d_partial, 0, n_partial * sizeof(double), c->stream));
+        HIPCHK(hipMalloc(&c->d_wacc, sizeof(hml_wide_acc)));
+        HIPCHK(hipMemsetAsync(c->d_wacc, 0, sizeof(hml_wide_acc), c->stream));
         return 0;
     }
     const int minL = std::min(std::min(c->fwdL, c->fwdL_dense), c->fwdL_many);
@@ -712,8 +727,7 @@ extern "C" {
 int hml_set_model(hml_ctx* c, int K, const float nig4[4], float a_off, float a_diag, float pi_alpha, int self_trans) {
     if (!c || !c->loaded) return set_err(HML_ERR_ARG, "no observations loaded");
     if (K < 2) return set_err(HML_ERR_MODEL, "Requested parameters would yield an HMM with less than 2 states!");
-    if (K > (c->compat ? HML_CAP_K : HML_MAX_K))
-        return set_err(HML_ERR_ARG, c->compat ? "number of states must be in [2,64]" : "number of states must be in [2,16] (up to 64 in the reference-compatible mode: option \"compat\")");
+    if (K > HML_CAP_K) return set_err(HML_ERR_ARG, "number of states must be in [2,64]");
     if (c->model_set) return set_err(HML_ERR_ARG, "model already set");
     if (c->D > 1 && c->P == 0) {   // the number of parameters follows from K = P^D
         for (int pp = 2; pp <= K; ++pp) { long k = 1; for (int d = 0; d < c->D; ++d) k *= pp; if (k == K) { c->P = pp; break; } if (k > K) break; }
@@ -728,7 +742,9 @@ int hml_set_model(hml_ctx* c, int K, const float nig4[4], float a_off, float a_d
     if (!(nig4[1] > 0)) return set_err(HML_ERR_MODEL, "Beta (" + std::to_string(nig4[1]) + ") must be positive!");
     if (!(nig4[3] > 0)) return set_err(HML_ERR_MODEL, "Nu (" + std::to_string(nig4[3]) + ")must be positive!");
     const hml_ktab* kt = nullptr;   // (before anything is allocated: a development build knows one K only; the reference-compatible mode takes K at run time)
-    if (!c->compat) { kt = ktab(K); if (!kt) return set_err(HML_ERR_ARG, "number of states must be in [2,16]"); }
+    // more than 16 states: the kernels that take the number of states at run time (hml_k_wide.h; HML_WIDE=1: from 2 states - tests)
+    c->wide = !c->compat && (K > HML_MAX_K || (getenv("HML_WIDE") && atoi(getenv("HML_WIDE")) != 0));
+    if (!c->compat && !c->wide) { kt = ktab(K); if (!kt) return set_err(HML_ERR_ARG, "number of states must be in [2,16]"); }
     if (int r = ctx_bind(c)) return r;
     free_sweep_buffers(c);   // (what an earlier call that failed half-way left behind)
     c->K = K;
@@ -786,7 +802,8 @@ int hml_set_model(hml_ctx* c, int K, const float nig4[4], float a_off, float a_d
         c->model_set = true;
         return 0;
     }
-    kt->params(c, 2);
+    if (c->wide) hipLaunchKernelGGL(hml_k_wide_params, dim3(1), dim3(1024), 0, c->stream, c->d_mdl, c->d_partial, (hml_wide_acc*)c->d_wacc, 2);
+    else kt->params(c, 2);
     KLAUNCH_CHECK();
     c->model_set = true;
     return 0;
@@ -798,6 +815,8 @@ int hml_sample_prior(hml_ctx* c) {
     if (int r = settle_if_limited(c)) return r;
     if (c->compat) {
         hipLaunchKernelGGL(hml_k_compat_draw, dim3(1), dim3(64), 0, c->stream, c->d_mdl, (hml_mt_state*)c->d_mt, 1);
+    } else if (c->wide) {
+        hipLaunchKernelGGL(hml_k_wide_params, dim3(1), dim3(1024), 0, c->stream, c->d_mdl, c->d_partial, (hml_wide_acc*)c->d_wacc, 1);
     } else { HML_KTAB(c->K, kt); kt->params(c, 1); }
     KLAUNCH_CHECK();
     if (c->dynamic) c->blocks_valid = false;
@@ -885,6 +904,37 @@ int hml_ctx_ensure_marginal_buffers(hml_ctx* c) { return ensure_marginal_buffers
 // A sweep of the reference-compatible mode (hml_k_compat.h): block starts and block statistics by the default path's
 // kernels, the order-dependent part in the reference's order (the number of states is a run-time value there), the
 // marginals by hml_k_record.
+static hml_compat_chunks chunk_views(const hml_ctx* c) {   // the arrays of d_cchunk (alloc_sweep_buffers)
+    hml_compat_chunks ch;
+    char* base = (char*)c->d_cchunk;
+    ch.entry = (float*)base; base += (uint64_t)HML_COMPAT_MAX_CHUNKS * c->K * sizeof(float);
+    ch.exitv = (float*)base; base += (uint64_t)HML_COMPAT_MAX_CHUNKS * c->K * sizeof(float);
+    ch.nfb = (uint32_t*)base; base += (uint64_t)HML_COMPAT_MAX_CHUNKS * sizeof(uint32_t);
+    ch.in_state = (int32_t*)base; base += (uint64_t)HML_COMPAT_MAX_CHUNKS * sizeof(int32_t);
+    ch.out_state = (int32_t*)base; base += (uint64_t)HML_COMPAT_MAX_CHUNKS * sizeof(int32_t);
+    ch.bad = (uint32_t*)base;
+    ch.W = 0u;
+    return ch;
+}
+
+// filter and backward draws in C chunks with a wavefront each (hml_k_compat.h): the chunks' entry rows against the exit rows
+// before them by as many threads as there are elements, then one wavefront that runs the rare wrong chunk again; the same for
+// the backward draws.  KC / PAD: the number of states at compile time, or (PAD) an upper bound of the model's.
+template <int KC, class M, bool PAD>
+static void launch_chunked_fb(hml_ctx* c, hipStream_t s, uint32_t C, const hml_compat_chunks& ch, float* aprobe) {
+    {
+        ProfScope ps(c, "forward");
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_compat_forward<KC, M, PAD>), dim3(C), dim3(64), 0, s, c->d_mdl, c->d_em, c->d_gsc, c->d_crows, aprobe, ch);
+        if (C > 1u) hipLaunchKernelGGL(hml_k_compat_forward_verify, dim3(grid_for((uint64_t)C * c->K, 256, 1, 4096)), dim3(256), 0, s, c->d_mdl, ch, C);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_compat_forward_check<KC, PAD>), dim3(1), dim3(256), 0, s, c->d_mdl, c->d_em, c->d_gsc, c->d_crows, ch, C);
+    }
+    {
+        ProfScope ps(c, "backward_maps");
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_compat_backward<KC, PAD>), dim3(C), dim3(64), 0, s, c->d_mdl, c->d_crows, c->d_cdraws, c->d_q, ch);
+        if (C > 1u) hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_compat_backward_check<KC, PAD>), dim3(1), dim3(256), 0, s, c->d_mdl, c->d_crows, c->d_cdraws, c->d_q, ch, C);
+    }
+}
+
 static int sweep_compat(hml_ctx* c, char method, bool record) {
     hipStream_t s = c->stream;
     if (c->dynamic || !c->blocks_valid) {
@@ -895,7 +945,7 @@ static int sweep_compat(hml_ctx* c, char method, bool record) {
     const uint32_t hint = c->B_hint ? c->B_hint : (uint32_t)std::min<uint64_t>(c->T, 1u << 20);
     const int mix = method == HML_METHOD_MIXTURE ? 1 : 0;
     hml_mt_state* const mt = (hml_mt_state*)c->d_mt;
-    hipLaunchKernelGGL(hml_k_compat_emission, dim3(grid_for(hint, 256, 64, 16384)), dim3(256), 0, s, c->d_mdl, c->d_starts, c->d_bstat, c->d_em, c->d_gsc, mix,
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_compat_emission<hml_glibc_exp>), dim3(grid_for(hint, 256, 64, 16384)), dim3(256), 0, s, c->d_mdl, c->d_starts, c->d_bstat, c->d_em, c->d_gsc, mix,
                        c->probes ? c->d_eprobe : nullptr);
     if (mix) hipLaunchKernelGGL(hml_k_compat_mixture, dim3(1), dim3(64), 0, s, c->d_mdl, mt, c->d_em, c->d_q);
     else {
@@ -904,32 +954,19 @@ static int sweep_compat(hml_ctx* c, char method, bool record) {
         // (hml_k_compat.h); one chunk - the sequential form - for short sweeps and when the rows are probed
         uint32_t C = 1u;
         if (!c->probes && c->compat_chunks > 1) C = std::min<uint32_t>((uint32_t)c->compat_chunks, HML_COMPAT_MAX_CHUNKS);   // (tests: any sweep in that many chunks)
-        else if (!c->probes && c->compat_chunks == 0 && hint >= 8192u) C = std::min<uint32_t>(1024u, hint / 128u);
-        hml_compat_chunks ch;
-        char* base = (char*)c->d_cchunk;
-        ch.entry = (float*)base; base += (uint64_t)HML_COMPAT_MAX_CHUNKS * c->K * sizeof(float);
-        ch.exitv = (float*)base; base += (uint64_t)HML_COMPAT_MAX_CHUNKS * c->K * sizeof(float);
-        ch.nfb = (uint32_t*)base; base += (uint64_t)HML_COMPAT_MAX_CHUNKS * sizeof(uint32_t);
-        ch.in_state = (int32_t*)base; base += (uint64_t)HML_COMPAT_MAX_CHUNKS * sizeof(int32_t);
-        ch.out_state = (int32_t*)base;
+        else if (!c->probes && c->compat_chunks == 0 && hint >= 8192u) C = std::min<uint32_t>((uint32_t)HML_COMPAT_MAX_CHUNKS, hint / 64u);
+        hml_compat_chunks ch = chunk_views(c);
         ch.W = c->compat_warmup > 0 ? (uint32_t)c->compat_warmup : c->compat_warmup < 0 ? 0u : (c->K <= 16 ? 64u : 128u);   // (< 0: none - tests)
-        hipLaunchKernelGGL(hml_k_compat_draws, dim3(1), dim3(64), 0, s, c->d_mdl, mt, c->d_cdraws, 2u);
-        // (up to 16 states: the number of states as a compile-time value - A in registers, loops unrolled; beyond: the model's value)
-#define HML_COMPAT_FB(KC)                                                                                                                       \
-        case KC:                                                                                                                                \
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_compat_forward<KC>), dim3(C), dim3(64), 0, s, c->d_mdl, c->d_em, c->d_gsc, c->d_crows, aprobe, ch); \
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_compat_forward_check<KC>), dim3(1), dim3(64), 0, s, c->d_mdl, c->d_em, c->d_gsc, c->d_crows, ch, C); \
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_compat_backward<KC>), dim3(C), dim3(64), 0, s, c->d_mdl, c->d_crows, c->d_cdraws, c->d_q, ch);  \
-            if (C > 1u) hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_compat_backward_check<KC>), dim3(1), dim3(64), 0, s, c->d_mdl, c->d_crows, c->d_cdraws, c->d_q, ch, C); \
-            break;
+        hipLaunchKernelGGL(hml_k_compat_draws, dim3(1), dim3(256), 0, s, c->d_mdl, mt, c->d_cdraws, 2u);
+        // (up to 16 states: the number of states as a compile-time value - A in registers, loops unrolled; beyond: loops unrolled
+        // over 32 or 64 in groups of four that stop at the model's value)
+#define HML_COMPAT_FB(KC) case KC: launch_chunked_fb<KC, hml_glibc_exp, false>(c, s, C, ch, aprobe); break;
         switch (c->K <= HML_MAX_K ? c->K : 0) {
             HML_COMPAT_FB(2) HML_COMPAT_FB(3) HML_COMPAT_FB(4) HML_COMPAT_FB(5) HML_COMPAT_FB(6) HML_COMPAT_FB(7) HML_COMPAT_FB(8) HML_COMPAT_FB(9)
             HML_COMPAT_FB(10) HML_COMPAT_FB(11) HML_COMPAT_FB(12) HML_COMPAT_FB(13) HML_COMPAT_FB(14) HML_COMPAT_FB(15) HML_COMPAT_FB(16)
             default:
-                hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_compat_forward<0>), dim3(C), dim3(64), 0, s, c->d_mdl, c->d_em, c->d_gsc, c->d_crows, aprobe, ch);
-                hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_compat_forward_check<0>), dim3(1), dim3(64), 0, s, c->d_mdl, c->d_em, c->d_gsc, c->d_crows, ch, C);
-                hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_compat_backward<0>), dim3(C), dim3(64), 0, s, c->d_mdl, c->d_crows, c->d_cdraws, c->d_q, ch);
-                if (C > 1u) hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_compat_backward_check<0>), dim3(1), dim3(64), 0, s, c->d_mdl, c->d_crows, c->d_cdraws, c->d_q, ch, C);
+                if (c->K <= 32) launch_chunked_fb<32, hml_glibc_exp, true>(c, s, C, ch, aprobe);
+                else launch_chunked_fb<64, hml_glibc_exp, true>(c, s, C, ch, aprobe);
         }
 #undef HML_COMPAT_FB
     }
@@ -938,7 +975,10 @@ static int sweep_compat(hml_ctx* c, char method, bool record) {
     {
         const uint64_t tiles = (c->cap + HML_COMPAT_PART_TILE - 1) / HML_COMPAT_PART_TILE;
         char* base = (char*)c->d_clists;
-        pl.item = (float4*)base; base += c->cap * sizeof(float4);
+        pl.sx = (float*)base; base += c->cap * sizeof(float);
+        pl.sq = (float*)base; base += c->cap * sizeof(float);
+        pl.n = (uint32_t*)base; base += c->cap * sizeof(uint32_t);
+        pl.same = (uint32_t*)base; base += c->cap * sizeof(uint32_t);
         pl.offdiag = (unsigned long long*)base; base += (uint64_t)HML_CAP_K * HML_CAP_K * sizeof(unsigned long long);
         pl.tile_count = (uint32_t*)base; base += tiles * c->K * sizeof(uint32_t);
         pl.state_off = (uint32_t*)base;
@@ -961,8 +1001,55 @@ static int sweep_compat(hml_ctx* c, char method, bool record) {
     return 0;
 }
 
+// A sweep of a model with more than 16 states (hml_k_wide.h): block starts and block statistics by the default path's kernels,
+// emission terms / filter / backward draws by the lane-per-state kernels of hml_k_compat.h in this path's arithmetic, the
+// uniforms of the draws from their Philox addresses ahead of them, the default path's count tree, hml_k_wide_params.
+static int sweep_wide(hml_ctx* c, char method, bool record) {
+    hipStream_t s = c->stream;
+    if (c->dynamic || !c->blocks_valid) {
+        if (int r = launch_compact(c, false, 0.0f)) return r;   // starts, block count, block statistics at the model's threshold
+        if (!c->dynamic) c->blocks_valid = true;
+    }
+    refresh_hint(c);
+    const uint32_t hint = c->B_hint ? c->B_hint : (uint32_t)std::min<uint64_t>(c->T, 1u << 20);
+    const int mix = method == HML_METHOD_MIXTURE ? 1 : 0;
+    {
+        ProfScope ps(c, "stats_emission");
+        hipLaunchKernelGGL(hml_k_wide_emission, dim3(grid_for(hint, 256, 1, 4096)), dim3(256), 0, s, c->d_mdl, c->d_starts, c->d_bstat,
+                           c->d_em, c->d_gsc, mix, c->probes ? c->d_eprobe : nullptr);
+    }
+    if (mix) hipLaunchKernelGGL(hml_k_wide_mixture, dim3(grid_for(hint, 256, 1, 16384)), dim3(256), 0, s, c->d_mdl, c->d_em, c->d_q);
+    else {
+        float* const aprobe = c->probes ? c->d_aprobe : nullptr;
+        uint32_t C = 1u;   // (one chunk - the sequential form - for short sweeps and when the rows are probed)
+        if (!c->probes && c->compat_chunks > 1) C = std::min<uint32_t>((uint32_t)c->compat_chunks, HML_COMPAT_MAX_CHUNKS);
+        else if (!c->probes && c->compat_chunks == 0 && hint >= 2048u) C = std::min<uint32_t>((uint32_t)HML_COMPAT_MAX_CHUNKS, hint / 64u);
+        hml_compat_chunks ch = chunk_views(c);
+        ch.W = c->compat_warmup > 0 ? (uint32_t)c->compat_warmup : c->compat_warmup < 0 ? 0u : 128u;
+        hipLaunchKernelGGL(hml_k_wide_uniforms, dim3(grid_for((hint + 1u) / 2u, 256, 1, 4096)), dim3(256), 0, s, c->d_mdl, c->d_cdraws);
+        if (c->K <= 32) launch_chunked_fb<32, hml_dev_exp, true>(c, s, C, ch, aprobe);
+        else launch_chunked_fb<64, hml_dev_exp, true>(c, s, C, ch, aprobe);
+    }
+    {
+        ProfScope ps(c, "counts");
+        hipLaunchKernelGGL(hml_k_wide_counts, dim3(HML_REDUCE_GROUPS), dim3(256), 0, s, c->d_q, c->d_starts, c->d_bstat, c->d_mdl, c->d_partial, (hml_wide_acc*)c->d_wacc);
+    }
+    if (record && c->rec_marginals) {
+        if (c->pooled) return set_err(HML_ERR_ARG, "the marginals of this context are pooled (common labels, several chains): further sweeps cannot be recorded into them");
+        if (int r = ensure_marginal_buffers(c)) return r;
+        hipLaunchKernelGGL(hml_k_record, dim3(grid_for(hint, 256, 64, 16384)), dim3(256), 0, s, c->d_q, c->d_starts, c->d_mdl, c->d_diff, c->d_boundary);
+    }
+    {
+        ProfScope ps(c, "params");
+        hipLaunchKernelGGL(hml_k_wide_params, dim3(1), dim3(1024), 0, s, c->d_mdl, c->d_partial, (hml_wide_acc*)c->d_wacc, 0);
+    }
+    KLAUNCH_CHECK();
+    return 0;
+}
+
 static int sweep_dispatch(hml_ctx* c, char method, bool record) {
     if (c->compat) return sweep_compat(c, method, record);
+    if (c->wide) return sweep_wide(c, method, record);
     HML_KTAB(c->K, kt);
     return kt->sweep(c, method, record);
 }
@@ -983,7 +1070,7 @@ int hml_iterate(hml_ctx* c, char method, uint64_t iterations, uint64_t thinning)
         if (chain_halted(c)) { if (int r = hml_settle(c)) return r; }
         refresh_hint(c);
         const bool tre_path = c->tre_fused && c->D == 1 && method == HML_METHOD_FB && c->B_hint >= c->dense_min_blocks;
-        if (c->use_graph && !c->compat && !record && !c->profiling && !c->probes && (c->dynamic || c->blocks_valid) &&
+        if (c->use_graph && !c->compat && !c->wide && !record && !c->profiling && !c->probes && (c->dynamic || c->blocks_valid) &&
             !(tre_path && tre_wants_measurement(c, c->B_hint))) {
             // replay a captured sweep; capture again when the launch geometry (grid hint / mode / chunk length) changed
             const uint32_t hint = c->B_hint;
@@ -1245,6 +1332,7 @@ int hml_set_parameters(hml_ctx* c, const float* mean_var, const float* A, const 
     memcpy(m.pi, pi, (size_t)K * sizeof(float));
     HIPCHK(hipMemcpyAsync(c->d_mdl, &m, sizeof m, hipMemcpyHostToDevice, c->stream));
     if (c->compat) hipLaunchKernelGGL(hml_k_compat_derive, dim3(1), dim3(64), 0, c->stream, c->d_mdl);   // (glibc's logf)
+    else if (c->wide) hipLaunchKernelGGL(hml_k_wide_derive, dim3(1), dim3(64), 0, c->stream, c->d_mdl);
     else { HML_KTAB(K, kt); kt->derive(c); }
     KLAUNCH_CHECK();
     HIPCHK(hipStreamSynchronize(c->stream));

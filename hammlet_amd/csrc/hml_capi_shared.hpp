@@ -34,6 +34,8 @@
 #include "hml_k_trellis.h"
 #include "hml_k_trellis_rows.h"
 #include "hml_k_compat.h"
+#include "hml_k_wide.h"
+#include "hml_k_blocks_split_many.h"
 #include "hml_k_many.h"
 #include "hml_k_params.h"
 #include "hml_state.h"
@@ -327,7 +329,7 @@ static bool many_eligible(hml_ctx* const* cs, int n, char method) {
     const hml_ctx* a = cs[0];
     for (int i = 0; i < n; ++i) {
         const hml_ctx* c = cs[i];
-        if (!c->model_set || c->device != a->device || c->K != a->K || c->T != a->T || c->D != 1 || c->compat || !c->dynamic || !c->use_keys ||
+        if (!c->model_set || c->device != a->device || c->K != a->K || c->T != a->T || c->D != 1 || c->compat || c->wide || !c->dynamic || !c->use_keys ||
             c->probes || c->profiling || c->fwdL != a->fwdL || c->fwdL_many != a->fwdL_many || c->late_rescale != a->late_rescale || c->n_spans != a->n_spans)
             return false;
         for (int j = 0; j < i; ++j) if (cs[j] == c) return false;

@@ -61,6 +61,7 @@ struct hml_ctx {
     uint32_t n_spans = 0;
     uint32_t* d_coarse1 = nullptr;   // block count per group of HML_GROUP_SPANS spans
     unsigned long long* d_group_word = nullptr;   // fused block kernel: {generation, starts, last start} per tile
+    uint32_t* d_wave_total = nullptr;             // split many-chain block kernels: starts per wavefront of a tile (hml_k_blocks_split_many.h)
     int fused_slots = 0;                          // workgroups of it that are resident at once (occupancy x compute units; 0: not asked yet)
     uint32_t fused_spin_limit = 4096;             // polls of a tile word before the waiting thread computes the word itself
     bool fused_keep = false;                      // option fused_blocks = 2 (tests): keep the kernel after it reported trouble
@@ -163,6 +164,8 @@ struct hml_ctx {
     void* d_clists = nullptr;      // its count pass's lists by state (hml_compat_lists)
     int compat_chunks = 0;         // 0: chosen from the block count; 1: the sequential form (HML_COMPAT_CHUNKS)
     int compat_warmup = 0;         // blocks a chunk runs ahead of its first; 0: 64 (128 beyond 16 states) (HML_COMPAT_WARMUP)
+    bool wide = false;             // more than 16 states on the default path: the number of states is a run-time value, a state a lane (hml_k_wide.h)
+    void* d_wacc = nullptr;        // its integer counts of a sweep (hml_wide_acc)
     bool pooled = false;           // the marginals are a pooled payload (hml_pool_install): common labels, counts of several chains
     std::vector<int32_t> pool_perm;   // perm[pooled label] = this chain's label, from the export that preceded the pooling
     int profiling = 0;             // 0 off, 1 dominant kernel only (blocks_compact, every 32nd launch), 2 every kernel family

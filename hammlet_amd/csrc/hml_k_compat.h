@@ -24,6 +24,11 @@
 #include "hml_math_glibc.h"
 #include "hml_state.h"
 
+// expf of the two modes that share the kernels below: the reference's libm (this mode) or hml_math.h's (the default path's
+// arithmetic: models of more than 16 states run these kernels with it, hml_k_wide.h)
+struct hml_glibc_exp { static __device__ __forceinline__ float expf_(float x) { return hml_glibc_expf(x); } };
+struct hml_dev_exp { static __device__ __forceinline__ float expf_(float x) { return hml_expf(x); } };
+
 struct hml_glibcmath {
     static __device__ __forceinline__ float logf_(float x) { return hml_glibc_logf(x); }
     static __device__ __forceinline__ float powf_(float u, float p) { return hml_glibc_powf_unit(u, p); }
@@ -163,7 +168,7 @@ HML_KERNEL __launch_bounds__(64) void hml_k_compat_draw(hml_model* __restrict__ 
 //                           draws.
 // ------------------------------------------------------------------------------------------------------------------------
 #define HML_COMPAT_TILE 1024   // floats staged per tile: min(64, 1024 / K) blocks
-#define HML_COMPAT_MAX_CHUNKS 2048
+#define HML_COMPAT_MAX_CHUNKS 16384   // (round 5: 2048 before - a chunk is one wavefront, and the machine holds 8000 of them)
 
 __device__ __forceinline__ float hml_lane_f32(float v, int i) {   // (i wave-uniform)
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), i));
@@ -234,15 +239,36 @@ __device__ __forceinline__ int hml_compat_categorical_exact(float w, int K, doub
 // relatively - K rounded quotients and their K rounded additions - so wherever t_i and u sum are further apart than 2^-30 sum,
 // `cp_i < u` is `t_i < u sum`.  A draw closer than that to a boundary, weights that are negative or not finite, and an all-zero
 // row (every probability NaN: index 0 in libstdc++) take the literal form.  KC as in the kernels.
-template <int KC>
+// The running sums t_i = (..(w_0 + w_1) + ..) + w_i, lane i its own, by SHIFTS (round 5): every lane repeats t <- t_of_the_lane_below
+// + w.  After step s the lanes up to s hold their final value and keep recomputing it from the same operands, so no lane needs
+// to be told when to stop: two DPP moves and an addition per step where the broadcast form took two v_readlane, the addition,
+// a comparison and two selects.  (t_0 = w_0 where the loop from zero had 0.0 + w_0: the same value but for a weight of -0.0,
+// and a row whose sum is a zero of either sign takes the literal form below.)
+// PAD: KC is an upper bound of the model's K (a multiple of four): the loop is unrolled over KC in groups of four that are skipped
+// from K on.
+__device__ __forceinline__ double hml_wave_shr1_f64(double v) {   // lane i <- lane i - 1, lane 0 <- 0.0 (DPP wave_shr:1)
+    const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(uint32_t)u, 0x138, 0xF, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(uint32_t)(u >> 32), 0x138, 0xF, 0xF, false);
+    return __builtin_bit_cast(double, ((unsigned long long)(uint32_t)hi << 32) | (uint32_t)lo);
+}
+template <int KC, bool PAD = false>
 __device__ __forceinline__ int hml_compat_categorical_wave(float w, int K, double u, int lane) {
     const double wd = (double)w;
-    double t = 0.0;   // lane i: t_i
-    if (KC) {
+    double t = wd;   // lane i: t_i
+    if (KC && PAD) {
 #pragma unroll
-        for (int i = 0; i < (KC ? KC : 1); ++i) { const double x = hml_lane_f64(wd, i); t = (lane >= i) ? t + x : t; }
+        for (int i0 = 0; i0 < (KC ? KC : 1); i0 += 4) {
+            if (i0 < K) {   // wave-uniform (steps beyond K - 1 recompute final values)
+#pragma unroll
+                for (int i = i0; i < i0 + 4; ++i) if (i > 0) t = hml_wave_shr1_f64(t) + wd;
+            }
+        }
+    } else if (KC) {
+#pragma unroll
+        for (int i = 1; i < (KC ? KC : 1); ++i) t = hml_wave_shr1_f64(t) + wd;
     } else {
-        for (int i = 0; i < K; ++i) { const double x = hml_lane_f64(wd, i); t = (lane >= i) ? t + x : t; }
+        for (int i = 1; i < K; ++i) t = hml_wave_shr1_f64(t) + wd;
     }
     const double sum = hml_lane_f64(t, K - 1);
     const double us = u * sum, margin = sum * 9.31322574615478515625e-10;   // 2^-30
@@ -257,6 +283,7 @@ __device__ __forceinline__ int hml_compat_categorical_wave(float w, int K, doubl
 
 // emission terms: em[b * K + s] = expf(E_s - max E) (method 0: with the self-transition term of a block, ForwardBackward.hpp:74-84);
 // g[b * K + s] = expf((N_b - 1) log A(s, s)), the factor the filter rescales the block's row with once the next row exists (:115-119)
+template <class M>
 HML_KERNEL __launch_bounds__(256) void hml_k_compat_emission(hml_model* __restrict__ mdl, const uint32_t* __restrict__ starts,
                                                              const float2* __restrict__ bstat, float* __restrict__ em, float* __restrict__ g,
                                                              int method, float* __restrict__ eprobe) {
@@ -286,8 +313,8 @@ HML_KERNEL __launch_bounds__(256) void hml_k_compat_emission(hml_model* __restri
             maxE = (E < maxE) ? maxE : E;
             if (eprobe) eprobe[b * (uint64_t)K + s] = E;
         }
-        for (int s = 0; s < K; ++s) e[s] = hml_glibc_expf(e[s] - maxE);
-        if (self) for (int s = 0; s < K; ++s) g[b * (uint64_t)K + s] = hml_glibc_expf((N - 1.0f) * mdl->logA[s]);
+        for (int s = 0; s < K; ++s) e[s] = M::expf_(e[s] - maxE);
+        if (self) for (int s = 0; s < K; ++s) g[b * (uint64_t)K + s] = M::expf_((N - 1.0f) * mdl->logA[s]);
     }
 }
 
@@ -301,6 +328,7 @@ HML_KERNEL __launch_bounds__(256) void hml_k_compat_emission(hml_model* __restri
 struct hml_compat_chunks {
     float* entry;        // [C][K] filter: the row a chunk reached at its first block (from its warm-up)
     float* exitv;        // [C][K] ... and the unscaled row it left behind its last block
+    uint32_t* bad;       // [C] filter: the chunk's entry row is not what the chunk before it left (hml_k_compat_forward_verify)
     uint32_t* nfb;       // [C] uniform fallbacks inside the chunk's own blocks
     int32_t* in_state;   // [C] backward draws: the state above the chunk's first row (from its warm-up)
     int32_t* out_state;  // [C] ... and the state of its last row
@@ -315,7 +343,7 @@ __device__ __forceinline__ uint32_t hml_compat_chunk_len(uint32_t B, uint32_t C)
 // prev: the row before block b_begin (in), behind block b_end - 1 (out, unscaled); entry_out: the row before block b_store.
 // KC: the number of states as a compile-time value (2 .. 16: A's column in registers, loops unrolled) or 0 = the model's
 // value (A in LDS).
-template <int KC>
+template <int KC, bool PAD = false>
 __device__ __forceinline__ void hml_compat_forward_range(int K, uint32_t B, bool self, const float* __restrict__ em, const float* __restrict__ g,
                                                          float* __restrict__ rows, float* __restrict__ aprobe, const float (&acol)[KC ? KC : 1],
                                                          const float* sA, float* tile, float* tile_g, uint32_t b_begin, uint32_t b_store, uint32_t b_end,
@@ -351,7 +379,15 @@ __device__ __forceinline__ void hml_compat_forward_range(int K, uint32_t B, bool
             if (r + 1u < nb) { e_nx = act ? tile[(r + 1u) * (uint32_t)K + (uint32_t)lane] : 0.0f; g_nx = act ? tile_g[(r + 1u) * (uint32_t)K + (uint32_t)lane] : 1.0f; }
             if (b == b_store && entry_out && act) entry_out[lane] = prev;
             float tt = 0.0f;
-            if (KC) {
+            if (KC && PAD) {   // (acol[i] = 0 and prev = 0 from K on: the padded terms are +0.0)
+#pragma unroll
+                for (int i0 = 0; i0 < (KC ? KC : 1); i0 += 4) {
+                    if (i0 < K) {
+#pragma unroll
+                        for (int i = i0; i < i0 + 4; ++i) tt += hml_lane_f32(prev, i) * acol[i];
+                    }
+                }
+            } else if (KC) {
 #pragma unroll
                 for (int i = 0; i < (KC ? KC : 1); ++i) tt += hml_lane_f32(prev, i) * acol[i];
             } else {
@@ -359,7 +395,15 @@ __device__ __forceinline__ void hml_compat_forward_range(int K, uint32_t B, bool
             }
             f *= tt;
             float Z = 0.0f;
-            if (KC) {
+            if (KC && PAD) {
+#pragma unroll
+                for (int j0 = 0; j0 < (KC ? KC : 1); j0 += 4) {
+                    if (j0 < K) {
+#pragma unroll
+                        for (int j = j0; j < j0 + 4; ++j) Z += hml_lane_f32(f, j);
+                    }
+                }
+            } else if (KC) {
 #pragma unroll
                 for (int j = 0; j < (KC ? KC : 1); ++j) Z += hml_lane_f32(f, j);
             } else {
@@ -377,17 +421,18 @@ __device__ __forceinline__ void hml_compat_forward_range(int K, uint32_t B, bool
     }
 }
 
-template <int KC>
+template <int KC, class M = hml_glibc_exp, bool PAD = false>
 HML_KERNEL __launch_bounds__(64) void hml_k_compat_forward(hml_model* __restrict__ mdl, const float* __restrict__ em, const float* __restrict__ g,
                                                            float* __restrict__ rows, float* __restrict__ aprobe, const hml_compat_chunks ch) {
     __shared__ float sA[KC ? 1 : HML_CAP_K * HML_CAP_K];   // row-major: lane j reads A(i, j)
     __shared__ float tile[HML_COMPAT_TILE], tile_g[HML_COMPAT_TILE];
     if (mdl->halted != 0u) return;
     const int lane = threadIdx.x;
-    const int K = KC ? KC : mdl->K;
+    const int K = (KC && !PAD) ? KC : mdl->K;
     const uint32_t B = mdl->B;
     const uint32_t C = gridDim.x, c = blockIdx.x, L = hml_compat_chunk_len(B, C);
     const uint32_t lo = c * L;
+    if (lane == 0) ch.bad[c] = 0u;
     if (lo >= B) return;
     const uint32_t hi = (lo + L < B) ? lo + L : B;
     const bool self = mdl->self_trans != 0;
@@ -395,7 +440,7 @@ HML_KERNEL __launch_bounds__(64) void hml_k_compat_forward(hml_model* __restrict
     float acol[KC ? KC : 1];
     if (KC) {
 #pragma unroll
-        for (int i = 0; i < (KC ? KC : 1); ++i) acol[i] = act ? mdl->A[i * K + lane] : 0.0f;
+        for (int i = 0; i < (KC ? KC : 1); ++i) acol[i] = (act && i < K) ? mdl->A[i * K + lane] : 0.0f;
     } else {
         for (int i = lane; i < K * K; i += 64) sA[i] = mdl->A[i];
     }
@@ -404,100 +449,189 @@ HML_KERNEL __launch_bounds__(64) void hml_k_compat_forward(hml_model* __restrict
     if (c == 0u && act) {
         if (aprobe) aprobe[lane] = prev;
         // row 0 with the factor of a "block" of size 1 before the first (prevN = 1, ForwardBackward.hpp:107)
-        rows[lane] = self ? prev * hml_glibc_expf((1.0f - 1.0f) * mdl->logA[lane]) : prev;
+        rows[lane] = self ? prev * M::expf_((1.0f - 1.0f) * mdl->logA[lane]) : prev;
     }
     uint32_t nfb = 0u;
-    hml_compat_forward_range<KC>(K, B, self, em, g, rows, aprobe, acol, sA, tile, tile_g, ws, lo, hi, prev, ch.entry + (uint64_t)c * K, nfb, lane);
+    hml_compat_forward_range<KC, PAD>(K, B, self, em, g, rows, aprobe, acol, sA, tile, tile_g, ws, lo, hi, prev, ch.entry + (uint64_t)c * K, nfb, lane);
     if (act) ch.exitv[(uint64_t)c * K + lane] = prev;
     if (lane == 0) ch.nfb[c] = nfb;
 }
 
+// which chunks started from another row than the chunk before them left: every element of every chunk's entry row against the
+// exit row before it, bit for bit, by as many threads as there are elements (round 5: one wavefront used to walk the chunks)
+HML_KERNEL __launch_bounds__(256) void hml_k_compat_forward_verify(const hml_model* __restrict__ mdl, const hml_compat_chunks ch, uint32_t C) {
+    if (mdl->halted != 0u) return;
+    const uint32_t B = mdl->B, K = (uint32_t)mdl->K;
+    const uint32_t L = hml_compat_chunk_len(B, C);
+    const uint32_t n_chunks = (B + L - 1u) / L;
+    const uint64_t n = (uint64_t)n_chunks * K;
+    for (uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t c = (uint32_t)(e / K);
+        // (a chunk whose warm-up reaches block 0 started from pi: exact)
+        if (c > 0u && (uint64_t)c * L > ch.W && hml_f2u(ch.entry[e]) != hml_f2u(ch.exitv[e - K])) ch.bad[c] = 1u;
+    }
+}
+
+// the chunks' flags of a check kernel as a bit map in LDS (bit c of word c / 64), by all of its 256 threads; returns with a barrier
+#define HML_COMPAT_MAP_WORDS (HML_COMPAT_MAX_CHUNKS / 64)
+template <class F>
+__device__ __forceinline__ void hml_compat_flag_map(unsigned long long* map, uint32_t n_chunks, int tid, F flag) {
+    const int lane = tid & 63, wave = tid >> 6;
+    for (uint32_t c0 = 0; c0 < n_chunks; c0 += 256u) {   // workgroup-uniform
+        const uint32_t cl = c0 + (uint32_t)tid;
+        const unsigned long long m = __ballot(cl < n_chunks && flag(cl));
+        if (lane == 0 && c0 + 64u * (uint32_t)wave < n_chunks) map[c0 / 64u + (uint32_t)wave] = m;
+    }
+    __syncthreads();
+}
+// bit of chunk c: cleared (the chunk was just compared with what its predecessor really left)
+__device__ __forceinline__ void hml_compat_flag_clear(unsigned long long* map, uint32_t c, int lane) {
+    if (lane == 0) map[c >> 6] &= ~(1ull << (c & 63u));
+    hml_compat_fence();
+}
+
 // the filter's chunks in order: a chunk whose first row is not what the chunk before it left runs again from that row
-template <int KC>
-HML_KERNEL __launch_bounds__(64) void hml_k_compat_forward_check(hml_model* __restrict__ mdl, const float* __restrict__ em, const float* __restrict__ g,
-                                                                 float* __restrict__ rows, const hml_compat_chunks ch, uint32_t C) {
+template <int KC, bool PAD = false>
+HML_KERNEL __launch_bounds__(256) void hml_k_compat_forward_check(hml_model* __restrict__ mdl, const float* __restrict__ em, const float* __restrict__ g,
+                                                                  float* __restrict__ rows, const hml_compat_chunks ch, uint32_t C) {
     __shared__ float sA[KC ? 1 : HML_CAP_K * HML_CAP_K];
     __shared__ float tile[HML_COMPAT_TILE], tile_g[HML_COMPAT_TILE];
+    __shared__ unsigned long long map[HML_COMPAT_MAP_WORDS];
+    __shared__ unsigned long long s_nfb[4];
     if (mdl->halted != 0u) return;
-    const int lane = threadIdx.x;
-    const int K = KC ? KC : mdl->K;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int K = (KC && !PAD) ? KC : mdl->K;
     const uint32_t B = mdl->B;
     const uint32_t L = hml_compat_chunk_len(B, C);
     const uint32_t n_chunks = (B + L - 1u) / L;
+    // the chunks' flags (hml_k_compat_forward_verify) and the sum of their uniform fallbacks, by all four wavefronts
+    {
+        unsigned long long mine = 0ull;
+        for (uint32_t cl = (uint32_t)tid; cl < n_chunks; cl += 256u) mine += (unsigned long long)ch.nfb[cl];
+        for (int m = 32; m >= 1; m >>= 1) mine += __shfl_xor(mine, m);
+        if (lane == 0) s_nfb[tid >> 6] = mine;
+    }
+    hml_compat_flag_map(map, n_chunks, tid, [&](uint32_t cl) { return ch.bad[cl] != 0u; });
+    if (tid >= 64) return;
     const bool self = mdl->self_trans != 0;
     const bool act = lane < K;
     float acol[KC ? KC : 1];
     if (KC) {
 #pragma unroll
-        for (int i = 0; i < (KC ? KC : 1); ++i) acol[i] = act ? mdl->A[i * K + lane] : 0.0f;
+        for (int i = 0; i < (KC ? KC : 1); ++i) acol[i] = (act && i < K) ? mdl->A[i * K + lane] : 0.0f;
     } else {
         for (int i = lane; i < K * K; i += 64) sA[i] = mdl->A[i];
     }
     hml_compat_fence();
-    unsigned long long total_nfb = 0ull, redone = 0ull;
+    unsigned long long total_nfb = s_nfb[0] + s_nfb[1] + s_nfb[2] + s_nfb[3], redone = 0ull;
     for (uint32_t c0 = 0; c0 < n_chunks; c0 += 64u) {
-        // lane l: is chunk c0 + l consistent with the chunk before it?  (what a chunk that runs again leaves is compared below)
-        const uint32_t cl = c0 + (uint32_t)lane;
-        bool bad = false;
-        if (cl < n_chunks && cl > 0u && cl * L > ch.W)   // (a chunk whose warm-up reaches block 0 started from pi: exact)
-            for (int s = 0; s < K; ++s) bad = bad || (hml_f2u(ch.entry[(uint64_t)cl * K + s]) != hml_f2u(ch.exitv[(uint64_t)(cl - 1u) * K + s]));
-        total_nfb += (cl < n_chunks) ? (unsigned long long)ch.nfb[cl] : 0ull;
-        unsigned long long todo = __ballot(bad);
-        while (todo != 0ull) {   // wave-uniform
+        while (true) {   // wave-uniform
+            const unsigned long long todo = map[c0 >> 6];
+            if (todo == 0ull) break;
             const uint32_t c = c0 + (uint32_t)(__ffsll((long long)todo) - 1);
-            todo &= todo - 1ull;
+            hml_compat_flag_clear(map, c, lane);
             // chunks c, c + 1, ... until one leaves what its successor started from
             for (uint32_t cc = c; cc < n_chunks; ++cc) {
                 const uint32_t lo = cc * L, hi = (lo + L < B) ? lo + L : B;
                 float prev = act ? ch.exitv[(uint64_t)(cc - 1u) * K + lane] : 0.0f;
                 uint32_t nfb = 0u;
                 const uint32_t old_nfb = ch.nfb[cc];
-                hml_compat_forward_range<KC>(K, B, self, em, g, rows, nullptr, acol, sA, tile, tile_g, lo, lo, hi, prev, nullptr, nfb, lane);
+                hml_compat_forward_range<KC, PAD>(K, B, self, em, g, rows, nullptr, acol, sA, tile, tile_g, lo, lo, hi, prev, nullptr, nfb, lane);
                 if (act) ch.exitv[(uint64_t)cc * K + lane] = prev;
                 if (lane == 0) ch.nfb[cc] = nfb;
-                total_nfb += (lane == 0) ? (unsigned long long)nfb - (unsigned long long)old_nfb : 0ull;
+                total_nfb += (unsigned long long)nfb - (unsigned long long)old_nfb;
                 redone++;
                 if (cc + 1u >= n_chunks) break;
-                if (cc + 1u - c0 < 64u) todo &= ~(1ull << (cc + 1u - c0));   // (the successor is compared right here)
+                hml_compat_flag_clear(map, cc + 1u, lane);   // (the successor is compared right here)
                 const float nx = act ? ch.entry[(uint64_t)(cc + 1u) * K + lane] : 0.0f;
-                const bool exact_next = (cc + 1u) * L <= ch.W;
+                const bool exact_next = (uint64_t)(cc + 1u) * L <= ch.W;
                 if (exact_next || __ballot(act && hml_f2u(nx) != hml_f2u(prev)) == 0ull) break;
             }
         }
     }
-    // (lane 0 holds its chunks' share plus the corrections; the others their chunks' share)
-    for (int m = 32; m >= 1; m >>= 1) total_nfb += __shfl_xor(total_nfb, m);
     if (lane == 0) { mdl->uniform_fallbacks += total_nfb; mdl->forward_refits += redone; }
 }
 
-// the engine's next n outputs -> out[0 .. n): the uniforms of a sweep's categorical draws do not depend on the data
-HML_KERNEL __launch_bounds__(64) void hml_k_compat_draws(hml_model* __restrict__ mdl, hml_mt_state* __restrict__ mts, uint32_t* __restrict__ out, uint32_t per_block) {
-    __shared__ uint32_t lmt[HML_MT_N];
-    __shared__ uint32_t buf[HML_MT_N];
-    if (mdl->halted != 0u) return;
-    const int lane = threadIdx.x;
-    const uint64_t n = (uint64_t)mdl->B * per_block;
-    for (int i = lane; i < HML_MT_N; i += 64) lmt[i] = mts->mt[i];
-    uint32_t idx = mts->idx;
-    hml_compat_fence();
-    for (uint64_t o = 0; o < n; ) {
-        const uint32_t m = (n - o < (uint64_t)HML_MT_N) ? (uint32_t)(n - o) : (uint32_t)HML_MT_N;
-        hml_mt_fill_wave(lmt, idx, buf, m, lane);
-        for (uint32_t k = (uint32_t)lane; k < m; k += 64u) out[o + k] = buf[k];
-        hml_compat_fence();
-        o += m;
+// the engine's next n outputs -> out[0 .. n): the uniforms of a sweep's categorical draws do not depend on the data.
+// Round 5: one workgroup of FOUR wavefronts and a twist in three steps.  mersenne_twister_engine::_M_gen_rand replaces the
+// state in place, k = 0 .. 623: x_k <- x_{k+397 mod 624} ^ f(x_k, x_{k+1 mod 624}).  For k < 227 all three operands are
+// old values; for 227 <= k < 454 the first is the NEW x_{k-227} of the first range; for 454 <= k < 624 the new x_{k-227} of
+// the second range (and x_623 also reads the new x_0).  So a twist is three ranges of at most 227 independent elements:
+// one element per thread, a barrier between the ranges, old and new state in two LDS arrays (no read-before-write hazards
+// inside a range) - 3 barriers per 624 outputs where round 4's single wavefront went through ten chunks of 64 with two
+// fences each (1.4 us per twist, 1.1 ms of config 3's sweep).
+#define HML_MT_M 397
+__device__ __forceinline__ uint32_t hml_mt_mix(uint32_t hi, uint32_t lo, uint32_t far) {
+    const uint32_t y = (hi & 0x80000000u) | (lo & 0x7fffffffu);
+    return far ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+}
+__device__ __forceinline__ uint32_t hml_mt_temper(uint32_t y) {
+    y ^= y >> 11;
+    y ^= (y << 7) & 0x9d2c5680u;
+    y ^= (y << 15) & 0xefc60000u;
+    y ^= y >> 18;
+    return y;
+}
+// old -> nw (two arrays of 624 words in LDS), 256 threads; ends with a barrier.  The first `m` words of the new state are also
+// the engine's next outputs: the thread that makes word k tempers it and stores it to out[k] (out may be null: m = 0).
+// a barrier that waits for the workgroup's LDS traffic only: the tempered outputs go to memory behind it without being waited
+// for (__syncthreads also waits for every outstanding store: a memory round trip per range of a twist)
+#define HML_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+__device__ __forceinline__ void hml_mt_twist_wg(const uint32_t* old, uint32_t* nw, int tid, uint32_t* __restrict__ out, uint32_t m) {
+    constexpr int R = HML_MT_N - HML_MT_M;   // 227
+    if (tid < R) {
+        const uint32_t v = hml_mt_mix(old[tid], old[tid + 1], old[tid + HML_MT_M]);
+        nw[tid] = v;
+        if ((uint32_t)tid < m) out[tid] = hml_mt_temper(v);
     }
-    for (int i = lane; i < HML_MT_N; i += 64) mts->mt[i] = lmt[i];
-    if (lane == 0) mts->idx = idx;
+    HML_LDS_BARRIER();
+    if (tid < R) {
+        const int k = R + tid;
+        const uint32_t v = hml_mt_mix(old[k], old[k + 1], nw[k - R]);
+        nw[k] = v;
+        if ((uint32_t)k < m) out[k] = hml_mt_temper(v);
+    }
+    HML_LDS_BARRIER();
+    if (tid < HML_MT_N - 2 * R) {   // 170 elements
+        const int k = 2 * R + tid;
+        const uint32_t v = hml_mt_mix(old[k], (k == HML_MT_N - 1) ? nw[0] : old[k + 1], nw[k - R]);
+        nw[k] = v;
+        if ((uint32_t)k < m) out[k] = hml_mt_temper(v);
+    }
+    HML_LDS_BARRIER();
+}
+HML_KERNEL __launch_bounds__(256) void hml_k_compat_draws(hml_model* __restrict__ mdl, hml_mt_state* __restrict__ mts, uint32_t* __restrict__ out, uint32_t per_block) {
+    __shared__ uint32_t st[2][HML_MT_N];
+    if (mdl->halted != 0u) return;
+    const int tid = threadIdx.x;
+    const uint64_t n = (uint64_t)mdl->B * per_block;
+    for (int i = tid; i < HML_MT_N; i += 256) st[0][i] = mts->mt[i];
+    uint32_t idx = mts->idx;
+    int cur = 0;
+    __syncthreads();
+    uint64_t o = 0;
+    if (idx < HML_MT_N && n > 0) {   // what the current state still holds
+        const uint32_t m = (n < (uint64_t)(HML_MT_N - idx)) ? (uint32_t)n : (uint32_t)(HML_MT_N - idx);
+        for (uint32_t k = (uint32_t)tid; k < m; k += 256u) out[k] = hml_mt_temper(st[0][idx + k]);
+        idx += m; o = m;
+    }
+    while (o < n) {   // workgroup-uniform: one twist per 624 outputs, tempered and stored as they are made
+        const uint32_t m = (n - o < (uint64_t)HML_MT_N) ? (uint32_t)(n - o) : (uint32_t)HML_MT_N;
+        hml_mt_twist_wg(st[cur], st[cur ^ 1], tid, out + o, m);
+        cur ^= 1; idx = m; o += m;
+    }
+    __syncthreads();
+    for (int i = tid; i < HML_MT_N; i += 256) mts->mt[i] = st[cur][i];
+    if (tid == 0) mts->idx = idx;
 }
 
 // StateSequence<ForwardBackward>::sample's backward draws (ForwardBackward.hpp:133-162; Trellis::sample, Trellis.hpp:61-66) over
 // rows t_begin, t_begin - 1, ..., t_end + 1 (row B: the weights are the row itself; below: rows[t][i] * A(i, q_{t+1})), the states
 // stored from row t_store down.  j: the state above row t_begin (in), of row t_end + 1 (out).  draws: two engine outputs per row, row
 // t at 2 (B - t).  Returns false if a weight was negative (the caller runs the rows again where it may raise: ForwardBackward.hpp:147-149).
-template <int KC, bool RAISE>
+template <int KC, bool RAISE, bool PAD = false>
 __device__ __forceinline__ bool hml_compat_backward_range(hml_model* mdl, int K, uint32_t B, const float* __restrict__ rows, const uint32_t* __restrict__ draws,
-                                                          int16_t* __restrict__ q, const float (&arow)[KC ? KC : 1], const float* sAT, float* tile, uint32_t* tile_d,
+                                                          int16_t* __restrict__ q, const float (&arow)[(KC && !PAD) ? KC : 1], const float* sAT, float* tile, uint32_t* tile_d,
                                                           int16_t* tile_q, uint32_t t_begin, uint32_t t_store, uint32_t t_end, int& j, int* in_out, int lane) {
     const bool act = lane < K;
     const uint32_t TB = (uint32_t)((HML_COMPAT_TILE / K) < 64 ? (HML_COMPAT_TILE / K) : 64);
@@ -543,7 +677,7 @@ __device__ __forceinline__ bool hml_compat_backward_range(hml_model* mdl, int K,
             if (t == B) w = act ? row : 0.0f;   // (the last row: no check, like Trellis::sample)
             else {
                 float a;
-                if (KC) {
+                if (KC && !PAD) {
                     a = arow[0];
 #pragma unroll
                     for (int jj = 1; jj < (KC ? KC : 1); ++jj) a = (j == jj) ? arow[jj] : a;
@@ -560,7 +694,7 @@ __device__ __forceinline__ bool hml_compat_backward_range(hml_model* mdl, int K,
                     }
                 }
             }
-            j = hml_compat_categorical_wave<KC>(w, K, u, lane);
+            j = hml_compat_categorical_wave<KC, PAD>(w, K, u, lane);
             if (lane == 0) tile_q[r] = (int16_t)j;
         }
         hml_compat_fence();
@@ -571,26 +705,27 @@ __device__ __forceinline__ bool hml_compat_backward_range(hml_model* mdl, int K,
     return clean;
 }
 
-template <int KC>
+template <int KC, bool PAD = false>
 HML_KERNEL __launch_bounds__(64) void hml_k_compat_backward(hml_model* __restrict__ mdl, const float* __restrict__ rows, const uint32_t* __restrict__ draws,
                                                             int16_t* __restrict__ q, const hml_compat_chunks ch) {
-    __shared__ float sAT[KC ? 1 : HML_CAP_K * HML_CAP_K];   // transposed: lane i reads A(i, j) at [j * K + i]
+    constexpr bool REG = KC && !PAD;                        // A's row in registers (a cascade of selects finds A(lane, j): up to 16 states)
+    __shared__ float sAT[REG ? 1 : HML_CAP_K * HML_CAP_K];   // transposed: lane i reads A(i, j) at [j * K + i]
     __shared__ float tile[HML_COMPAT_TILE];
     __shared__ uint32_t tile_d[128];
     __shared__ int16_t tile_q[64];
     if (mdl->halted != 0u) return;
     const int lane = threadIdx.x;
-    const int K = KC ? KC : mdl->K;
+    const int K = REG ? KC : mdl->K;
     const uint32_t B = mdl->B;
     const uint32_t C = gridDim.x, c = blockIdx.x, L = hml_compat_chunk_len(B, C);
     if (c * L >= B) return;
     const uint32_t hi = B - c * L;                                   // rows hi .. lo + 1 (chunk 0 holds row B)
     const uint32_t lo = (hi > L) ? hi - L : 0u;
     const bool act = lane < K;
-    float arow[KC ? KC : 1];   // A(lane, j)
-    if (KC) {
+    float arow[REG ? KC : 1];   // A(lane, j)
+    if (REG) {
 #pragma unroll
-        for (int j = 0; j < (KC ? KC : 1); ++j) arow[j] = act ? mdl->A[lane * K + j] : 0.0f;
+        for (int j = 0; j < (REG ? KC : 1); ++j) arow[j] = act ? mdl->A[lane * K + j] : 0.0f;
     } else {
         for (int idx = lane; idx < K * K; idx += 64) { const int i = idx / K, j = idx - i * K; sAT[j * K + i] = mdl->A[idx]; }
     }
@@ -598,8 +733,8 @@ HML_KERNEL __launch_bounds__(64) void hml_k_compat_backward(hml_model* __restric
     int j = 0, in_state = -1;
     const bool single = (C == 1u);
     bool clean;
-    if (single) clean = hml_compat_backward_range<KC, true>(mdl, K, B, rows, draws, q, arow, sAT, tile, tile_d, tile_q, tw, hi, lo, j, &in_state, lane);
-    else clean = hml_compat_backward_range<KC, false>(mdl, K, B, rows, draws, q, arow, sAT, tile, tile_d, tile_q, tw, hi, lo, j, &in_state, lane);
+    if (single) clean = hml_compat_backward_range<KC, true, PAD>(mdl, K, B, rows, draws, q, arow, sAT, tile, tile_d, tile_q, tw, hi, lo, j, &in_state, lane);
+    else clean = hml_compat_backward_range<KC, false, PAD>(mdl, K, B, rows, draws, q, arow, sAT, tile, tile_d, tile_q, tw, hi, lo, j, &in_state, lane);
     if (lane == 0) {
         ch.out_state[c] = j;
         // (a chunk that met a negative weight is run again by the checking launch, which raises; -2 never equals a state)
@@ -608,50 +743,53 @@ HML_KERNEL __launch_bounds__(64) void hml_k_compat_backward(hml_model* __restric
 }
 // the chunks of the backward draws from the top: a chunk that started from another state than the chunk above it ended in (or met
 // a negative weight) runs again from that state
-template <int KC>
-HML_KERNEL __launch_bounds__(64) void hml_k_compat_backward_check(hml_model* __restrict__ mdl, const float* __restrict__ rows, const uint32_t* __restrict__ draws,
-                                                                  int16_t* __restrict__ q, const hml_compat_chunks ch, uint32_t C) {
-    __shared__ float sAT[KC ? 1 : HML_CAP_K * HML_CAP_K];
+template <int KC, bool PAD = false>
+HML_KERNEL __launch_bounds__(256) void hml_k_compat_backward_check(hml_model* __restrict__ mdl, const float* __restrict__ rows, const uint32_t* __restrict__ draws,
+                                                                   int16_t* __restrict__ q, const hml_compat_chunks ch, uint32_t C) {
+    constexpr bool REG = KC && !PAD;
+    __shared__ float sAT[REG ? 1 : HML_CAP_K * HML_CAP_K];
     __shared__ float tile[HML_COMPAT_TILE];
     __shared__ uint32_t tile_d[128];
     __shared__ int16_t tile_q[64];
+    __shared__ unsigned long long map[HML_COMPAT_MAP_WORDS];
     if (mdl->halted != 0u) return;
-    const int lane = threadIdx.x;
-    const int K = KC ? KC : mdl->K;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int K = REG ? KC : mdl->K;
     const uint32_t B = mdl->B;
     const uint32_t L = hml_compat_chunk_len(B, C);
     const uint32_t n_chunks = (B + L - 1u) / L;
+    hml_compat_flag_map(map, n_chunks, tid, [&](uint32_t cl) {
+        if (cl == 0u) return false;
+        const int in = ch.in_state[cl];
+        return (in == -2) || (in >= 0 && in != ch.out_state[cl - 1u]);
+    });
+    if (tid >= 64) return;
     const bool act = lane < K;
-    float arow[KC ? KC : 1];
-    if (KC) {
+    float arow[REG ? KC : 1];
+    if (REG) {
 #pragma unroll
-        for (int j = 0; j < (KC ? KC : 1); ++j) arow[j] = act ? mdl->A[lane * K + j] : 0.0f;
+        for (int j = 0; j < (REG ? KC : 1); ++j) arow[j] = act ? mdl->A[lane * K + j] : 0.0f;
     } else {
         for (int idx = lane; idx < K * K; idx += 64) { const int i = idx / K, j = idx - i * K; sAT[j * K + i] = mdl->A[idx]; }
     }
     hml_compat_fence();
     unsigned long long redone = 0ull;
     for (uint32_t c0 = 0; c0 < n_chunks; c0 += 64u) {
-        const uint32_t cl = c0 + (uint32_t)lane;
-        bool bad = false;
-        if (cl < n_chunks && cl > 0u) {
-            const int in = ch.in_state[cl];
-            bad = (in == -2) || (in >= 0 && in != ch.out_state[cl - 1u]);
-        }
-        unsigned long long todo = __ballot(bad);
-        while (todo != 0ull) {   // wave-uniform
+        while (true) {   // wave-uniform
+            const unsigned long long todo = map[c0 >> 6];
+            if (todo == 0ull) break;
             const uint32_t c = c0 + (uint32_t)(__ffsll((long long)todo) - 1);
-            todo &= todo - 1ull;
+            hml_compat_flag_clear(map, c, lane);
             for (uint32_t cc = c; cc < n_chunks; ++cc) {
                 const uint32_t hi = B - cc * L, lo = (hi > L) ? hi - L : 0u;
                 int j = ch.out_state[cc - 1u];
-                hml_compat_backward_range<KC, true>(mdl, K, B, rows, draws, q, arow, sAT, tile, tile_d, tile_q, hi, hi, lo, j, nullptr, lane);
+                hml_compat_backward_range<KC, true, PAD>(mdl, K, B, rows, draws, q, arow, sAT, tile, tile_d, tile_q, hi, hi, lo, j, nullptr, lane);
                 hml_compat_fence();
                 if (lane == 0) ch.out_state[cc] = j;
                 hml_compat_fence();
                 redone++;
                 if (cc + 1u >= n_chunks) break;
-                if (cc + 1u - c0 < 64u) todo &= ~(1ull << (cc + 1u - c0));   // (the successor is compared right here)
+                hml_compat_flag_clear(map, cc + 1u, lane);   // (the successor is compared right here)
                 const int in = ch.in_state[cc + 1u];
                 if (in == -1 || in == j) break;
             }
@@ -695,8 +833,12 @@ struct hml_compat_lists {
     uint32_t* tile_count;   // [tiles][K] blocks of state s in the tile, then their exclusive prefix over the tiles
     uint32_t* state_off;    // [K + 1] first list position of state s
     unsigned long long* offdiag;   // [K * K] transitions between different states
-    float4* item;           // [B] per list position: the block's statistics (Sx, Sxx), its size, and whether the block before it has
-                            // the same state (prev_0 = 0, ForwardBackward.hpp:172) - 16 bytes, one load
+    // per list position, one array per quantity (round 5: each of the four wavefronts of the walk reads only what its chain adds -
+    // sixteen entries are one 64-byte run per lane and array where they were sixteen 16-byte structures):
+    float* sx;              // [B] the block's Sx
+    float* sq;              // [B] the block's Sxx
+    uint32_t* n;            // [B] its size
+    uint32_t* same;         // [B] 1 if the block before it has the same state (prev_0 = 0, ForwardBackward.hpp:172)
 };
 HML_KERNEL __launch_bounds__(256) void hml_k_compat_part_count(const hml_model* __restrict__ mdl, const int16_t* __restrict__ q, const hml_compat_lists pl) {
     __shared__ uint32_t h[HML_CAP_K];
@@ -769,7 +911,7 @@ HML_KERNEL __launch_bounds__(256) void hml_k_compat_part_scatter(const hml_model
             uint32_t pos = cnt[s] + rank;
             for (int w2 = 0; w2 < wave; ++w2) pos += pw[w2][s];
             const float2 st = bstat[b];
-            pl.item[pos] = make_float4(st.x, st.y, hml_u2f(starts[b + 1u] - starts[b]), hml_u2f(prev == s ? 1u : 0u));
+            pl.sx[pos] = st.x; pl.sq[pos] = st.y; pl.n[pos] = starts[b + 1u] - starts[b]; pl.same[pos] = prev == s ? 1u : 0u;
             if (prev != s) atomicAdd(&pl.offdiag[prev * K + s], 1ull);
         }
         __syncthreads();
@@ -779,6 +921,54 @@ HML_KERNEL __launch_bounds__(256) void hml_k_compat_part_scatter(const hml_model
         }
         __syncthreads();
     }
+    }
+}
+
+// A lane's list (hml_compat_lists: `cnt` entries from `off` on) walked in batches of NB entries with THREE batches of loads in
+// flight ahead of the one being added: step(a_i) or, TWO, step(a_i, b_i) in list order.  The walk is a chain of dependent
+// operations per entry, and what it used to wait for was memory (round 5): round 4 loaded one batch ahead, every load behind its
+// own `entry < count` test - divergent code, at whose end the compiler waits for all loads it issued - so each batch paid a whole
+// memory round trip (2.7 us per 32 entries, 5 ms per sweep of config 3).  The loads are now straight-line code: the index is
+// clamped into the lane's list instead of the load being skipped (a lane without a list reads entry 0 of the array), and only the
+// ADDITIONS of a lane's last batch are predicated.  `longest`: the longest list of the wavefront (wave-uniform trip count).
+#define HML_WALK_NB 16
+template <bool TWO>
+__device__ __forceinline__ void hml_compat_walk_fetch(const uint32_t* __restrict__ a, const uint32_t* __restrict__ b, uint32_t off, uint32_t last, uint32_t b0,
+                                                      uint32_t (&va)[HML_WALK_NB], uint32_t (&vb)[TWO ? HML_WALK_NB : 1]) {
+#pragma unroll
+    for (int k = 0; k < HML_WALK_NB; ++k) {
+        const uint32_t i = b0 + (uint32_t)k;
+        const uint32_t at = off + (i < last ? i : last);
+        va[k] = a[at];
+        if (TWO) vb[k] = b[at];
+    }
+}
+template <bool TWO, class Step>
+__device__ __forceinline__ void hml_compat_walk_batch(uint32_t cnt, uint32_t b0, const uint32_t (&va)[HML_WALK_NB], const uint32_t (&vb)[TWO ? HML_WALK_NB : 1], Step& step) {
+    if (b0 + (uint32_t)HML_WALK_NB <= cnt) {
+#pragma unroll
+        for (int k = 0; k < HML_WALK_NB; ++k) step(va[k], vb[TWO ? k : 0]);
+    } else if (b0 < cnt) {
+#pragma unroll
+        for (int k = 0; k < HML_WALK_NB; ++k) if (b0 + (uint32_t)k < cnt) step(va[k], vb[TWO ? k : 0]);
+    }
+}
+template <bool TWO, class Step>
+__device__ __forceinline__ void hml_compat_walk(const uint32_t* __restrict__ a, const uint32_t* __restrict__ b, uint32_t off, uint32_t cnt, uint32_t longest, Step step) {
+    constexpr uint32_t NB = HML_WALK_NB;
+    const uint32_t last = cnt ? cnt - 1u : 0u;
+    // (four sets of registers, each named: an array indexed by the set would live in scratch memory)
+    uint32_t a0[NB], a1[NB], a2[NB], a3[NB];
+    uint32_t c0[TWO ? NB : 1], c1[TWO ? NB : 1], c2[TWO ? NB : 1], c3[TWO ? NB : 1];
+    if (!TWO) { c0[0] = c1[0] = c2[0] = c3[0] = 0u; }
+    hml_compat_walk_fetch<TWO>(a, b, off, last, 0u, a0, c0);
+    hml_compat_walk_fetch<TWO>(a, b, off, last, NB, a1, c1);
+    hml_compat_walk_fetch<TWO>(a, b, off, last, 2u * NB, a2, c2);
+    for (uint32_t base = 0; base < longest; base += 4u * NB) {   // wave-uniform
+        hml_compat_walk_fetch<TWO>(a, b, off, last, base + 3u * NB, a3, c3); hml_compat_walk_batch<TWO>(cnt, base, a0, c0, step);
+        hml_compat_walk_fetch<TWO>(a, b, off, last, base + 4u * NB, a0, c0); hml_compat_walk_batch<TWO>(cnt, base + NB, a1, c1, step);
+        hml_compat_walk_fetch<TWO>(a, b, off, last, base + 5u * NB, a1, c1); hml_compat_walk_batch<TWO>(cnt, base + 2u * NB, a2, c2, step);
+        hml_compat_walk_fetch<TWO>(a, b, off, last, base + 6u * NB, a2, c2); hml_compat_walk_batch<TWO>(cnt, base + 3u * NB, a3, c3, step);
     }
 }
 
@@ -830,44 +1020,40 @@ HML_KERNEL __launch_bounds__(256) void hml_k_compat_update(hml_model* __restrict
         const uint32_t cnt = (lane < K) ? pl.state_off[lane + 1] - off : 0u;
         uint32_t longest = cnt;
         for (int m = 32; m >= 1; m >>= 1) { const uint32_t o = (uint32_t)__shfl_xor((int)longest, m); longest = o > longest ? o : longest; }
-        constexpr int NB = 16;
-        float4 bi[2][NB];
-        auto fetch_list = [&](uint32_t base, int set) {
-#pragma unroll
-            for (int k = 0; k < NB; ++k) bi[set][k] = (base + (uint32_t)k < cnt) ? pl.item[off + base + k] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        };
-        auto run = [&](auto step) {
-            fetch_list(0u, 0);
-            for (uint32_t base = 0; base < longest; base += 2u * NB) {   // wave-uniform
-                fetch_list(base + NB, 1);
-#pragma unroll
-                for (int k = 0; k < NB; ++k) if (base + (uint32_t)k < cnt) step(bi[0][k]);
-                fetch_list(base + 2u * NB, 0);
-#pragma unroll
-                for (int k = 0; k < NB; ++k) if (base + NB + (uint32_t)k < cnt) step(bi[1][k]);
-            }
-        };
         if (wave == 0) {
-            run([&](const float4& it) { const float y = it.x - es, t = ps + y; es = (t - ps) - y; ps = t; });
+            const uint32_t* const arr = reinterpret_cast<const uint32_t*>(pl.sx);
+            hml_compat_walk<false>(arr, arr, off, cnt, longest, [&](uint32_t xb, uint32_t) { const float x = hml_u2f(xb); const float y = x - es, t = ps + y; es = (t - ps) - y; ps = t; });
             if (lane < K) s_ps[lane] = ps;
         } else if (wave == 1) {
-            run([&](const float4& it) { const float y = it.y - eq, t = pq + y; eq = (t - pq) - y; pq = t; });
+            const uint32_t* const arr = reinterpret_cast<const uint32_t*>(pl.sq);
+            hml_compat_walk<false>(arr, arr, off, cnt, longest, [&](uint32_t xb, uint32_t) { const float x = hml_u2f(xb); const float y = x - eq, t = pq + y; eq = (t - pq) - y; pq = t; });
             if (lane < K) s_pq[lane] = pq;
         } else if (wave == 2) {
-            run([&](const float4& it) {
-                const uint32_t n = hml_f2u(it.z);
-                if (method == 1) diag += (double)(n - 1u);
-                else diag = (double)((float)diag + ((float)n - 1.0f));   // size_t += float: the sum goes through a float
-                if (hml_f2u(it.w) != 0u) diag += 1.0;
+            // A(s, s)'s count: `size_t += float` (ForwardBackward.hpp:183-187) - the sum goes through a float, then the block's
+            // entering transition is an exact increment.  While the float sum stays below 2^24 every value on the way is an
+            // integer a float holds exactly, so the whole step is two float additions (fd = (float)count throughout); above,
+            // the increment needs the double (it may land between two floats) - once there, always there (the count only grows).
+            float fd = 0.0f;
+            bool above = false;
+            hml_compat_walk<true>(pl.n, pl.same, off, cnt, longest, [&](uint32_t n, uint32_t same) {
+                if (method == 1) { diag += (double)(n - 1u) + (same != 0u ? 1.0 : 0.0); return; }
+                const float one = same != 0u ? 1.0f : 0.0f;
+                const float s1 = fd + ((float)n - 1.0f);
+                if (s1 < 16777216.0f) fd = s1 + one;
+                else { diag = (double)s1 + (double)one; fd = (float)diag; above = true; }
             });
+            if (method != 1 && !above) diag = (double)fd;
             if (lane < K) s_trans[lane * K + lane] = (unsigned long long)diag;
         } else {
-            run([&](const float4& it) {
-                const uint32_t n = hml_f2u(it.z);
+            // the occupancy: `size_t += float` is one float addition per block ((float)(size_t)x == x for the integers a float sum
+            // can be: the round trip through the integer changes nothing)
+            float fo = 0.0f;
+            hml_compat_walk<false>(pl.n, pl.n, off, cnt, longest, [&](uint32_t n, uint32_t) {
                 if (method == 1) occ += (double)n;
-                else occ = (double)((float)occ + (float)n);
+                else fo = fo + (float)n;
                 n_terms += n;
             });
+            if (method != 1) occ = (double)fo;
             if (lane < K) { s_occ[lane] = (unsigned long long)occ; s_n[lane] = n_terms; }
         }
         for (int i = tid; i < K * K; i += 256) if (i / K != i % K) s_trans[i] = pl.offdiag[i];

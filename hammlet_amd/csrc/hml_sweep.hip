@@ -334,7 +334,19 @@ static int iterate_many_k(hml_ctx* const* cs, int n, uint64_t first, uint64_t it
     bool fm = c0->trace != nullptr && c0->fused_blocks;
     for (int k = 0; k < n; ++k) fm = fm && cs[k]->trace == c0->trace && cs[k]->fused_blocks && cs[k]->key_base == c0->key_base;
     uint32_t fm_sub = 0u, fm_wg = 0u;
-    if (fm) {
+    // HML_FM_SPLIT (default 1): the block structure of attached chains in two launches that no workgroup waits in
+    // (hml_k_blocks_split_many.h) instead of the fused kernel; tiles of 2^17 positions (more per tile only beyond 4096 tiles)
+    bool fm_split = true;
+    if (const char* e = getenv("HML_FM_SPLIT")) fm_split = atoi(e) != 0;
+    uint32_t fs_sub = 1u, fs_wg = 0u;
+    {
+        const uint64_t batches = (c0->T + HML_FUSED_SUB_POSITIONS - 1) / HML_FUSED_SUB_POSITIONS;
+        fs_sub = (uint32_t)std::max<uint64_t>(1, (batches + 4095) / 4096);
+        if (const char* e = getenv("HML_FM_SPLIT_SUB")) fs_sub = (uint32_t)std::max(1, atoi(e));   // (tests: tiles of several batches)
+        if (fs_sub > HML_FUSED_MAX_SUB) fm_split = false;
+        fs_wg = (uint32_t)((c0->T + (uint64_t)fs_sub * HML_FUSED_SUB_POSITIONS - 1) / ((uint64_t)fs_sub * HML_FUSED_SUB_POSITIONS));
+    }
+    if (fm && !fm_split) {
         if (c0->fm_slots == 0) {
             int per_cu = 0, cus = 0;
             if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, hml_m_blocks_fused<KK>, HML_FUSED_WAVES * 64, 0) != hipSuccess ||
@@ -381,7 +393,23 @@ static int iterate_many_k(hml_ctx* const* cs, int n, uint64_t first, uint64_t it
             for (int k = g0; k < g0 + gn; ++k) hint = std::max(hint, cs[k]->B_hint ? cs[k]->B_hint : (uint32_t)std::min<uint64_t>(T, 1u << 20));
             const unsigned ny = (unsigned)gn;
             const unsigned gB = (unsigned)grid_for(hint, 256, 64, 16384);
-            if (fm) {
+            if (fm && fm_split) {
+                // two launches without a wait between workgroups (hml_k_blocks_split_many.h): the chains' block starts, then
+                // statistics and emission terms - up to sixteen chains to a launch
+                for (int k0 = g0; k0 < g0 + gn; k0 += HML_FS_MAX_CHAINS) {
+                    const int nk = std::min(g0 + gn - k0, (int)HML_FS_MAX_CHAINS);
+                    hml_fs_args fa;
+                    memset(&fa, 0, sizeof fa);
+                    for (int k = 0; k < nk; ++k) {
+                        hml_ctx* c = cs[k0 + k];
+                        hml_fs_chain& f = fa.c[k];
+                        f.mdl = c->d_mdl; f.group_word = c->d_group_word; f.wave_total = c->d_wave_total; f.stage = c->d_stage; f.starts = c->d_starts;
+                        f.bstat = c->d_bstat; f.em = c->d_em; f.gsc = with_gsc ? c->d_gsc : nullptr; f.host_words = c->d_hB; f.lay = c->lay_many;
+                    }
+                    hipLaunchKernelGGL(hml_m_blocks_list, dim3(fs_wg), dim3(HML_FUSED_WAVES * 64), 0, s, c0->d_summary, c0->d_w, T, c0->key_base, fa, nk, fs_sub);
+                    hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_m_blocks_emit<KK>), dim3(fs_wg), dim3(HML_FUSED_WAVES * 64), 0, s, c0->d_ia, T, fa, nk, fs_sub);
+                }
+            } else if (fm) {
                 for (int k0 = g0; k0 < g0 + gn; k0 += HML_FM_MAX_CHAINS) {
                     const int nk = std::min(g0 + gn - k0, (int)HML_FM_MAX_CHAINS);
                     hml_fm_args fa;

@@ -52,7 +52,8 @@ static const char* kHelp =
     "  -device N  -chain N            GPU and Philox sub-key of the chain (extensions)\n"
     "  -compat                        reference-compatible mode: the reference's mt19937 stream, libm arithmetic and\n"
     "                                 summation orders on the GPU - the same files as the reference for the same -R\n"
-    "                                 (univariate models; one lane walks the blocks: for traces up to ~10^6 positions)\n"
+    "                                 (any model the default path takes: up to 64 states, -s C P D; about a hundred times\n"
+    "                                 slower per sweep than the default path, ten times faster than the reference)\n"
     "  -chains N                      N independent chains, one per GPU, marginals pooled over RCCL (extension);\n"
     "                                 chains beyond the number of GPUs share a GPU and the construction it holds.\n"
     "                                 The pooled marginals / maxsegmentation files use common labels (states by\n"
@@ -347,12 +348,7 @@ int main(int argc, const char* argv[]) {
         }
         Mapping mapping(nrDataDim, nrParams, combinations);
         const size_t nrStates = mapping.nrStates();
-        // more than 16 states: the library's default path is compiled for 2 .. 16; its reference-compatible mode takes any number
-        // up to 64 (the reference's own chain, see -compat), so such a model runs there
-        if (nrStates > 16 && !args.isSet("-compat")) {
-            setenv("HML_COMPAT", "1", 1);
-            if (verbose) cout << "More than 16 states: running in the reference-compatible mode (-compat)." << endl;
-        }
+        // (more than 16 states: the library's default path takes the number of states at run time there - hml_k_wide.h - up to 64)
 
         // first token = off-diagonal, second = diagonal (reference main.cpp:144-149)
         const real_t trans = args.parse<real_t>("-t", 0);

@@ -178,10 +178,9 @@ int hml_set_option(hml_ctx* ctx, const char* name, int value);
  * `rng_t RNG(seed)` (src/main.cpp:107-108) and consumed in its order, glibc's expf / logf / powf bit for bit
  * (hml_math_glibc.h), float Kahan sums in block order, `size_t += float` counts - so that a run with the reference's
  * seed leaves the reference's states, parameters and marginals.  The order-dependent part of a sweep keeps the reference's
- * order but runs in chunks that are checked against each other (hml_k_compat.h; 6.7 ms per sweep of config 3's 1.8 10^5 blocks -
- * fifteen times the reference binary on one core; the default path is the fast one: 0.056 ms).  The number of
- * states is a run-time value in this mode, so it also takes the models the default path is not compiled for: 2 .. 64 states
- * (hml_set_model refuses more than 16 without it).  Environment: HML_COMPAT. */
+ * order but runs in chunks that are checked against each other (hml_k_compat.h; a few milliseconds per sweep of config 3's
+ * 1.8 10^5 blocks - the default path is the fast one: 0.056 ms).  2 .. 64 states, like the default path (which takes the
+ * number of states as a run-time value from 17 states on: hml_k_wide.h).  Environment: HML_COMPAT. */
 
 /* hml_iterate for SEVERAL chains at once: `iterations` sweeps of every chain, sweep i of all chains before sweep i + 1.
  * Chains that live on one device, have the same shape (positions, states) and are in the strongly compressed regime of a

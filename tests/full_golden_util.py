@@ -12,6 +12,19 @@ with open(os.path.join(FULL, "manifest.json")) as f:
     MANIFEST = json.load(f)
 
 
+def matches_golden(case, output, path):
+    """does the file at `path` hold the bytes the reference binary wrote?  (a file above 256 MB would be kept as its checksum)"""
+    e = MANIFEST[case]["files"][output]
+    if e["file"] is not None:
+        with open(path, "rb") as f:
+            return f.read() == golden_bytes(case, output)
+    h = hashlib.sha256()
+    with open(path, "rb") as f:
+        for piece in iter(lambda: f.read(1 << 24), b""):
+            h.update(piece)
+    return os.path.getsize(path) == e["bytes"] and h.hexdigest() == e["sha256"]
+
+
 def golden_bytes(case, output):
     """the reference's file as it was written (stored xz-compressed above 1 MB)"""
     e = MANIFEST[case]["files"][output]

@@ -12,20 +12,24 @@ from tests.test_gpu_parity import run_both
 
 ENV_KEYS = ("HML_DENSE_MIN_BLOCKS", "HML_FWD_CHUNK_DENSE", "HML_TRELLIS_FUSED", "HML_TRELLIS_L", "HML_TRELLIS_ROWS", "HML_TRELLIS_CKPT",
             "HML_STAGE_BITS", "HML_FWD_WARMUP", "HML_LATE_RESCALE", "HML_FWD_CHUNK",
-            "HML_MANY_GROUPS", "HML_FUSED_MANY_SLOTS", "HML_MAX_BLOCKS", "HML_FWD_CHUNK_MANY", "HML_COMPAT_CHUNKS", "HML_COMPAT_WARMUP")
+            "HML_MANY_GROUPS", "HML_FUSED_MANY_SLOTS", "HML_MAX_BLOCKS", "HML_FWD_CHUNK_MANY", "HML_COMPAT_CHUNKS", "HML_COMPAT_WARMUP", "HML_WIDE", "HML_FM_SPLIT", "HML_FM_SPLIT_SUB")
 
 
-def fuzz(hml, n_cfg, seed, log=None, many=False, compat=False):
+def fuzz(hml, n_cfg, seed, log=None, many=False, compat=False, wide=False):
     """n_cfg random configurations; returns the number that ran identical (all, or an AssertionError names the first
     that differs).  The environment switches it sets are restored afterwards.  many: several chains through
     hml_iterate_many (_fuzz_many) instead of one through hml_iterate.  compat: the reference-compatible mode against the
     checker's REFERENCE mode (mt19937, libm, Kahan sums, size_t += float) - up to 64 states, chunk geometries that force
-    wrong chunks."""
+    wrong chunks.  wide: the default path's kernels for more than 16 states (hml_k_wide.h: the number of states at run time, a
+    state a lane) against the checker's device mode - 2-64 states (HML_WIDE=1 sends models of up to 16 states there too), the
+    same chunk geometries."""
     saved = {k: os.environ.get(k) for k in ENV_KEYS}
     try:
         if many:
             return _fuzz_many(hml, n_cfg, seed, log or (lambda *a, **k: None))
-        return _fuzz(hml, n_cfg, seed, log or (lambda *a, **k: None), compat=compat)
+        if wide:
+            os.environ["HML_WIDE"] = "1"
+        return _fuzz(hml, n_cfg, seed, log or (lambda *a, **k: None), compat=compat, wide=wide)
     finally:
         for k, v in saved.items():
             if v is None:
@@ -34,7 +38,7 @@ def fuzz(hml, n_cfg, seed, log=None, many=False, compat=False):
                 os.environ[k] = v
 
 
-def _fuzz(hml, n_cfg, seed, log, compat=False):
+def _fuzz(hml, n_cfg, seed, log, compat=False, wide=False):
     rng = np.random.default_rng(seed)
     bits = lambda a: np.ascontiguousarray(a, np.float32).view(np.uint32)
     t_start = time.time()
@@ -43,10 +47,10 @@ def _fuzz(hml, n_cfg, seed, log, compat=False):
         D = int(rng.choice([1, 1, 1, 2, 2, 3]))
         if D == 1:
             P = None; K = int(rng.integers(2, 17))
-            if compat and rng.random() < 0.3:
+            if (compat and rng.random() < 0.3) or (wide and rng.random() < 0.5):
                 K = int(rng.choice([17, 20, 31, 32, 33, 48, 64]))
         else:
-            P = int(rng.choice(([2, 3, 4, 5, 7] if compat else [2, 3, 4]) if D == 2 else ([2, 3] if compat else [2]))); K = P ** D
+            P = int(rng.choice(([2, 3, 4, 5, 7] if (compat or wide) else [2, 3, 4]) if D == 2 else ([2, 3] if (compat or wide) else [2]))); K = P ** D
         T = int(rng.choice([17, 1000, 4097, 30000, 65535, 65537, 120000, 300000]))
         if K > 8 or D > 1:
             T = min(T, 120000)
@@ -68,7 +72,7 @@ def _fuzz(hml, n_cfg, seed, log, compat=False):
         else: os.environ.pop("HML_FWD_WARMUP", None)
         os.environ["HML_LATE_RESCALE"] = str(int(rng.choice([1, 1, 0])))
         os.environ["HML_FWD_CHUNK"] = str(int(rng.choice([4, 4, 1, 2, 8])))
-        if compat:   # chunks of the filter / backward draws: the default, the sequential form, many chunks with hardly any warm-up
+        if compat or wide:   # chunks of the filter / backward draws: the default, the sequential form, many chunks with hardly any warm-up
             _setenv("HML_COMPAT_CHUNKS", rng.choice([None, None, 1, 7, 60, 500]))
             _setenv("HML_COMPAT_WARMUP", rng.choice([None, None, -1, 1, 4]))
             if K > 16:
@@ -155,7 +159,9 @@ def _fuzz_many(hml, n_cfg, seed, log):
         env = {"HML_MANY_GROUPS": rng.choice([None, None, 1, 2, 3, 4]), "HML_FUSED_MANY_SLOTS": rng.choice([None, None, None, 2, 5]),
                "HML_MAX_BLOCKS": rng.choice([None, None, 64]), "HML_FWD_CHUNK_MANY": rng.choice([None, None, 4, 16]),
                "HML_DENSE_MIN_BLOCKS": rng.choice([1 << 22, 1 << 22, 1 << 22, 400]), "HML_LATE_RESCALE": rng.choice([1, 1, 0]),
-               "HML_FWD_WARMUP": rng.choice([None, None, 4, 8])}
+               "HML_FWD_WARMUP": rng.choice([None, None, 4, 8]),
+               # round 5: the block structure of attached chains in two launches (the default) or by the fused kernel; tiles of several batches
+               "HML_FM_SPLIT": rng.choice([None, None, 1, 0]), "HML_FM_SPLIT_SUB": rng.choice([None, None, 2, 4])}
         for k, v in env.items():
             _setenv(k, v)
         seed_c = int(rng.integers(0, 1 << 30))

@@ -27,5 +27,4 @@ def test_cli_compat_writes_the_full_size_reference_files(case):
                            capture_output=True, text=True)
         assert r.returncode == 0, r.stderr
         for o in m["outputs"]:
-            with open(os.path.join(tmp, "g-%s.csv" % o), "rb") as f:
-                assert f.read() == fg.golden_bytes(case, o), (case, o)
+            assert fg.matches_golden(case, o, os.path.join(tmp, "g-%s.csv" % o)), (case, o)

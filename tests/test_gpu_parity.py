@@ -12,7 +12,7 @@ def bits(a):
 
 
 def make_pair(hml, T, K, data_seed, seed, chain=0, x=None, weight_keys=None, **kw):
-    x = ol.trace(T, K, data_seed) if x is None else x
+    x = ol.trace(T, K if K in ol.LEVELS else 6, data_seed) if x is None else x   # (models of more states than the trace has levels)
     o = ol.OracleChain(K=K, seed=seed, chain=chain, rng=ol.RNG_CTR, math=ol.MATH_DEV, reduce=ol.REDUCE_DEV, **kw)
     o.load(x)
     g = hml.Chain(device=0, seed=seed, chain_id=chain)
@@ -115,6 +115,15 @@ def compare_state(o, g, what=""):
     (1000, 3, [("M", 5, 1), ("F", 20, 1)]),
     (4096, 3, [("F", 20, 1)]),
     (65537, 3, [("F", 20, 2)]),
+    # more than 16 states (round 5): the default path with the number of states as a run-time value, a state a lane (hml_k_wide.h);
+    # the reference takes any `-s K` (src/main.cpp:112-137)
+    (60000, 17, [("F", 8, 2)]),
+    (60000, 20, [("F", 12, 3)]),
+    (30000, 20, [("M", 6, 2), "S", "P", ("F", 6, 0), ("F", 6, 3), "D", ("F", 4, 1)]),
+    (40000, 33, [("F", 6, 2)]),
+    (30000, 40, [("M", 4, 1), "S", "P", ("F", 8, 2), "D", ("F", 3, 1)]),
+    (20000, 64, [("F", 6, 1)]),
+    (300000, 24, [("F", 10, 5)]),       # enough blocks for the chunked form: chunks checked against each other
 ])
 def test_sweeps_match_checker(hml, T, K, scheme):
     """Whole sweeps (a7-a17): blocks, states, parameters and marginals equal the checker's, bit for bit."""
@@ -152,6 +161,8 @@ EMISSION_TOLERANCE = 1e-6    # BASELINE.json north_star: "emission log-likelihoo
     ("c22_multivariate", 60000, 4, "gauss", 2, False, 1),
     ("k5_static_blocks", 100000, 5, "gauss", 1, True, 1),
     ("k5_gauss_settled", 200000, 5, "gauss", 1, False, 20),
+    ("k20_gauss_wide_path", 100000, 20, "gauss", 1, False, 1),
+    ("k40_gauss_wide_path_settled", 60000, 40, "gauss", 1, False, 8),
 ])
 def test_first_sweep_probes(hml, case, T, K, kind, dims, static, sweeps):
     """Kernel-level probes: E_s bit-exact vs the checker in device-math mode, within 1e-6 relative of the
@@ -164,7 +175,7 @@ def test_first_sweep_probes(hml, case, T, K, kind, dims, static, sweeps):
     gpurun_out/r5_emission_tolerance.json (reported in BASELINE.md)."""
     import json
     import os
-    levels = K if dims == 1 and kind == "gauss" else 2 if dims > 1 else 5
+    levels = (K if K in ol.LEVELS else 6) if dims == 1 and kind == "gauss" else 2 if dims > 1 else 5
     x = _probe_trace(kind, T, levels, dims)
     P = 2 if dims > 1 else 0
     o = ol.OracleChain(K=K, seed=3, rng=ol.RNG_CTR, math=ol.MATH_DEV, reduce=ol.REDUCE_DEV)
@@ -515,11 +526,12 @@ def test_batched_chains_are_the_chains_run_alone(hml, K, n_chains):
         g.close()
 
 
+@pytest.mark.parametrize("split", [1, 0])
 @pytest.mark.parametrize("K,n_chains,T,slots,spin,groups", [(5, 8, 300_000, None, None, None), (3, 2, 300_000, None, None, None), (10, 3, 200_000, None, None, None),
                                                             (5, 9, 140_000, None, None, None), (4, 3, 1_200_000, 3, None, None), (5, 4, 300_000, None, 0, None),
                                                             (16, 2, 70_000, None, None, None), (5, 7, 200_000, None, None, 1), (5, 7, 200_000, None, None, 3),
                                                             (4, 5, 150_000, None, None, 4), (5, 18, 100_000, None, None, 2), (3, 36, 40_000, None, None, 2), (5, 17, 60_000, None, None, 1)])
-def test_attached_chains_batched_through_the_many_chain_block_kernel(hml, monkeypatch, K, n_chains, T, slots, spin, groups):
+def test_attached_chains_batched_through_the_many_chain_block_kernel(hml, monkeypatch, K, n_chains, T, slots, spin, groups, split):
     """hml_attach_observations + hml_iterate_many: chains that share ONE construction (weights, summary, integral array)
     take hml_m_blocks_fused (hml_k_blocks_fused_many.h) - block starts, block statistics and emission terms of all chains
     from one pass over the shared trace - and every chain must stay, bit for bit, the chain the checker runs alone:
@@ -527,11 +539,18 @@ def test_attached_chains_batched_through_the_many_chain_block_kernel(hml, monkey
     forces n_sub > 1), every tile word computed by the waiting workgroup (spin limit 0), integral-array cells crossed.
     The batch runs as groups of chains on streams of their own (two by default; HML_MANY_GROUPS): one group, three and four
     uneven ones, eighteen chains (groups of nine: two launches of the block kernel each), and groups of eighteen and seventeen
-    chains: the other kernels take up to sixteen chains per launch (their pointers travel as a kernel argument)."""
+    chains: the other kernels take up to sixteen chains per launch (their pointers travel as a kernel argument).
+    split = 1 (round 5, the default): the block structure in TWO launches no workgroup waits in - hml_m_blocks_list +
+    hml_m_blocks_emit (hml_k_blocks_split_many.h), up to sixteen chains per launch; `slots` then stands for tiles of several
+    batches (HML_FM_SPLIT_SUB).  split = 0: the fused kernel."""
+    monkeypatch.setenv("HML_FM_SPLIT", str(split))
+    if split and spin is not None:
+        pytest.skip("the bounded wait belongs to the fused kernel")
     if groups is not None:
         monkeypatch.setenv("HML_MANY_GROUPS", str(groups))
     if slots is not None:
         monkeypatch.setenv("HML_FUSED_MANY_SLOTS", str(slots))
+        monkeypatch.setenv("HML_FM_SPLIT_SUB", "3")
     if spin is not None:
         monkeypatch.setenv("HML_FUSED_SPIN_LIMIT", str(spin))
         monkeypatch.setenv("HML_FUSED_BLOCKS", "2")   # keep the kernel although every wait "expires"

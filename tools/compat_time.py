@@ -1,4 +1,4 @@
-"""Time of a sweep of the reference-compatible mode (option "compat"): python tools/r4_compat_time.py [workload] [sweeps]   (BURNIN=n sweeps first)"""
+"""Time of a sweep of the reference-compatible mode (option "compat"): python tools/compat_time.py [workload] [sweeps]   (BURNIN=n sweeps first)"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench, hammlet_amd
