@@ -257,7 +257,7 @@ static int alloc_block_buffers(hml_ctx* c) {
         const uint64_t n_tiles = (T + HML_FUSED_SUB_POSITIONS - 1) / HML_FUSED_SUB_POSITIONS;   // (tiles of one batch: the most there can be)
         HIPCHK(hipMalloc(&c->d_group_word, (n_tiles + 1) * sizeof(unsigned long long)));
         HIPCHK(hipMemsetAsync(c->d_group_word, 0, (n_tiles + 1) * sizeof(unsigned long long), c->stream));
-        HIPCHK(hipMalloc(&c->d_wave_total, (n_tiles + 1) * HML_FUSED_WAVES * sizeof(uint32_t)));
+        HIPCHK(hipMalloc(&c->d_wave_total, (n_tiles + 1) * (HML_FUSED_WAVES + 2) * sizeof(uint32_t)));   // (+ tile_before, tile_prev)
         if (getenv("HML_FUSED_DEBUG")) { HIPCHK(hipMalloc(&c->d_dbg, 4096 * 8 * 8)); HIPCHK(hipMemset(c->d_dbg, 0, 4096 * 8 * 8)); }
     }
     HIPCHK(hipMalloc(&c->d_bstat, c->cap * (uint64_t)c->D * sizeof(float2)));   // (D > 1: cap = T, the planes lie T apart)
@@ -572,6 +572,10 @@ int hml_autoprior(hml_ctx* c, float s2, float p, float out4[4]) {
 
 }  // extern "C"
 
+// entries of one array of the reference-compatible mode's lists by state (hml_compat_lists): the blocks and up to three entries of
+// padding per state, rounded to whole 16-byte groups
+static uint64_t compat_list_entries(const hml_ctx* c) { return (c->cap + 4u * (uint64_t)HML_CAP_K + 3u) & ~(uint64_t)3u; }
+
 // the per-block sweep buffers, sized by the context's block capacity (hml_ctx.hpp; c->K set)
 static int alloc_sweep_buffers(hml_ctx* c) {
     const int K = c->K;
@@ -584,8 +588,9 @@ static int alloc_sweep_buffers(hml_ctx* c) {
         HIPCHK(hipMalloc(&c->d_cchunk, (uint64_t)HML_COMPAT_MAX_CHUNKS * (2 * K * sizeof(float) + 4 * sizeof(uint32_t))));
         HIPCHK(hipMalloc(&c->d_cdraws, 2 * cap * sizeof(uint32_t)));
         // the count pass's lists by state (hml_compat_lists): statistics, sizes, per-tile counts, flags
-        HIPCHK(hipMalloc(&c->d_clists, cap * sizeof(float4) + (uint64_t)HML_CAP_K * HML_CAP_K * sizeof(unsigned long long) +
-                                        ((cap + HML_COMPAT_PART_TILE - 1) / HML_COMPAT_PART_TILE) * K * sizeof(uint32_t) + (HML_CAP_K + 1) * sizeof(uint32_t) + 64));
+        // (three arrays of cap + 4 K entries, each 16-byte aligned: a state's list starts at a multiple of four entries)
+        HIPCHK(hipMalloc(&c->d_clists, 3 * compat_list_entries(c) * sizeof(uint32_t) + (uint64_t)HML_CAP_K * HML_CAP_K * sizeof(unsigned long long) +
+                                        ((cap + HML_COMPAT_PART_TILE - 1) / HML_COMPAT_PART_TILE) * K * sizeof(uint32_t) + 2 * (HML_CAP_K + 1) * sizeof(uint32_t) + 64));
         HIPCHK(hipMalloc(&c->d_q, cap * sizeof(int16_t)));
         return 0;
     }
@@ -975,15 +980,15 @@ static int sweep_compat(hml_ctx* c, char method, bool record) {
     {
         const uint64_t tiles = (c->cap + HML_COMPAT_PART_TILE - 1) / HML_COMPAT_PART_TILE;
         char* base = (char*)c->d_clists;
-        pl.sx = (float*)base; base += c->cap * sizeof(float);
-        pl.sq = (float*)base; base += c->cap * sizeof(float);
-        pl.n = (uint32_t*)base; base += c->cap * sizeof(uint32_t);
-        pl.same = (uint32_t*)base; base += c->cap * sizeof(uint32_t);
+        pl.sx = (float*)base; base += compat_list_entries(c) * sizeof(float);
+        pl.sq = (float*)base; base += compat_list_entries(c) * sizeof(float);
+        pl.n = (uint32_t*)base; base += compat_list_entries(c) * sizeof(uint32_t);
         pl.offdiag = (unsigned long long*)base; base += (uint64_t)HML_CAP_K * HML_CAP_K * sizeof(unsigned long long);
         pl.tile_count = (uint32_t*)base; base += tiles * c->K * sizeof(uint32_t);
         pl.state_off = (uint32_t*)base;
     }
-    const int by_state = (c->D == 1 && (c->compat_chunks > 1 || (c->compat_chunks == 0 && hint >= 8192u))) ? 1 : 0;
+    // (by state: a block's size and a flag share a word of the lists - traces below 2^31 positions)
+    const int by_state = (c->D == 1 && c->T < (1ull << 31) && (c->compat_chunks > 1 || (c->compat_chunks == 0 && hint >= 8192u))) ? 1 : 0;
     if (by_state) {
         const unsigned tiles_now = (unsigned)(((uint64_t)hint + hint / 8 + HML_COMPAT_PART_TILE) / HML_COMPAT_PART_TILE);   // (kernels find B themselves; tiles beyond it return)
         const unsigned tg = std::min<uint64_t>(std::max(1u, tiles_now), (c->cap + HML_COMPAT_PART_TILE - 1) / HML_COMPAT_PART_TILE);

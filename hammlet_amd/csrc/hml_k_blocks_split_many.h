@@ -11,9 +11,12 @@
 //                          wavefront's part of the tile, all of them in the chain's staging array - their count per wavefront and
 //                          the tile's word {generation, starts, last start}; up to SIXTEEN chains share one pass over the summary
 //                          and the opened groups' weights;
-//   hml_m_blocks_emit<K>   per tile: the words of the tiles before it (all there: a launch boundary lies between), then the
-//                          items - one per block - of all chains in one sequence: integral-array gathers two items ahead,
-//                          statistics, emission terms, stores.
+//   hml_m_blocks_offsets   one workgroup per chain: the exclusive prefix of the tiles' words - blocks before every tile, the last start
+//                          before it - and the chain's block count (or its halt, hml_state.h);
+//   hml_m_blocks_emit<K>   per tile the items - one per block - of all chains in one sequence, FOUR per thread and round: their
+//                          starts (staging array) requested together, then their integral-array gathers together, then
+//                          statistics, emission terms, stores.  A workgroup's life is five memory round trips however many
+//                          chains it serves (the fused kernel: the hand-off, then two dependent round trips per pair of items).
 // No workgroup waits for another, no grid has to be resident, tiles are always 2^17 positions.  Per chain the same block
 // starts, statistics and terms as hml_m_blocks_fused / hml_k_blocks_fused, bit for bit (tests: test_gpu_parity.py
 // test_attached_chains_batched..., test_gpu_fuzz.py test_bounded_fuzz_of_batched_chains; HML_FM_SPLIT=0 takes the fused kernel).
@@ -30,6 +33,8 @@ struct hml_fs_chain {
     hml_model* mdl;
     unsigned long long* group_word;   // [tiles] {generation, starts, last start} (hml_group_word)
     uint32_t* wave_total;             // [tiles * 8] starts per wavefront of a tile
+    uint32_t* tile_before;            // [tiles] block starts in the tiles before (hml_m_blocks_offsets)
+    uint32_t* tile_prev;              // [tiles] position of the last start before the tile
     uint16_t* stage;                  // [T] the starts of wavefront v of tile g: offsets into its part, from (g * 8 + v) * part on
     uint32_t* starts;
     float2* bstat;
@@ -39,7 +44,7 @@ struct hml_fs_chain {
     hml_layout lay;
 };
 struct hml_fs_args { hml_fs_chain c[HML_FS_MAX_CHAINS]; };
-static_assert(sizeof(hml_fs_args) + 128 <= 4096, "kernel arguments");
+static_assert(sizeof(hml_fs_args) + 64 <= 4096, "kernel arguments");
 
 HML_KERNEL __launch_bounds__(HML_FUSED_WAVES * 64) void hml_m_blocks_list(const uint8_t* __restrict__ summary, const float* __restrict__ w, uint32_t T,
                                                                            int32_t base, const hml_fs_args args, int n, uint32_t n_sub) {
@@ -201,6 +206,61 @@ HML_KERNEL __launch_bounds__(HML_FUSED_WAVES * 64) void hml_m_blocks_list(const 
     }
 }
 
+// One workgroup per chain (blockIdx.y): tile_before[g] = block starts in tiles 0 .. g - 1, tile_prev[g] = position of the last start
+// before tile g, and the chain's block count - or its halt when the blocks outgrow its buffers (hml_state.h).
+HML_KERNEL __launch_bounds__(1024) void hml_m_blocks_offsets(const hml_fs_args args, uint32_t n_tiles, uint32_t n_sub) {
+    __shared__ uint32_t w_sum[16];
+    __shared__ unsigned long long w_near[16];
+    const hml_fs_chain& ch = args.c[blockIdx.y];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t tile_positions = n_sub * (uint32_t)HML_FUSED_SUB_POSITIONS;
+    const uint32_t per = (n_tiles + 1023u) / 1024u;
+    const uint32_t a = (uint32_t)tid * per < n_tiles ? (uint32_t)tid * per : n_tiles;
+    const uint32_t b = (a + per < n_tiles) ? a + per : n_tiles;
+    // this thread's tiles: their starts, and (1 + tile) << POS_BITS | last start's offset of the last non-empty one
+    uint32_t sum = 0u;
+    unsigned long long near = 0ull;
+    for (uint32_t g = a; g < b; ++g) {
+        const unsigned long long d = ch.group_word[g];
+        const uint32_t tot = (uint32_t)(d >> HML_FUSED_POS_BITS) & ((2u << HML_FUSED_POS_BITS) - 1u);
+        sum += tot;
+        if (tot) near = ((unsigned long long)(g + 1u) << HML_FUSED_POS_BITS) | (d & ((1ull << HML_FUSED_POS_BITS) - 1ull));
+    }
+    // exclusive scan over the threads: sums add, `near` takes the later one (keys grow with the tile)
+    uint32_t isum = sum;
+    unsigned long long inear = near;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t os = __shfl_up(isum, d);
+        const unsigned long long on = __shfl_up(inear, d);
+        if (lane >= d) { isum += os; inear = on > inear ? on : inear; }
+    }
+    if (lane == 63) { w_sum[wave] = isum; w_near[wave] = inear; }
+    __syncthreads();
+    uint32_t before = isum - sum;
+    unsigned long long prev = __shfl_up(inear, 1);
+    if (lane == 0) prev = 0ull;
+    for (int wv = 0; wv < wave; ++wv) { before += w_sum[wv]; prev = w_near[wv] > prev ? w_near[wv] : prev; }
+    for (uint32_t g = a; g < b; ++g) {
+        const unsigned long long d = ch.group_word[g];
+        const uint32_t tot = (uint32_t)(d >> HML_FUSED_POS_BITS) & ((2u << HML_FUSED_POS_BITS) - 1u);
+        ch.tile_before[g] = before;
+        ch.tile_prev[g] = prev ? (uint32_t)(((prev >> HML_FUSED_POS_BITS) - 1ull) * tile_positions + (prev & ((1ull << HML_FUSED_POS_BITS) - 1ull))) : 0u;
+        before += tot;
+        if (tot) prev = ((unsigned long long)(g + 1u) << HML_FUSED_POS_BITS) | (d & ((1ull << HML_FUSED_POS_BITS) - 1ull));
+    }
+    if (tid == 1023) {   // (the last thread's range ends at the last tile: `before` is the number of starts = blocks)
+        const uint32_t Bn = before;
+        const uint32_t cap = ch.mdl->cap;
+        if (Bn > cap) hml_halt(ch.mdl, Bn, ch.host_words);
+        else {
+            ch.mdl->B = Bn;
+            hml_warmup_for_many_blocks(ch.mdl, Bn);
+            if (ch.host_words) __hip_atomic_store(ch.host_words, Bn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
+
 template <int K>
 HML_KERNEL __launch_bounds__(HML_FUSED_WAVES * 64, HML_FM_MIN_WAVES) void hml_m_blocks_emit(const float2* __restrict__ ia, uint32_t T, const hml_fs_args args, int n,
                                                                                             uint32_t n_sub) {
@@ -225,7 +285,10 @@ HML_KERNEL __launch_bounds__(HML_FUSED_WAVES * 64, HML_FM_MIN_WAVES) void hml_m_
         const hml_model* m = args.c[c].mdl;
         hml_emit_lds_fill<K>(sm_emit[c].plain, m, lane);
         hml_tr2_params_fill<K>(sm_emit[c].fast, m, lane);
-        if (lane == 0) { s_self[c] = m->self_trans; s_cap[c] = m->cap; s_ch[c] = args.c[c]; }
+        if (lane == 0) {
+            s_self[c] = m->self_trans; s_cap[c] = m->cap; s_ch[c] = args.c[c];
+            s_before[c] = args.c[c].tile_before[g]; s_prev_start[c] = args.c[c].tile_prev[g];
+        }
         if (lane < NW) wave_total[c][lane] = args.c[c].wave_total[(uint64_t)g * NW + lane];
     }
     __syncthreads();
@@ -241,52 +304,7 @@ HML_KERNEL __launch_bounds__(HML_FUSED_WAVES * 64, HML_FM_MIN_WAVES) void hml_m_
         }
         s_item0[n] = run;
     }
-    // ---------------- offsets: per chain the sum of the words of all earlier tiles and the last start before this tile (wavefront w:
-    // chains w, w + 8, ...; a lane takes tiles lane, lane + 64, ..., four loads in flight)
-#pragma unroll 1
-    for (int c = wave; c < n; c += NW) {
-        const unsigned long long* const gword = s_ch[c].group_word;
-        uint32_t acc = 0u;
-        unsigned long long near = 0ull;   // (1 + tile index) << POS_BITS | last_rel of the last non-empty earlier tile
-        for (uint32_t i0 = (uint32_t)lane; i0 < g; i0 += 256u) {
-            unsigned long long d[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const uint32_t i = i0 + 64u * (uint32_t)u;
-                d[u] = (i < g) ? gword[i] : 0ull;
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const uint32_t i = i0 + 64u * (uint32_t)u;
-                if (i >= g) break;   // (i grows with u)
-                const uint32_t tot = (uint32_t)(d[u] >> HML_FUSED_POS_BITS) & ((2u << HML_FUSED_POS_BITS) - 1u);
-                acc += tot;
-                if (tot) near = ((unsigned long long)(i + 1u) << HML_FUSED_POS_BITS) | (d[u] & ((1ull << HML_FUSED_POS_BITS) - 1ull));   // i grows within a lane
-            }
-        }
-#pragma unroll
-        for (int m = 1; m < 64; m <<= 1) {
-            acc += __shfl_xor(acc, m);
-            const unsigned long long o = __shfl_xor(near, m);
-            near = o > near ? o : near;
-        }
-        if (lane == 0) {
-            s_before[c] = acc;
-            // global position of the last start before this tile (tile 0 holds position 0, so it exists for g > 0)
-            s_prev_start[c] = near ? (uint32_t)(((near >> HML_FUSED_POS_BITS) - 1ull) * tile_positions + (near & ((1ull << HML_FUSED_POS_BITS) - 1ull))) : 0u;
-        }
-    }
     __syncthreads();
-    if (last_wg && threadIdx.x < (uint32_t)n) {   // the block count
-        const int c = (int)threadIdx.x;
-        const uint32_t Bn = s_before[c] + (s_item0[c + 1] - s_item0[c] - 1u);
-        if (Bn > s_cap[c]) hml_halt(s_ch[c].mdl, Bn, s_ch[c].host_words);
-        else {
-            s_ch[c].mdl->B = Bn;
-            hml_warmup_for_many_blocks(s_ch[c].mdl, Bn);
-            if (s_ch[c].host_words) __hip_atomic_store(s_ch[c].host_words, Bn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        }
-    }
     // the k-th start of the workgroup in chain c, as a global position (k < the chain's total); idx_out: its index in its wavefront's list
     auto start_at2 = [&](int c, uint32_t k, uint32_t& wv_out, uint32_t& idx_out) -> uint32_t {
         uint32_t wv = 0u, first = 0u, run = 0u;
@@ -339,22 +357,24 @@ HML_KERNEL __launch_bounds__(HML_FUSED_WAVES * 64, HML_FM_MIN_WAVES) void hml_m_
         ch.bstat[b - 1u] = make_float2(sx, sq);
         hml_fm_emit<K>(sm_emit[it.c], s_self[it.c] != 0, ch.mdl, b - 1u, sx, sq, (float)(it.t - it.prev), ch.em, ch.gsc, ch.lay, sm_exp_tab);
     };
-    // ---------------- items: two per round, the next round's gathers under way
-    item_t it0, it1;
-    it0.t = 0u; it0.k = 0u; it0.c = 0u; it0.prev = 0u; it0.ax = it0.ay = it0.zx = it0.zy = 0.0f;
-    it1 = it0;
-    if (threadIdx.x < total_items) { locate(threadIdx.x, it0); request(it0); }
-    if (threadIdx.x + NT < total_items) { locate(threadIdx.x + NT, it1); request(it1); }
+    // ---------------- items: four per thread and round - locate all (their staging loads travel together), gather all, finish all
+    constexpr int NI = 4;
 #pragma unroll 1
-    for (uint32_t j = threadIdx.x; j < total_items; j += 2u * NT) {
-        item_t n0, n1;
-        n0 = it0; n1 = it1;
-        const uint32_t ja = j + 2u * NT, jb = j + 3u * NT;
-        if (ja < total_items) { locate(ja, n0); request(n0); }
-        if (jb < total_items) { locate(jb, n1); request(n1); }
-        finish(it0);
-        if (j + NT < total_items) finish(it1);
-        it0 = n0; it1 = n1;
+    for (uint32_t j0 = threadIdx.x; j0 < total_items; j0 += (uint32_t)NI * NT) {
+        item_t it[NI];
+#pragma unroll
+        for (int u = 0; u < NI; ++u) {
+            const uint32_t j = j0 + (uint32_t)u * NT;
+            it[u].t = 0u; it[u].k = 0u; it[u].c = 0u; it[u].prev = 0u;
+            if (j < total_items) locate(j, it[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < NI; ++u) {
+            it[u].ax = it[u].ay = it[u].zx = it[u].zy = 0.0f;
+            if (j0 + (uint32_t)u * NT < total_items) request(it[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < NI; ++u) if (j0 + (uint32_t)u * NT < total_items) finish(it[u]);
     }
 }
 

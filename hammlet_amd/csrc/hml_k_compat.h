@@ -831,14 +831,16 @@ HML_KERNEL __launch_bounds__(64) void hml_k_compat_mixture(hml_model* __restrict
 #define HML_COMPAT_PART_TILE 4096
 struct hml_compat_lists {
     uint32_t* tile_count;   // [tiles][K] blocks of state s in the tile, then their exclusive prefix over the tiles
-    uint32_t* state_off;    // [K + 1] first list position of state s
+    uint32_t* state_off;    // [2 (K + 1)] first list position of state s (a multiple of four), then from K + 1 on the length of its list
     unsigned long long* offdiag;   // [K * K] transitions between different states
     // per list position, one array per quantity (round 5: each of the four wavefronts of the walk reads only what its chain adds -
     // sixteen entries are one 64-byte run per lane and array where they were sixteen 16-byte structures):
-    float* sx;              // [B] the block's Sx
-    float* sq;              // [B] the block's Sxx
-    uint32_t* n;            // [B] its size
-    uint32_t* same;         // [B] 1 if the block before it has the same state (prev_0 = 0, ForwardBackward.hpp:172)
+    float* sx;              // the block's Sx
+    float* sq;              // the block's Sxx
+    uint32_t* n;            // its size (below 2^31: the host takes the walk in block order for longer traces) and, in bit 31, whether
+                            // the block before it has the same state (prev_0 = 0, ForwardBackward.hpp:172)
+    // (every state's list starts at a multiple of four entries and the arrays are 16-byte aligned: four entries are one load;
+    // the arrays hold B + 4 K entries)
 };
 HML_KERNEL __launch_bounds__(256) void hml_k_compat_part_count(const hml_model* __restrict__ mdl, const int16_t* __restrict__ q, const hml_compat_lists pl) {
     __shared__ uint32_t h[HML_CAP_K];
@@ -875,8 +877,13 @@ HML_KERNEL __launch_bounds__(64) void hml_k_compat_part_scan(const hml_model* __
     // first list position of every state: exclusive prefix of the totals over the states
     uint32_t incl = run;
     for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(incl, d); if (lane >= d) incl += o; }
-    if (lane < K) pl.state_off[lane] = incl - run;
-    if (lane == K - 1) pl.state_off[K] = incl;
+    // (lists start at multiples of four entries: at most 3 K entries of padding - the exclusive prefix of the rounded lengths)
+    const uint32_t padded = (lane < K) ? ((run + 3u) & ~3u) : 0u;
+    uint32_t pincl = padded;
+    for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(pincl, d); if (lane >= d) pincl += o; }
+    (void)incl;
+    if (lane < K) { pl.state_off[lane] = pincl - padded; pl.state_off[K + 1 + lane] = run; }
+    if (lane == K - 1) pl.state_off[K] = pincl;
 }
 HML_KERNEL __launch_bounds__(256) void hml_k_compat_part_scatter(const hml_model* __restrict__ mdl, const int16_t* __restrict__ q, const uint32_t* __restrict__ starts,
                                                                  const float2* __restrict__ bstat, const hml_compat_lists pl) {
@@ -911,7 +918,7 @@ HML_KERNEL __launch_bounds__(256) void hml_k_compat_part_scatter(const hml_model
             uint32_t pos = cnt[s] + rank;
             for (int w2 = 0; w2 < wave; ++w2) pos += pw[w2][s];
             const float2 st = bstat[b];
-            pl.sx[pos] = st.x; pl.sq[pos] = st.y; pl.n[pos] = starts[b + 1u] - starts[b]; pl.same[pos] = prev == s ? 1u : 0u;
+            pl.sx[pos] = st.x; pl.sq[pos] = st.y; pl.n[pos] = (starts[b + 1u] - starts[b]) | (prev == s ? 0x80000000u : 0u);
             if (prev != s) atomicAdd(&pl.offdiag[prev * K + s], 1ull);
         }
         __syncthreads();
@@ -924,51 +931,54 @@ HML_KERNEL __launch_bounds__(256) void hml_k_compat_part_scatter(const hml_model
     }
 }
 
-// A lane's list (hml_compat_lists: `cnt` entries from `off` on) walked in batches of NB entries with THREE batches of loads in
-// flight ahead of the one being added: step(a_i) or, TWO, step(a_i, b_i) in list order.  The walk is a chain of dependent
-// operations per entry, and what it used to wait for was memory (round 5): round 4 loaded one batch ahead, every load behind its
-// own `entry < count` test - divergent code, at whose end the compiler waits for all loads it issued - so each batch paid a whole
-// memory round trip (2.7 us per 32 entries, 5 ms per sweep of config 3).  The loads are now straight-line code: the index is
-// clamped into the lane's list instead of the load being skipped (a lane without a list reads entry 0 of the array), and only the
-// ADDITIONS of a lane's last batch are predicated.  `longest`: the longest list of the wavefront (wave-uniform trip count).
+// A lane's list (hml_compat_lists: `cnt` entries from `off` on, `off` a multiple of four) walked in batches of 16 entries - four
+// 16-byte loads - with SEVEN batches of loads in flight ahead of the one being added: step(entry) in list order.  The walk is a
+// chain of dependent operations per entry, and what it used to wait for was memory (round 5): round 4 loaded one batch ahead,
+// every load behind its own `entry < count` test - divergent code, at whose end the compiler waits for all loads it issued - so
+// each batch paid a whole memory round trip (2.7 us per 32 entries, 5 ms per sweep of config 3); with straight-line loads of
+// single words three batches ahead it still waited (96 cycles per entry: the lists come from the other end of the chip, 2 us
+// away).  The loads are straight-line code: the group of four is clamped into the lane's list instead of the load being skipped
+// (a lane without a list reads the array's first group), only the ADDITIONS of a lane's last batch are predicated.
+// `longest`: the longest list of the wavefront (wave-uniform trip count).
 #define HML_WALK_NB 16
-template <bool TWO>
-__device__ __forceinline__ void hml_compat_walk_fetch(const uint32_t* __restrict__ a, const uint32_t* __restrict__ b, uint32_t off, uint32_t last, uint32_t b0,
-                                                      uint32_t (&va)[HML_WALK_NB], uint32_t (&vb)[TWO ? HML_WALK_NB : 1]) {
+#define HML_WALK_DEPTH 8
+__device__ __forceinline__ void hml_compat_walk_fetch(const uint4* __restrict__ a4, uint32_t last4, uint32_t b0, uint4 (&v)[HML_WALK_NB / 4]) {
 #pragma unroll
-    for (int k = 0; k < HML_WALK_NB; ++k) {
-        const uint32_t i = b0 + (uint32_t)k;
-        const uint32_t at = off + (i < last ? i : last);
-        va[k] = a[at];
-        if (TWO) vb[k] = b[at];
+    for (int q = 0; q < HML_WALK_NB / 4; ++q) {
+        const uint32_t g4 = b0 / 4u + (uint32_t)q;
+        v[q] = a4[g4 < last4 ? g4 : last4];
     }
 }
-template <bool TWO, class Step>
-__device__ __forceinline__ void hml_compat_walk_batch(uint32_t cnt, uint32_t b0, const uint32_t (&va)[HML_WALK_NB], const uint32_t (&vb)[TWO ? HML_WALK_NB : 1], Step& step) {
+template <class Step>
+__device__ __forceinline__ void hml_compat_walk_batch(uint32_t cnt, uint32_t b0, const uint4 (&v)[HML_WALK_NB / 4], Step& step) {
     if (b0 + (uint32_t)HML_WALK_NB <= cnt) {
 #pragma unroll
-        for (int k = 0; k < HML_WALK_NB; ++k) step(va[k], vb[TWO ? k : 0]);
+        for (int q = 0; q < HML_WALK_NB / 4; ++q) { step(v[q].x); step(v[q].y); step(v[q].z); step(v[q].w); }
     } else if (b0 < cnt) {
 #pragma unroll
-        for (int k = 0; k < HML_WALK_NB; ++k) if (b0 + (uint32_t)k < cnt) step(va[k], vb[TWO ? k : 0]);
+        for (int q = 0; q < HML_WALK_NB / 4; ++q) {
+            if (b0 + 4u * q + 0u < cnt) step(v[q].x);
+            if (b0 + 4u * q + 1u < cnt) step(v[q].y);
+            if (b0 + 4u * q + 2u < cnt) step(v[q].z);
+            if (b0 + 4u * q + 3u < cnt) step(v[q].w);
+        }
     }
 }
-template <bool TWO, class Step>
-__device__ __forceinline__ void hml_compat_walk(const uint32_t* __restrict__ a, const uint32_t* __restrict__ b, uint32_t off, uint32_t cnt, uint32_t longest, Step step) {
+template <class Step>
+__device__ __forceinline__ void hml_compat_walk(const uint32_t* __restrict__ a, uint32_t off, uint32_t cnt, uint32_t longest, Step step) {
     constexpr uint32_t NB = HML_WALK_NB;
-    const uint32_t last = cnt ? cnt - 1u : 0u;
-    // (four sets of registers, each named: an array indexed by the set would live in scratch memory)
-    uint32_t a0[NB], a1[NB], a2[NB], a3[NB];
-    uint32_t c0[TWO ? NB : 1], c1[TWO ? NB : 1], c2[TWO ? NB : 1], c3[TWO ? NB : 1];
-    if (!TWO) { c0[0] = c1[0] = c2[0] = c3[0] = 0u; }
-    hml_compat_walk_fetch<TWO>(a, b, off, last, 0u, a0, c0);
-    hml_compat_walk_fetch<TWO>(a, b, off, last, NB, a1, c1);
-    hml_compat_walk_fetch<TWO>(a, b, off, last, 2u * NB, a2, c2);
-    for (uint32_t base = 0; base < longest; base += 4u * NB) {   // wave-uniform
-        hml_compat_walk_fetch<TWO>(a, b, off, last, base + 3u * NB, a3, c3); hml_compat_walk_batch<TWO>(cnt, base, a0, c0, step);
-        hml_compat_walk_fetch<TWO>(a, b, off, last, base + 4u * NB, a0, c0); hml_compat_walk_batch<TWO>(cnt, base + NB, a1, c1, step);
-        hml_compat_walk_fetch<TWO>(a, b, off, last, base + 5u * NB, a1, c1); hml_compat_walk_batch<TWO>(cnt, base + 2u * NB, a2, c2, step);
-        hml_compat_walk_fetch<TWO>(a, b, off, last, base + 6u * NB, a2, c2); hml_compat_walk_batch<TWO>(cnt, base + 3u * NB, a3, c3, step);
+    constexpr int DEPTH = HML_WALK_DEPTH;
+    const uint4* __restrict__ a4 = reinterpret_cast<const uint4*>(a) + off / 4u;
+    const uint32_t last4 = cnt ? (cnt - 1u) / 4u : 0u;
+    uint4 ring[DEPTH][NB / 4];   // (indexed by constants only once the loops below are unrolled: registers)
+#pragma unroll
+    for (int u = 0; u < DEPTH - 1; ++u) hml_compat_walk_fetch(a4, last4, (uint32_t)u * NB, ring[u]);
+    for (uint32_t base = 0; base < longest; base += (uint32_t)DEPTH * NB) {   // wave-uniform
+#pragma unroll
+        for (int u = 0; u < DEPTH; ++u) {
+            hml_compat_walk_fetch(a4, last4, base + (uint32_t)(u + DEPTH - 1) * NB, ring[(u + DEPTH - 1) % DEPTH]);
+            hml_compat_walk_batch(cnt, base + (uint32_t)u * NB, ring[u], step);
+        }
     }
 }
 
@@ -1017,43 +1027,44 @@ HML_KERNEL __launch_bounds__(256) void hml_k_compat_update(hml_model* __restrict
         // four chains that a state's blocks feed (Kahan sum of Sx, of Sxx, diagonal count, occupancy) are independent of each
         // other: FOUR wavefronts (the launch has 256 threads in this mode), each walks all lists for one of them
         const uint32_t off = (lane < K) ? pl.state_off[lane] : 0u;
-        const uint32_t cnt = (lane < K) ? pl.state_off[lane + 1] - off : 0u;
+        const uint32_t cnt = (lane < K) ? pl.state_off[K + 1 + lane] : 0u;
         uint32_t longest = cnt;
         for (int m = 32; m >= 1; m >>= 1) { const uint32_t o = (uint32_t)__shfl_xor((int)longest, m); longest = o > longest ? o : longest; }
         if (wave == 0) {
-            const uint32_t* const arr = reinterpret_cast<const uint32_t*>(pl.sx);
-            hml_compat_walk<false>(arr, arr, off, cnt, longest, [&](uint32_t xb, uint32_t) { const float x = hml_u2f(xb); const float y = x - es, t = ps + y; es = (t - ps) - y; ps = t; });
+            hml_compat_walk(reinterpret_cast<const uint32_t*>(pl.sx), off, cnt, longest, [&](uint32_t xb) { const float x = hml_u2f(xb); const float y = x - es, t = ps + y; es = (t - ps) - y; ps = t; });
             if (lane < K) s_ps[lane] = ps;
         } else if (wave == 1) {
-            const uint32_t* const arr = reinterpret_cast<const uint32_t*>(pl.sq);
-            hml_compat_walk<false>(arr, arr, off, cnt, longest, [&](uint32_t xb, uint32_t) { const float x = hml_u2f(xb); const float y = x - eq, t = pq + y; eq = (t - pq) - y; pq = t; });
+            hml_compat_walk(reinterpret_cast<const uint32_t*>(pl.sq), off, cnt, longest, [&](uint32_t xb) { const float x = hml_u2f(xb); const float y = x - eq, t = pq + y; eq = (t - pq) - y; pq = t; });
             if (lane < K) s_pq[lane] = pq;
         } else if (wave == 2) {
             // A(s, s)'s count: `size_t += float` (ForwardBackward.hpp:183-187) - the sum goes through a float, then the block's
             // entering transition is an exact increment.  While the float sum stays below 2^24 every value on the way is an
             // integer a float holds exactly, so the whole step is two float additions (fd = (float)count throughout); above,
             // the increment needs the double (it may land between two floats) - once there, always there (the count only grows).
-            float fd = 0.0f;
-            bool above = false;
-            hml_compat_walk<true>(pl.n, pl.same, off, cnt, longest, [&](uint32_t n, uint32_t same) {
-                if (method == 1) { diag += (double)(n - 1u) + (same != 0u ? 1.0 : 0.0); return; }
-                const float one = same != 0u ? 1.0f : 0.0f;
-                const float s1 = fd + ((float)n - 1.0f);
-                if (s1 < 16777216.0f) fd = s1 + one;
-                else { diag = (double)s1 + (double)one; fd = (float)diag; above = true; }
-            });
-            if (method != 1 && !above) diag = (double)fd;
+            if (method == 1) {   // (a mixture sweep counts exactly, Mixture.hpp:113-128)
+                hml_compat_walk(pl.n, off, cnt, longest, [&](uint32_t nf) { diag += (double)((nf & 0x7fffffffu) - 1u) + ((nf >> 31) ? 1.0 : 0.0); });
+            } else {
+                float fd = 0.0f;
+                bool above = false;
+                hml_compat_walk(pl.n, off, cnt, longest, [&](uint32_t nf) {
+                    const float one = (nf >> 31) ? 1.0f : 0.0f;
+                    const float s1 = fd + ((float)(nf & 0x7fffffffu) - 1.0f);
+                    if (s1 < 16777216.0f) fd = s1 + one;
+                    else { diag = (double)s1 + (double)one; fd = (float)diag; above = true; }
+                });
+                if (!above) diag = (double)fd;
+            }
             if (lane < K) s_trans[lane * K + lane] = (unsigned long long)diag;
         } else {
             // the occupancy: `size_t += float` is one float addition per block ((float)(size_t)x == x for the integers a float sum
             // can be: the round trip through the integer changes nothing)
-            float fo = 0.0f;
-            hml_compat_walk<false>(pl.n, pl.n, off, cnt, longest, [&](uint32_t n, uint32_t) {
-                if (method == 1) occ += (double)n;
-                else fo = fo + (float)n;
-                n_terms += n;
-            });
-            if (method != 1) occ = (double)fo;
+            if (method == 1) {
+                hml_compat_walk(pl.n, off, cnt, longest, [&](uint32_t nf) { const uint32_t n = nf & 0x7fffffffu; occ += (double)n; n_terms += n; });
+            } else {
+                float fo = 0.0f;
+                hml_compat_walk(pl.n, off, cnt, longest, [&](uint32_t nf) { const uint32_t n = nf & 0x7fffffffu; fo = fo + (float)n; n_terms += n; });
+                occ = (double)fo;
+            }
             if (lane < K) { s_occ[lane] = (unsigned long long)occ; s_n[lane] = n_terms; }
         }
         for (int i = tid; i < K * K; i += 256) if (i / K != i % K) s_trans[i] = pl.offdiag[i];

@@ -339,6 +339,7 @@ static int iterate_many_k(hml_ctx* const* cs, int n, uint64_t first, uint64_t it
     bool fm_split = true;
     if (const char* e = getenv("HML_FM_SPLIT")) fm_split = atoi(e) != 0;
     uint32_t fs_sub = 1u, fs_wg = 0u;
+    const uint64_t fs_tiles1 = (c0->T + HML_FUSED_SUB_POSITIONS - 1) / HML_FUSED_SUB_POSITIONS;   // (tiles of one batch: what the per-tile arrays are sized for)
     {
         const uint64_t batches = (c0->T + HML_FUSED_SUB_POSITIONS - 1) / HML_FUSED_SUB_POSITIONS;
         fs_sub = (uint32_t)std::max<uint64_t>(1, (batches + 4095) / 4096);
@@ -404,9 +405,11 @@ static int iterate_many_k(hml_ctx* const* cs, int n, uint64_t first, uint64_t it
                         hml_ctx* c = cs[k0 + k];
                         hml_fs_chain& f = fa.c[k];
                         f.mdl = c->d_mdl; f.group_word = c->d_group_word; f.wave_total = c->d_wave_total; f.stage = c->d_stage; f.starts = c->d_starts;
+                        f.tile_before = c->d_wave_total + (fs_tiles1 + 1) * HML_FUSED_WAVES; f.tile_prev = f.tile_before + (fs_tiles1 + 1);
                         f.bstat = c->d_bstat; f.em = c->d_em; f.gsc = with_gsc ? c->d_gsc : nullptr; f.host_words = c->d_hB; f.lay = c->lay_many;
                     }
                     hipLaunchKernelGGL(hml_m_blocks_list, dim3(fs_wg), dim3(HML_FUSED_WAVES * 64), 0, s, c0->d_summary, c0->d_w, T, c0->key_base, fa, nk, fs_sub);
+                    hipLaunchKernelGGL(hml_m_blocks_offsets, dim3(1, (unsigned)nk), dim3(1024), 0, s, fa, fs_wg, fs_sub);
                     hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_m_blocks_emit<KK>), dim3(fs_wg), dim3(HML_FUSED_WAVES * 64), 0, s, c0->d_ia, T, fa, nk, fs_sub);
                 }
             } else if (fm) {

@@ -114,7 +114,10 @@ int hml_autoprior(hml_ctx* ctx, float s2, float p, float out4[4]);
 /* Mapping/Transitions/Initial/TransitionHyperParam/InitialHyperParam/ThetaHyperParam/Theta
  * construction (src/main.cpp:133-166,354-362).  nig4 = {alpha,beta,mu0,nu} shared by all K
  * emission parameters; a_off/a_diag = "-t" tokens; pi_alpha = "-I"; self_trans = !"-S".
- * Like Theta's constructor (src/Theta.hpp:126-127) this draws theta once from the prior. */
+ * Like Theta's constructor (src/Theta.hpp:126-127) this draws theta once from the prior.
+ * K: 2 .. 64 (the reference takes any -s K, src/main.cpp:112-137).  Up to 16 states the sweep runs kernels instantiated for that
+ * number of states; from 17 on the number of states is a run-time value and a state is a lane (hml_k_wide.h) - the same chain
+ * semantics (Philox addresses, hml_math.h, the count tree), about three times the time per block of a 16-state model. */
 int hml_set_model(hml_ctx* ctx, int K, const float nig4[4], float a_off, float a_diag, float pi_alpha,
                   int self_trans);
 
