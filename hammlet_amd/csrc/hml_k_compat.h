@@ -1038,21 +1038,16 @@ HML_KERNEL __launch_bounds__(256) void hml_k_compat_update(hml_model* __restrict
             if (lane < K) s_pq[lane] = pq;
         } else if (wave == 2) {
             // A(s, s)'s count: `size_t += float` (ForwardBackward.hpp:183-187) - the sum goes through a float, then the block's
-            // entering transition is an exact increment.  While the float sum stays below 2^24 every value on the way is an
-            // integer a float holds exactly, so the whole step is two float additions (fd = (float)count throughout); above,
-            // the increment needs the double (it may land between two floats) - once there, always there (the count only grows).
+            // entering transition is an exact increment (it may land between two floats once the count exceeds 2^24, hence the
+            // double).  fd = (float)count throughout: four dependent operations per block, no branch.
             if (method == 1) {   // (a mixture sweep counts exactly, Mixture.hpp:113-128)
                 hml_compat_walk(pl.n, off, cnt, longest, [&](uint32_t nf) { diag += (double)((nf & 0x7fffffffu) - 1u) + ((nf >> 31) ? 1.0 : 0.0); });
             } else {
                 float fd = 0.0f;
-                bool above = false;
                 hml_compat_walk(pl.n, off, cnt, longest, [&](uint32_t nf) {
-                    const float one = (nf >> 31) ? 1.0f : 0.0f;
-                    const float s1 = fd + ((float)(nf & 0x7fffffffu) - 1.0f);
-                    if (s1 < 16777216.0f) fd = s1 + one;
-                    else { diag = (double)s1 + (double)one; fd = (float)diag; above = true; }
+                    diag = (double)(fd + ((float)(nf & 0x7fffffffu) - 1.0f)) + ((nf >> 31) ? 1.0 : 0.0);
+                    fd = (float)diag;
                 });
-                if (!above) diag = (double)fd;
             }
             if (lane < K) s_trans[lane * K + lane] = (unsigned long long)diag;
         } else {

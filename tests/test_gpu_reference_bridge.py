@@ -180,7 +180,8 @@ def test_many_state_models_against_reference_files(hml, case):
         g.close()
         return sig
 
-    assert rmse(run(golden_seed, True), ref) < 1e-9      # the anchor: the reference's chain at the golden seed IS the golden run
+    # the anchor: the reference's chain at the golden seed IS the golden run (its parameters file prints six decimals)
+    assert rmse(run(golden_seed, True), ref) < 1e-5
     n = 12
     seeds = [s for s in range(1, n + 2) if s != golden_seed][:n]
     err_ref = rmse(ref, truth)
