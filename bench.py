@@ -376,7 +376,7 @@ def main():
                                     "latency: three dependent memory round trips + one inter-workgroup hand-off per launch",
                          "profile_pair": None if dense_workload else
                                          "rocprofv3 adds 1.5-2 us to every dispatch of this kernel: the line that pairs with "
-                                         "profiles/round4_kernel_stats_c3_bench.csv is profiles/round4_bench_c3_under_rocprof.json",
+                                         "profiles/round5_kernel_stats_c3_bench.csv is profiles/round5_bench_c3_under_rocprof.json",
                          "algorithmic_bytes_per_launch": algo_bytes,
                          "algorithmic_equivalent_gbs": algo_bytes / scan_avg_s / 1e9,
                          "algorithmic_speedup_vs_peak_float_stream": algo_bytes / scan_avg_s / 1e9 / HBM_PEAK_GBS,

@@ -703,6 +703,28 @@ def test_static_blocks_on_a_reduced_block_capacity(hml):
     g.close()
 
 
+def test_many_states_with_a_reduced_block_capacity(hml):
+    """The path for more than 16 states (hml_k_wide.h) on per-block buffers for 64 blocks: its kernels return while the chain is
+    halted, the host grows the buffers and runs the skipped sweeps again (hml_settle) - the checker's chain, bit for bit."""
+    K, T = 18, 120_000
+    x, o, g = make_pair(hml, T, K, 5, 77)
+    g.close()
+    g = hml.Chain(device=0, seed=77)
+    g.set_option("max_blocks", 64)
+    g.load(x)
+    setup_model(o, g, K)
+    g._pending_prior = True
+    o.set_record(marginals=True)
+    seen = []
+    g.set_recording(marginals=True, callback=lambda ch, sweep: seen.append(int(sweep)))
+    run_both(o, g, [("F", 6, 2), "P", ("M", 3, 1), ("F", 5, 1)])
+    compare_state(o, g, what="18 states, reduced capacity")
+    assert g.stats()["buffer_growths"] >= 1 and seen == [1, 3, 5, 0, 1, 2, 0, 1, 2, 3, 4]
+    seg, cnt = g.marginals_rle()
+    assert hml.marginals_text(seg, cnt) == o.text("marginals")
+    g.close()
+
+
 def test_attached_chains_start_with_a_reduced_block_capacity(hml):
     """a context attached to another one's observations reserves room for max(2^20, T / 16) blocks per sweep instead of T - and
     the source, like every ordinary context, for the worst case"""
