@@ -217,18 +217,26 @@ def main():
     # HML_BENCH_FORCE_DIST=1: take the multi-rank branches (process group over RCCL, communicator id by broadcast, pooling
     # through hml_pool_marginals) whatever the world size - what tests/test_gpu_bench_dist.py runs on a one-GPU box
     dist_mode = world > 1 or os.environ.get("HML_BENCH_FORCE_DIST") == "1"
-    import torch
+    # HML_BENCH_NO_TORCH=1 (one rank; the counter passes of tools/round_profiles.sh): PyTorch is not loaded - rocprofv3 --pmc ended in a
+    # segmentation fault inside the profiler with it in the process on round 5's boxes.  Chains synchronise their own streams
+    # (hml_sync) in every timed region, so the single-rank timings do not need it; the device-memory figures of the chain legs do.
+    no_torch = (not dist_mode) and os.environ.get("HML_BENCH_NO_TORCH") == "1"
+    torch = None
+    if not no_torch:
+        import torch
     dist = None
     if dist_mode:
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    else:
+    elif torch is not None:
         torch.cuda.set_device(local_rank)
 
     import hammlet_amd
     T, K, levels, sigma, dwell, data_seed = WORKLOADS[args.workload]
     nthr = max(1, min(64, (os.cpu_count() or 8) // max(1, world)))
+    if os.environ.get("HML_BENCH_THREADS"):   # (threads of the synthetic-trace generator)
+        nthr = max(1, int(os.environ["HML_BENCH_THREADS"]))
     if levels is None:
         x = hammlet_amd.synth_depth(T, depth=dwell, ln_sigma=sigma, seed=data_seed, nthreads=nthr)
     else:
@@ -237,7 +245,8 @@ def main():
     def barrier():
         if dist is not None:
             dist.barrier()
-        torch.cuda.synchronize()
+        if torch is not None:
+            torch.cuda.synchronize()
 
     def run_leg(weight_summary, profile_level, steps=None):
         """warm-up + K timed sweeps of a fresh chain; returns (chain, elapsed, blocks, stats0, stats1)"""
@@ -682,7 +691,7 @@ def main():
         # eight (sixteen) chains attached to one construction, launched by one host thread (hml_iterate_many: the many-chain
         # block kernel of hml_k_blocks_fused_many.h; two groups of chains on a stream each)
         def attached(n_chains):
-            free0 = torch.cuda.mem_get_info()[0]
+            free0 = torch.cuda.mem_get_info()[0] if torch is not None else 0
             group = []
             mem = []
             for r in range(n_chains):
@@ -696,7 +705,7 @@ def main():
                 ch.set_recording(marginals=False)
                 ch.sync()
                 group.append(ch)
-                mem.append(free0 - torch.cuda.mem_get_info()[0])
+                mem.append(free0 - torch.cuda.mem_get_info()[0] if torch is not None else 0)
             hammlet_amd.iterate_many(group, "F", max(args.warmup, 64), 0)
             for ch in group:
                 ch.sync()

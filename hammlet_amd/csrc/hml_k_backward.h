@@ -2,6 +2,8 @@
 #ifndef HML_K_BACKWARD_H
 #define HML_K_BACKWARD_H
 
+#include <type_traits>
+
 #include "hml_dist.h"
 #include "hml_k_forward.h"
 #include "hml_philox.h"
@@ -810,54 +812,74 @@ HML_KERNEL __launch_bounds__(256) void hml_k_counts_dense(int16_t* __restrict__ 
     // 4 of the pass's 14 bytes per block
     const bool unit_blocks = (B == mdl->T);
     struct in_t { unsigned long long m1, m0; uint32_t e1, e0, s1, s0; float2 v; int16_t q1, q0; };
-    auto fetch = [&](uint32_t b, in_t& r) {
-        r.m1 = r.m0 = 0ull; r.e1 = r.e0 = 0u; r.s1 = r.s0 = 0u; r.v = make_float2(0.0f, 0.0f); r.q1 = r.q0 = 0;
+    // The loads of a block are STRAIGHT-LINE code (round 5): the block index is clamped into the sweep instead of the loads being
+    // skipped, and only the additions are predicated.  Round 3's form fetched behind `b < B` and `c + GROUPS < nchunks` - divergent
+    // code, at whose end the compiler waits for every load it issued (s_waitcnt vmcnt(0) at the loop's head) - so every chunk step was
+    // one whole memory round trip "however many chunks are requested ahead" (381 steps of 0.79 us).  A workgroup now
+    // requests FOUR of its chunks together and then adds them in chunk order: the same terms into the same accumulators in the
+    // same order, a quarter of the round trips.
+    const uint32_t Bm1 = B ? B - 1u : 0u;
+    auto fetch = [&](auto unit_c, uint32_t b, in_t& r) __attribute__((always_inline)) {
+        constexpr bool UNIT = decltype(unit_c)::value;    // (a compile-time value: no branch between the loads)
+        const uint32_t bc = b < Bm1 ? b : Bm1;            // (a block beyond the sweep reads the last block's words; nothing is added for it)
+        const uint32_t bp = bc ? bc - 1u : 0u;
+        r.m1 = r.m0 = 0ull; r.e1 = r.e0 = 0u; r.q1 = r.q0 = 0;
+        if (FB) {
+            r.m1 = smap[bc + 1u]; r.e1 = entry[bc / HML_BWD_CHUNK];
+            r.m0 = smap[bp + 1u]; r.e0 = entry[bp / HML_BWD_CHUNK];      // (b = 0: unused)
+        } else {
+            r.q1 = q[bc];
+            r.q0 = q[bp];
+        }
+        if (UNIT) { r.s1 = 1u; r.s0 = 0u; }
+        else { r.s1 = starts[bc + 1u]; r.s0 = starts[bc]; }
+        r.v = bstat[bc];
+    };
+    auto add = [&](uint32_t b, const in_t& cur) __attribute__((always_inline)) {
         if (b < B) {
+            int st, prev;
             if (FB) {
-                r.m1 = smap[b + 1]; r.e1 = entry[b / HML_BWD_CHUNK];
-                if (b != 0) { r.m0 = smap[b]; r.e0 = entry[(b - 1) / HML_BWD_CHUNK]; }
+                st = (int)((cur.m1 >> (4 * cur.e1)) & 15ull);
+                prev = (b == 0) ? 0 : (int)((cur.m0 >> (4 * cur.e0)) & 15ull);
+                q[b] = (int16_t)st;
             } else {
-                r.q1 = q[b];
-                if (b != 0) r.q0 = q[b - 1];
+                st = cur.q1;
+                prev = (b == 0) ? 0 : (int)cur.q0;
             }
-            if (unit_blocks) r.s1 = 1u;
-            else { r.s1 = starts[b + 1]; r.s0 = starts[b]; }
-            r.v = bstat[b];
+            const uint32_t n = cur.s1 - cur.s0;
+            const double vx = (double)cur.v.x, vq = (double)cur.v.y;
+#pragma unroll
+            for (int s = 0; s < K; ++s) {
+                if (st == s) {
+                    n_pos[s] += (unsigned long long)n; n_blk[s] += 1u;
+                    if (prev == s) n_stay[s] += 1u;
+                    acc_s[s] = acc_s[s] + vx; acc_q[s] = acc_q[s] + vq;
+                }
+            }
+            if (prev != st) atomicAdd(&h_trans[prev * K + st], 1ull);
         }
     };
     // workgroup g owns chunks g, g + GROUPS, g + 2 GROUPS, ...; wavefront w streams quarter w of each of them, every lane
     // adding its block's term to its own accumulator - no tree, no barrier in the loop
-    {
-        in_t nxt;
-        fetch(g * HML_REDUCE_CHUNK + (uint32_t)tid, nxt);
-        for (uint32_t c = g; c < nchunks; c += HML_REDUCE_GROUPS) {
-            const uint32_t b = c * HML_REDUCE_CHUNK + (uint32_t)tid;
-            const in_t cur = nxt;
-            if (c + HML_REDUCE_GROUPS < nchunks) fetch(b + HML_REDUCE_GROUPS * HML_REDUCE_CHUNK, nxt);
-            if (b < B) {
-                int st, prev;
-                if (FB) {
-                    st = (int)((cur.m1 >> (4 * cur.e1)) & 15ull);
-                    prev = (b == 0) ? 0 : (int)((cur.m0 >> (4 * cur.e0)) & 15ull);
-                    q[b] = (int16_t)st;
-                } else {
-                    st = cur.q1;
-                    prev = (b == 0) ? 0 : (int)cur.q0;
-                }
-                const uint32_t n = cur.s1 - cur.s0;
-                const double vx = (double)cur.v.x, vq = (double)cur.v.y;
-#pragma unroll
-                for (int s = 0; s < K; ++s) {
-                    if (st == s) {
-                        n_pos[s] += (unsigned long long)n; n_blk[s] += 1u;
-                        if (prev == s) n_stay[s] += 1u;
-                        acc_s[s] = acc_s[s] + vx; acc_q[s] = acc_q[s] + vq;
-                    }
-                }
-                if (prev != st) atomicAdd(&h_trans[prev * K + st], 1ull);
-            }
+    auto stream = [&](auto unit_c) __attribute__((always_inline)) {
+        constexpr uint32_t STEP = HML_REDUCE_GROUPS * HML_REDUCE_CHUNK;
+        for (uint32_t c = g; c < nchunks; c += 4u * HML_REDUCE_GROUPS) {   // workgroup-uniform
+            const uint32_t b0 = c * HML_REDUCE_CHUNK + (uint32_t)tid;
+            in_t r0, r1, r2, r3;
+            // (blocks of chunks beyond the sweep: index B, for which nothing is added)
+            const uint64_t b1 = (uint64_t)b0 + STEP, b2 = (uint64_t)b0 + 2ull * STEP, b3 = (uint64_t)b0 + 3ull * STEP;
+            const uint32_t c1 = b1 < B ? (uint32_t)b1 : B, c2 = b2 < B ? (uint32_t)b2 : B, c3 = b3 < B ? (uint32_t)b3 : B;
+            fetch(unit_c, b0, r0);
+            fetch(unit_c, c1, r1);
+            fetch(unit_c, c2, r2);
+            fetch(unit_c, c3, r3);
+            add(b0, r0);
+            add(c1, r1);
+            add(c2, r2);
+            add(c3, r3);
         }
-    }
+    };
+    if (unit_blocks) stream(std::true_type{}); else stream(std::false_type{});
 #pragma unroll
     for (int s = 0; s < K; ++s) {
         const double a = hml_wave_tree_f64(acc_s[s]), d = hml_wave_tree_f64(acc_q[s]);

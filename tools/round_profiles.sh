@@ -18,10 +18,10 @@ if [ "$PART" != "2" ]; then
 echo "== bench (driver settings)"; python3 $R/bench.py --steps 20 --warmup 5 > $O/bench_driver.json 2> $O/bench_driver.err
 echo "== bench (defaults)";        python3 $R/bench.py > $O/bench_default.json 2> $O/bench_default.err
 echo "== kernel stats";  rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o run -- python3 $R/bench.py --no-cpu-baseline --no-config-legs > $O/bench_under_rocprof.json 2> $O/stats.err
-echo "== pmc fetch";     rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o run -- python3 $R/bench.py --steps 200 --warmup 50 --no-cpu-baseline --no-uncompressed-leg --no-config-legs > $O/pmc_fetch.json 2> $O/pmc_fetch.err
-echo "== pmc write";     rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o run -- python3 $R/bench.py --steps 200 --warmup 50 --no-cpu-baseline --no-uncompressed-leg --no-config-legs > $O/pmc_write.json 2> $O/pmc_write.err
-echo "== c4 pmc fetch";  rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/c4_fetch -o run -- python3 $R/bench.py --workload c4_1e8_k10 --steps 200 --warmup 64 --no-cpu-baseline --no-stream-leg --no-two-chain-leg > $O/c4_fetch.json 2> $O/c4_fetch.err
-echo "== c4 pmc write";  rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/c4_write -o run -- python3 $R/bench.py --workload c4_1e8_k10 --steps 200 --warmup 64 --no-cpu-baseline --no-stream-leg --no-two-chain-leg > $O/c4_write.json 2> $O/c4_write.err
+echo "== pmc fetch";     HML_BENCH_NO_TORCH=1 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o run -- python3 $R/bench.py --steps 200 --warmup 50 --no-cpu-baseline --no-uncompressed-leg --no-config-legs > $O/pmc_fetch.json 2> $O/pmc_fetch.err
+echo "== pmc write";     HML_BENCH_NO_TORCH=1 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o run -- python3 $R/bench.py --steps 200 --warmup 50 --no-cpu-baseline --no-uncompressed-leg --no-config-legs > $O/pmc_write.json 2> $O/pmc_write.err
+echo "== c4 pmc fetch";  HML_BENCH_NO_TORCH=1 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/c4_fetch -o run -- python3 $R/bench.py --workload c4_1e8_k10 --steps 200 --warmup 64 --no-cpu-baseline --no-stream-leg --no-two-chain-leg > $O/c4_fetch.json 2> $O/c4_fetch.err
+echo "== c4 pmc write";  HML_BENCH_NO_TORCH=1 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/c4_write -o run -- python3 $R/bench.py --workload c4_1e8_k10 --steps 200 --warmup 64 --no-cpu-baseline --no-stream-leg --no-two-chain-leg > $O/c4_write.json 2> $O/c4_write.err
 fi
 if [ "$PART" = "1" ]; then
 cd $R
