@@ -783,6 +783,7 @@ int hml_set_model(hml_ctx* c, int K, const float nig4[4], float a_off, float a_d
     if (const char* e = getenv("HML_TRE_REFIT_SHIFTS")) { unsigned a = 17, b = 20; if (sscanf(e, "%u,%u", &a, &b) == 2 && a < 32 && b < 32) { m.tre_hi_shift = a; m.tre_lo_shift = b; } }
     m.fwd_W0 = (uint32_t)c->fwdW;
     m.fwd_W = m.fwd_W_burnin = (uint32_t)std::max(c->fwdW, c->fwdW_init);
+    if (c->compat || c->wide) { m.fwd_W = 64u; m.fwd_W0 = 32u; }   // the chunked lane-per-state kernels' own policy (hml_chunk_warmup_adapt)
     m.fwd_burnin_sweeps = c->fwd_burnin_sweeps;
     m.fwd_quiet_need = c->fwd_quiet_need;
     m.n_spans = c->n_spans;
@@ -961,7 +962,7 @@ static int sweep_compat(hml_ctx* c, char method, bool record) {
         if (!c->probes && c->compat_chunks > 1) C = std::min<uint32_t>((uint32_t)c->compat_chunks, HML_COMPAT_MAX_CHUNKS);   // (tests: any sweep in that many chunks)
         else if (!c->probes && c->compat_chunks == 0 && hint >= 8192u) C = std::min<uint32_t>((uint32_t)HML_COMPAT_MAX_CHUNKS, hint / 64u);
         hml_compat_chunks ch = chunk_views(c);
-        ch.W = c->compat_warmup > 0 ? (uint32_t)c->compat_warmup : c->compat_warmup < 0 ? 0u : (c->K <= 16 ? 64u : 128u);   // (< 0: none - tests)
+        ch.W = c->compat_warmup > 0 ? (uint32_t)c->compat_warmup : c->compat_warmup < 0 ? 0u : HML_CHUNK_W_ADAPTIVE;   // (< 0: none - tests)
         hipLaunchKernelGGL(hml_k_compat_draws, dim3(1), dim3(256), 0, s, c->d_mdl, mt, c->d_cdraws, 2u);
         // (up to 16 states: the number of states as a compile-time value - A in registers, loops unrolled; beyond: loops unrolled
         // over 32 or 64 in groups of four that stop at the model's value)
@@ -1030,7 +1031,7 @@ static int sweep_wide(hml_ctx* c, char method, bool record) {
         if (!c->probes && c->compat_chunks > 1) C = std::min<uint32_t>((uint32_t)c->compat_chunks, HML_COMPAT_MAX_CHUNKS);
         else if (!c->probes && c->compat_chunks == 0 && hint >= 2048u) C = std::min<uint32_t>((uint32_t)HML_COMPAT_MAX_CHUNKS, hint / 64u);
         hml_compat_chunks ch = chunk_views(c);
-        ch.W = c->compat_warmup > 0 ? (uint32_t)c->compat_warmup : c->compat_warmup < 0 ? 0u : 128u;
+        ch.W = c->compat_warmup > 0 ? (uint32_t)c->compat_warmup : c->compat_warmup < 0 ? 0u : HML_CHUNK_W_ADAPTIVE;
         hipLaunchKernelGGL(hml_k_wide_uniforms, dim3(grid_for((hint + 1u) / 2u, 256, 1, 4096)), dim3(256), 0, s, c->d_mdl, c->d_cdraws);
         if (c->K <= 32) launch_chunked_fb<32, hml_dev_exp, true>(c, s, C, ch, aprobe);
         else launch_chunked_fb<64, hml_dev_exp, true>(c, s, C, ch, aprobe);

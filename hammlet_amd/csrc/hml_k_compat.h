@@ -332,8 +332,26 @@ struct hml_compat_chunks {
     uint32_t* nfb;       // [C] uniform fallbacks inside the chunk's own blocks
     int32_t* in_state;   // [C] backward draws: the state above the chunk's first row (from its warm-up)
     int32_t* out_state;  // [C] ... and the state of its last row
-    uint32_t W;          // warm-up, blocks
+    uint32_t W;          // warm-up, blocks; HML_CHUNK_W_ADAPTIVE: the model's own (mdl->fwd_W: it follows the chunks that had to run again)
 };
+#define HML_CHUNK_W_ADAPTIVE 0xffffffffu
+// The warm-up of the chunks (results never depend on it: a chunk is accepted only on bit equality with what the chunk before it
+// left).  Adaptive (round 5): it starts at 64 blocks, doubles when a sweep had chunks that ran again and falls by a quarter after
+// sixteen sweeps without one, down to a floor of 32 (mdl->fwd_W / fwd_W0 / fwd_quiet, which the kernels of this family own in
+// their modes) - models of 20-64 states on config 3's trace run no chunk again at 32 blocks, and 128 (round 4's constant beyond 16
+// states) was 58 % of a chunk's steps.
+__device__ __forceinline__ uint32_t hml_chunk_warmup(const hml_model* mdl, const uint32_t W) { return W == HML_CHUNK_W_ADAPTIVE ? mdl->fwd_W : W; }
+__device__ __forceinline__ void hml_chunk_warmup_adapt(hml_model* mdl, const uint32_t W, unsigned long long ran_again, bool may_shrink) {
+    if (W != HML_CHUNK_W_ADAPTIVE) return;
+    uint32_t w = mdl->fwd_W;
+    if (ran_again != 0ull) { w = (2u * w < 1024u) ? 2u * w : 1024u; mdl->fwd_quiet = 0u; }
+    else if (may_shrink && ++mdl->fwd_quiet >= 16u) {
+        const uint32_t lower = (w - w / 4u) & ~7u;
+        w = lower > mdl->fwd_W0 ? lower : mdl->fwd_W0;
+        mdl->fwd_quiet = 0u;
+    }
+    mdl->fwd_W = w;
+}
 // blocks per chunk of a launch of C chunks over B blocks
 __device__ __forceinline__ uint32_t hml_compat_chunk_len(uint32_t B, uint32_t C) { const uint32_t L = (B + C - 1u) / C; return L < 64u ? 64u : L; }
 
@@ -444,7 +462,8 @@ HML_KERNEL __launch_bounds__(64) void hml_k_compat_forward(hml_model* __restrict
     } else {
         for (int i = lane; i < K * K; i += 64) sA[i] = mdl->A[i];
     }
-    const uint32_t ws = (lo > ch.W) ? lo - ch.W : 0u;
+    const uint32_t W = hml_chunk_warmup(mdl, ch.W);
+    const uint32_t ws = (lo > W) ? lo - W : 0u;
     float prev = act ? ((ws == 0u) ? mdl->pi[lane] : (float)(1.0 / (double)(float)K)) : 0.0f;
     if (c == 0u && act) {
         if (aprobe) aprobe[lane] = prev;
@@ -465,10 +484,11 @@ HML_KERNEL __launch_bounds__(256) void hml_k_compat_forward_verify(const hml_mod
     const uint32_t L = hml_compat_chunk_len(B, C);
     const uint32_t n_chunks = (B + L - 1u) / L;
     const uint64_t n = (uint64_t)n_chunks * K;
+    const uint32_t W = hml_chunk_warmup(mdl, ch.W);
     for (uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (uint64_t)gridDim.x * blockDim.x) {
         const uint32_t c = (uint32_t)(e / K);
         // (a chunk whose warm-up reaches block 0 started from pi: exact)
-        if (c > 0u && (uint64_t)c * L > ch.W && hml_f2u(ch.entry[e]) != hml_f2u(ch.exitv[e - K])) ch.bad[c] = 1u;
+        if (c > 0u && (uint64_t)c * L > W && hml_f2u(ch.entry[e]) != hml_f2u(ch.exitv[e - K])) ch.bad[c] = 1u;
     }
 }
 
@@ -523,6 +543,7 @@ HML_KERNEL __launch_bounds__(256) void hml_k_compat_forward_check(hml_model* __r
         for (int i = lane; i < K * K; i += 64) sA[i] = mdl->A[i];
     }
     hml_compat_fence();
+    const uint32_t W = hml_chunk_warmup(mdl, ch.W);   // (the warm-up this sweep's chunks ran with: adapted at the very end)
     unsigned long long total_nfb = s_nfb[0] + s_nfb[1] + s_nfb[2] + s_nfb[3], redone = 0ull;
     for (uint32_t c0 = 0; c0 < n_chunks; c0 += 64u) {
         while (true) {   // wave-uniform
@@ -544,12 +565,12 @@ HML_KERNEL __launch_bounds__(256) void hml_k_compat_forward_check(hml_model* __r
                 if (cc + 1u >= n_chunks) break;
                 hml_compat_flag_clear(map, cc + 1u, lane);   // (the successor is compared right here)
                 const float nx = act ? ch.entry[(uint64_t)(cc + 1u) * K + lane] : 0.0f;
-                const bool exact_next = (uint64_t)(cc + 1u) * L <= ch.W;
+                const bool exact_next = (uint64_t)(cc + 1u) * L <= W;
                 if (exact_next || __ballot(act && hml_f2u(nx) != hml_f2u(prev)) == 0ull) break;
             }
         }
     }
-    if (lane == 0) { mdl->uniform_fallbacks += total_nfb; mdl->forward_refits += redone; }
+    if (lane == 0) { mdl->uniform_fallbacks += total_nfb; mdl->forward_refits += redone; hml_chunk_warmup_adapt(mdl, ch.W, redone, true); }
 }
 
 // the engine's next n outputs -> out[0 .. n): the uniforms of a sweep's categorical draws do not depend on the data.
@@ -729,7 +750,8 @@ HML_KERNEL __launch_bounds__(64) void hml_k_compat_backward(hml_model* __restric
     } else {
         for (int idx = lane; idx < K * K; idx += 64) { const int i = idx / K, j = idx - i * K; sAT[j * K + i] = mdl->A[idx]; }
     }
-    const uint32_t tw = (hi + ch.W < B) ? hi + ch.W : B;   // (tw = B: the chain of draws from its true start)
+    const uint32_t W = hml_chunk_warmup(mdl, ch.W);
+    const uint32_t tw = (hi + W < B) ? hi + W : B;   // (tw = B: the chain of draws from its true start)
     int j = 0, in_state = -1;
     const bool single = (C == 1u);
     bool clean;
@@ -795,7 +817,7 @@ HML_KERNEL __launch_bounds__(256) void hml_k_compat_backward_check(hml_model* __
             }
         }
     }
-    if (lane == 0) mdl->forward_refits += redone;   // (the statistic counts chunks of either pass that ran again)
+    if (lane == 0) { mdl->forward_refits += redone; hml_chunk_warmup_adapt(mdl, ch.W, redone, false); }   // (the statistic counts chunks of either pass that ran again)
 }
 
 // StateSequence<Mixture>::sample's draws (Mixture.hpp:90-112): one per block in block order, no transitions
