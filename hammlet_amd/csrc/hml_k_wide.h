@@ -2,9 +2,10 @@
 // The kernels of hml_k_forward.h / hml_k_backward.h keep a chunk's K-vector and the transition matrix in registers and pack a
 // candidate map into 4-bit fields; they are instantiated for 2 .. 16 states.  Beyond that the number of states is a RUN-TIME
 // value and a state is a LANE:
-//   * emission terms, filter and backward draws are the chunked lane-per-state kernels of hml_k_compat.h (chunks that start
-//     from a guess some blocks early and are checked against each other, bit for bit: the stored rows and states are the
-//     sequential recursion's) - instantiated with THIS path's arithmetic (hml_math.h's expf, hml_dev_exp) instead of glibc's;
+//   * filter and backward draws are the chunked lane-per-state kernels of hml_k_compat.h (chunks that start from a guess some
+//     blocks early and are checked against each other, bit for bit: the stored rows and states are the sequential
+//     recursion's) - instantiated with THIS path's arithmetic (hml_math.h's expf, hml_dev_exp) instead of glibc's and with their
+//     loops unrolled over 32 or 64 states in groups of four; the emission terms have a kernel of their own (hml_k_wide_emission);
 //   * the random decisions are the default path's: every backward row's uniform from its own Philox address
 //     (hml_cat_uniform: blocks 2m and 2m + 1 share Philox block m), generated ahead of the draws by all lanes of the machine
 //     (hml_k_wide_uniforms); every parameter variate from its own sub-stream (hml_k_wide_params);
