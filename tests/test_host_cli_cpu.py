@@ -50,3 +50,20 @@ def test_help_exits_zero(cli):
     assert r.returncode == 0 and "-auto-priors" in r.stdout
     r = run(cli, "--help")
     assert r.returncode == 0
+
+
+@pytest.mark.parametrize("case", ["c1_fb", "k4_mixed_scheme", "mv_c22"])
+def test_segments_rule_of_the_driver_on_the_reference_binarys_own_sequences(case, tmp_path):
+    """`-O segments` (reference src/Records.hpp:208-209: #marginal segments and the length of StateMarginals' count queue,
+    src/StateMarginals.hpp:51-137,204, written BEFORE the sweep's last run is added): the driver's rule
+    (hammlet::MarginalSegmentSets, include/hammlet/Records.hpp) fed with the recorded sweeps of a `sequences` file the unmodified
+    reference binary wrote must print the `segments` file the same run wrote (tests/golden/<case>/) - host logic, no GPU."""
+    from hammlet_amd import build
+    build.build_library()
+    exe = str(tmp_path / "segment_sets")
+    subprocess.run(["g++", "-O2", "-std=c++17", "-I", os.path.join(REPO, "include"), "-o", exe,
+                    os.path.join(REPO, "tests", "fixtures", "segment_sets_driver.cpp"), "-L", os.path.join(REPO, "hammlet_amd"), "-lhammlet_hip",
+                    "-Wl,-rpath," + os.path.join(REPO, "hammlet_amd")], check=True)
+    r = subprocess.run([exe, os.path.join(GOLD, case, "sequences.csv")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert r.stdout == open(os.path.join(GOLD, case, "segments.csv")).read()
