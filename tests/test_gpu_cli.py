@@ -47,6 +47,8 @@ def run_pair(x, flags, text_input=False):
     (100000, 3, "-s 3 -R 7 -m 1.5 -t 1 10 -I 2 -e normal 0.1 0.8 -i M 20 1 F 50 1", False),
     (100000, 3, "-s 6 -R 8 -t 0.1 -i S F 50 1 P D F 20 1", False),
     (300000, 5, "-s 5 -R 2 -i F 30 3", False),
+    (60000, 6, "-s 20 -R 12 -i F 30 1", False),                                  # more than 16 states: the default path takes them (round 5)
+    (30000, 5, "-s 40 -R 13 -t 0.2 2 -i M 10 1 S P F 15 2 D F 5 1", True),
 ])
 def test_cli_files_equal_checker_files(T, K, flags, text):
     x = ol.trace(T, K, 1)

@@ -11,7 +11,7 @@ pytestmark = pytest.mark.gpu
 T, K = 60000, 4
 
 
-def checker_chain(x, chain, seed=21, sweeps=(24, 3)):
+def checker_chain(x, chain, seed=21, sweeps=(24, 3), K=K):
     o = ol.OracleChain(K=K, seed=seed, chain=chain, rng=ol.RNG_CTR, math=ol.MATH_DEV, reduce=ol.REDUCE_DEV)
     o.load(x)
     o.autoprior()
@@ -24,7 +24,7 @@ def checker_chain(x, chain, seed=21, sweeps=(24, 3)):
     return o.marginals_dense(), o.theta()[0::2].copy(), bnd
 
 
-def gpu_chain(hml, x, chain, seed=21, sweeps=(24, 3)):
+def gpu_chain(hml, x, chain, seed=21, sweeps=(24, 3), K=K):
     g = hml.Chain(device=0, seed=seed, chain_id=chain)
     g.load(x)
     g.set_model(K, g.autoprior(0.2, 0.9))
@@ -34,13 +34,13 @@ def gpu_chain(hml, x, chain, seed=21, sweeps=(24, 3)):
     return g
 
 
-def expected_pooled(x, chain_ids):
+def expected_pooled(x, chain_ids, K=K):
     from hammlet_amd import chains
     dense = np.zeros((K, T), np.int64)
     bnd = np.zeros(T, np.int64)
     perms = []
     for c in chain_ids:
-        d, means, b = checker_chain(x, c)
+        d, means, b = checker_chain(x, c, K=K)
         perm = chains.relabel_permutation(means)
         perms.append(perm)
         dense += d[perm]
@@ -124,6 +124,32 @@ def test_allreduce_marginals_of_three_chains_on_one_device(hml):
         assert np.all(cnt.sum(1) == 24)
     ln, st = cs[0].max_segmentation()
     assert int(ln.sum()) == T
+    for g in cs:
+        g.close()
+
+
+def test_allreduce_marginals_of_chains_with_many_states(hml):
+    """The same for a model of 20 states (round 5: more than 16 states on the default path, hml_k_wide.h): relabelling by ascending
+    mean, payload, pooled run-length marginals and the arg-max segmentation take the number of states at run time."""
+    K20 = 20
+    x = ol.trace(T, 6, 3)
+    cs = [gpu_chain(hml, x, c, sweeps=(12, 3), K=K20) for c in (0, 1)]
+    hml.allreduce_marginals(cs)
+    from hammlet_amd import chains
+    dense = np.zeros((K20, T), np.int64)
+    bnd = np.zeros(T, np.int64)
+    for c in (0, 1):
+        d, means, b = checker_chain(x, c, sweeps=(12, 3), K=K20)
+        dense += d[chains.relabel_permutation(means)]
+        bnd += b
+    starts = np.flatnonzero(bnd)
+    cols = int(np.flatnonzero(dense.any(axis=1)).max()) + 1
+    for g in cs:
+        seg, cnt = g.marginals_rle()
+        assert np.array_equal(seg, np.diff(np.append(starts, T))) and np.array_equal(cnt, dense[:cols, starts].T)
+        assert np.all(cnt.sum(1) == 2 * 4)
+    ln, st = cs[0].max_segmentation()
+    assert int(ln.sum()) == T and int(st.max()) < K20
     for g in cs:
         g.close()
 
