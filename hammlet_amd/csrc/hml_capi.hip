@@ -159,6 +159,11 @@ int hml_create(hml_ctx** out, int device, uint64_t seed, uint32_t chain_id, void
     if (const char* e = getenv("HML_PARAMS_SPREAD")) c->params_spread = atoi(e) != 0;
     if (const char* e = getenv("HML_COMPAT_CHUNKS")) c->compat_chunks = atoi(e);   // (1: the sequential form; > 1: that many chunks)
     if (const char* e = getenv("HML_COMPAT_WARMUP")) c->compat_warmup = atoi(e);   // (tests: a warm-up too short to forget the start)
+    if (const char* e = getenv("HML_WIDE_LANES")) c->wide_lanes = atoi(e);   // (0: models of more than 16 states with a state a lane)
+    if (const char* e = getenv("HML_WIDE_L")) {   // (tests: chunks of that many blocks, a power of two)
+        const int L = atoi(e);
+        if (L >= 1) { int sh = 0; while ((1 << sh) < L && sh < 20) ++sh; c->wide_lshift = sh; }
+    }
     if (const char* e = getenv("HML_COMPAT")) c->compat = atoi(e) != 0;   // option "compat" for unmodified callers (`hammlet -compat`)
     if (const char* e = getenv("HML_TRELLIS_TUNE")) c->tre_autotune = atoi(e) != 0;
     if (const char* e = getenv("HML_FUSED_SPIN_LIMIT")) c->fused_spin_limit = (uint32_t)strtoul(e, nullptr, 10);
@@ -191,7 +196,7 @@ static bool trace_shared(const hml_ctx* c) { return c->trace && c->trace->refs.l
 static void free_sweep_buffers(hml_ctx* c, bool keep_engine = false) {
     void** ptrs[] = {(void**)&c->d_em, (void**)&c->d_gsc, (void**)&c->d_rows, (void**)&c->d_entry, (void**)&c->d_exitA, (void**)&c->d_redo, (void**)&c->d_touched,
                      (void**)&c->d_fb, (void**)&c->d_smap, (void**)&c->d_cmap, (void**)&c->d_scmap, (void**)&c->d_super, (void**)&c->d_bentry2, (void**)&c->d_bentry,
-                     (void**)&c->d_q, (void**)&c->d_partial, (void**)&c->d_redo2, (void**)&c->d_tre_bitmap, (void**)&c->d_tre_ckpt, (void**)&c->d_crows, (void**)&c->d_cchunk, (void**)&c->d_cdraws, (void**)&c->d_clists, (void**)&c->d_wacc};
+                     (void**)&c->d_q, (void**)&c->d_partial, (void**)&c->d_redo2, (void**)&c->d_tre_bitmap, (void**)&c->d_tre_ckpt, (void**)&c->d_crows, (void**)&c->d_cchunk, (void**)&c->d_cdraws, (void**)&c->d_clists, (void**)&c->d_wacc, (void**)&c->d_wA};
     for (void** p : ptrs) if (*p) { hipFree(*p); *p = nullptr; }
     if (!keep_engine && c->d_mt) { hipFree(c->d_mt); c->d_mt = nullptr; }
 }
@@ -594,11 +599,18 @@ static int alloc_sweep_buffers(hml_ctx* c) {
         HIPCHK(hipMalloc(&c->d_q, cap * sizeof(int16_t)));
         return 0;
     }
-    if (c->wide) {   // more than 16 states (hml_k_wide.h): the lane-per-state kernels' plain layouts, the default path's count tree
-        HIPCHK(hipMalloc(&c->d_em, cap * K * sizeof(float)));
-        HIPCHK(hipMalloc(&c->d_gsc, cap * K * sizeof(float)));
-        HIPCHK(hipMalloc(&c->d_crows, (cap + 1) * K * sizeof(float)));
-        HIPCHK(hipMalloc(&c->d_cchunk, (uint64_t)HML_COMPAT_MAX_CHUNKS * (2 * K * sizeof(float) + 4 * sizeof(uint32_t))));
+    if (c->wide) {   // more than 16 states (hml_k_wide.h, hml_k_wide_lanes.h): [b][s] arrays or chunk-transposed ones, the default path's count tree
+        // (chunk-transposed: L K cstride floats with cstride = the chunks rounded up to 64 - at most K (B + 64 L), L the longest chunk
+        // hml_k_wl_prepare can choose for this capacity)
+        uint64_t Lmax = 1ull << HML_WL_MIN_LSHIFT;
+        if (c->wide_lshift >= 0) Lmax = std::max<uint64_t>(Lmax, 1ull << c->wide_lshift);
+        while ((cap + Lmax - 1) / Lmax > (uint64_t)HML_WL_MAX_CHUNKS) Lmax *= 2;
+        const uint64_t plane = (cap + 1 + 64 * Lmax) * K;
+        HIPCHK(hipMalloc(&c->d_em, plane * sizeof(float)));
+        HIPCHK(hipMalloc(&c->d_gsc, plane * sizeof(float)));
+        HIPCHK(hipMalloc(&c->d_crows, plane * sizeof(float)));
+        HIPCHK(hipMalloc(&c->d_cchunk, (uint64_t)HML_WL_MAX_CHUNKS * (2 * K * sizeof(float) + 4 * sizeof(uint32_t))));
+        HIPCHK(hipMalloc(&c->d_wA, (uint64_t)HML_WL_PITCH * HML_WL_PITCH * sizeof(float)));
         HIPCHK(hipMalloc(&c->d_cdraws, 2 * (cap + 1) * sizeof(uint32_t)));
         HIPCHK(hipMalloc(&c->d_q, cap * sizeof(int16_t)));
         const uint64_t n_partial = (uint64_t)HML_REDUCE_GROUPS * K * 2;
@@ -913,11 +925,12 @@ int hml_ctx_ensure_marginal_buffers(hml_ctx* c) { return ensure_marginal_buffers
 static hml_compat_chunks chunk_views(const hml_ctx* c) {   // the arrays of d_cchunk (alloc_sweep_buffers)
     hml_compat_chunks ch;
     char* base = (char*)c->d_cchunk;
-    ch.entry = (float*)base; base += (uint64_t)HML_COMPAT_MAX_CHUNKS * c->K * sizeof(float);
-    ch.exitv = (float*)base; base += (uint64_t)HML_COMPAT_MAX_CHUNKS * c->K * sizeof(float);
-    ch.nfb = (uint32_t*)base; base += (uint64_t)HML_COMPAT_MAX_CHUNKS * sizeof(uint32_t);
-    ch.in_state = (int32_t*)base; base += (uint64_t)HML_COMPAT_MAX_CHUNKS * sizeof(int32_t);
-    ch.out_state = (int32_t*)base; base += (uint64_t)HML_COMPAT_MAX_CHUNKS * sizeof(int32_t);
+    const uint64_t n = c->wide ? (uint64_t)HML_WL_MAX_CHUNKS : (uint64_t)HML_COMPAT_MAX_CHUNKS;
+    ch.entry = (float*)base; base += n * c->K * sizeof(float);
+    ch.exitv = (float*)base; base += n * c->K * sizeof(float);
+    ch.nfb = (uint32_t*)base; base += n * sizeof(uint32_t);
+    ch.in_state = (int32_t*)base; base += n * sizeof(int32_t);
+    ch.out_state = (int32_t*)base; base += n * sizeof(int32_t);
     ch.bad = (uint32_t*)base;
     ch.W = 0u;
     return ch;
@@ -1019,6 +1032,44 @@ static int sweep_wide(hml_ctx* c, char method, bool record) {
     refresh_hint(c);
     const uint32_t hint = c->B_hint ? c->B_hint : (uint32_t)std::min<uint64_t>(c->T, 1u << 20);
     const int mix = method == HML_METHOD_MIXTURE ? 1 : 0;
+    // filter and backward draws with a chunk a lane over chunk-transposed arrays (hml_k_wide_lanes.h) - unless the rows are probed,
+    // a test asked for a number of chunks of the other form, or the sweep has no filter at all
+    const bool lanes = c->wide_lanes != 0 && !c->probes && !mix && c->compat_chunks == 0;
+    if (lanes) {
+        hml_compat_chunks ch = chunk_views(c);
+        ch.W = c->compat_warmup > 0 ? (uint32_t)c->compat_warmup : c->compat_warmup < 0 ? 0u : HML_CHUNK_W_ADAPTIVE;
+        const uint64_t room = (uint64_t)hint + hint / 4 + 1024;   // (the kernels find B themselves: their loops stride over any grid)
+        hipLaunchKernelGGL(hml_k_wl_prepare, dim3(1), dim3(256), 0, s, c->d_mdl, c->d_wA, c->wide_lshift);
+        {
+            ProfScope ps(c, "stats_emission");
+            // (a wavefront: 64 chunks x 8 rows)
+            hipLaunchKernelGGL(hml_k_wl_emission, dim3(grid_for(room, 512 * 4, 1, 16384)), dim3(256), 0, s, c->d_mdl, c->d_starts, c->d_bstat, c->d_em, c->d_gsc);
+        }
+        const uint64_t minL = c->wide_lshift >= 0 ? (1ull << c->wide_lshift) : (1ull << HML_WL_MIN_LSHIFT);
+        const int tiles = grid_for(room, (int)std::min<uint64_t>(64 * minL, 1u << 30), 1, HML_WL_MAX_CHUNKS / 64);
+#define HML_WL_FB(KC)                                                                                                                                   \
+        case KC: {                                                                                                                                      \
+            constexpr int KS = (KC <= 32) ? 32 : 64;                                                                                                    \
+            {                                                                                                                                           \
+                ProfScope ps(c, "forward");                                                                                                             \
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_wl_forward<KC>), dim3(tiles), dim3(64), 0, s, c->d_mdl, c->d_wA, c->d_em, c->d_gsc, c->d_crows, ch); \
+                hipLaunchKernelGGL(hml_k_wl_forward_verify, dim3(grid_for(room / 16 * c->K, 256, 1, 4096)), dim3(256), 0, s, c->d_mdl, ch);             \
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_wl_forward_check<KS>), dim3(1), dim3(256), 0, s, c->d_mdl, c->d_em, c->d_gsc, c->d_crows, ch);  \
+            }                                                                                                                                           \
+            {                                                                                                                                           \
+                ProfScope ps(c, "backward_maps");                                                                                                       \
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_wl_backward<KC>), dim3(tiles), dim3(64), 0, s, c->d_mdl, c->d_crows, c->d_q, ch);               \
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_wl_backward_check<KS>), dim3(1), dim3(256), 0, s, c->d_mdl, c->d_crows, c->d_q, ch);          \
+            }                                                                                                                                           \
+        } break;
+        switch ((c->K + 3) / 4 * 4) {
+            HML_WL_FB(4) HML_WL_FB(8) HML_WL_FB(12) HML_WL_FB(16)   // (HML_WIDE=1: this path for any model - tests)
+            HML_WL_FB(20) HML_WL_FB(24) HML_WL_FB(28) HML_WL_FB(32) HML_WL_FB(36) HML_WL_FB(40) HML_WL_FB(44) HML_WL_FB(48) HML_WL_FB(52) HML_WL_FB(56)
+            HML_WL_FB(60) HML_WL_FB(64)
+            default: return set_err(HML_ERR_HIP, "internal error: a model of this many states on the path for more than 16");
+        }
+#undef HML_WL_FB
+    } else {
     {
         ProfScope ps(c, "stats_emission");
         hipLaunchKernelGGL(hml_k_wide_emission, dim3(grid_for(hint, 256, 1, 4096)), dim3(256), 0, s, c->d_mdl, c->d_starts, c->d_bstat,
@@ -1035,6 +1086,7 @@ static int sweep_wide(hml_ctx* c, char method, bool record) {
         hipLaunchKernelGGL(hml_k_wide_uniforms, dim3(grid_for((hint + 1u) / 2u, 256, 1, 4096)), dim3(256), 0, s, c->d_mdl, c->d_cdraws);
         if (c->K <= 32) launch_chunked_fb<32, hml_dev_exp, true>(c, s, C, ch, aprobe);
         else launch_chunked_fb<64, hml_dev_exp, true>(c, s, C, ch, aprobe);
+    }
     }
     {
         ProfScope ps(c, "counts");

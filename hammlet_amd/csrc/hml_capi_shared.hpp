@@ -35,6 +35,7 @@
 #include "hml_k_trellis_rows.h"
 #include "hml_k_compat.h"
 #include "hml_k_wide.h"
+#include "hml_k_wide_lanes.h"
 #include "hml_k_blocks_split_many.h"
 #include "hml_k_many.h"
 #include "hml_k_params.h"

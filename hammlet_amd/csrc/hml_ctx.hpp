@@ -166,6 +166,9 @@ struct hml_ctx {
     int compat_warmup = 0;         // blocks a chunk runs ahead of its first; 0: 64 (128 beyond 16 states) (HML_COMPAT_WARMUP)
     bool wide = false;             // more than 16 states on the default path: the number of states is a run-time value, a state a lane (hml_k_wide.h)
     void* d_wacc = nullptr;        // its integer counts of a sweep (hml_wide_acc)
+    float* d_wA = nullptr;         // ... the transition matrix padded to 64 x 64 (hml_k_wide_lanes.h)
+    int wide_lanes = 1;            // ... filter and backward draws with a chunk a lane (0: a state a lane, hml_k_compat.h's kernels) (HML_WIDE_LANES)
+    int wide_lshift = -1;          // ... log2 of a forced chunk length (tests: HML_WIDE_L), -1: from the block count
     bool pooled = false;           // the marginals are a pooled payload (hml_pool_install): common labels, counts of several chains
     std::vector<int32_t> pool_perm;   // perm[pooled label] = this chain's label, from the export that preceded the pooling
     int profiling = 0;             // 0 off, 1 dominant kernel only (blocks_compact, every 32nd launch), 2 every kernel family

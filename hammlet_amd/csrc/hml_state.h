@@ -121,6 +121,8 @@ struct hml_model {
     unsigned long long fwd_refits_seen, fwd_serial_seen;
     uint32_t params_ticket;      // arrivals of the parameter kernel's workgroups (hml_k_params.h: the last of every 16 goes on)
     unsigned long long dbg_t[12];   // wall_clock64 stamps of the parameter kernel's stages (printed by hml_sync with HML_PARAMS_DEBUG)
+    // more than 16 states, a chunk a lane (hml_k_wide_lanes.h): this sweep's chunk length (log2) and the chunk-transposed arrays' stride
+    uint32_t wl_lshift, wl_cstride;
 };
 
 #if defined(__HIPCC__)

@@ -12,7 +12,8 @@ from tests.test_gpu_parity import run_both
 
 ENV_KEYS = ("HML_DENSE_MIN_BLOCKS", "HML_FWD_CHUNK_DENSE", "HML_TRELLIS_FUSED", "HML_TRELLIS_L", "HML_TRELLIS_ROWS", "HML_TRELLIS_CKPT",
             "HML_STAGE_BITS", "HML_FWD_WARMUP", "HML_LATE_RESCALE", "HML_FWD_CHUNK",
-            "HML_MANY_GROUPS", "HML_FUSED_MANY_SLOTS", "HML_MAX_BLOCKS", "HML_FWD_CHUNK_MANY", "HML_COMPAT_CHUNKS", "HML_COMPAT_WARMUP", "HML_WIDE", "HML_FM_SPLIT", "HML_FM_SPLIT_SUB")
+            "HML_MANY_GROUPS", "HML_FUSED_MANY_SLOTS", "HML_MAX_BLOCKS", "HML_FWD_CHUNK_MANY", "HML_COMPAT_CHUNKS", "HML_COMPAT_WARMUP", "HML_WIDE", "HML_FM_SPLIT", "HML_FM_SPLIT_SUB",
+            "HML_WIDE_L", "HML_WIDE_LANES")
 
 
 def fuzz(hml, n_cfg, seed, log=None, many=False, compat=False, wide=False):
@@ -20,8 +21,8 @@ def fuzz(hml, n_cfg, seed, log=None, many=False, compat=False, wide=False):
     that differs).  The environment switches it sets are restored afterwards.  many: several chains through
     hml_iterate_many (_fuzz_many) instead of one through hml_iterate.  compat: the reference-compatible mode against the
     checker's REFERENCE mode (mt19937, libm, Kahan sums, size_t += float) - up to 64 states, chunk geometries that force
-    wrong chunks.  wide: the default path's kernels for more than 16 states (hml_k_wide.h: the number of states at run time, a
-    state a lane) against the checker's device mode - 2-64 states (HML_WIDE=1 sends models of up to 16 states there too), the
+    wrong chunks.  wide: the default path's kernels for more than 16 states (hml_k_wide.h, hml_k_wide_lanes.h: the number of states at run
+    time; a chunk a lane or a state a lane) against the checker's device mode - 2-64 states (HML_WIDE=1 sends models of up to 16 states there too), the
     same chunk geometries."""
     saved = {k: os.environ.get(k) for k in ENV_KEYS}
     try:
@@ -75,6 +76,9 @@ def _fuzz(hml, n_cfg, seed, log, compat=False, wide=False):
         if compat or wide:   # chunks of the filter / backward draws: the default, the sequential form, many chunks with hardly any warm-up
             _setenv("HML_COMPAT_CHUNKS", rng.choice([None, None, 1, 7, 60, 500]))
             _setenv("HML_COMPAT_WARMUP", rng.choice([None, None, -1, 1, 4]))
+            if wide:   # ... a chunk a lane (hml_k_wide_lanes.h; taken when no number of chunks is asked for): the chunk length, or a state a lane
+                _setenv("HML_WIDE_L", rng.choice([None, None, 1, 2, 4, 8, 64]))
+                _setenv("HML_WIDE_LANES", rng.choice([None, None, None, 0]))
             if K > 16:
                 T = min(T, 65537)
         seed = int(rng.integers(0, 1 << 30))

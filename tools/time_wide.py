@@ -12,7 +12,8 @@ T = int(os.environ.get("HML_TIME_T", "100000000"))
 x = h.synth_gauss(T, 5, [-2, -1, 0, 1, 2], 0.3, 5000.0, 3, nthreads=16)
 for K in [int(a) for a in sys.argv[1:]] or [20, 40, 64]:
     res = {}
-    for mode, burn, n in (("default", 60, 100), ("compat", 12, 12)):
+    modes = (("default", 60, 100),) if os.environ.get("HML_TIME_NO_COMPAT") else (("default", 60, 100), ("compat", 12, 12))
+    for mode, burn, n in modes:
         c = h.Chain(device=0, seed=1)
         if mode == "compat":
             c.set_option("compat", 1)
@@ -39,8 +40,11 @@ for K in [int(a) for a in sys.argv[1:]] or [20, 40, 64]:
                 ms, cnt = c.profile_get(nm)
                 if cnt:
                     fam[nm] = round(1e3 * ms / cnt - 5.3, 1)
+        if mode == "default":
+            fam["warmup"] = (s0["forward_warmup"], s1["forward_warmup"])
         res[mode] = (1e3 * dt / n, blocks, s1["forward_refits"] - s0["forward_refits"], fam)
         c.close()
-    d, cp = res["default"], res["compat"]
+    d = res["default"]
+    cp = res.get("compat", (float("nan"), float("nan")))
     print("K=%d T=%d: default %.3f ms/sweep (%.0f blocks, %.3g block-updates/s, %d chunks run again) %s | compat %.3f ms/sweep (%.0f blocks, %.3g/s) | %.1fx"
           % (K, T, d[0], d[1], d[1] / d[0] * 1e3, d[2], d[3], cp[0], cp[1], cp[1] / cp[0] * 1e3, (d[1] / d[0]) / (cp[1] / cp[0])), flush=True)
