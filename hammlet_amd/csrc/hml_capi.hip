@@ -590,7 +590,7 @@ static int alloc_sweep_buffers(hml_ctx* c) {
         HIPCHK(hipMalloc(&c->d_gsc, cap * K * sizeof(float)));
         HIPCHK(hipMalloc(&c->d_crows, (cap + 1) * K * sizeof(float)));
         // chunks of the filter and of the backward draws (hml_compat_chunks), the engine's outputs of a sweep (two per block)
-        HIPCHK(hipMalloc(&c->d_cchunk, (uint64_t)HML_COMPAT_MAX_CHUNKS * (2 * K * sizeof(float) + 4 * sizeof(uint32_t))));
+        HIPCHK(hipMalloc(&c->d_cchunk, (uint64_t)HML_COMPAT_MAX_CHUNKS * (2 * K * sizeof(float) + 4 * sizeof(uint32_t)) + 64));
         HIPCHK(hipMalloc(&c->d_cdraws, 2 * cap * sizeof(uint32_t)));
         // the count pass's lists by state (hml_compat_lists): statistics, sizes, per-tile counts, flags
         // (three arrays of cap + 4 K entries, each 16-byte aligned: a state's list starts at a multiple of four entries)
@@ -609,7 +609,7 @@ static int alloc_sweep_buffers(hml_ctx* c) {
         HIPCHK(hipMalloc(&c->d_em, plane * sizeof(float)));
         HIPCHK(hipMalloc(&c->d_gsc, plane * sizeof(float)));
         HIPCHK(hipMalloc(&c->d_crows, plane * sizeof(float)));
-        HIPCHK(hipMalloc(&c->d_cchunk, (uint64_t)HML_WL_MAX_CHUNKS * (2 * K * sizeof(float) + 4 * sizeof(uint32_t))));
+        HIPCHK(hipMalloc(&c->d_cchunk, (uint64_t)HML_WL_MAX_CHUNKS * (2 * K * sizeof(float) + 4 * sizeof(uint32_t)) + 64));
         HIPCHK(hipMalloc(&c->d_wA, (uint64_t)HML_WL_PITCH * HML_WL_PITCH * sizeof(float)));
         HIPCHK(hipMalloc(&c->d_cdraws, 2 * (cap + 1) * sizeof(uint32_t)));
         HIPCHK(hipMalloc(&c->d_q, cap * sizeof(int16_t)));
@@ -931,7 +931,8 @@ static hml_compat_chunks chunk_views(const hml_ctx* c) {   // the arrays of d_cc
     ch.nfb = (uint32_t*)base; base += n * sizeof(uint32_t);
     ch.in_state = (int32_t*)base; base += n * sizeof(int32_t);
     ch.out_state = (int32_t*)base; base += n * sizeof(int32_t);
-    ch.bad = (uint32_t*)base;
+    ch.bad = (uint32_t*)base; base += n * sizeof(uint32_t);
+    ch.tot = (unsigned long long*)base;
     ch.W = 0u;
     return ch;
 }
@@ -1042,8 +1043,8 @@ static int sweep_wide(hml_ctx* c, char method, bool record) {
         hipLaunchKernelGGL(hml_k_wl_prepare, dim3(1), dim3(256), 0, s, c->d_mdl, c->d_wA, c->wide_lshift);
         {
             ProfScope ps(c, "stats_emission");
-            // (a wavefront: 64 chunks x 8 rows)
-            hipLaunchKernelGGL(hml_k_wl_emission, dim3(grid_for(room, 512 * 4, 1, 16384)), dim3(256), 0, s, c->d_mdl, c->d_starts, c->d_bstat, c->d_em, c->d_gsc);
+            // (a wavefront: 64 chunks x HML_WL_EMIT_ROWS rows)
+            hipLaunchKernelGGL(hml_k_wl_emission, dim3(grid_for(room, 64 * HML_WL_EMIT_ROWS * 4, 1, 32768)), dim3(256), 0, s, c->d_mdl, c->d_starts, c->d_bstat, c->d_em, c->d_gsc);
         }
         const uint64_t minL = c->wide_lshift >= 0 ? (1ull << c->wide_lshift) : (1ull << HML_WL_MIN_LSHIFT);
         const int tiles = grid_for(room, (int)std::min<uint64_t>(64 * minL, 1u << 30), 1, HML_WL_MAX_CHUNKS / 64);
@@ -1059,6 +1060,7 @@ static int sweep_wide(hml_ctx* c, char method, bool record) {
             {                                                                                                                                           \
                 ProfScope ps(c, "backward_maps");                                                                                                       \
                 hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_wl_backward<KC>), dim3(tiles), dim3(64), 0, s, c->d_mdl, c->d_crows, c->d_q, ch);               \
+                hipLaunchKernelGGL(hml_k_wl_backward_verify, dim3(grid_for(room / 16, 256, 1, 256)), dim3(256), 0, s, c->d_mdl, ch);                     \
                 hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_wl_backward_check<KS>), dim3(1), dim3(256), 0, s, c->d_mdl, c->d_crows, c->d_q, ch);          \
             }                                                                                                                                           \
         } break;

@@ -333,6 +333,7 @@ struct hml_compat_chunks {
     int32_t* in_state;   // [C] backward draws: the state above the chunk's first row (from its warm-up)
     int32_t* out_state;  // [C] ... and the state of its last row
     uint32_t W;          // warm-up, blocks; HML_CHUNK_W_ADAPTIVE: the model's own (mdl->fwd_W: it follows the chunks that had to run again)
+    unsigned long long* tot;   // [3] (hml_k_wide_lanes.h) wrong chunks of the filter, the sum of nfb, wrong chunks of the backward draws
 };
 #define HML_CHUNK_W_ADAPTIVE 0xffffffffu
 // The warm-up of the chunks (results never depend on it: a chunk is accepted only on bit equality with what the chunk before it

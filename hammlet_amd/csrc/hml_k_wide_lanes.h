@@ -3,10 +3,13 @@
 // v_readlane broadcasts - 470 cycles of a SIMD per block and chunk step at 20 states).  Here a wavefront runs 64 chunks side
 // by side, every lane the whole K-vector of its own chunk - the shape of the kernels for up to 16 states (hml_k_forward.h) with
 // the number of states at run time:
-//   * the per-block K-vectors (emission terms, rescale factors, trellis rows) are CHUNK-TRANSPOSED (hml_state.h: hml_layout /
-//     hml_bk - element (block b, state s) at ((b mod L) K + s) cstride + b / L): the 64 lanes of a wavefront - 64 consecutive
-//     chunks at the same row of their chunk - read and write 64 consecutive floats.  The chunk length L (a power of two) is
-//     decided on the device once the sweep's blocks are known (hml_k_wl_prepare: at most 65 536 chunks, at least 16 blocks each);
+//   * the per-block K-vectors (emission terms, rescale factors, trellis rows) are CHUNK-TRANSPOSED, a TILE of 64 chunks at a
+//     time (hml_wl_at): element (block b, state s) of chunk c = b / L, row r = b mod L, lies at (((c / 64) L + r) K + s) 64 +
+//     c mod 64 - the 64 lanes of a wavefront, 64 consecutive chunks at the same row of their chunk, read and write 64
+//     consecutive floats, and a wavefront's steps walk ONE contiguous stream of L K 256 bytes (the layout of hml_bk, whole
+//     planes per (row, state), had every one of a step's 3 K accesses in a DRAM page of its own: 2.5 TB/s).  The chunk length L (a
+//     power of two) is decided on the device once the sweep's blocks are known (hml_k_wl_prepare: at most 65 536 chunks, at
+//     least 16 blocks each);
 //   * the transition matrix comes from SCALAR loads (the same for every lane: a row of a zero-padded 64 x 64 copy, sixteen
 //     columns at a time), the lane's own vector of the step before from its column of LDS (the accumulators are registers:
 //     static indices), K x K multiply-adds per lane and step and nothing that crosses lanes;
@@ -31,6 +34,11 @@
 #define HML_WL_MAP_WORDS (HML_WL_MAX_CHUNKS / 64)
 #define HML_WL_PITCH 64   // floats between the rows of the padded transition matrix
 
+// element (block b, state s) of a chunk-transposed array (chunks of 1 << lshift blocks)
+__device__ __forceinline__ uint64_t hml_wl_at(const uint32_t lshift, const int K, const uint32_t b, const int s) {
+    const uint32_t c = b >> lshift, r = b & ((1u << lshift) - 1u);
+    return ((((uint64_t)(c >> 6) << lshift) + r) * (uint32_t)K + (uint32_t)s) * 64u + (c & 63u);
+}
 __device__ __forceinline__ hml_layout hml_wl_layout(const hml_model* mdl) {
     hml_layout lay;
     lay.lshift = mdl->wl_lshift;
@@ -58,11 +66,11 @@ HML_KERNEL __launch_bounds__(256) void hml_k_wl_prepare(hml_model* mdl, float* _
 }
 
 // Emission terms and rescale factors in the chunk-transposed layout: hml_k_wide_emission's values (same arithmetic, same order),
-// a lane per CHUNK: a wavefront takes 64 consecutive chunks and up to eight of their rows, and every store is 64 consecutive
-// floats.  The eight rows go through the states together - a state's parameters are read once for eight independent chains of
+// a lane per CHUNK: a wavefront takes 64 consecutive chunks and up to four of their rows, and every store is 64 consecutive
+// floats.  The rows go through the states together - a state's parameters are read once for four independent chains of
 // arithmetic - and twice: first for the rows' maxima, then for the terms themselves (the energies are cheap to compute again,
 // and a lane has no room to keep 64 of them per row).
-#define HML_WL_EMIT_ROWS 8
+#define HML_WL_EMIT_ROWS 4
 HML_KERNEL __launch_bounds__(256) void hml_k_wl_emission(hml_model* __restrict__ mdl, const uint32_t* __restrict__ starts, const float2* __restrict__ bstat,
                                                          float* __restrict__ em, float* __restrict__ g) {
     __shared__ float s_mu[HML_CAP_K], s_var[HML_CAP_K], s_logNs[HML_CAP_K], s_logA[HML_CAP_K];
@@ -85,7 +93,6 @@ HML_KERNEL __launch_bounds__(256) void hml_k_wl_emission(hml_model* __restrict__
     __syncthreads();
     const hml_layout lay = hml_wl_layout(mdl);
     const uint32_t L = 1u << lay.lshift, C = (uint32_t)(((uint64_t)B + L - 1u) >> lay.lshift);
-    const uint64_t cs = lay.cstride;
     constexpr int R = HML_WL_EMIT_ROWS;
     const uint32_t RG = L < (uint32_t)R ? L : (uint32_t)R, GPT = L / RG;
     const uint64_t n_items = (uint64_t)((C + 63u) / 64u) * GPT;
@@ -143,7 +150,7 @@ HML_KERNEL __launch_bounds__(256) void hml_k_wl_emission(hml_model* __restrict__
 #pragma unroll
             for (int r = 0; r < R; ++r) maxE[r] = (E[r] < maxE[r]) ? maxE[r] : E[r];
         }
-        const uint64_t a00 = (uint64_t)(r0 * (uint32_t)K) * cs + c;
+        const uint64_t a00 = ((((uint64_t)tile << lay.lshift) + r0) * (uint32_t)K) * 64u + (uint32_t)lane;
         for (int st = 0; st < K; ++st) {
             float E[R];
             energies(st, E, false);
@@ -153,7 +160,7 @@ HML_KERNEL __launch_bounds__(256) void hml_k_wl_emission(hml_model* __restrict__
                 const float v = hml_expf_tab(E[r] - maxE[r], s_tab);
                 const float gv = hml_expf_tab((N[r] - 1.0f) * lA, s_tab);
                 if (in[r]) {
-                    const uint64_t a = a00 + (uint64_t)((uint32_t)r * (uint32_t)K + (uint32_t)st) * cs;
+                    const uint64_t a = a00 + (uint64_t)((uint32_t)r * (uint32_t)K + (uint32_t)st) * 64u;
                     em[a] = v;
                     if (self) g[a] = gv;
                 }
@@ -164,51 +171,78 @@ HML_KERNEL __launch_bounds__(256) void hml_k_wl_emission(hml_model* __restrict__
 
 // one pass of the filter's matrix-vector product over NJ columns from j0: out[j] = sum_i prev_i A(i, j0 + j), i = 0 .. K-1 in
 // order from 0.0f (products and sums rounded separately, like `tt += prev_i * A(i, j)` everywhere else); prev from the lane's
-// column of LDS, A's rows from the padded copy (uniform addresses: scalar loads)
+// column of LDS, A's rows from the workgroup's padded copy in LDS (every lane the same address: broadcast reads of 16 bytes,
+// several rows in flight - scalar loads of the rows were measured first: a wavefront alone on its SIMD waited 100 ns for
+// each of them, 40 times a step)
 template <int NJ>
-__device__ __forceinline__ void hml_wl_mv(const float* __restrict__ wA, const int j0, const float* sp, const int K, float (&out)[NJ]) {
+__device__ __forceinline__ void hml_wl_mv(const float* sA, const int j0, const float* sp, const int K, float (&out)[NJ]) {
+    static_assert(NJ % 4 == 0, "columns in groups of four");
+    constexpr int Q = NJ / 4;
 #pragma unroll
     for (int j = 0; j < NJ; ++j) out[j] = 0.0f;
-    // (row i + 1 and prev_{i+1} are requested before row i is used: a scalar load and an LDS read per row, both waited for
-    // behind the row's multiply-adds instead of in front of them)
-    float cur[NJ], nxt[NJ];
-    float pc = sp[0], pn;
-    {
-        const float* __restrict__ row = wA + j0;
+    // two rows a stage, the next stage's reads issued before this stage's multiply-adds (left to itself the compiler, short of
+    // registers, waited for every 16-byte read before the four instructions that use it: an LDS round trip per read)
+    float4 a0[Q], a1[Q], b0[Q], b1[Q];
+    float p0, p1, q0, q1;
+    auto fetch = [&](const int i, float4 (&r0)[Q], float4 (&r1)[Q], float& x0, float& x1) {
+        const int i1 = (i + 1 < K) ? i + 1 : i;
+        const float4* const row0 = (const float4*)(sA + i * HML_WL_PITCH + j0);
+        const float4* const row1 = (const float4*)(sA + i1 * HML_WL_PITCH + j0);
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) cur[j] = row[j];
+        for (int k = 0; k < Q; ++k) { r0[k] = row0[k]; r1[k] = row1[k]; }
+        x0 = sp[i * 64]; x1 = sp[i1 * 64];
+    };
+    auto madd = [&](const float4 (&r)[Q], const float x) {
+#pragma unroll
+        for (int k = 0; k < Q; ++k) {
+            out[4 * k + 0] += x * r[k].x;
+            out[4 * k + 1] += x * r[k].y;
+            out[4 * k + 2] += x * r[k].z;
+            out[4 * k + 3] += x * r[k].w;
+        }
+    };
+    fetch(0, a0, a1, p0, p1);
+    int i = 0;
+    for (; i + 4 <= K; i += 4) {   // rows i .. i + 3; rows i + 4, i + 5 (if any) on their way at the end
+        fetch(i + 2, b0, b1, q0, q1);
+        madd(a0, p0); madd(a1, p1);
+        const int in = (i + 4 < K) ? i + 4 : i;
+        fetch(in, a0, a1, p0, p1);
+        madd(b0, q0); madd(b1, q1);
     }
-#pragma unroll 2
-    for (int i = 0; i < K; ++i) {
-        const int in = (i + 1 < K) ? i + 1 : i;
-        const float* __restrict__ row = wA + in * HML_WL_PITCH + j0;
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) nxt[j] = row[j];
-        pn = sp[in * 64];
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) out[j] += pc * cur[j];
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) cur[j] = nxt[j];
-        pc = pn;
+    // up to three rows left (a0, a1 hold rows i, i + 1 when i < K)
+    if (i < K) {
+        if (i + 2 < K) fetch(i + 2, b0, b1, q0, q1);
+        madd(a0, p0);
+        if (i + 1 < K) madd(a1, p1);
+        if (i + 2 < K) madd(b0, q0);
     }
 }
 
-// The filter, a chunk a lane.  KC: the model's number of states rounded up to a multiple of four (20 .. 64).
+// The filter, a chunk a lane.  KC: the model's number of states rounded up to a multiple of four (4 .. 64).
+// Step s of a wavefront's 64 chunks is block lo + s - W of every one of them: the same row of the chunk-transposed arrays for
+// all lanes (a scalar offset) and the lane's own chunk index plus a common shift - a load or store is a scalar base and a
+// 32-bit lane offset.  Lanes whose block lies outside the trace (the first chunks' warm-up, the last chunk's tail) read some
+// element inside the arrays and keep what they have.
 template <int KC>
 HML_KERNEL __launch_bounds__(64) void hml_k_wl_forward(hml_model* __restrict__ mdl, const float* __restrict__ wA, const float* __restrict__ em,
                                                        const float* __restrict__ g, float* __restrict__ rows, const hml_compat_chunks ch) {
     __shared__ float s_prev[KC * 64];   // [state][lane]: the lane's row of the step before
+    __shared__ __attribute__((aligned(16))) float sA[KC * HML_WL_PITCH];
     if (mdl->halted != 0u) return;
     const int lane = threadIdx.x;
     const int K = mdl->K;
     const uint32_t B = mdl->B;
     const hml_layout lay = hml_wl_layout(mdl);
     const uint32_t L = 1u << lay.lshift, C = (uint32_t)(((uint64_t)B + L - 1u) >> lay.lshift);
-    const uint64_t cs = lay.cstride;
+    if (blockIdx.x == 0u && lane < 3) ch.tot[lane] = 0ull;   // (the verifying launches behind this one count into them)
+    if (blockIdx.x * 64u >= C) return;
     const bool self = mdl->self_trans != 0;
     const uint32_t W = hml_chunk_warmup(mdl, ch.W);
     const float invK = (float)(1.0 / (double)(float)K);
     float* const sp = s_prev + lane;
+    for (int idx = lane; idx < K * (HML_WL_PITCH / 4); idx += 64) ((float4*)sA)[idx] = ((const float4*)wA)[idx];
+    hml_compat_fence();
     for (uint32_t c0 = blockIdx.x * 64u; c0 < C; c0 += gridDim.x * 64u) {   // wave-uniform
         const uint32_t c = c0 + (uint32_t)lane;
         const bool valid = c < C;
@@ -219,43 +253,44 @@ HML_KERNEL __launch_bounds__(64) void hml_k_wl_forward(hml_model* __restrict__ m
         for (int j = 0; j < KC; ++j) sp[j * 64] = (j < KC - 3 || j < K) ? (exact ? mdl->pi[j] : invK) : 0.0f;
         if (valid) ch.bad[c] = 0u;
         uint32_t nfb = 0u;
-        // (block index -> the address of its state 0; blocks outside the trace are read as the nearest one inside)
-        auto addr = [&](int64_t b) -> uint64_t {
-            const uint32_t bc = b < 0 ? 0u : (b >= (int64_t)B ? B - 1u : (uint32_t)b);
-            return (uint64_t)((bc & (L - 1u)) * (uint32_t)K) * cs + (bc >> lay.lshift);
+        // step d: the lane's element of state 0 - the row of the chunk (the same for all lanes) in the tile of the lane's chunk
+        // index, kept inside the arrays
+        auto at = [&](int64_t d) -> uint64_t {
+            const int64_t cc = (int64_t)c + (d >> lay.lshift);
+            const uint32_t cl = cc < 0 ? 0u : (cc >= (int64_t)C ? C - 1u : (uint32_t)cc);
+            return ((((uint64_t)(cl >> 6) << lay.lshift) + ((uint32_t)d & (L - 1u))) * (uint32_t)K) * 64u + (cl & 63u);
         };
-        int64_t b = lo - (int64_t)W;
-        uint64_t a0 = addr(b);
         float e[KC];
+        {
+            const float* const pe = em + at(-(int64_t)W);
 #pragma unroll
-        for (int j = 0; j < KC; ++j) e[j] = (j < KC - 3 || j < K) ? em[a0 + (uint64_t)j * cs] : 0.0f;
-        const uint32_t steps = W + L;
-        for (uint32_t s = 0; s < steps; ++s, ++b) {
+            for (int j = 0; j < KC; ++j) e[j] = (j < KC - 3 || j < K) ? pe[j * 64] : 0.0f;
+        }
+        auto step = [&](const int64_t d, auto own_tag) {
+            constexpr bool OWN = decltype(own_tag)::value;
+            const int64_t b = lo + d;
             const bool active = valid && b >= 0 && b < hi;
-            const bool own = s >= W;   // (wave-uniform: b >= lo)
             // the next step's terms and this step's factors travel during the step
-            const uint64_t a1 = addr(b + 1);
             float en[KC], gc[KC];
+            {
+                const float* const pe = em + at(d + 1);
 #pragma unroll
-            for (int j = 0; j < KC; ++j) en[j] = (j < KC - 3 || j < K) ? em[a1 + (uint64_t)j * cs] : 0.0f;
-            if (self && own) {
-#pragma unroll
-                for (int j = 0; j < KC; ++j) gc[j] = (j < KC - 3 || j < K) ? g[a0 + (uint64_t)j * cs] : 1.0f;
-            } else {
-#pragma unroll
-                for (int j = 0; j < KC; ++j) gc[j] = 1.0f;
+                for (int j = 0; j < KC; ++j) en[j] = (j < KC - 3 || j < K) ? pe[j * 64] : 0.0f;
             }
-            if (s == W && valid) {
-                for (int j = 0; j < K; ++j) ch.entry[(uint64_t)c * K + j] = sp[j * 64];
+            const uint64_t a0 = at(d);   // (an active lane's own element)
+            if (OWN && self) {
+                const float* const pg = g + a0;
+#pragma unroll
+                for (int j = 0; j < KC; ++j) gc[j] = (j < KC - 3 || j < K) ? pg[j * 64] : 1.0f;
             }
             float f[KC];
 #define HML_WL_PASS(J0, NJ)                                                              \
             if constexpr ((NJ) > 0) {                                                    \
-                float o[(NJ) > 0 ? (NJ) : 1];                                            \
-                hml_wl_mv<((NJ) > 0 ? (NJ) : 1)>(wA, J0, sp, K, o);                      \
+                float o[(NJ) > 0 ? (NJ) : 4];                                            \
+                hml_wl_mv<((NJ) > 0 ? (NJ) : 4)>(sA, J0, sp, K, o);                      \
                 _Pragma("unroll") for (int j = 0; j < (NJ); ++j) f[(J0) + j] = e[(J0) + j] * o[j]; \
             }
-            // (passes of at most sixteen columns: a pass's row sits in scalar registers twice)
+            // (passes of at most sixteen columns: a pass's accumulators and two stages of A's rows are registers next to e, en, g)
             constexpr int NP = (KC + 15) / 16, PW = ((KC + NP - 1) / NP + 3) / 4 * 4;
             constexpr int W0 = PW < KC ? PW : KC, W1 = (KC - W0) < PW ? (KC - W0) : PW, W2 = (KC - W0 - W1) < PW ? (KC - W0 - W1) : PW, W3 = KC - W0 - W1 - W2;
             HML_WL_PASS(0, W0) HML_WL_PASS(W0, W1) HML_WL_PASS(W0 + W1, W2) HML_WL_PASS(W0 + W1 + W2, W3)
@@ -269,25 +304,30 @@ HML_KERNEL __launch_bounds__(64) void hml_k_wl_forward(hml_model* __restrict__ m
             float fw[KC];
 #pragma unroll
             for (int j = 0; j < KC; ++j) fw[j] = hml_tr2_quotient(f[j], Zd, rz);
-            if (__builtin_expect(!(Z > 0.0f) || !(Z < 3.4028234663852886e38f), 0)) {   // 0: the uniform vector; negative, infinite or NaN: whatever the division says
+            if (__builtin_expect(active && (!(Z > 0.0f) || !(Z < 3.4028234663852886e38f)), 0)) {   // 0: the uniform vector; negative, infinite or NaN: whatever the division says
                 const bool ok = (Z != 0.0f);
 #pragma unroll
                 for (int j = 0; j < KC; ++j) fw[j] = ok ? f[j] / Z : invK;
-                if (!ok && active && own) nfb++;
+                if (OWN && !ok) nfb++;
             }
             if (active) {
 #pragma unroll
                 for (int j = 0; j < KC; ++j) if (j < KC - 3 || j < K) sp[j * 64] = fw[j];
-                if (own) {
+                if (OWN) {
                     const bool scaled = self && (b + 1 < (int64_t)B);
+                    float* const pr = rows + a0;
 #pragma unroll
-                    for (int j = 0; j < KC; ++j) if (j < KC - 3 || j < K) rows[a0 + (uint64_t)j * cs] = scaled ? fw[j] * gc[j] : fw[j];
+                    for (int j = 0; j < KC; ++j) if (j < KC - 3 || j < K) pr[j * 64] = scaled ? fw[j] * gc[j] : fw[j];
                 }
             }
 #pragma unroll
             for (int j = 0; j < KC; ++j) e[j] = en[j];
-            a0 = a1;
+        };
+        for (int64_t d = -(int64_t)W; d < 0; ++d) step(d, std::false_type{});
+        if (valid) {
+            for (int j = 0; j < K; ++j) ch.entry[(uint64_t)c * K + j] = sp[j * 64];
         }
+        for (int64_t d = 0; d < (int64_t)L; ++d) step(d, std::true_type{});
         if (valid) {
             for (int j = 0; j < K; ++j) ch.exitv[(uint64_t)c * K + j] = sp[j * 64];
             ch.nfb[c] = nfb;
@@ -303,9 +343,39 @@ HML_KERNEL __launch_bounds__(256) void hml_k_wl_forward_verify(const hml_model* 
     const uint32_t n_chunks = (uint32_t)(((uint64_t)B + (1ull << lshift) - 1ull) >> lshift);
     const uint64_t n = (uint64_t)n_chunks * K;
     const uint32_t W = hml_chunk_warmup(mdl, ch.W);
+    // (the one workgroup that walks the chunks in order returns at once when these say there is nothing to do: it took 100 us to
+    // look at 47 000 flags)
+    unsigned long long n_bad = 0ull, nfb = 0ull;
     for (uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (uint64_t)gridDim.x * blockDim.x) {
         const uint32_t c = (uint32_t)(e / K);
-        if (c > 0u && ((uint64_t)c << lshift) > W && hml_f2u(ch.entry[e]) != hml_f2u(ch.exitv[e - K])) ch.bad[c] = 1u;
+        if (c > 0u && ((uint64_t)c << lshift) > W && hml_f2u(ch.entry[e]) != hml_f2u(ch.exitv[e - K])) { ch.bad[c] = 1u; n_bad++; }
+        if (e == (uint64_t)c * K) nfb += (unsigned long long)ch.nfb[c];
+    }
+    if (__ballot(n_bad != 0ull || nfb != 0ull) != 0ull) {   // (rare)
+        for (int m = 32; m >= 1; m >>= 1) { n_bad += __shfl_xor(n_bad, m); nfb += __shfl_xor(nfb, m); }
+        if ((threadIdx.x & 63u) == 0u) {
+            if (n_bad) atomicAdd(&ch.tot[0], n_bad);
+            if (nfb) atomicAdd(&ch.tot[1], nfb);
+        }
+    }
+}
+
+// which chunks of the backward draws started from another state than the chunk above them ended in (or met a negative weight)
+__device__ __forceinline__ bool hml_wl_backward_wrong(const hml_compat_chunks& ch, uint32_t cl, uint32_t n_chunks) {
+    const int in = ch.in_state[cl];
+    if (in == -2) return true;
+    return cl + 1u < n_chunks && in >= 0 && in != ch.out_state[cl + 1u];
+}
+HML_KERNEL __launch_bounds__(256) void hml_k_wl_backward_verify(const hml_model* __restrict__ mdl, const hml_compat_chunks ch) {
+    if (mdl->halted != 0u) return;
+    const uint32_t B = mdl->B;
+    const uint32_t lshift = mdl->wl_lshift;
+    const uint32_t n_chunks = (uint32_t)(((uint64_t)B + (1ull << lshift) - 1ull) >> lshift);
+    unsigned long long n_bad = 0ull;
+    for (uint32_t cl = blockIdx.x * blockDim.x + threadIdx.x; cl < n_chunks; cl += gridDim.x * blockDim.x) n_bad += hml_wl_backward_wrong(ch, cl, n_chunks) ? 1ull : 0ull;
+    if (__ballot(n_bad != 0ull) != 0ull) {
+        for (int m = 32; m >= 1; m >>= 1) n_bad += __shfl_xor(n_bad, m);
+        if ((threadIdx.x & 63u) == 0u) atomicAdd(&ch.tot[2], n_bad);
     }
 }
 
@@ -318,7 +388,7 @@ __device__ __forceinline__ void hml_wl_forward_again(const int K, const uint32_t
     const bool act = lane < K;
     const int sl = act ? lane : 0;
     for (uint32_t b = lo; b < hi; ++b) {
-        const uint64_t a = hml_bk(lay, b, K, sl);
+        const uint64_t a = hml_wl_at(lay.lshift, K, b, sl);
         const float ev = em[a];
         const float gv = self ? g[a] : 1.0f;
         float tt = 0.0f;
@@ -360,6 +430,10 @@ HML_KERNEL __launch_bounds__(256) void hml_k_wl_forward_check(hml_model* __restr
     const hml_layout lay = hml_wl_layout(mdl);
     const uint32_t L = 1u << lay.lshift;
     const uint32_t n_chunks = (uint32_t)(((uint64_t)B + L - 1u) >> lay.lshift);
+    if (ch.tot[0] == 0ull) {   // every chunk started from what the chunk before it left (hml_k_wl_forward_verify)
+        if (tid == 0) { mdl->uniform_fallbacks += ch.tot[1]; hml_chunk_warmup_adapt(mdl, ch.W, 0ull, true); }
+        return;
+    }
     {
         unsigned long long mine = 0ull;
         for (uint32_t cl = (uint32_t)tid; cl < n_chunks; cl += 256u) mine += (unsigned long long)ch.nfb[cl];
@@ -435,7 +509,6 @@ HML_KERNEL __launch_bounds__(64) void hml_k_wl_backward(hml_model* __restrict__ 
     const uint32_t B = mdl->B;
     const hml_layout lay = hml_wl_layout(mdl);
     const uint32_t L = 1u << lay.lshift, C = (uint32_t)(((uint64_t)B + L - 1u) >> lay.lshift);
-    const uint64_t cs = lay.cstride;
     for (int idx = lane; idx < KC * KC; idx += 64) {
         const int qq = idx / KC, i = idx - qq * KC;
         sAT[qq * PITCH + i] = (i < K && qq < K) ? mdl->A[i * K + qq] : 0.0f;
@@ -452,7 +525,7 @@ HML_KERNEL __launch_bounds__(64) void hml_k_wl_backward(hml_model* __restrict__ 
         const bool from_last = top >= (int64_t)B - 1;            // ... or at the trellis's last row: the true start
         auto addr = [&](int64_t b) -> uint64_t {
             const uint32_t bc = b < 0 ? 0u : (b >= (int64_t)B ? B - 1u : (uint32_t)b);
-            return (uint64_t)((bc & (L - 1u)) * (uint32_t)K) * cs + (bc >> lay.lshift);
+            return hml_wl_at(lay.lshift, K, bc, 0);
         };
         int64_t b = top;
         int j = 0, in_rec = 0;
@@ -461,7 +534,7 @@ HML_KERNEL __launch_bounds__(64) void hml_k_wl_backward(hml_model* __restrict__ 
         {
             const uint64_t a = addr(b);
 #pragma unroll
-            for (int i = 0; i < KC; ++i) r[i] = (i < KC - 3 || i < K) ? rows[a + (uint64_t)i * cs] : 0.0f;
+            for (int i = 0; i < KC; ++i) r[i] = (i < KC - 3 || i < K) ? rows[a + (uint64_t)i * 64u] : 0.0f;
         }
         const uint32_t steps = W + L;
         for (uint32_t s = 0; s < steps; ++s, --b) {
@@ -472,7 +545,7 @@ HML_KERNEL __launch_bounds__(64) void hml_k_wl_backward(hml_model* __restrict__ 
             {
                 const uint64_t a = addr(b - 1);
 #pragma unroll
-                for (int i = 0; i < KC; ++i) rn[i] = (i < KC - 3 || i < K) ? rows[a + (uint64_t)i * cs] : 0.0f;
+                for (int i = 0; i < KC; ++i) rn[i] = (i < KC - 3 || i < K) ? rows[a + (uint64_t)i * 64u] : 0.0f;
             }
             if (s == W) in_rec = j;
             // the row's uniform from its own Philox address (hml_cat_uniform: nothing to read, no kernel ahead of this one)
@@ -543,11 +616,11 @@ HML_KERNEL __launch_bounds__(256) void hml_k_wl_backward_check(hml_model* __rest
     const hml_layout lay = hml_wl_layout(mdl);
     const uint32_t L = 1u << lay.lshift;
     const uint32_t n_chunks = (uint32_t)(((uint64_t)B + L - 1u) >> lay.lshift);
-    hml_compat_flag_map(map, n_chunks, tid, [&](uint32_t cl) {
-        const int in = ch.in_state[cl];
-        if (in == -2) return true;
-        return cl + 1u < n_chunks && in >= 0 && in != ch.out_state[cl + 1u];
-    });
+    if (ch.tot[2] == 0ull) {   // every chunk started from the state the chunk above it ended in (hml_k_wl_backward_verify)
+        if (tid == 0) hml_chunk_warmup_adapt(mdl, ch.W, 0ull, false);
+        return;
+    }
+    hml_compat_flag_map(map, n_chunks, tid, [&](uint32_t cl) { return hml_wl_backward_wrong(ch, cl, n_chunks); });
     if (tid >= 64) return;
     const bool act = lane < K;
     const int sl = act ? lane : 0;
@@ -565,7 +638,7 @@ HML_KERNEL __launch_bounds__(256) void hml_k_wl_backward_check(hml_model* __rest
                 const uint32_t lo = cc << lay.lshift, hi = ((uint64_t)lo + L < (uint64_t)B) ? lo + L : B;
                 for (uint32_t b = hi; b-- > lo; ) {
                     const uint32_t t = b + 1u;
-                    const float row = rows[hml_bk(lay, b, K, sl)];
+                    const float row = rows[hml_wl_at(lay.lshift, K, b, sl)];
                     const double u = hml_cat_uniform(key, epoch, t);
                     float w;
                     if (t == B) w = act ? row : 0.0f;
