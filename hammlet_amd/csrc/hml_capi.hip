@@ -160,6 +160,7 @@ int hml_create(hml_ctx** out, int device, uint64_t seed, uint32_t chain_id, void
     if (const char* e = getenv("HML_COMPAT_CHUNKS")) c->compat_chunks = atoi(e);   // (1: the sequential form; > 1: that many chunks)
     if (const char* e = getenv("HML_COMPAT_WARMUP")) c->compat_warmup = atoi(e);   // (tests: a warm-up too short to forget the start)
     if (const char* e = getenv("HML_WIDE_LANES")) c->wide_lanes = atoi(e);   // (0: models of more than 16 states with a state a lane)
+    if (const char* e = getenv("HML_WIDE_W0")) c->wide_w0 = std::max(8, atoi(e));
     if (const char* e = getenv("HML_WIDE_L")) {   // (tests: chunks of that many blocks, a power of two)
         const int L = atoi(e);
         if (L >= 1) { int sh = 0; while ((1 << sh) < L && sh < 20) ++sh; c->wide_lshift = sh; }
@@ -609,7 +610,9 @@ static int alloc_sweep_buffers(hml_ctx* c) {
         HIPCHK(hipMalloc(&c->d_em, plane * sizeof(float)));
         HIPCHK(hipMalloc(&c->d_gsc, plane * sizeof(float)));
         HIPCHK(hipMalloc(&c->d_crows, plane * sizeof(float)));
-        HIPCHK(hipMalloc(&c->d_cchunk, (uint64_t)HML_WL_MAX_CHUNKS * (2 * K * sizeof(float) + 4 * sizeof(uint32_t)) + 64));
+        const uint64_t chunk_bytes = (uint64_t)HML_WL_MAX_CHUNKS * (2 * K * sizeof(float) + 4 * sizeof(uint32_t));
+        HIPCHK(hipMalloc(&c->d_cchunk, chunk_bytes + HML_WL_TOT_WORDS * sizeof(unsigned long long)));
+        HIPCHK(hipMemsetAsync((char*)c->d_cchunk + chunk_bytes, 0, HML_WL_TOT_WORDS * sizeof(unsigned long long), c->stream));   // (counters and bit maps of wrong chunks)
         HIPCHK(hipMalloc(&c->d_wA, (uint64_t)HML_WL_PITCH * HML_WL_PITCH * sizeof(float)));
         HIPCHK(hipMalloc(&c->d_cdraws, 2 * (cap + 1) * sizeof(uint32_t)));
         HIPCHK(hipMalloc(&c->d_q, cap * sizeof(int16_t)));
@@ -795,7 +798,7 @@ int hml_set_model(hml_ctx* c, int K, const float nig4[4], float a_off, float a_d
     if (const char* e = getenv("HML_TRE_REFIT_SHIFTS")) { unsigned a = 17, b = 20; if (sscanf(e, "%u,%u", &a, &b) == 2 && a < 32 && b < 32) { m.tre_hi_shift = a; m.tre_lo_shift = b; } }
     m.fwd_W0 = (uint32_t)c->fwdW;
     m.fwd_W = m.fwd_W_burnin = (uint32_t)std::max(c->fwdW, c->fwdW_init);
-    if (c->compat || c->wide) { m.fwd_W = 64u; m.fwd_W0 = 32u; }   // the chunked lane-per-state kernels' own policy (hml_chunk_warmup_adapt)
+    if (c->compat || c->wide) { m.fwd_W = 64u; m.fwd_W0 = c->wide ? (uint32_t)c->wide_w0 : 32u; }   // the chunked lane-per-state kernels' own policy (hml_chunk_warmup_adapt)
     m.fwd_burnin_sweeps = c->fwd_burnin_sweeps;
     m.fwd_quiet_need = c->fwd_quiet_need;
     m.n_spans = c->n_spans;

@@ -33,6 +33,11 @@
 #define HML_WL_MIN_LSHIFT 4
 #define HML_WL_MAP_WORDS (HML_WL_MAX_CHUNKS / 64)
 #define HML_WL_PITCH 64   // floats between the rows of the padded transition matrix
+// hml_compat_chunks::tot on this path: [0] wrong chunks of the filter, [1] the sum of nfb, [2] wrong chunks of the backward draws,
+// then a bit per wrong chunk of the filter and of the backward draws (set by the verifying launches, cleared by the checking ones)
+#define HML_WL_MAP_F 4
+#define HML_WL_MAP_B (HML_WL_MAP_F + HML_WL_MAP_WORDS)
+#define HML_WL_TOT_WORDS (HML_WL_MAP_B + HML_WL_MAP_WORDS)
 
 // element (block b, state s) of a chunk-transposed array (chunks of 1 << lshift blocks)
 __device__ __forceinline__ uint64_t hml_wl_at(const uint32_t lshift, const int K, const uint32_t b, const int s) {
@@ -251,7 +256,6 @@ HML_KERNEL __launch_bounds__(64) void hml_k_wl_forward(hml_model* __restrict__ m
         const bool exact = lo <= (int64_t)W;   // the warm-up reaches block 0: the chunk starts from pi itself
 #pragma unroll
         for (int j = 0; j < KC; ++j) sp[j * 64] = (j < KC - 3 || j < K) ? (exact ? mdl->pi[j] : invK) : 0.0f;
-        if (valid) ch.bad[c] = 0u;
         uint32_t nfb = 0u;
         // step d: the lane's element of state 0 - the row of the chunk (the same for all lanes) in the tile of the lane's chunk
         // index, kept inside the arrays
@@ -348,7 +352,10 @@ HML_KERNEL __launch_bounds__(256) void hml_k_wl_forward_verify(const hml_model* 
     unsigned long long n_bad = 0ull, nfb = 0ull;
     for (uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (uint64_t)gridDim.x * blockDim.x) {
         const uint32_t c = (uint32_t)(e / K);
-        if (c > 0u && ((uint64_t)c << lshift) > W && hml_f2u(ch.entry[e]) != hml_f2u(ch.exitv[e - K])) { ch.bad[c] = 1u; n_bad++; }
+        if (c > 0u && ((uint64_t)c << lshift) > W && hml_f2u(ch.entry[e]) != hml_f2u(ch.exitv[e - K])) {
+            atomicOr(&ch.tot[HML_WL_MAP_F + (c >> 6)], 1ull << (c & 63u));
+            n_bad++;
+        }
         if (e == (uint64_t)c * K) nfb += (unsigned long long)ch.nfb[c];
     }
     if (__ballot(n_bad != 0ull || nfb != 0ull) != 0ull) {   // (rare)
@@ -372,7 +379,9 @@ HML_KERNEL __launch_bounds__(256) void hml_k_wl_backward_verify(const hml_model*
     const uint32_t lshift = mdl->wl_lshift;
     const uint32_t n_chunks = (uint32_t)(((uint64_t)B + (1ull << lshift) - 1ull) >> lshift);
     unsigned long long n_bad = 0ull;
-    for (uint32_t cl = blockIdx.x * blockDim.x + threadIdx.x; cl < n_chunks; cl += gridDim.x * blockDim.x) n_bad += hml_wl_backward_wrong(ch, cl, n_chunks) ? 1ull : 0ull;
+    for (uint32_t cl = blockIdx.x * blockDim.x + threadIdx.x; cl < n_chunks; cl += gridDim.x * blockDim.x) {
+        if (hml_wl_backward_wrong(ch, cl, n_chunks)) { atomicOr(&ch.tot[HML_WL_MAP_B + (cl >> 6)], 1ull << (cl & 63u)); n_bad++; }
+    }
     if (__ballot(n_bad != 0ull) != 0ull) {
         for (int m = 32; m >= 1; m >>= 1) n_bad += __shfl_xor(n_bad, m);
         if ((threadIdx.x & 63u) == 0u) atomicAdd(&ch.tot[2], n_bad);
@@ -422,7 +431,6 @@ template <int KS>
 HML_KERNEL __launch_bounds__(256) void hml_k_wl_forward_check(hml_model* __restrict__ mdl, const float* __restrict__ em, const float* __restrict__ g,
                                                               float* __restrict__ rows, const hml_compat_chunks ch) {
     __shared__ unsigned long long map[HML_WL_MAP_WORDS];
-    __shared__ unsigned long long s_nfb[4];
     if (mdl->halted != 0u) return;
     const int tid = threadIdx.x, lane = tid & 63;
     const int K = mdl->K;
@@ -434,13 +442,12 @@ HML_KERNEL __launch_bounds__(256) void hml_k_wl_forward_check(hml_model* __restr
         if (tid == 0) { mdl->uniform_fallbacks += ch.tot[1]; hml_chunk_warmup_adapt(mdl, ch.W, 0ull, true); }
         return;
     }
-    {
-        unsigned long long mine = 0ull;
-        for (uint32_t cl = (uint32_t)tid; cl < n_chunks; cl += 256u) mine += (unsigned long long)ch.nfb[cl];
-        for (int m = 32; m >= 1; m >>= 1) mine += __shfl_xor(mine, m);
-        if (lane == 0) s_nfb[tid >> 6] = mine;
+    for (uint32_t w = (uint32_t)tid; w < (n_chunks + 63u) / 64u; w += 256u) {   // the wrong chunks' bits (and zeros behind them for the next sweep)
+        const unsigned long long v = ch.tot[HML_WL_MAP_F + w];
+        map[w] = v;
+        if (v) ch.tot[HML_WL_MAP_F + w] = 0ull;
     }
-    hml_compat_flag_map(map, n_chunks, tid, [&](uint32_t cl) { return ch.bad[cl] != 0u; });
+    __syncthreads();
     if (tid >= 64) return;
     const bool self = mdl->self_trans != 0;
     const bool act = lane < K;
@@ -448,7 +455,7 @@ HML_KERNEL __launch_bounds__(256) void hml_k_wl_forward_check(hml_model* __restr
 #pragma unroll
     for (int i = 0; i < KS; ++i) acol[i] = (act && i < K) ? mdl->A[i * K + lane] : 0.0f;
     const uint32_t W = hml_chunk_warmup(mdl, ch.W);   // (the warm-up this sweep's chunks ran with: adapted at the very end)
-    unsigned long long total_nfb = s_nfb[0] + s_nfb[1] + s_nfb[2] + s_nfb[3], redone = 0ull;
+    unsigned long long total_nfb = ch.tot[1], redone = 0ull;
     for (uint32_t c0 = 0; c0 < n_chunks; c0 += 64u) {
         while (true) {   // wave-uniform
             const unsigned long long todo = map[c0 >> 6];
@@ -620,7 +627,12 @@ HML_KERNEL __launch_bounds__(256) void hml_k_wl_backward_check(hml_model* __rest
         if (tid == 0) hml_chunk_warmup_adapt(mdl, ch.W, 0ull, false);
         return;
     }
-    hml_compat_flag_map(map, n_chunks, tid, [&](uint32_t cl) { return hml_wl_backward_wrong(ch, cl, n_chunks); });
+    for (uint32_t w = (uint32_t)tid; w < (n_chunks + 63u) / 64u; w += 256u) {
+        const unsigned long long v = ch.tot[HML_WL_MAP_B + w];
+        map[w] = v;
+        if (v) ch.tot[HML_WL_MAP_B + w] = 0ull;
+    }
+    __syncthreads();
     if (tid >= 64) return;
     const bool act = lane < K;
     const int sl = act ? lane : 0;

@@ -42,9 +42,10 @@ def test_bounded_fuzz_of_the_reference_compatible_mode(hml):
 
 
 def test_bounded_fuzz_of_the_path_for_many_states(hml):
-    """Round 5: the default path's kernels for models of more than 16 states (hml_k_wide.h - the number of states a run-time value, a
-    state a lane; the reference takes any `-s K`, src/main.cpp:112-137) against the checker's DEVICE mode on 120 random
-    configurations: 2-64 states (HML_WIDE=1 sends the small models there as well), 1-3 data dimensions (up to 7^2 = 49 states
-    with shared parameters), random schemes of M / F / S / D / P tokens, read-depth input, and chunk geometries from the sequential
-    form to hundreds of chunks without warm-up, where chunks start wrong and run again."""
-    assert fuzz(hml, 120, 20261007, wide=True) == 120
+    """Round 5: the default path's kernels for models of more than 16 states (hml_k_wide.h, hml_k_wide_lanes.h - the number of states
+    a run-time value; a chunk a lane over chunk-transposed arrays, or a state a lane; the reference takes any `-s K`,
+    src/main.cpp:112-137) against the checker's DEVICE mode on 160 random configurations: 2-64 states (HML_WIDE=1 sends the small
+    models there as well), 1-3 data dimensions (up to 7^2 = 49 states with shared parameters), random schemes of M / F / S / D / P
+    tokens, read-depth input, and chunk geometries from the sequential form to chunks of one block without warm-up, where chunks
+    start wrong and run again."""
+    assert fuzz(hml, 160, 20261007, wide=True) == 160

@@ -725,6 +725,37 @@ def test_many_states_with_a_reduced_block_capacity(hml):
     g.close()
 
 
+@pytest.mark.parametrize("K,L,warmup,lanes", [(17, None, None, 1), (20, 1, -1, 1), (24, 2, 1, 1), (33, 4, -1, 1), (40, 16, 4, 1), (64, 8, -1, 1), (5, 4, -1, 1),
+                                             (20, 64, None, 1), (20, None, None, 0), (48, None, -1, 0)])
+def test_many_states_a_chunk_a_lane(hml, monkeypatch, K, L, warmup, lanes):
+    """More than 16 states with a chunk a lane (hml_k_wide_lanes.h): chunk-transposed arrays, chunk lengths from one block up, chunks
+    that start from the wrong row or state (no warm-up, or hardly any) and run again - and the other form, a state a lane
+    (HML_WIDE_LANES=0).  The checker's chain bit for bit: blocks, states, parameters, marginals; the statistics show that chunks
+    ran again exactly where the warm-up was taken away."""
+    monkeypatch.setenv("HML_WIDE", "1")   # (this path for the model of 5 states too)
+    monkeypatch.setenv("HML_WIDE_LANES", str(lanes))
+    if L is not None:
+        monkeypatch.setenv("HML_WIDE_L", str(L))
+    if warmup is not None:
+        monkeypatch.setenv("HML_COMPAT_WARMUP", str(warmup))
+    T = 40_000
+    x, o, g = make_pair(hml, T, K, 9, 123, x=ol.trace(T, 5, 9))
+    setup_model(o, g, K)
+    g._pending_prior = True
+    o.set_record(marginals=True)
+    g.set_recording(marginals=True)
+    run_both(o, g, [("F", 5, 2), "S", ("F", 3, 1), "D", ("F", 4, 1)])
+    compare_state(o, g, what="%d states, chunks of %s blocks, warm-up %s, lanes %d" % (K, L, warmup, lanes))
+    seg, cnt = g.marginals_rle()
+    assert hml.marginals_text(seg, cnt) == o.text("marginals")
+    st = g.stats()
+    if warmup == -1 and (L is None or L < 64):
+        assert st["forward_refits"] > 0, st
+    if warmup is None:
+        assert st["forward_refits"] == 0, st
+    g.close()
+
+
 def test_attached_chains_start_with_a_reduced_block_capacity(hml):
     """a context attached to another one's observations reserves room for max(2^20, T / 16) blocks per sweep instead of T - and
     the source, like every ordinary context, for the worst case"""
