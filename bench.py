@@ -845,7 +845,7 @@ def main():
                              "sweep_frac": (4.0 * T4 + b4 * (36 + 8 * K4)) / ((t1 - t0) / 400) / 1e9 / HBM_PEAK_GBS,
                              "kernels": tab4,
                              "note": "BASELINE config 4's workload on ONE GPU (one of its 8 chains): sweeps 64..464; latency-bound like the headline"}
-        # more than 16 states (round 5, hml_k_wide.h: the number of states a run-time value, a state a lane): the headline's trace with 20
+        # more than 16 states (round 5, hml_k_wide.h / hml_k_wide_lanes.h: the number of states a run-time value, a chunk a lane): the headline's trace with 20
         # states in the model (more states than levels: states of tiny variance lower the threshold - 1.5 10^6 blocks per sweep)
         ch = hammlet_amd.Chain(device=local_rank, seed=args.seed, chain_id=rank)
         ch.load(x)
@@ -867,8 +867,8 @@ def main():
                                 "ms_per_step": 1e3 * (t1 - t0) / 100, "positions": T, "states": 20,
                                 "blocks_per_sweep": (w1["block_updates"] - w0["block_updates"]) / 100.0,
                                 "chunks_run_again": w1["forward_refits"] - w0["forward_refits"],
-                                "note": "the default path for models of 17-64 states: chunked lane-per-state filter and backward draws, Philox uniforms, "
-                                        "the count tree (DESIGN.md 3e); sweeps 60..160 of a chain on the headline's trace"}
+                                "note": "the default path for models of 17-64 states: filter and backward draws with a chunk a lane over chunk-transposed arrays "
+                                        "(hml_k_wide_lanes.h), Philox uniforms, the count tree (DESIGN.md 3e); sweeps 60..160 of a chain on the headline's trace"}
         # config 5's workload on one GPU: 2.5 10^8 simulated read-depth positions, 5 states, weakly compressed
         T5, K5, _, sg5, dw5, ds5 = WORKLOADS["c5_2.5e8_depth_k5"]
         x5 = hammlet_amd.synth_depth(T5, depth=dw5, ln_sigma=sg5, seed=ds5, nthreads=nthr)
