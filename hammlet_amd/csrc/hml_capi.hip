@@ -798,7 +798,8 @@ int hml_set_model(hml_ctx* c, int K, const float nig4[4], float a_off, float a_d
     if (const char* e = getenv("HML_TRE_REFIT_SHIFTS")) { unsigned a = 17, b = 20; if (sscanf(e, "%u,%u", &a, &b) == 2 && a < 32 && b < 32) { m.tre_hi_shift = a; m.tre_lo_shift = b; } }
     m.fwd_W0 = (uint32_t)c->fwdW;
     m.fwd_W = m.fwd_W_burnin = (uint32_t)std::max(c->fwdW, c->fwdW_init);
-    if (c->compat || c->wide) { m.fwd_W = 64u; m.fwd_W0 = c->wide ? (uint32_t)c->wide_w0 : 32u; }   // the chunked lane-per-state kernels' own policy (hml_chunk_warmup_adapt)
+    if (c->compat || c->wide) { m.fwd_W = 64u; m.fwd_W0 = c->wide ? (uint32_t)c->wide_w0 : 32u; }
+    m.wl_bwd_W = 64u; m.wl_bwd_quiet = 0u; m.wl_retry = 0u; m.wl_W_need = 0u; m.wl_need_age = 0u;   // the chunked lane-per-state kernels' own policy (hml_chunk_warmup_adapt)
     m.fwd_burnin_sweeps = c->fwd_burnin_sweeps;
     m.fwd_quiet_need = c->fwd_quiet_need;
     m.n_spans = c->n_spans;
@@ -1056,8 +1057,12 @@ static int sweep_wide(hml_ctx* c, char method, bool record) {
             constexpr int KS = (KC <= 32) ? 32 : 64;                                                                                                    \
             {                                                                                                                                           \
                 ProfScope ps(c, "forward");                                                                                                             \
-                hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_wl_forward<KC>), dim3(tiles), dim3(64), 0, s, c->d_mdl, c->d_wA, c->d_em, c->d_gsc, c->d_crows, ch); \
-                hipLaunchKernelGGL(hml_k_wl_forward_verify, dim3(grid_for(room / 16 * c->K, 256, 1, 4096)), dim3(256), 0, s, c->d_mdl, ch);             \
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_wl_forward<KC>), dim3(tiles), dim3(64), 0, s, c->d_mdl, c->d_wA, c->d_em, c->d_gsc, c->d_crows, ch, 0); \
+                hipLaunchKernelGGL(hml_k_wl_forward_verify, dim3(grid_for(room / 16 * c->K, 256, 1, 4096)), dim3(256), 0, s, c->d_mdl, ch, 0);          \
+                /* many wrong chunks: the filter once more with a longer warm-up (the three launches return at once otherwise) */                      \
+                hipLaunchKernelGGL(hml_k_wl_retry_decide, dim3(1), dim3(256), 0, s, c->d_mdl, ch);                                                      \
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_wl_forward<KC>), dim3(tiles), dim3(64), 0, s, c->d_mdl, c->d_wA, c->d_em, c->d_gsc, c->d_crows, ch, 1); \
+                hipLaunchKernelGGL(hml_k_wl_forward_verify, dim3(grid_for(room / 16 * c->K, 256, 1, 4096)), dim3(256), 0, s, c->d_mdl, ch, 1);          \
                 hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_wl_forward_check<KS>), dim3(1), dim3(256), 0, s, c->d_mdl, c->d_em, c->d_gsc, c->d_crows, ch);  \
             }                                                                                                                                           \
             {                                                                                                                                           \

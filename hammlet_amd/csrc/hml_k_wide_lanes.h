@@ -224,6 +224,33 @@ __device__ __forceinline__ void hml_wl_mv(const float* sA, const int j0, const f
     }
 }
 
+// The warm-up of the filter's chunks on this path (mdl->fwd_W; results never depend on it).  It starts at 64 blocks.  A sweep with
+// wrong chunks doubles it (eight times, if the whole filter ran again: hml_k_wl_retry_decide); sweeps without one walk it down -
+// by half every four of them while it is above 64 (a young chain's first sweeps need a long warm-up once: parameters from the prior),
+// by a quarter every sixteen below that, to the floor (32) - but not below twice a warm-up that failed on a settled chain (from its
+// ninth sweep on) for the 512 sweeps after that.
+__device__ __forceinline__ void hml_wl_fwd_adapt(hml_model* mdl, const uint32_t Wspec, const bool failed, const uint32_t W_used, const uint32_t W_next) {
+    if (Wspec != HML_CHUNK_W_ADAPTIVE) return;
+    if (failed) {
+        if (mdl->sweeps >= 8ull) { mdl->wl_W_need = W_used; mdl->wl_need_age = 0u; }
+        mdl->fwd_W = W_next;
+        mdl->fwd_quiet = 0u;
+        return;
+    }
+    if (mdl->wl_W_need != 0u && ++mdl->wl_need_age > 512u) mdl->wl_W_need = 0u;
+    uint32_t floor_w = mdl->fwd_W0;
+    if (mdl->wl_W_need != 0u) { const uint32_t keep = 2u * mdl->wl_W_need < 1024u ? 2u * mdl->wl_W_need : 1024u; floor_w = keep > floor_w ? keep : floor_w; }
+    uint32_t w = mdl->fwd_W;
+    const uint32_t quiet = ++mdl->fwd_quiet;
+    if (w > 64u && w / 2u >= floor_w && quiet >= 4u) { w = w / 2u; mdl->fwd_quiet = 0u; }
+    else if (quiet >= 16u) {
+        const uint32_t lower = (w - w / 4u) & ~7u;
+        w = lower > floor_w ? lower : (w < floor_w ? w : floor_w);
+        mdl->fwd_quiet = 0u;
+    }
+    mdl->fwd_W = w;
+}
+
 // The filter, a chunk a lane.  KC: the model's number of states rounded up to a multiple of four (4 .. 64).
 // Step s of a wavefront's 64 chunks is block lo + s - W of every one of them: the same row of the chunk-transposed arrays for
 // all lanes (a scalar offset) and the lane's own chunk index plus a common shift - a load or store is a scalar base and a
@@ -231,16 +258,17 @@ __device__ __forceinline__ void hml_wl_mv(const float* sA, const int j0, const f
 // element inside the arrays and keep what they have.
 template <int KC>
 HML_KERNEL __launch_bounds__(64) void hml_k_wl_forward(hml_model* __restrict__ mdl, const float* __restrict__ wA, const float* __restrict__ em,
-                                                       const float* __restrict__ g, float* __restrict__ rows, const hml_compat_chunks ch) {
+                                                       const float* __restrict__ g, float* __restrict__ rows, const hml_compat_chunks ch, const int retry) {
     __shared__ float s_prev[KC * 64];   // [state][lane]: the lane's row of the step before
     __shared__ __attribute__((aligned(16))) float sA[KC * HML_WL_PITCH];
     if (mdl->halted != 0u) return;
+    if (retry && mdl->wl_retry == 0u) return;   // (the second launch of a sweep: only if hml_k_wl_retry_decide asked for it)
     const int lane = threadIdx.x;
     const int K = mdl->K;
     const uint32_t B = mdl->B;
     const hml_layout lay = hml_wl_layout(mdl);
     const uint32_t L = 1u << lay.lshift, C = (uint32_t)(((uint64_t)B + L - 1u) >> lay.lshift);
-    if (blockIdx.x == 0u && lane < 3) ch.tot[lane] = 0ull;   // (the verifying launches behind this one count into them)
+    if (!retry && blockIdx.x == 0u && lane < 3) ch.tot[lane] = 0ull;   // (the verifying launches behind this one count into them)
     if (blockIdx.x * 64u >= C) return;
     const bool self = mdl->self_trans != 0;
     const uint32_t W = hml_chunk_warmup(mdl, ch.W);
@@ -340,8 +368,9 @@ HML_KERNEL __launch_bounds__(64) void hml_k_wl_forward(hml_model* __restrict__ m
 }
 
 // which chunks started from another row than the chunk before them left (hml_k_compat_forward_verify with this path's chunks)
-HML_KERNEL __launch_bounds__(256) void hml_k_wl_forward_verify(const hml_model* __restrict__ mdl, const hml_compat_chunks ch) {
+HML_KERNEL __launch_bounds__(256) void hml_k_wl_forward_verify(const hml_model* __restrict__ mdl, const hml_compat_chunks ch, const int retry) {
     if (mdl->halted != 0u) return;
+    if (retry && mdl->wl_retry == 0u) return;
     const uint32_t B = mdl->B, K = (uint32_t)mdl->K;
     const uint32_t lshift = mdl->wl_lshift;
     const uint32_t n_chunks = (uint32_t)(((uint64_t)B + (1ull << lshift) - 1ull) >> lshift);
@@ -365,6 +394,30 @@ HML_KERNEL __launch_bounds__(256) void hml_k_wl_forward_verify(const hml_model* 
             if (nfb) atomicAdd(&ch.tot[1], nfb);
         }
     }
+}
+
+// A sweep whose filter left MANY chunks wrong (a young chain: parameters from the prior, rows that forget slowly) does not hand them
+// to the one wavefront that runs wrong chunks again in order - 40 000 chunks of 64 blocks took it 1.4 s - but runs the whole
+// filter once more, a chunk a lane, with eight times the warm-up, which then is the model's for the sweeps that follow (the
+// adaptation walks it down again).  One workgroup between the first verification and the second launch, which returns at once
+// unless asked for.  A warm-up fixed by the caller (tests) stays as it is.
+#define HML_WL_RETRY_MIN 32u
+HML_KERNEL __launch_bounds__(256) void hml_k_wl_retry_decide(hml_model* __restrict__ mdl, const hml_compat_chunks ch) {
+    if (mdl->halted != 0u) return;
+    const unsigned long long n_bad = ch.tot[0];
+    const uint32_t W = hml_chunk_warmup(mdl, ch.W);
+    const bool take = ch.W == HML_CHUNK_W_ADAPTIVE && n_bad > (unsigned long long)HML_WL_RETRY_MIN && W < 1024u;   // (workgroup-uniform)
+    if (take) {
+        for (uint32_t w = threadIdx.x; w < (uint32_t)HML_WL_MAP_WORDS; w += 256u) ch.tot[HML_WL_MAP_F + w] = 0ull;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const uint32_t nw = (8u * W < 1024u) ? 8u * W : 1024u;
+            ch.tot[0] = 0ull; ch.tot[1] = 0ull;
+            mdl->forward_refits += n_bad;
+            hml_wl_fwd_adapt(mdl, ch.W, true, W, nw);
+            mdl->wl_retry = nw;
+        }
+    } else if (threadIdx.x == 0) mdl->wl_retry = 0u;
 }
 
 // which chunks of the backward draws started from another state than the chunk above them ended in (or met a negative weight)
@@ -439,7 +492,7 @@ HML_KERNEL __launch_bounds__(256) void hml_k_wl_forward_check(hml_model* __restr
     const uint32_t L = 1u << lay.lshift;
     const uint32_t n_chunks = (uint32_t)(((uint64_t)B + L - 1u) >> lay.lshift);
     if (ch.tot[0] == 0ull) {   // every chunk started from what the chunk before it left (hml_k_wl_forward_verify)
-        if (tid == 0) { mdl->uniform_fallbacks += ch.tot[1]; hml_chunk_warmup_adapt(mdl, ch.W, 0ull, true); }
+        if (tid == 0) { mdl->uniform_fallbacks += ch.tot[1]; if (mdl->wl_retry == 0u) hml_wl_fwd_adapt(mdl, ch.W, false, 0u, 0u); }
         return;
     }
     for (uint32_t w = (uint32_t)tid; w < (n_chunks + 63u) / 64u; w += 256u) {   // the wrong chunks' bits (and zeros behind them for the next sweep)
@@ -480,7 +533,11 @@ HML_KERNEL __launch_bounds__(256) void hml_k_wl_forward_check(hml_model* __restr
             }
         }
     }
-    if (lane == 0) { mdl->uniform_fallbacks += total_nfb; mdl->forward_refits += redone; hml_chunk_warmup_adapt(mdl, ch.W, redone, true); }
+    if (lane == 0) {
+        mdl->uniform_fallbacks += total_nfb; mdl->forward_refits += redone;
+        if (redone != 0ull) hml_wl_fwd_adapt(mdl, ch.W, true, W, (2u * W < 1024u) ? 2u * W : 1024u);
+        else if (mdl->wl_retry == 0u) hml_wl_fwd_adapt(mdl, ch.W, false, 0u, 0u);
+    }
 }
 
 // hml_categorical's literal form over a lane's own weights (hml_compat_categorical_exact, a chunk a lane)
@@ -503,6 +560,25 @@ __device__ __forceinline__ int hml_wl_categorical_exact(const float (&w)[KC], co
     return res;
 }
 
+// the warm-up of the backward draws' chunks (rows): the model's own unless the caller fixed one - it starts at 64, doubles when a sweep
+// had chunks that ran again, falls by half after four sweeps without one while above 16 and by a quarter after sixteen below, floor 8
+__device__ __forceinline__ uint32_t hml_wl_bwd_warmup(const hml_model* mdl, const uint32_t W) { return W == HML_CHUNK_W_ADAPTIVE ? mdl->wl_bwd_W : W; }
+__device__ __forceinline__ void hml_wl_bwd_warmup_adapt(hml_model* mdl, const uint32_t W, const unsigned long long ran_again) {
+    if (W != HML_CHUNK_W_ADAPTIVE) return;
+    uint32_t w = mdl->wl_bwd_W;
+    if (ran_again != 0ull) { w = (2u * w < 1024u) ? 2u * w : 1024u; mdl->wl_bwd_quiet = 0u; }
+    else {
+        const uint32_t quiet = ++mdl->wl_bwd_quiet;
+        if (w > 16u && quiet >= 4u) { w = w / 2u; mdl->wl_bwd_quiet = 0u; }
+        else if (quiet >= 16u) {
+            const uint32_t lower = w - w / 4u;
+            w = lower > 8u ? lower : 8u;
+            mdl->wl_bwd_quiet = 0u;
+        }
+    }
+    mdl->wl_bwd_W = w;
+}
+
 // The backward draws, a chunk a lane: rows (c + 1) L .. c L + 1 of the trellis (blocks b = t - 1 from the chunk's last down),
 // from state 0 W rows above (or from the trellis's last row, whose weights do not depend on a state above).
 template <int KC>
@@ -521,7 +597,7 @@ HML_KERNEL __launch_bounds__(64) void hml_k_wl_backward(hml_model* __restrict__ 
         sAT[qq * PITCH + i] = (i < K && qq < K) ? mdl->A[i * K + qq] : 0.0f;
     }
     hml_compat_fence();
-    const uint32_t W = hml_chunk_warmup(mdl, ch.W);
+    const uint32_t W = hml_wl_bwd_warmup(mdl, ch.W);
     const hml_key key = mdl->key;
     const unsigned long long epoch = mdl->epoch;
     for (uint32_t c0 = blockIdx.x * 64u; c0 < C; c0 += gridDim.x * 64u) {   // wave-uniform
@@ -624,7 +700,7 @@ HML_KERNEL __launch_bounds__(256) void hml_k_wl_backward_check(hml_model* __rest
     const uint32_t L = 1u << lay.lshift;
     const uint32_t n_chunks = (uint32_t)(((uint64_t)B + L - 1u) >> lay.lshift);
     if (ch.tot[2] == 0ull) {   // every chunk started from the state the chunk above it ended in (hml_k_wl_backward_verify)
-        if (tid == 0) hml_chunk_warmup_adapt(mdl, ch.W, 0ull, false);
+        if (tid == 0) hml_wl_bwd_warmup_adapt(mdl, ch.W, 0ull);
         return;
     }
     for (uint32_t w = (uint32_t)tid; w < (n_chunks + 63u) / 64u; w += 256u) {
@@ -678,7 +754,7 @@ HML_KERNEL __launch_bounds__(256) void hml_k_wl_backward_check(hml_model* __rest
             }
         }
     }
-    if (lane == 0) { mdl->forward_refits += redone; hml_chunk_warmup_adapt(mdl, ch.W, redone, false); }   // (the statistic counts chunks of either pass that ran again)
+    if (lane == 0) { mdl->forward_refits += redone; hml_wl_bwd_warmup_adapt(mdl, ch.W, redone); }   // (the statistic counts chunks of either pass that ran again)
 }
 
 #endif

@@ -123,6 +123,11 @@ struct hml_model {
     unsigned long long dbg_t[12];   // wall_clock64 stamps of the parameter kernel's stages (printed by hml_sync with HML_PARAMS_DEBUG)
     // more than 16 states, a chunk a lane (hml_k_wide_lanes.h): this sweep's chunk length (log2) and the chunk-transposed arrays' stride
     uint32_t wl_lshift, wl_cstride;
+    // ... the warm-up of its backward draws' chunks, adapted on its own (chains of draws from different states coalesce within a few
+    // rows, long before a filter forgets its start): rows, sweeps without a chunk that ran again
+    uint32_t wl_bwd_W, wl_bwd_quiet;
+    uint32_t wl_W_need, wl_need_age;   // ... a warm-up that failed on a settled chain, and the sweeps since (the adaptation stays above twice that for a while)
+    uint32_t wl_retry;           // ... this sweep's filter runs once more with a longer warm-up (hml_k_wl_retry_decide): the warm-up, or 0
 };
 
 #if defined(__HIPCC__)

@@ -756,6 +756,40 @@ def test_many_states_a_chunk_a_lane(hml, monkeypatch, K, L, warmup, lanes):
     g.close()
 
 
+def test_many_wrong_chunks_run_the_filter_again(hml, monkeypatch):
+    """hml_k_wide_lanes.h on adversarial parameters (twin states, sticky transitions, every position a block: the rows forget their
+    start very slowly): nearly every chunk starts from the wrong row, the sweep runs its whole filter once more with eight times
+    the warm-up (hml_k_wl_retry_decide) instead of handing thousands of chunks to the one wavefront that runs wrong chunks again in
+    order - which still gets the ones that remain.  Rows and states are the sequential recursion's whatever happened: the
+    checker's chain, bit for bit."""
+    monkeypatch.setenv("HML_WIDE", "1")
+    T, K = 200_000, 3
+    x = ol.trace(T, 3, 1)
+    xx, o, g = make_pair(hml, T, K, 0, 1, x=x, weight_mult=1e9)
+    setup_model(o, g, K)
+    o.token("F")
+    g.sample_prior()
+    mv = np.array([-1.0, 0.04, 0.5, 0.04, 0.5, 0.04], np.float32)    # states 1 and 2 are twins
+    A = np.array([[0.999, 0.0005, 0.0005], [0.0005, 0.9994, 0.0001], [0.0005, 0.0001, 0.9994]], np.float32)
+    pi = np.array([0.2, 0.5, 0.3], np.float32)
+    o.set_params(mv, A, pi)
+    g.set_parameters(mv, A, pi)
+    s0 = g.stats()
+    o.iterate("F", 1, 0)
+    g.iterate("F", 1, 0)
+    g.sync()
+    s1 = g.stats()
+    assert np.array_equal(o.blocks(), g.blocks())
+    assert np.array_equal(o.states(), g.states())
+    assert s1["forward_refits"] - s0["forward_refits"] > 32, (s0, s1)      # many chunks were wrong ...
+    assert s1["forward_warmup"] >= 8 * s0["forward_warmup"], (s0, s1)     # ... and the filter ran again with a longer warm-up
+    o.iterate("F", 4, 0)
+    g.iterate("F", 4, 0)
+    g.sync()
+    compare_state(o, g)
+    g.close()
+
+
 def test_attached_chains_start_with_a_reduced_block_capacity(hml):
     """a context attached to another one's observations reserves room for max(2^20, T / 16) blocks per sweep instead of T - and
     the source, like every ordinary context, for the worst case"""
