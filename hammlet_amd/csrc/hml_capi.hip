@@ -613,7 +613,7 @@ static int alloc_sweep_buffers(hml_ctx* c) {
         const uint64_t chunk_bytes = (uint64_t)HML_WL_MAX_CHUNKS * (2 * K * sizeof(float) + 4 * sizeof(uint32_t));
         HIPCHK(hipMalloc(&c->d_cchunk, chunk_bytes + HML_WL_TOT_WORDS * sizeof(unsigned long long)));
         HIPCHK(hipMemsetAsync((char*)c->d_cchunk + chunk_bytes, 0, HML_WL_TOT_WORDS * sizeof(unsigned long long), c->stream));   // (counters and bit maps of wrong chunks)
-        HIPCHK(hipMalloc(&c->d_wA, (uint64_t)HML_WL_PITCH * HML_WL_PITCH * sizeof(float)));
+        HIPCHK(hipMalloc(&c->d_wA, ((uint64_t)HML_WL_PITCH * HML_WL_PITCH + (uint64_t)HML_CAP_K * HML_WL_GTAB) * sizeof(float)));   // (... and the table of rescale factors behind it)
         HIPCHK(hipMalloc(&c->d_cdraws, 2 * (cap + 1) * sizeof(uint32_t)));
         HIPCHK(hipMalloc(&c->d_q, cap * sizeof(int16_t)));
         const uint64_t n_partial = (uint64_t)HML_REDUCE_GROUPS * K * 2;
@@ -1045,10 +1045,11 @@ static int sweep_wide(hml_ctx* c, char method, bool record) {
         ch.W = c->compat_warmup > 0 ? (uint32_t)c->compat_warmup : c->compat_warmup < 0 ? 0u : HML_CHUNK_W_ADAPTIVE;
         const uint64_t room = (uint64_t)hint + hint / 4 + 1024;   // (the kernels find B themselves: their loops stride over any grid)
         hipLaunchKernelGGL(hml_k_wl_prepare, dim3(1), dim3(256), 0, s, c->d_mdl, c->d_wA, c->wide_lshift);
+        hipLaunchKernelGGL(hml_k_wl_gtable, dim3(grid_for((uint64_t)c->K * HML_WL_GTAB, 256, 1, 512)), dim3(256), 0, s, c->d_mdl, c->d_wA + HML_WL_PITCH * HML_WL_PITCH);
         {
             ProfScope ps(c, "stats_emission");
             // (a wavefront: 64 chunks x HML_WL_EMIT_ROWS rows)
-            hipLaunchKernelGGL(hml_k_wl_emission, dim3(grid_for(room, 64 * HML_WL_EMIT_ROWS * 4, 1, 32768)), dim3(256), 0, s, c->d_mdl, c->d_starts, c->d_bstat, c->d_em, c->d_gsc);
+            hipLaunchKernelGGL(hml_k_wl_emission, dim3(grid_for(room, 64 * HML_WL_EMIT_ROWS * 4, 1, 32768)), dim3(256), 0, s, c->d_mdl, c->d_starts, c->d_bstat, c->d_em, c->d_gsc, c->d_wA + HML_WL_PITCH * HML_WL_PITCH);
         }
         const uint64_t minL = c->wide_lshift >= 0 ? (1ull << c->wide_lshift) : (1ull << HML_WL_MIN_LSHIFT);
         const int tiles = grid_for(room, (int)std::min<uint64_t>(64 * minL, 1u << 30), 1, HML_WL_MAX_CHUNKS / 64);

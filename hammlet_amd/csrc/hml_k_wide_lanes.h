@@ -70,6 +70,19 @@ HML_KERNEL __launch_bounds__(256) void hml_k_wl_prepare(hml_model* mdl, float* _
     }
 }
 
+// The rescale factors g_s(N) = expf((N - 1) log A(s, s)) of the block sizes below HML_WL_GTAB, [s][N]: the emission kernel looks
+// a block's K factors up instead of evaluating them (40 of its 142 instructions per block and state; the same expression, the same
+// floats) - a model's blocks are mostly short (of 3.4 10^6 blocks at 64 states on config 3's trace none reaches 2048 positions).
+#define HML_WL_GTAB 2048
+HML_KERNEL __launch_bounds__(256) void hml_k_wl_gtable(const hml_model* __restrict__ mdl, float* __restrict__ gtab) {
+    if (mdl->halted != 0u || mdl->self_trans == 0) return;
+    const int K = mdl->K;
+    for (uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x; idx < (uint32_t)K * HML_WL_GTAB; idx += gridDim.x * blockDim.x) {
+        const uint32_t st = idx / HML_WL_GTAB, n = idx % HML_WL_GTAB;
+        gtab[idx] = hml_expf_tab(((float)n - 1.0f) * mdl->logA[st], HML_EXP2F_TAB);
+    }
+}
+
 // Emission terms and rescale factors in the chunk-transposed layout: hml_k_wide_emission's values (same arithmetic, same order),
 // a lane per CHUNK: a wavefront takes 64 consecutive chunks and up to four of their rows, and every store is 64 consecutive
 // floats.  The rows go through the states together - a state's parameters are read once for four independent chains of
@@ -77,7 +90,7 @@ HML_KERNEL __launch_bounds__(256) void hml_k_wl_prepare(hml_model* mdl, float* _
 // and a lane has no room to keep 64 of them per row).
 #define HML_WL_EMIT_ROWS 4
 HML_KERNEL __launch_bounds__(256) void hml_k_wl_emission(hml_model* __restrict__ mdl, const uint32_t* __restrict__ starts, const float2* __restrict__ bstat,
-                                                         float* __restrict__ em, float* __restrict__ g) {
+                                                         float* __restrict__ em, float* __restrict__ g, const float* __restrict__ gtab) {
     __shared__ float s_mu[HML_CAP_K], s_var[HML_CAP_K], s_logNs[HML_CAP_K], s_logA[HML_CAP_K];
     __shared__ double s_rvar[HML_CAP_K];
     __shared__ uint8_t s_map[HML_CAP_K][HML_MAX_D];
@@ -107,13 +120,16 @@ HML_KERNEL __launch_bounds__(256) void hml_k_wl_emission(hml_model* __restrict__
         const uint32_t c = tile * 64u + (uint32_t)lane;
         const uint64_t bfirst = ((uint64_t)c << lay.lshift) + r0;
         float N[R], sx[R][HML_MAX_D], sq[R][HML_MAX_D], maxE[R];
+        uint32_t Nt[R];   // the block's size as an index into the table of factors (HML_WL_GTAB - 1: not in it)
         bool in[R];
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const uint64_t b = bfirst + (uint32_t)r;
             in[r] = (uint32_t)r < RG && b < (uint64_t)B;
             const uint32_t bl = in[r] ? (uint32_t)b : B - 1u;   // (rows beyond the last block compute on it and store nothing)
-            N[r] = (float)(starts[bl + 1u] - starts[bl]);   // (size_t N, converted where it meets a float)
+            const uint32_t Ni = starts[bl + 1u] - starts[bl];
+            N[r] = (float)Ni;   // (size_t N, converted where it meets a float)
+            Nt[r] = Ni < (uint32_t)HML_WL_GTAB - 1u ? Ni : (uint32_t)HML_WL_GTAB - 1u;
 #pragma unroll
             for (int d = 0; d < HML_MAX_D; ++d) {
                 const float2 v = bstat[(uint64_t)(d < D ? d : 0) * dstride + bl];
@@ -163,7 +179,11 @@ HML_KERNEL __launch_bounds__(256) void hml_k_wl_emission(hml_model* __restrict__
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 const float v = hml_expf_tab(E[r] - maxE[r], s_tab);
-                const float gv = hml_expf_tab((N[r] - 1.0f) * lA, s_tab);
+                float gv = 1.0f;
+                if (self) {
+                    gv = gtab[(uint32_t)st * HML_WL_GTAB + Nt[r]];
+                    if (__builtin_expect(Nt[r] == (uint32_t)HML_WL_GTAB - 1u, 0)) gv = hml_expf_tab((N[r] - 1.0f) * lA, s_tab);   // (a long block)
+                }
                 if (in[r]) {
                     const uint64_t a = a00 + (uint64_t)((uint32_t)r * (uint32_t)K + (uint32_t)st) * 64u;
                     em[a] = v;
