@@ -161,6 +161,7 @@ int hml_create(hml_ctx** out, int device, uint64_t seed, uint32_t chain_id, void
     if (const char* e = getenv("HML_COMPAT_WARMUP")) c->compat_warmup = atoi(e);   // (tests: a warm-up too short to forget the start)
     if (const char* e = getenv("HML_WIDE_LANES")) c->wide_lanes = atoi(e);   // (0: models of more than 16 states with a state a lane)
     if (const char* e = getenv("HML_WIDE_W0")) c->wide_w0 = std::max(8, atoi(e));
+    if (const char* e = getenv("HML_WIDE_MAX_CHUNKS")) c->wide_max_chunks = (uint32_t)std::max(64, atoi(e));
     if (const char* e = getenv("HML_WIDE_L")) {   // (tests: chunks of that many blocks, a power of two)
         const int L = atoi(e);
         if (L >= 1) { int sh = 0; while ((1 << sh) < L && sh < 20) ++sh; c->wide_lshift = sh; }
@@ -610,7 +611,10 @@ static int alloc_sweep_buffers(hml_ctx* c) {
         HIPCHK(hipMalloc(&c->d_em, plane * sizeof(float)));
         HIPCHK(hipMalloc(&c->d_gsc, plane * sizeof(float)));
         HIPCHK(hipMalloc(&c->d_crows, plane * sizeof(float)));
-        const uint64_t chunk_bytes = (uint64_t)HML_WL_MAX_CHUNKS * (2 * K * sizeof(float) + 4 * sizeof(uint32_t));
+        // (per-chunk arrays: as many chunks as the shortest chunk length makes of the capacity - at least what the lane-per-state form may ask for)
+        const uint64_t Lmin = c->wide_lshift >= 0 ? (1ull << c->wide_lshift) : (1ull << HML_WL_MIN_LSHIFT);
+        c->wide_chunks_cap = std::max<uint64_t>(HML_COMPAT_MAX_CHUNKS, std::min<uint64_t>(HML_WL_MAX_CHUNKS, (cap + Lmin - 1) / Lmin + 64));
+        const uint64_t chunk_bytes = c->wide_chunks_cap * (2 * K * sizeof(float) + 4 * sizeof(uint32_t));
         HIPCHK(hipMalloc(&c->d_cchunk, chunk_bytes + HML_WL_TOT_WORDS * sizeof(unsigned long long)));
         HIPCHK(hipMemsetAsync((char*)c->d_cchunk + chunk_bytes, 0, HML_WL_TOT_WORDS * sizeof(unsigned long long), c->stream));   // (counters and bit maps of wrong chunks)
         HIPCHK(hipMalloc(&c->d_wA, ((uint64_t)HML_WL_PITCH * HML_WL_PITCH + (uint64_t)HML_CAP_K * HML_WL_GTAB) * sizeof(float)));   // (... and the table of rescale factors behind it)
@@ -929,7 +933,7 @@ int hml_ctx_ensure_marginal_buffers(hml_ctx* c) { return ensure_marginal_buffers
 static hml_compat_chunks chunk_views(const hml_ctx* c) {   // the arrays of d_cchunk (alloc_sweep_buffers)
     hml_compat_chunks ch;
     char* base = (char*)c->d_cchunk;
-    const uint64_t n = c->wide ? (uint64_t)HML_WL_MAX_CHUNKS : (uint64_t)HML_COMPAT_MAX_CHUNKS;
+    const uint64_t n = c->wide ? c->wide_chunks_cap : (uint64_t)HML_COMPAT_MAX_CHUNKS;
     ch.entry = (float*)base; base += n * c->K * sizeof(float);
     ch.exitv = (float*)base; base += n * c->K * sizeof(float);
     ch.nfb = (uint32_t*)base; base += n * sizeof(uint32_t);
@@ -1044,7 +1048,8 @@ static int sweep_wide(hml_ctx* c, char method, bool record) {
         hml_compat_chunks ch = chunk_views(c);
         ch.W = c->compat_warmup > 0 ? (uint32_t)c->compat_warmup : c->compat_warmup < 0 ? 0u : HML_CHUNK_W_ADAPTIVE;
         const uint64_t room = (uint64_t)hint + hint / 4 + 1024;   // (the kernels find B themselves: their loops stride over any grid)
-        hipLaunchKernelGGL(hml_k_wl_prepare, dim3(1), dim3(256), 0, s, c->d_mdl, c->d_wA, c->wide_lshift);
+        hipLaunchKernelGGL(hml_k_wl_prepare, dim3(1), dim3(256), 0, s, c->d_mdl, c->d_wA, c->wide_lshift,
+                           c->wide_max_chunks ? std::min<uint32_t>(c->wide_max_chunks, HML_WL_MAX_CHUNKS) : (c->K <= 32 ? (uint32_t)HML_WL_MAX_CHUNKS : (uint32_t)HML_WL_MAX_CHUNKS / 2u));
         hipLaunchKernelGGL(hml_k_wl_gtable, dim3(grid_for((uint64_t)c->K * HML_WL_GTAB, 256, 1, 512)), dim3(256), 0, s, c->d_mdl, c->d_wA + HML_WL_PITCH * HML_WL_PITCH);
         {
             ProfScope ps(c, "stats_emission");
@@ -1139,7 +1144,7 @@ int hml_iterate(hml_ctx* c, char method, uint64_t iterations, uint64_t thinning)
         if (chain_halted(c)) { if (int r = hml_settle(c)) return r; }
         refresh_hint(c);
         const bool tre_path = c->tre_fused && c->D == 1 && method == HML_METHOD_FB && c->B_hint >= c->dense_min_blocks;
-        if (c->use_graph && !c->compat && !c->wide && !record && !c->profiling && !c->probes && (c->dynamic || c->blocks_valid) &&
+        if (c->use_graph && !c->compat && !record && !c->profiling && !c->probes && (c->dynamic || c->blocks_valid) &&
             !(tre_path && tre_wants_measurement(c, c->B_hint))) {
             // replay a captured sweep; capture again when the launch geometry (grid hint / mode / chunk length) changed
             const uint32_t hint = c->B_hint;

@@ -169,6 +169,8 @@ struct hml_ctx {
     float* d_wA = nullptr;         // ... the transition matrix padded to 64 x 64 (hml_k_wide_lanes.h)
     int wide_lanes = 1;            // ... filter and backward draws with a chunk a lane (0: a state a lane, hml_k_compat.h's kernels) (HML_WIDE_LANES)
     int wide_w0 = 32;              // ... the floor of its chunks' adaptive warm-up, blocks (HML_WIDE_W0)
+    uint32_t wide_max_chunks = 0;  // ... the most chunks a sweep is cut into (HML_WIDE_MAX_CHUNKS; 0: HML_WL_MAX_CHUNKS)
+    uint64_t wide_chunks_cap = 0;  // ... chunks its per-chunk arrays hold (alloc_sweep_buffers)
     int wide_lshift = -1;          // ... log2 of a forced chunk length (tests: HML_WIDE_L), -1: from the block count
     bool pooled = false;           // the marginals are a pooled payload (hml_pool_install): common labels, counts of several chains
     std::vector<int32_t> pool_perm;   // perm[pooled label] = this chain's label, from the export that preceded the pooling

@@ -8,8 +8,8 @@
 //     c mod 64 - the 64 lanes of a wavefront, 64 consecutive chunks at the same row of their chunk, read and write 64
 //     consecutive floats, and a wavefront's steps walk ONE contiguous stream of L K 256 bytes (the layout of hml_bk, whole
 //     planes per (row, state), had every one of a step's 3 K accesses in a DRAM page of its own: 2.5 TB/s).  The chunk length L (a
-//     power of two) is decided on the device once the sweep's blocks are known (hml_k_wl_prepare: at most 65 536 chunks, at
-//     least 16 blocks each);
+//     power of two) is decided on the device once the sweep's blocks are known (hml_k_wl_prepare: the shortest
+//     chunks, at least four blocks, that make at most 65 536 chunks - 131 072 up to 32 states);
 //   * the transition matrix comes from SCALAR loads (the same for every lane: a row of a zero-padded 64 x 64 copy, sixteen
 //     columns at a time), the lane's own vector of the step before from its column of LDS (the accumulators are registers:
 //     static indices), K x K multiply-adds per lane and step and nothing that crosses lanes;
@@ -29,8 +29,8 @@
 
 #if defined(__HIPCC__)
 
-#define HML_WL_MAX_CHUNKS 65536
-#define HML_WL_MIN_LSHIFT 4
+#define HML_WL_MAX_CHUNKS 131072
+#define HML_WL_MIN_LSHIFT 2
 #define HML_WL_MAP_WORDS (HML_WL_MAX_CHUNKS / 64)
 #define HML_WL_PITCH 64   // floats between the rows of the padded transition matrix
 // hml_compat_chunks::tot on this path: [0] wrong chunks of the filter, [1] the sum of nfb, [2] wrong chunks of the backward draws,
@@ -52,8 +52,11 @@ __device__ __forceinline__ hml_layout hml_wl_layout(const hml_model* mdl) {
 }
 
 // The sweep's geometry and the padded copy of the transition matrix (one workgroup, behind the block enumeration).
-// force_lshift >= 0: that chunk length (tests), raised if it would make more than HML_WL_MAX_CHUNKS chunks.
-HML_KERNEL __launch_bounds__(256) void hml_k_wl_prepare(hml_model* mdl, float* __restrict__ wA, int force_lshift) {
+// force_lshift >= 0: that chunk length (tests), raised if it would make more than max_chunks chunks.  max_chunks: 65 536 - a
+// wavefront for each of the machine's 1024 SIMDs - where the filter's registers let one wavefront onto a SIMD (more than 32 states),
+// twice that where they let two (measured at 20 / 40 / 64 states with 65 536, 131 072, 262 144: 0.69 / 1.67 / 3.51, 0.62 / 1.95 / 4.13,
+// 0.68 / 2.20 / 4.62 ms per sweep).
+HML_KERNEL __launch_bounds__(256) void hml_k_wl_prepare(hml_model* mdl, float* __restrict__ wA, int force_lshift, uint32_t max_chunks) {
     if (mdl->halted != 0u) return;
     const int K = mdl->K;
     for (int idx = threadIdx.x; idx < HML_WL_PITCH * HML_WL_PITCH; idx += 256) {
@@ -63,7 +66,7 @@ HML_KERNEL __launch_bounds__(256) void hml_k_wl_prepare(hml_model* mdl, float* _
     if (threadIdx.x == 0) {
         const uint32_t B = mdl->B;
         uint32_t sh = force_lshift >= 0 ? (uint32_t)force_lshift : (uint32_t)HML_WL_MIN_LSHIFT;
-        while ((((uint64_t)B + (1ull << sh) - 1ull) >> sh) > (uint64_t)HML_WL_MAX_CHUNKS) ++sh;
+        while ((((uint64_t)B + (1ull << sh) - 1ull) >> sh) > (uint64_t)max_chunks) ++sh;
         const uint32_t C = (uint32_t)(((uint64_t)B + (1ull << sh) - 1ull) >> sh);
         mdl->wl_lshift = sh;
         mdl->wl_cstride = (C + 63u) / 64u * 64u + (C == 0u ? 64u : 0u);
