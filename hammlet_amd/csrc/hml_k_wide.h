@@ -174,6 +174,44 @@ HML_KERNEL __launch_bounds__(256) void hml_k_wide_counts(const int16_t* __restri
         double acc_s[HML_WIDE_PASS], acc_q[HML_WIDE_PASS];
 #pragma unroll
         for (int i = 0; i < HML_WIDE_PASS; ++i) { acc_s[i] = 0.0; acc_q[i] = 0.0; }
+        if (D == 1) {
+            // (the group's next chunk is asked for before this one is used - a chunk was a chain of three memory round trips, five
+            // or six chunks a group and pass; lanes beyond the last block read it and add nothing: no load waits in a branch)
+            struct item { int st, prev; uint32_t n; float2 v; bool in; };
+            auto fetch = [&](const uint32_t c) {
+                item it;
+                const uint64_t b = (uint64_t)c * HML_REDUCE_CHUNK + (uint32_t)tid;
+                it.in = c < nchunks && b < (uint64_t)B;
+                const uint32_t bl = it.in ? (uint32_t)b : B - 1u;
+                it.st = q[bl];
+                it.v = bstat[bl];
+                it.prev = 0; it.n = 0u;
+                if (p0 == 0) {   // (workgroup-uniform)
+                    const int before = (int)q[bl ? bl - 1u : 0u];
+                    it.prev = bl ? before : 0;
+                    it.n = starts[bl + 1u] - starts[bl];
+                }
+                return it;
+            };
+            item cur = fetch(g);
+            for (uint32_t c = g; c < nchunks; c += HML_REDUCE_GROUPS) {
+                const item nxt = fetch(c + HML_REDUCE_GROUPS);
+                if (cur.in) {
+                    if (p0 == 0) {
+                        atomicAdd(&h_trans[cur.st * K + cur.st], (unsigned long long)(cur.n - 1u));
+                        atomicAdd(&h_trans[cur.prev * K + cur.st], 1ull);
+                        atomicAdd(&h_occ[cur.st], (unsigned long long)cur.n);
+                    }
+                    const int i = cur.st - p0;
+                    if (i >= 0 && i < HML_WIDE_PASS) {
+                        const double vx = (double)cur.v.x, vq = (double)cur.v.y;
+#pragma unroll
+                        for (int k = 0; k < HML_WIDE_PASS; ++k) if (i == k) { acc_s[k] = acc_s[k] + vx; acc_q[k] = acc_q[k] + vq; }
+                    }
+                }
+                cur = nxt;
+            }
+        } else {
         for (uint32_t c = g; c < nchunks; c += HML_REDUCE_GROUPS) {
             const uint32_t b = c * HML_REDUCE_CHUNK + (uint32_t)tid;
             if (b < B) {
@@ -185,15 +223,7 @@ HML_KERNEL __launch_bounds__(256) void hml_k_wide_counts(const int16_t* __restri
                     atomicAdd(&h_trans[prev * K + st], 1ull);
                     atomicAdd(&h_occ[st], (unsigned long long)n);
                 }
-                if (D == 1) {
-                    const int i = st - p0;
-                    if (i >= 0 && i < HML_WIDE_PASS) {
-                        const float2 v = bstat[b];
-                        const double vx = (double)v.x, vq = (double)v.y;
-#pragma unroll
-                        for (int k = 0; k < HML_WIDE_PASS; ++k) if (i == k) { acc_s[k] = acc_s[k] + vx; acc_q[k] = acc_q[k] + vq; }
-                    }
-                } else {
+                {
                     // the term for parameter p: the block's statistics of the dimensions mapped to p, added in dimension order
 #pragma unroll
                     for (int k = 0; k < HML_WIDE_PASS; ++k) {
@@ -209,6 +239,7 @@ HML_KERNEL __launch_bounds__(256) void hml_k_wide_counts(const int16_t* __restri
                     }
                 }
             }
+        }
         }
         __syncthreads();   // (wsum of the pass before has been read)
 #pragma unroll
