@@ -942,6 +942,11 @@ def mv_trace(T, levels, D, seed):
     (2, 3, 30000, [("F", 10, 1)]),
     (4, 2, 70000, [("F", 6, 2)]),
     (2, 4, 20000, [("M", 3, 1), ("F", 5, 1)]),
+    # more than 16 states with shared parameters (hml_k_wide.h / hml_k_wide_lanes.h): 5^2, 8^2 = 64, 4^3 = 64, 3^3
+    (5, 2, 30000, [("F", 6, 2), "S", ("F", 3, 1)]),
+    (8, 2, 24000, [("M", 2, 1), ("F", 5, 1), "D", ("F", 3, 1)]),
+    (4, 3, 20000, [("F", 5, 1), "S", "P", ("F", 3, 1)]),
+    (3, 3, 20000, [("F", 6, 3)]),
 ])
 def test_multivariate_sweeps_match_checker(hml, P, D, T, scheme):
     """`-s C P D` (reference src/Mapping.hpp): D interleaved data dimensions, P emission parameters
