@@ -1049,7 +1049,7 @@ static int sweep_wide(hml_ctx* c, char method, bool record) {
         ch.W = c->compat_warmup > 0 ? (uint32_t)c->compat_warmup : c->compat_warmup < 0 ? 0u : HML_CHUNK_W_ADAPTIVE;
         const uint64_t room = (uint64_t)hint + hint / 4 + 1024;   // (the kernels find B themselves: their loops stride over any grid)
         hipLaunchKernelGGL(hml_k_wl_prepare, dim3(1), dim3(256), 0, s, c->d_mdl, c->d_wA, c->wide_lshift,
-                           c->wide_max_chunks ? std::min<uint32_t>(c->wide_max_chunks, HML_WL_MAX_CHUNKS) : (c->K <= 32 ? (uint32_t)HML_WL_MAX_CHUNKS : (uint32_t)HML_WL_MAX_CHUNKS / 2u));
+                           c->wide_max_chunks ? std::min<uint32_t>(c->wide_max_chunks, HML_WL_MAX_CHUNKS) : (c->K <= HML_WL_TWO_WAVES_KC ? (uint32_t)HML_WL_MAX_CHUNKS : (uint32_t)HML_WL_MAX_CHUNKS / 2u));
         hipLaunchKernelGGL(hml_k_wl_gtable, dim3(grid_for((uint64_t)c->K * HML_WL_GTAB, 256, 1, 512)), dim3(256), 0, s, c->d_mdl, c->d_wA + HML_WL_PITCH * HML_WL_PITCH);
         {
             ProfScope ps(c, "stats_emission");

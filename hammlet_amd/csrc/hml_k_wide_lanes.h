@@ -9,7 +9,7 @@
 //     consecutive floats, and a wavefront's steps walk ONE contiguous stream of L K 256 bytes (the layout of hml_bk, whole
 //     planes per (row, state), had every one of a step's 3 K accesses in a DRAM page of its own: 2.5 TB/s).  The chunk length L (a
 //     power of two) is decided on the device once the sweep's blocks are known (hml_k_wl_prepare: the shortest
-//     chunks, at least four blocks, that make at most 65 536 chunks - 131 072 up to 32 states);
+//     chunks, at least four blocks, that make at most 65 536 chunks - 131 072 up to 36 states);
 //   * the transition matrix comes from SCALAR loads (the same for every lane: a row of a zero-padded 64 x 64 copy, sixteen
 //     columns at a time), the lane's own vector of the step before from its column of LDS (the accumulators are registers:
 //     static indices), K x K multiply-adds per lane and step and nothing that crosses lanes;
@@ -33,6 +33,10 @@
 #define HML_WL_MIN_LSHIFT 2
 #define HML_WL_MAP_WORDS (HML_WL_MAX_CHUNKS / 64)
 #define HML_WL_PITCH 64   // floats between the rows of the padded transition matrix
+// the filter's registers let two wavefronts onto a SIMD up to this many (padded) states - up to 32 as the compiler allocates them, at
+// 36 when told to and with the step's loads asked for behind the products (219 registers; 40 states fit too, 240 registers, and gain
+// nothing; from 48 on the kernel would spill) - and a sweep is then cut into twice the chunks (hml_k_wl_prepare)
+#define HML_WL_TWO_WAVES_KC 36
 // hml_compat_chunks::tot on this path: [0] wrong chunks of the filter, [1] the sum of nfb, [2] wrong chunks of the backward draws,
 // then a bit per wrong chunk of the filter and of the backward draws (set by the verifying launches, cleared by the checking ones)
 #define HML_WL_MAP_F 4
@@ -280,7 +284,7 @@ __device__ __forceinline__ void hml_wl_fwd_adapt(hml_model* mdl, const uint32_t 
 // 32-bit lane offset.  Lanes whose block lies outside the trace (the first chunks' warm-up, the last chunk's tail) read some
 // element inside the arrays and keep what they have.
 template <int KC>
-HML_KERNEL __launch_bounds__(64) void hml_k_wl_forward(hml_model* __restrict__ mdl, const float* __restrict__ wA, const float* __restrict__ em,
+HML_KERNEL __launch_bounds__(64, ((KC > 32 && KC <= HML_WL_TWO_WAVES_KC) ? 2 : 1)) void hml_k_wl_forward(hml_model* __restrict__ mdl, const float* __restrict__ wA, const float* __restrict__ em,
                                                        const float* __restrict__ g, float* __restrict__ rows, const hml_compat_chunks ch, const int retry) {
     __shared__ float s_prev[KC * 64];   // [state][lane]: the lane's row of the step before
     __shared__ __attribute__((aligned(16))) float sA[KC * HML_WL_PITCH];
@@ -325,19 +329,24 @@ HML_KERNEL __launch_bounds__(64) void hml_k_wl_forward(hml_model* __restrict__ m
             constexpr bool OWN = decltype(own_tag)::value;
             const int64_t b = lo + d;
             const bool active = valid && b >= 0 && b < hi;
-            // the next step's terms and this step's factors travel during the step
+            // the next step's terms and this step's factors travel during the step - asked for in front of the products, or (LATE) behind
+            // them: during the products their registers are needed, and 36 states fit two wavefronts per SIMD only so
             float en[KC], gc[KC];
+            const uint64_t a0 = at(d);   // (an active lane's own element)
+            auto ask = [&]() {
             {
                 const float* const pe = em + at(d + 1);
 #pragma unroll
                 for (int j = 0; j < KC; ++j) en[j] = (j < KC - 3 || j < K) ? pe[j * 64] : 0.0f;
             }
-            const uint64_t a0 = at(d);   // (an active lane's own element)
             if (OWN && self) {
                 const float* const pg = g + a0;
 #pragma unroll
                 for (int j = 0; j < KC; ++j) gc[j] = (j < KC - 3 || j < K) ? pg[j * 64] : 1.0f;
             }
+            };
+            constexpr bool LATE = KC > 32 && KC <= HML_WL_TWO_WAVES_KC;
+            if constexpr (!LATE) ask();
             float f[KC];
 #define HML_WL_PASS(J0, NJ)                                                              \
             if constexpr ((NJ) > 0) {                                                    \
@@ -350,6 +359,7 @@ HML_KERNEL __launch_bounds__(64) void hml_k_wl_forward(hml_model* __restrict__ m
             constexpr int W0 = PW < KC ? PW : KC, W1 = (KC - W0) < PW ? (KC - W0) : PW, W2 = (KC - W0 - W1) < PW ? (KC - W0 - W1) : PW, W3 = KC - W0 - W1 - W2;
             HML_WL_PASS(0, W0) HML_WL_PASS(W0, W1) HML_WL_PASS(W0 + W1, W2) HML_WL_PASS(W0 + W1 + W2, W3)
 #undef HML_WL_PASS
+            if constexpr (LATE) ask();
             float Z = 0.0f;
 #pragma unroll
             for (int j = 0; j < KC; ++j) Z += f[j];   // (the padded terms are +0.0)
