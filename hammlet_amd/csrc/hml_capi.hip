@@ -145,6 +145,8 @@ int hml_create(hml_ctx** out, int device, uint64_t seed, uint32_t chain_id, void
     if (const char* e = getenv("HML_FWD_BURNIN_SWEEPS")) c->fwd_burnin_sweeps = (uint32_t)std::max(0, atoi(e));
     if (const char* e = getenv("HML_FWD_QUIET")) c->fwd_quiet_need = (uint32_t)std::max(1, atoi(e));
     if (const char* e = getenv("HML_FWD_CHUNK_MANY")) { int l = std::max(1, atoi(e)); int sh = 0; while ((1 << (sh + 1)) <= l && sh < 6) ++sh; c->fwdL_many = 1 << sh; }
+    if (const char* e = getenv("HML_FWD_CHUNK_MID")) { int l = std::max(1, atoi(e)); int sh = 0; while ((1 << (sh + 1)) <= l && sh < 10) ++sh; c->fwdL_mid = 1 << sh; }
+    if (const char* e = getenv("HML_MID_MIN_BLOCKS")) c->mid_min_blocks = (uint32_t)strtoul(e, nullptr, 10);
     if (const char* e = getenv("HML_FWD_CHUNK_DENSE")) { int l = std::max(1, atoi(e)); int sh = 0; while ((1 << (sh + 1)) <= l && sh < 10) ++sh; c->fwdL_dense = 1 << sh; }
     if (const char* e = getenv("HML_DENSE_MIN_BLOCKS")) c->dense_min_blocks = (uint32_t)strtoul(e, nullptr, 10);
     if (const char* e = getenv("HML_USE_GRAPH")) c->use_graph = atoi(e) != 0;
@@ -627,7 +629,7 @@ static int alloc_sweep_buffers(hml_ctx* c) {
         HIPCHK(hipMemsetAsync(c->d_wacc, 0, sizeof(hml_wide_acc), c->stream));
         return 0;
     }
-    const int minL = std::min(std::min(c->fwdL, c->fwdL_dense), c->fwdL_many);
+    const int minL = std::min(std::min(std::min(c->fwdL, c->fwdL_dense), c->fwdL_many), c->fwdL_mid);
     const uint64_t maxChunks = (cap + minL - 1) / minL + 1;   // per-chunk arrays serve either geometry
     uint64_t plane = 0;   // floats in one chunk-transposed [L][K][cstride] array
     auto layout = [&](int L, hml_layout& lay) {
@@ -638,6 +640,7 @@ static int alloc_sweep_buffers(hml_ctx* c) {
     };
     layout(c->fwdL, c->lay);
     layout(c->fwdL_dense, c->lay_dense);
+    layout(c->fwdL_mid, c->lay_mid);
     layout(c->fwdL_many, c->lay_many);
     HIPCHK(hipMalloc(&c->d_em, plane * sizeof(float)));
     HIPCHK(hipMalloc(&c->d_gsc, plane * sizeof(float)));
@@ -1154,7 +1157,7 @@ int hml_iterate(hml_ctx* c, char method, uint64_t iterations, uint64_t thinning)
             const bool wants_fused = c->fused_blocks && !(c->h_B[1] && !c->fused_keep) && !shares_device(c);
             const bool stale = !c->graph_exec || c->graph_method != method || c->graph_dynamic != c->dynamic ||
                                hint > c->graph_hint || hint * 2u < c->graph_hint || c->graph_fused != wants_fused ||
-                               c->graph_dense != (hint >= c->dense_min_blocks) ||
+                               c->graph_dense != (hint >= c->dense_min_blocks) || c->graph_mid != (hint >= c->mid_min_blocks) ||
                                (tre_path && c->graph_tre_L != tre_pick_L(c, hint, true, &unused));
             if (stale && hint) {
                 if (c->graph_exec) { hipGraphExecDestroy(c->graph_exec); c->graph_exec = nullptr; }
@@ -1174,6 +1177,7 @@ int hml_iterate(hml_ctx* c, char method, uint64_t iterations, uint64_t thinning)
                 if (ei != hipSuccess) { c->graph_exec = nullptr; return set_err(HML_ERR_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(ei)); }
                 c->graph_method = method; c->graph_dynamic = c->dynamic; c->graph_hint = c->B_hint; c->graph_fused = wants_fused;
                 c->graph_dense = c->B_hint >= c->dense_min_blocks;
+                c->graph_mid = c->B_hint >= c->mid_min_blocks;
             }
             if (c->graph_exec) {
                 log_sweep(c, method, false);

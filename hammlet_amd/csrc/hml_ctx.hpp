@@ -142,13 +142,20 @@ struct hml_ctx {
     // of the work - in their own chunk-transposed layout; which geometry a sweep uses never changes its results
     int fwdL_dense = 16;
     hml_layout lay_dense = {4, 0};
+    // in between (B_hint >= mid_min_blocks = 2^18: 33 000 chunks of 8 still put a wavefront on every second SIMD): chunks of 8 - 32 filter
+    // steps per 8 blocks instead of 28 per 4.  Measured on config 3's trace with 8 / 10 / 12 / 16 states in the model (3.0 / 5.2 / 7.2 /
+    // 9.7 10^5 blocks per sweep): 0.188 / 0.228 / 0.489 / 0.498 -> 0.165 / 0.224 / 0.429 / 0.437 ms per sweep; with 5 states (1.8 10^5 blocks:
+    // below the threshold) chunks of 8 cost 0.063 against 0.060 ms (profiles/round5_wide_path.txt).  HML_FWD_CHUNK_MID, HML_MID_MIN_BLOCKS.
+    int fwdL_mid = 8;
+    hml_layout lay_mid = {3, 0};
+    uint32_t mid_min_blocks = 1u << 18;
     // chains batched by hml_iterate_many are bound by throughput, not latency: chunks of 8 pay the warm-up over twice as many
     // blocks (20 filter steps per 8 blocks instead of 16 per 4; measured with eight chains of config 3: 0.181 against 0.188 ms
     // per round; 16 and 32 are slower again - too few wavefronts).  HML_FWD_CHUNK_MANY.
     int fwdL_many = 8;
     hml_layout lay_many = {3, 0};
     uint32_t dense_min_blocks = 1u << 22;
-    bool graph_dense = false;
+    bool graph_dense = false, graph_mid = false;
     bool probes = false;
     bool rec_marginals = true;
     hml_record_cb cb = nullptr;

@@ -55,8 +55,9 @@ static int sweep_k(hml_ctx* c, char method, bool record) {
     const bool dense_geo = c->B_hint >= c->dense_min_blocks;
     // weakly compressed univariate FB sweeps: emission terms, filter and candidate maps fused per tile (hml_k_trellis.h)
     const bool trellis = dense_geo && !mix && c->D == 1 && c->tre_fused;
-    const int L = dense_geo ? c->fwdL_dense : c->fwdL;
-    const hml_layout lay = dense_geo ? c->lay_dense : c->lay;
+    const bool mid_geo = !dense_geo && c->fwdL_mid > c->fwdL && c->B_hint >= c->mid_min_blocks;   // (hml_ctx.hpp: chunks of 8 from 2^18 blocks on)
+    const int L = dense_geo ? c->fwdL_dense : mid_geo ? c->fwdL_mid : c->fwdL;
+    const hml_layout lay = dense_geo ? c->lay_dense : mid_geo ? c->lay_mid : c->lay;
     // strongly compressed univariate sweeps keep no plane of rescale factors: the forward rows stay unscaled and the
     // backward maps apply the factor where they read a row (hml_bwd_row_load) - 3.5 of the block kernel's 11 MB of
     // stores at 10^8 positions, and what a dependent launch waits for is the write-back of its predecessor's stores

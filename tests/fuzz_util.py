@@ -13,7 +13,7 @@ from tests.test_gpu_parity import run_both
 ENV_KEYS = ("HML_DENSE_MIN_BLOCKS", "HML_FWD_CHUNK_DENSE", "HML_TRELLIS_FUSED", "HML_TRELLIS_L", "HML_TRELLIS_ROWS", "HML_TRELLIS_CKPT",
             "HML_STAGE_BITS", "HML_FWD_WARMUP", "HML_LATE_RESCALE", "HML_FWD_CHUNK",
             "HML_MANY_GROUPS", "HML_FUSED_MANY_SLOTS", "HML_MAX_BLOCKS", "HML_FWD_CHUNK_MANY", "HML_COMPAT_CHUNKS", "HML_COMPAT_WARMUP", "HML_WIDE", "HML_FM_SPLIT", "HML_FM_SPLIT_SUB",
-            "HML_WIDE_L", "HML_WIDE_LANES")
+            "HML_WIDE_L", "HML_WIDE_LANES", "HML_MID_MIN_BLOCKS")
 
 
 def fuzz(hml, n_cfg, seed, log=None, many=False, compat=False, wide=False):
@@ -73,6 +73,7 @@ def _fuzz(hml, n_cfg, seed, log, compat=False, wide=False):
         else: os.environ.pop("HML_FWD_WARMUP", None)
         os.environ["HML_LATE_RESCALE"] = str(int(rng.choice([1, 1, 0])))
         os.environ["HML_FWD_CHUNK"] = str(int(rng.choice([4, 4, 1, 2, 8])))
+        os.environ["HML_MID_MIN_BLOCKS"] = str(int(rng.choice([262144, 2000, 200])))   # (chunks of 8 from that many blocks on: hml_ctx.hpp)
         if compat or wide:   # chunks of the filter / backward draws: the default, the sequential form, many chunks with hardly any warm-up
             _setenv("HML_COMPAT_CHUNKS", rng.choice([None, None, 1, 7, 60, 500]))
             _setenv("HML_COMPAT_WARMUP", rng.choice([None, None, -1, 1, 4]))
