@@ -396,11 +396,26 @@ __device__ __forceinline__ void hml_b_params(hml_model* __restrict__ mdl, typena
                 }
                 if (W > (uint32_t)HML_TRE_HALO_MAX) W = (uint32_t)HML_TRE_HALO_MAX;
             } else
-            if (serial != 0ull || refits > handful) { W = (2u * W < 1024u) ? 2u * W : 1024u; mdl->fwd_quiet = 0u; }
-            else if (refits == 0ull) {
-                const uint32_t floorW = (mdl->sweeps < (unsigned long long)mdl->fwd_burnin_sweeps) ? mdl->fwd_W_burnin : mdl->fwd_W0;
-                if (++mdl->fwd_quiet >= mdl->fwd_quiet_need) { const uint32_t w2 = W - W / 4u; W = (w2 > floorW) ? ((w2 & ~7u) > floorW ? (w2 & ~7u) : floorW) : floorW; mdl->fwd_quiet = 0u; }
+            {
+            // (end of round 5) A warm-up that FAILED on a settled chain is remembered for 512 sweeps and the walk down stops one step (8
+            // rows) above it: a sweep with stale chunks costs a repair by ONE workgroup - with 8 states on config 3's trace (3 10^5
+            // blocks) the warm-up went 48 -> 36 -> 24 -> some two hundred stale chunks -> 48 every 33 sweeps, and the repairs were 137 us
+            // of the 169 us average sweep.  (wl_W_need / wl_need_age: the fields of hml_k_wide_lanes.h's rule; a context has one path.)
+            if (mdl->wl_W_need != 0u && ++mdl->wl_need_age > 512u) mdl->wl_W_need = 0u;
+            if (serial != 0ull || refits > handful) {
+                if (mdl->sweeps >= (unsigned long long)mdl->fwd_burnin_sweeps) { mdl->wl_W_need = W; mdl->wl_need_age = 0u; }
+                W = (2u * W < 1024u) ? 2u * W : 1024u; mdl->fwd_quiet = 0u;
+            } else if (refits == 0ull) {
+                uint32_t floorW = (mdl->sweeps < (unsigned long long)mdl->fwd_burnin_sweeps) ? mdl->fwd_W_burnin : mdl->fwd_W0;
+                if (mdl->wl_W_need != 0u) { const uint32_t keep = ((mdl->wl_W_need + 8u) & ~7u) < 1024u ? ((mdl->wl_W_need + 8u) & ~7u) : 1024u; floorW = keep > floorW ? keep : floorW; }
+                if (++mdl->fwd_quiet >= mdl->fwd_quiet_need) {
+                    const uint32_t w2 = W - W / 4u;
+                    const uint32_t lower = (w2 > floorW) ? ((w2 & ~7u) > floorW ? (w2 & ~7u) : floorW) : floorW;
+                    W = lower < W ? lower : W;   // (the floor may lie above the warm-up: the walk down never raises it)
+                    mdl->fwd_quiet = 0u;
+                }
             } else mdl->fwd_quiet = 0u;
+            }
             mdl->fwd_W = W;
             mdl->fwd_refits_seen = mdl->forward_refits;
             mdl->fwd_serial_seen = mdl->forward_serial;

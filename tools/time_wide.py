@@ -12,7 +12,8 @@ T = int(os.environ.get("HML_TIME_T", "100000000"))
 x = h.synth_gauss(T, 5, [-2, -1, 0, 1, 2], 0.3, 5000.0, 3, nthreads=16)
 for K in [int(a) for a in sys.argv[1:]] or [20, 40, 64]:
     res = {}
-    modes = (("default", 60, 100),) if os.environ.get("HML_TIME_NO_COMPAT") else (("default", 60, 100), ("compat", 12, 12))
+    burn, n_timed = int(os.environ.get("HML_TIME_BURN", "60")), int(os.environ.get("HML_TIME_N", "100"))
+    modes = (("default", burn, n_timed),) if os.environ.get("HML_TIME_NO_COMPAT") else (("default", burn, n_timed), ("compat", 12, 12))
     for mode, burn, n in modes:
         c = h.Chain(device=0, seed=1)
         if mode == "compat":
@@ -36,7 +37,7 @@ for K in [int(a) for a in sys.argv[1:]] or [20, 40, 64]:
             c.iterate("F", 20, 0)
             c.sync()
             c.profile_enable(0)
-            for nm in ("blocks_compact", "blocks_scatter", "block_stats", "stats_emission", "forward", "backward_maps", "counts", "params"):
+            for nm in ("blocks_compact", "blocks_scatter", "block_stats", "stats_emission", "emission", "forward", "backward_maps", "backward_chain", "counts", "params"):
                 ms, cnt = c.profile_get(nm)
                 if cnt:
                     fam[nm] = round(1e3 * ms / cnt - 5.3, 1)
