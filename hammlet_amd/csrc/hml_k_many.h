@@ -88,7 +88,7 @@ HML_KERNEL __launch_bounds__(256) void hml_m_record(const hml_many_args a, unsig
 template <int K>
 HML_KERNEL __launch_bounds__(1024) void hml_m_params(const hml_many_args a) {
     const hml_chain_dev& c = a.c[blockIdx.y];
-    hml_b_params<K, true>(c.mdl, c.partial, 0, (int)blockIdx.x, (int)gridDim.x);
+    hml_b_params<K, true, true>(c.mdl, c.partial, 0, (int)blockIdx.x, (int)gridDim.x);
 }
 
 #endif

@@ -74,7 +74,7 @@ HML_KERNEL __launch_bounds__(64) void hml_k_set_dynamic(hml_model* mdl, int on, 
 // written before the ticket is known - so none of this lies on the path of the one that goes on.  Same summation tree, same
 // bits (D3 fixes the order, not who adds).  Config 4's sweep (10 states) 0.0938 -> 0.0869 ms, eight chains of config 3 0.161 ->
 // 0.154 ms per round; config 3's single chain gains nothing (0.0557 / 0.0564) and keeps the one-workgroup form.
-template <int K, bool SPREAD>
+template <int K, bool SPREAD, bool MANY = false>
 __device__ __forceinline__ void hml_b_params(hml_model* __restrict__ mdl, typename std::conditional<SPREAD, double, const double>::type* __restrict__ partial,
                                                      int mode, int leaf, int nleaf) {
     __shared__ double wp[16][K][2];
@@ -397,13 +397,17 @@ __device__ __forceinline__ void hml_b_params(hml_model* __restrict__ mdl, typena
                 if (W > (uint32_t)HML_TRE_HALO_MAX) W = (uint32_t)HML_TRE_HALO_MAX;
             } else
             {
-            // (end of round 5) A warm-up that FAILED on a settled chain is remembered for 512 sweeps and the walk down stops one step (8
+            // (end of round 5) A warm-up that FAILED on a settled chain is remembered for 128 sweeps and the walk down stops one step (8
             // rows) above it: a sweep with stale chunks costs a repair by ONE workgroup - with 8 states on config 3's trace (3 10^5
             // blocks) the warm-up went 48 -> 36 -> 24 -> some two hundred stale chunks -> 48 every 33 sweeps, and the repairs were 137 us
             // of the 169 us average sweep.  (wl_W_need / wl_need_age: the fields of hml_k_wide_lanes.h's rule; a context has one path.)
-            if (mdl->wl_W_need != 0u && ++mdl->wl_need_age > 512u) mdl->wl_W_need = 0u;
+            if (mdl->wl_W_need != 0u && ++mdl->wl_need_age > 128u) mdl->wl_W_need = 0u;
             if (serial != 0ull || refits > handful) {
-                if (mdl->sweeps >= (unsigned long long)mdl->fwd_burnin_sweeps) { mdl->wl_W_need = W; mdl->wl_need_age = 0u; }
+                // (a failure of a few chunks is cheap and a short warm-up worth more: the headline's chain walks down to 12 rows and repairs 1-5
+                // chunks every twenty-odd sweeps - held at 20-24 rows for 512 sweeps it lost 3 %; remembered from 16 stale chunks on, or a serial
+                // pass, and for 128 sweeps; not for chains batched by hml_iterate_many (MANY), whose launches are bound by throughput: eight
+                // chains lost 6 % with it)
+                if (mdl->sweeps >= (unsigned long long)mdl->fwd_burnin_sweeps && (serial != 0ull || refits >= 16ull) && !MANY) { mdl->wl_W_need = W; mdl->wl_need_age = 0u; }
                 W = (2u * W < 1024u) ? 2u * W : 1024u; mdl->fwd_quiet = 0u;
             } else if (refits == 0ull) {
                 uint32_t floorW = (mdl->sweeps < (unsigned long long)mdl->fwd_burnin_sweeps) ? mdl->fwd_W_burnin : mdl->fwd_W0;
