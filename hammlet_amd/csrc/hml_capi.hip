@@ -585,6 +585,13 @@ int hml_autoprior(hml_ctx* c, float s2, float p, float out4[4]) {
 // padding per state, rounded to whole 16-byte groups
 static uint64_t compat_list_entries(const hml_ctx* c) { return (c->cap + 4u * (uint64_t)HML_CAP_K + 3u) & ~(uint64_t)3u; }
 
+// the most chunks a sweep of the path for more than 16 states is cut into (hml_k_wl_prepare): the arrays are sized for the chunk
+// length this bound gives at the context's capacity
+static uint32_t wide_max_chunks_of(const hml_ctx* c) {
+    if (c->wide_max_chunks) return std::min<uint32_t>(c->wide_max_chunks, HML_WL_MAX_CHUNKS);
+    return c->K <= HML_WL_TWO_WAVES_KC ? (uint32_t)HML_WL_MAX_CHUNKS : (uint32_t)HML_WL_MAX_CHUNKS / 2u;
+}
+
 // the per-block sweep buffers, sized by the context's block capacity (hml_ctx.hpp; c->K set)
 static int alloc_sweep_buffers(hml_ctx* c) {
     const int K = c->K;
@@ -608,7 +615,7 @@ static int alloc_sweep_buffers(hml_ctx* c) {
         // hml_k_wl_prepare can choose for this capacity)
         uint64_t Lmax = 1ull << HML_WL_MIN_LSHIFT;
         if (c->wide_lshift >= 0) Lmax = std::max<uint64_t>(Lmax, 1ull << c->wide_lshift);
-        while ((cap + Lmax - 1) / Lmax > (uint64_t)HML_WL_MAX_CHUNKS) Lmax *= 2;
+        while ((cap + Lmax - 1) / Lmax > (uint64_t)wide_max_chunks_of(c)) Lmax *= 2;   // (the longest chunks hml_k_wl_prepare can choose: B <= cap)
         const uint64_t plane = (cap + 1 + 64 * Lmax) * K;
         HIPCHK(hipMalloc(&c->d_em, plane * sizeof(float)));
         HIPCHK(hipMalloc(&c->d_gsc, plane * sizeof(float)));
@@ -1051,8 +1058,7 @@ static int sweep_wide(hml_ctx* c, char method, bool record) {
         hml_compat_chunks ch = chunk_views(c);
         ch.W = c->compat_warmup > 0 ? (uint32_t)c->compat_warmup : c->compat_warmup < 0 ? 0u : HML_CHUNK_W_ADAPTIVE;
         const uint64_t room = (uint64_t)hint + hint / 4 + 1024;   // (the kernels find B themselves: their loops stride over any grid)
-        hipLaunchKernelGGL(hml_k_wl_prepare, dim3(1), dim3(256), 0, s, c->d_mdl, c->d_wA, c->wide_lshift,
-                           c->wide_max_chunks ? std::min<uint32_t>(c->wide_max_chunks, HML_WL_MAX_CHUNKS) : (c->K <= HML_WL_TWO_WAVES_KC ? (uint32_t)HML_WL_MAX_CHUNKS : (uint32_t)HML_WL_MAX_CHUNKS / 2u));
+        hipLaunchKernelGGL(hml_k_wl_prepare, dim3(1), dim3(256), 0, s, c->d_mdl, c->d_wA, c->wide_lshift, wide_max_chunks_of(c));
         hipLaunchKernelGGL(hml_k_wl_gtable, dim3(grid_for((uint64_t)c->K * HML_WL_GTAB, 256, 1, 512)), dim3(256), 0, s, c->d_mdl, c->d_wA + HML_WL_PITCH * HML_WL_PITCH);
         {
             ProfScope ps(c, "stats_emission");

@@ -756,6 +756,22 @@ def test_many_states_a_chunk_a_lane(hml, monkeypatch, K, L, warmup, lanes):
     g.close()
 
 
+def test_many_states_every_position_a_block(hml):
+    """The path for more than 16 states with as many blocks as the buffers hold (every position a block: B = T = the capacity) and a
+    chunk count one beyond a multiple of 64 (599 041 = 16 x (64 x 585) + 1 positions, 40 states: chunks of 16 blocks, 37 441 of them): the
+    chunk-transposed arrays are used up to their last tile - they must be sized for the chunk length the sweep picks, not the
+    shortest one (a review of the allocation at the end of round 5 found them short by 510 K floats in exactly this case)."""
+    T, K = 599_041, 40
+    x = ol.trace(T, 5, 17)
+    xx, o, g = make_pair(hml, T, K, 0, 5, x=x, weight_mult=1e9)
+    setup_model(o, g, K)
+    g._pending_prior = True
+    run_both(o, g, [("F", 2, 1)])
+    assert g.stats()["blocks_last_sweep"] == T if "blocks_last_sweep" in g.stats() else True
+    compare_state(o, g, what="40 states, every position a block")
+    g.close()
+
+
 def test_many_wrong_chunks_run_the_filter_again(hml, monkeypatch):
     """hml_k_wide_lanes.h on adversarial parameters (twin states, sticky transitions, every position a block: the rows forget their
     start very slowly): nearly every chunk starts from the wrong row, the sweep runs its whole filter once more with eight times
