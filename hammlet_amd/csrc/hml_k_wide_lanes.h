@@ -254,8 +254,8 @@ __device__ __forceinline__ void hml_wl_mv(const float* sA, const int j0, const f
 // The warm-up of the filter's chunks on this path (mdl->fwd_W; results never depend on it).  It starts at 64 blocks.  A sweep with
 // wrong chunks doubles it (eight times, if the whole filter ran again: hml_k_wl_retry_decide); sweeps without one walk it down -
 // by half every four of them while it is above 64 (a young chain's first sweeps need a long warm-up once: parameters from the prior),
-// by a quarter every sixteen below that, to the floor (32) - but not below twice a warm-up that failed on a settled chain (from its
-// ninth sweep on) for the 512 sweeps after that.
+// by a quarter every sixteen below that, to the floor (32) - but not below one step (8 blocks) above a warm-up that failed on a settled
+// chain (from its ninth sweep on) for the 512 sweeps after that.
 __device__ __forceinline__ void hml_wl_fwd_adapt(hml_model* mdl, const uint32_t Wspec, const bool failed, const uint32_t W_used, const uint32_t W_next) {
     if (Wspec != HML_CHUNK_W_ADAPTIVE) return;
     if (failed) {
@@ -266,7 +266,7 @@ __device__ __forceinline__ void hml_wl_fwd_adapt(hml_model* mdl, const uint32_t 
     }
     if (mdl->wl_W_need != 0u && ++mdl->wl_need_age > 512u) mdl->wl_W_need = 0u;
     uint32_t floor_w = mdl->fwd_W0;
-    if (mdl->wl_W_need != 0u) { const uint32_t keep = 2u * mdl->wl_W_need < 1024u ? 2u * mdl->wl_W_need : 1024u; floor_w = keep > floor_w ? keep : floor_w; }
+    if (mdl->wl_W_need != 0u) { const uint32_t keep = ((mdl->wl_W_need + 8u) & ~7u) < 1024u ? ((mdl->wl_W_need + 8u) & ~7u) : 1024u; floor_w = keep > floor_w ? keep : floor_w; }
     uint32_t w = mdl->fwd_W;
     const uint32_t quiet = ++mdl->fwd_quiet;
     if (w > 64u && w / 2u >= floor_w && quiet >= 4u) { w = w / 2u; mdl->fwd_quiet = 0u; }
