@@ -785,6 +785,7 @@ HML_KERNEL __launch_bounds__(256) void hml_k_counts(int16_t* __restrict__ q, con
 // same sums and the same tree as hml_k_counts, as a streaming loop - per-lane integer counters always (registers;
 // changes of state - rare - in LDS), loads one chunk ahead, nothing but the lane's own accumulators in the loop.
 // ------------------------------------------------------------------------------------------
+#define HML_CNT_DENSE_AHEAD 2   // chunks of a workgroup per group of requests (one group is requested ahead)
 template <int K, bool FB>
 HML_KERNEL __launch_bounds__(256) void hml_k_counts_dense(int16_t* __restrict__ q, const uint32_t* __restrict__ starts,
                                                           const float2* __restrict__ bstat, hml_model* __restrict__ mdl,
@@ -815,9 +816,9 @@ HML_KERNEL __launch_bounds__(256) void hml_k_counts_dense(int16_t* __restrict__ 
     // The loads of a block are STRAIGHT-LINE code (round 5): the block index is clamped into the sweep instead of the loads being
     // skipped, and only the additions are predicated.  Round 3's form fetched behind `b < B` and `c + GROUPS < nchunks` - divergent
     // code, at whose end the compiler waits for every load it issued (s_waitcnt vmcnt(0) at the loop's head) - so every chunk step was
-    // one whole memory round trip "however many chunks are requested ahead" (381 steps of 0.79 us).  A workgroup now
-    // requests FOUR of its chunks together and then adds them in chunk order: the same terms into the same accumulators in the
-    // same order, a quarter of the round trips.
+    // one whole memory round trip "however many chunks are requested ahead" (381 steps of 0.79 us).  A workgroup
+    // requests several of its chunks together and adds them in chunk order: the same terms into the same accumulators in the same
+    // order (the loop below).
     const uint32_t Bm1 = B ? B - 1u : 0u;
     auto fetch = [&](auto unit_c, uint32_t b, in_t& r) __attribute__((always_inline)) {
         constexpr bool UNIT = decltype(unit_c)::value;    // (a compile-time value: no branch between the loads)
@@ -835,48 +836,64 @@ HML_KERNEL __launch_bounds__(256) void hml_k_counts_dense(int16_t* __restrict__ 
         else { r.s1 = starts[bc + 1u]; r.s0 = starts[bc]; }
         r.v = bstat[bc];
     };
-    auto add = [&](uint32_t b, const in_t& cur) __attribute__((always_inline)) {
-        if (b < B) {
-            int st, prev;
-            if (FB) {
-                st = (int)((cur.m1 >> (4 * cur.e1)) & 15ull);
-                prev = (b == 0) ? 0 : (int)((cur.m0 >> (4 * cur.e0)) & 15ull);
-                q[b] = (int16_t)st;
-            } else {
-                st = cur.q1;
-                prev = (b == 0) ? 0 : (int)cur.q0;
-            }
-            const uint32_t n = cur.s1 - cur.s0;
-            const double vx = (double)cur.v.x, vq = (double)cur.v.y;
-#pragma unroll
-            for (int s = 0; s < K; ++s) {
-                if (st == s) {
-                    n_pos[s] += (unsigned long long)n; n_blk[s] += 1u;
-                    if (prev == s) n_stay[s] += 1u;
-                    acc_s[s] = acc_s[s] + vx; acc_q[s] = acc_q[s] + vq;
-                }
-            }
-            if (prev != st) atomicAdd(&h_trans[prev * K + st], 1ull);
+    // A block beyond the sweep is "in no state" (nothing matches it) instead of being branched around: the compiler sank the loads of
+    // a step's first chunk into that branch and waited for ALL loads there (s_waitcnt vmcnt(0)).  A state's terms stay behind a branch
+    // of their own: the 64 consecutive blocks of a wavefront are mostly in one or two states (selecting the terms instead of branching
+    // to them was measured: 315 against 287 us per launch at 10^8 blocks, profiles/round5_dense_counts_states.txt).
+    auto add = [&](auto unit_c, uint32_t b, const in_t& cur) __attribute__((always_inline)) {
+        constexpr bool UNIT = decltype(unit_c)::value;
+        const bool in = b < B;
+        int st, prev;
+        if (FB) {
+            st = (int)((cur.m1 >> (4 * cur.e1)) & 15ull);
+            prev = (b == 0) ? 0 : (int)((cur.m0 >> (4 * cur.e0)) & 15ull);
+        } else {
+            st = cur.q1;
+            prev = (b == 0) ? 0 : (int)cur.q0;
         }
+        st = in ? st : -1;
+        if (FB) { if (in) q[b] = (int16_t)st; }
+        const uint32_t n = UNIT ? 1u : cur.s1 - cur.s0;
+        const double vx = (double)cur.v.x, vq = (double)cur.v.y;
+#pragma unroll
+        for (int s = 0; s < K; ++s) {
+            if (st == s) {
+                n_pos[s] += (unsigned long long)n; n_blk[s] += 1u;
+                if (prev == s) n_stay[s] += 1u;
+                acc_s[s] = acc_s[s] + vx; acc_q[s] = acc_q[s] + vq;
+            }
+        }
+        if (in && prev != st) atomicAdd(&h_trans[prev * K + st], 1ull);
     };
     // workgroup g owns chunks g, g + GROUPS, g + 2 GROUPS, ...; wavefront w streams quarter w of each of them, every lane
     // adding its block's term to its own accumulator - no tree, no barrier in the loop
     auto stream = [&](auto unit_c) __attribute__((always_inline)) {
         constexpr uint32_t STEP = HML_REDUCE_GROUPS * HML_REDUCE_CHUNK;
-        for (uint32_t c = g; c < nchunks; c += 4u * HML_REDUCE_GROUPS) {   // workgroup-uniform
-            const uint32_t b0 = c * HML_REDUCE_CHUNK + (uint32_t)tid;
-            in_t r0, r1, r2, r3;
-            // (blocks of chunks beyond the sweep: index B, for which nothing is added)
-            const uint64_t b1 = (uint64_t)b0 + STEP, b2 = (uint64_t)b0 + 2ull * STEP, b3 = (uint64_t)b0 + 3ull * STEP;
-            const uint32_t c1 = b1 < B ? (uint32_t)b1 : B, c2 = b2 < B ? (uint32_t)b2 : B, c3 = b3 < B ? (uint32_t)b3 : B;
-            fetch(unit_c, b0, r0);
-            fetch(unit_c, c1, r1);
-            fetch(unit_c, c2, r2);
-            fetch(unit_c, c3, r3);
-            add(b0, r0);
-            add(c1, r1);
-            add(c2, r2);
-            add(c3, r3);
+        // The NEXT group of HML_CNT_DENSE_AHEAD chunks is requested before this group's terms are added (same terms into the same
+        // accumulators in the same order).  Two chunks a group: 253-262 us per launch at 10^8 blocks against 274-287 for round 5's four
+        // chunks at once without the look-ahead; one, three, four or eight chunks a group, and two register sets that swap roles so
+        // that twice as many loads stay in flight, are all slower (262-350 us) - more requests in flight cost more than they hide here.
+        in_t r[HML_CNT_DENSE_AHEAD], nx[HML_CNT_DENSE_AHEAD];
+        uint32_t bi[HML_CNT_DENSE_AHEAD], bn[HML_CNT_DENSE_AHEAD];
+        auto index = [&](uint32_t c, uint32_t (&o)[HML_CNT_DENSE_AHEAD]) __attribute__((always_inline)) {
+#pragma unroll
+            for (int k = 0; k < HML_CNT_DENSE_AHEAD; ++k) {   // (blocks of chunks beyond the sweep: index B, for which nothing is added)
+                const uint64_t bk = (uint64_t)c * HML_REDUCE_CHUNK + (uint32_t)tid + (uint64_t)k * STEP;
+                o[k] = (c < nchunks && bk < B) ? (uint32_t)bk : B;
+            }
+        };
+        index(g, bi);
+#pragma unroll
+        for (int k = 0; k < HML_CNT_DENSE_AHEAD; ++k) fetch(unit_c, bi[k], r[k]);
+        for (uint32_t c = g; c < nchunks; c += (uint32_t)HML_CNT_DENSE_AHEAD * HML_REDUCE_GROUPS) {   // workgroup-uniform
+            const uint64_t cn = (uint64_t)c + (uint64_t)HML_CNT_DENSE_AHEAD * HML_REDUCE_GROUPS;
+            index(cn < nchunks ? (uint32_t)cn : nchunks, bn);
+#pragma unroll
+            for (int k = 0; k < HML_CNT_DENSE_AHEAD; ++k) fetch(unit_c, bn[k], nx[k]);
+#pragma unroll
+            for (int k = 0; k < HML_CNT_DENSE_AHEAD; ++k) add(unit_c, bi[k], r[k]);
+#pragma unroll
+            for (int k = 0; k < HML_CNT_DENSE_AHEAD; ++k) { r[k] = nx[k]; bi[k] = bn[k]; }
         }
     };
     if (unit_blocks) stream(std::true_type{}); else stream(std::false_type{});

@@ -691,12 +691,27 @@ HML_KERNEL __launch_bounds__(64) void hml_k_trellis_states(const unsigned long l
         // lane = (chunk, row): half a wavefront reads one chunk's 32 consecutive maps; all 32 loads of a lane in flight, and the
         // NEXT batch's loads are issued before the current batch is walked (the walk and the stores hide their latency)
         auto fetch = [&](int rel0, map_t (&v)[RB]) {
+            // one scalar base per load and ONE 32-bit lane offset for all of them, clamped into the array instead of predicated (what
+            // a row beyond the sweep loads is never used): round 5's form held a 64-bit address per load - 225 vector registers,
+            // two wavefronts per SIMD; this one 129 and three (177 -> 168 us per launch at 10^8 blocks)
+            if (rel0 < 0) return;                                    // (wavefront-uniform: the prefetch behind the chunks' first batch)
+            const uint32_t off_lane = ((uint32_t)lane / (uint32_t)RB) * L + ((uint32_t)lane % (uint32_t)RB) + 1u;   // row t = b + 1
+            const char* __restrict__ cmb = reinterpret_cast<const char*>(cm);
+            if ((uint64_t)(f0 + (uint32_t)HML_TRE_NCH) * L <= (uint64_t)B) {   // every chunk of the group inside the sweep (all groups but the last)
+                const uint32_t boff = off_lane * (uint32_t)sizeof(map_t);
 #pragma unroll
-            for (int k = 0; k < RB; ++k) {
-                const int slot = k * 64 + lane;
-                const int c = slot / RB, r = slot % RB;
-                const uint64_t b = (uint64_t)(f0 + (uint32_t)c) * L + (uint32_t)rel0 + (uint32_t)r;   // row t = b + 1
-                v[k] = (rel0 >= 0 && f0 + (uint32_t)c < NC && b < B) ? cm[b + 1u] : (map_t)0;
+                for (int k = 0; k < RB; ++k) {
+                    const uint64_t u = (uint64_t)(f0 + (uint32_t)(k * (64 / RB))) * L + (uint32_t)rel0;   // wavefront-uniform
+                    v[k] = *reinterpret_cast<const map_t*>(cmb + u * sizeof(map_t) + boff);
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < RB; ++k) {
+                    const uint64_t u = (uint64_t)(f0 + (uint32_t)(k * (64 / RB))) * L + (uint32_t)rel0;
+                    const uint32_t rem = u < (uint64_t)B ? (uint32_t)((uint64_t)B - u) : 0u;            // (cand has B + 1 entries)
+                    const uint64_t uc = u < (uint64_t)B ? u : (uint64_t)B;
+                    v[k] = *reinterpret_cast<const map_t*>(cmb + uc * sizeof(map_t) + (off_lane < rem ? off_lane : rem) * (uint32_t)sizeof(map_t));
+                }
             }
         };
         map_t v[RB];

@@ -36,3 +36,6 @@ B = (s1["block_updates"] - s0["block_updates"]) / n
 print("%s T=%d: %.3f ms/sweep, %.3e blocks/sweep, %.3e block-updates/s, refits %d serial %d warm-up %d, sweep_frac %.4f" % (
     which, T, 1e3 * dt / n, B, B * n / dt, s1["forward_refits"] - s0["forward_refits"], s1["forward_serial"] - s0["forward_serial"],
     s1["forward_warmup"], (4.0 * T + B * (36 + 8 * K)) / (dt / n) / 8e12))
+import zlib  # noqa: E402
+import numpy as np  # noqa: E402
+print("  check: theta crc %08x, states crc %08x" % (zlib.crc32(np.ascontiguousarray(c.theta()).tobytes()), zlib.crc32(np.ascontiguousarray(c.states()).tobytes())))
