@@ -155,6 +155,7 @@ int hml_create(hml_ctx** out, int device, uint64_t seed, uint32_t chain_id, void
     if (const char* e = getenv("HML_TRELLIS_FUSED")) c->tre_fused = atoi(e) != 0;
     if (const char* e = getenv("HML_TRELLIS_L")) { const int l = atoi(e); c->tre_L = (l <= 0) ? 0u : (l >= HML_TRE_MAX_L) ? (uint32_t)HML_TRE_MAX_L : (l < 32) ? 32u : (uint32_t)l / 32u * 32u; }   // a multiple of 32
     if (const char* e = getenv("HML_TRELLIS_CKPT")) c->tre_ckpt = atoi(e) != 0;
+    if (const char* e = getenv("HML_TRELLIS_REFIT_ROUNDS")) { const int r = atoi(e); c->tre_refit_rounds = r < 0 ? 0u : r > 6 ? 6u : (uint32_t)r; }
     if (const char* e = getenv("HML_STAGE_BITS")) c->stage_bits = atoi(e) != 0;
     if (const char* e = getenv("HML_TRELLIS_ROWS")) c->tre_rows = atoi(e) != 0;   // 0: round 2's first pass (hml_k_trellis_tile) for comparison
     if (const char* e = getenv("HML_LATE_RESCALE")) c->late_rescale = atoi(e) != 0;

@@ -160,7 +160,7 @@ static int sweep_k(hml_ctx* c, char method, bool record) {
             hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_trellis_verify<KK>), dim3(grid_for(tchunks, 256, 16, 1 << 14)), dim3(256), 0, s, c->d_mdl,
                                c->d_entry, c->d_exitA, c->d_redo, TL);
             int in_a = 1;
-            for (uint32_t round = 0; round < 4u; ++round, in_a ^= 1) {
+            for (uint32_t round = 0; round < c->tre_refit_rounds; ++round, in_a ^= 1) {
                 uint32_t* lin = in_a ? c->d_redo : c->d_redo2;
                 uint32_t* lout = in_a ? c->d_redo2 : c->d_redo;
                 hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_trellis_refit<KK>), dim3(4096), dim3(64), 0, s, c->d_ia, c->d_starts, c->d_mdl, c->d_smap,
