@@ -96,7 +96,9 @@ struct hml_ctx {
     uint32_t graph_tre_L = 0;      // chunk length of the captured sweep
     int tre_slots = 0;             // wavefronts of hml_k_trellis_rows the device holds at once (0: not asked yet, -1: unknown)
     bool stage_bits = true;        // weakly compressed sweeps stage block-start FLAGS between scan and scatter (HML_STAGE_BITS=0: 16-bit offsets)
-    uint32_t tre_refit_rounds = 4; // parallel refit rounds before the sequential finisher (HML_TRELLIS_REFIT_ROUNDS, 0 ... 6: the rounds tag the chunks they list with 3 bits)
+    uint32_t tre_refit_rounds = 2; // parallel refit rounds before the sequential finisher (HML_TRELLIS_REFIT_ROUNDS, 0 ... 6: the rounds tag the chunks they list with 3 bits).
+                                   // Four until the end of round 5: on configs 3u and 5 rounds 2-4 never had a chunk to refit in 240 sweeps and cost 9 us each
+                                   // (two launches at the 4.6 us floor of a kernel in a stream; profiles/round5_refit_rounds.txt)
     bool tre_ckpt = true;          // refits stop where they meet the first pass's checkpoint again (HML_TRELLIS_CKPT=0: always the whole chunk)
     bool tre_rows = true;          // its first pass is hml_k_trellis_rows (round 3); HML_TRELLIS_ROWS=0: hml_k_trellis_tile (round 2)
     bool tre_fused = true;         // weakly compressed FB sweeps take the fused trellis kernels (HML_TRELLIS_FUSED=0: the separate ones)

@@ -15,8 +15,8 @@
 //     (block start, integral-array gathers) and 8 + 8 written (statistics for the count pass, candidate map);
 //   * the warm-up (W <= HML_TRE_HALO blocks before the chunk, emission terms included) is short and paid once per L
 //     blocks; chunks whose filter had not forgotten its start by then are REFITTED IN PARALLEL (hml_k_trellis_refit: one
-//     wavefront per stale chunk, starting from its predecessor's end vector; four rounds, each verified again) instead
-//     of lengthening everybody's warm-up until nobody fails; runs of more than four consecutive stale chunks are
+//     wavefront per stale chunk, starting from its predecessor's end vector; a few rounds - hml_ctx.hpp: tre_refit_rounds -, each verified again) instead
+//     of lengthening everybody's warm-up until nobody fails; runs of more consecutive stale chunks than there are rounds are
 //     finished sequentially (hml_k_trellis_serial).  As in hml_k_forward.h the rows are bit for bit those of the sequential recursion: a chunk
 //     is accepted only when the vector it started from equals, bit for bit, the vector its predecessor ended in, and
 //     induction from chunk 0 (which starts from pi) does the rest.
@@ -553,7 +553,7 @@ HML_KERNEL __launch_bounds__(64) void hml_k_trellis_refit(const float2* __restri
     }
 }
 
-// what four refit rounds left inconsistent: marked in a bitmap, visited in increasing order by ONE lane, each recomputed
+// what the refit rounds left inconsistent: marked in a bitmap, visited in increasing order by ONE lane, each recomputed
 // from its predecessor's true end vector; the walk follows a chain while the recomputed end vector makes the next chunk
 // inconsistent.  After this pass induction from chunk 0 holds.  One workgroup of 256 threads.
 template <int K>

@@ -154,7 +154,7 @@ static int sweep_k(hml_ctx* c, char method, bool record) {
                                c->d_ia, c->d_starts, c->d_mdl, c->d_mdl, c->d_bstat, c->d_smap, c->d_cmap, c->d_entry, c->d_exitA, c->d_fb, ep, ap, TL);
         }
         {
-            // verification, four rounds of parallel refits from the predecessors' end vectors (the lists of stale chunks
+            // verification, rounds of parallel refits from the predecessors' end vectors (two by default, hml_ctx.hpp; the lists of stale chunks
             // alternate between d_redo and d_redo2), then the sequential finisher: each exits at once when its list is empty
             ProfScope ps(c, "trellis_repair");
             hipLaunchKernelGGL(HIP_KERNEL_NAME(hml_k_trellis_verify<KK>), dim3(grid_for(tchunks, 256, 16, 1 << 14)), dim3(256), 0, s, c->d_mdl,

@@ -10,7 +10,7 @@ import numpy as np
 from tests import oracle_lib as ol
 from tests.test_gpu_parity import run_both
 
-ENV_KEYS = ("HML_DENSE_MIN_BLOCKS", "HML_FWD_CHUNK_DENSE", "HML_TRELLIS_FUSED", "HML_TRELLIS_L", "HML_TRELLIS_ROWS", "HML_TRELLIS_CKPT",
+ENV_KEYS = ("HML_DENSE_MIN_BLOCKS", "HML_FWD_CHUNK_DENSE", "HML_TRELLIS_FUSED", "HML_TRELLIS_L", "HML_TRELLIS_ROWS", "HML_TRELLIS_CKPT", "HML_TRELLIS_REFIT_ROUNDS",
             "HML_STAGE_BITS", "HML_FWD_WARMUP", "HML_LATE_RESCALE", "HML_FWD_CHUNK",
             "HML_MANY_GROUPS", "HML_FUSED_MANY_SLOTS", "HML_MAX_BLOCKS", "HML_FWD_CHUNK_MANY", "HML_COMPAT_CHUNKS", "HML_COMPAT_WARMUP", "HML_WIDE", "HML_FM_SPLIT", "HML_FM_SPLIT_SUB",
             "HML_WIDE_L", "HML_WIDE_LANES", "HML_MID_MIN_BLOCKS")
@@ -68,6 +68,7 @@ def _fuzz(hml, n_cfg, seed, log, compat=False, wide=False):
         # round 3's switches: first pass (rows | tile), checkpointed refits, flag staging of the dense scan, a short warm-up
         os.environ["HML_TRELLIS_ROWS"] = str(int(rng.choice([1, 1, 1, 0])))
         os.environ["HML_TRELLIS_CKPT"] = str(int(rng.choice([1, 1, 0])))
+        os.environ["HML_TRELLIS_REFIT_ROUNDS"] = str((2, 2, 0, 1, 4, 3, 6)[(T + K) % 7])   # (no draw: the configurations of earlier rounds stay what they were)
         os.environ["HML_STAGE_BITS"] = str(int(rng.choice([1, 1, 0])))
         if rng.random() < 0.3: os.environ["HML_FWD_WARMUP"] = str(int(rng.choice([4, 8, 16])))
         else: os.environ.pop("HML_FWD_WARMUP", None)

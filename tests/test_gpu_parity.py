@@ -1078,17 +1078,20 @@ def test_fused_block_kernel_retires_itself_after_an_expired_wait(hml, monkeypatc
     assert g.profile_get("blocks_scatter")[1] >= 10
 
 
-@pytest.mark.parametrize("chunk,fused", [(32, 1), (96, 1), (128, 1), (256, 1), (512, 1), (1024, 1), (32, 0), (96, 2), (256, 3)])
-def test_fused_trellis_repair_paths_on_twin_states(hml, monkeypatch, chunk, fused):
+@pytest.mark.parametrize("chunk,fused,rounds", [(32, 1, None), (96, 1, None), (128, 1, None), (256, 1, None), (512, 1, None), (1024, 1, None), (32, 0, None),
+                                                (96, 2, None), (256, 3, None), (96, 1, 0), (128, 1, 1), (256, 1, 3), (96, 1, 4), (32, 1, 6)])
+def test_fused_trellis_repair_paths_on_twin_states(hml, monkeypatch, chunk, fused, rounds):
     """The fused trellis kernels of weakly compressed sweeps (hml_k_trellis.h; HML_TRELLIS_FUSED=0 runs the separate
     kernels for comparison) on the adversarial twin-state parameters: an uncompressed trace on which the filter hardly
-    forgets, so most chunks are stale after the first pass, the parallel refits run four rounds and the sequential
+    forgets, so most chunks are stale after the first pass, the parallel refits run all their rounds and the sequential
     finisher walks long chains - and forward rows, states and parameters must still be the checker's, bit for bit, for
     every chunk length.  (Round 3: refits stop where they meet the first pass's checkpoint again, the filter step shares
     the candidate maps' sums on uncompressed input, the scan stages flags - all on by default here.)"""
     monkeypatch.setenv("HML_DENSE_MIN_BLOCKS", "1")
     monkeypatch.setenv("HML_TRELLIS_L", str(chunk))
     monkeypatch.setenv("HML_TRELLIS_FUSED", "1" if fused else "0")
+    if rounds is not None:
+        monkeypatch.setenv("HML_TRELLIS_REFIT_ROUNDS", str(rounds))   # parallel refit rounds before the sequential finisher (default 2; odd: the lists end swapped)
     if fused == 2:
         monkeypatch.setenv("HML_TRELLIS_ROWS", "0")     # round 2's first pass (hml_k_trellis_tile), kept for comparison
     if fused == 3:
@@ -1116,9 +1119,10 @@ def test_fused_trellis_repair_paths_on_twin_states(hml, monkeypatch, chunk, fuse
     assert np.array_equal(bits(o.loglik()), bits(g.block_loglik()))
     assert np.array_equal(bits(o.forward_rows()), bits(g.forward_rows()))
     assert np.array_equal(o.states(), g.states())
-    assert s1["forward_refits"] > s0["forward_refits"]
+    if rounds != 0:
+        assert s1["forward_refits"] > s0["forward_refits"]            # (no parallel round: every stale chunk is the finisher's)
     if fused:
-        assert s1["forward_serial"] > s0["forward_serial"]          # runs of stale chunks longer than the four parallel rounds
+        assert s1["forward_serial"] > s0["forward_serial"]          # runs of stale chunks longer than the parallel rounds
     o.set_record(marginals=True)
     o.iterate("F", 4, 2)
     g.iterate("F", 4, 2)
