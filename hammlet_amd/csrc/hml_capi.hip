@@ -671,7 +671,7 @@ static int alloc_sweep_buffers(hml_ctx* c) {
     HIPCHK(hipMalloc(&c->d_redo2, bchunks * sizeof(uint32_t)));
     HIPCHK(hipMalloc(&c->d_tre_bitmap, (bchunks / 32 + 2) * sizeof(uint32_t)));
     // (checkpoints of the fused trellis path: (L / 64 - 1) x ceil(B / L) <= B / 64 + 16 vectors of K + 1 words)
-    HIPCHK(hipMalloc(&c->d_tre_ckpt, (cap / 64 + 64) * (uint64_t)(K + 1) * sizeof(uint32_t)));
+    HIPCHK(hipMalloc(&c->d_tre_ckpt, (cap / HML_TRE_CKPT_ROWS + 64) * (uint64_t)(K + 1) * sizeof(uint32_t)));
     HIPCHK(hipMalloc(&c->d_q, cap * sizeof(int16_t)));
     // (the count pass's group partials [2 K][1024] and, behind them, the first level of their tree [16][2 K]: hml_k_params.h)
     const uint64_t n_partial = ((uint64_t)HML_REDUCE_GROUPS + HML_PARAMS_TREE_WGS) * K * 2;

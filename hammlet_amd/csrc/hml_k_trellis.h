@@ -31,6 +31,7 @@
 #include "hml_k_backward.h"
 #include "hml_k_forward.h"
 
+#define HML_TRE_CKPT_ROWS 32  // rows between the first pass's checkpoints = rows per batch of a refit (a power of two, 32 or 64; chunk lengths are multiples of 32)
 #define HML_TRE_NCH 64      // forward chunks per wavefront = lanes of the filter
 #define HML_TRE_R 4         // rows per batch
 #define HML_TRE_HALO HML_TRE_HALO_MAX   // longest warm-up of the first pass (a multiple of HML_TRE_R and of 16; hml_state.h)
@@ -439,6 +440,7 @@ HML_KERNEL __launch_bounds__(64) void hml_k_trellis_refit(const float2* __restri
     const uint32_t Wt = hml_tre_warmup(mdl);
     const unsigned long long epoch = mdl->epoch;
     const hml_key key = mdl->key;
+    constexpr uint32_t CKR = HML_TRE_CKPT_ROWS;
     for (uint32_t i = blockIdx.x; i < n; i += gridDim.x) {   // workgroup-uniform
         const uint32_t f = list[i];
         if (hml_tre_exact(f, L, Wt)) continue;
@@ -454,10 +456,11 @@ HML_KERNEL __launch_bounds__(64) void hml_k_trellis_refit(const float2* __restri
         uint32_t nfb = 0u;
         unsigned long long m = HML_MAP_IDENTITY;
         bool stopped = false;
-        for (uint32_t bb = first; bb < last; bb += 64u) {
+        for (uint32_t bb = first; bb < last; bb += CKR) {   // batches of CKR rows (lanes CKR ... 63 idle): a refit stops at the first checkpoint it meets
             const uint32_t b = bb + (uint32_t)lane;
+            const bool mine = (uint32_t)lane < CKR && b < last;
             uint32_t nb = 0u;
-            if (b < last) {
+            if (mine) {
                 const uint32_t st = starts[b], en = starts[b + 1];
                 float sx, sq, E[K], ev[K];
                 hml_block_stats_one(ia, st, en, sx, sq);
@@ -471,7 +474,7 @@ HML_KERNEL __launch_bounds__(64) void hml_k_trellis_refit(const float2* __restri
             }
             __syncthreads();
             if (lane == 0) {
-                for (uint32_t l = 0; l < 64u && bb + l < last; ++l) {
+                for (uint32_t l = 0; l < CKR && bb + l < last; ++l) {
                     float e[K];
 #pragma unroll
                     for (int s = 0; s < K; ++s) e[s] = sm_e[s * 65 + l];
@@ -482,13 +485,14 @@ HML_KERNEL __launch_bounds__(64) void hml_k_trellis_refit(const float2* __restri
                         if (aprobe) aprobe[(uint64_t)(bb + l + 1u) * K + s] = alpha[s];
                     }
                 }
-                // The first pass left its forward vector after every 64 rows of the chunk (hml_k_trellis_rows).  Where the
+                // The first pass left its forward vector after every HML_TRE_CKPT_ROWS rows of the chunk (hml_k_trellis_rows).  Where the
                 // refitted filter meets it again, bit for bit, every later row of the chunk - emission terms, filter,
                 // uniforms, candidate maps - is what it was: the refit stops there.  (A filter that started a few rows
-                // too early to have forgotten its start has nearly always done so 64 rows later.)
+                // too early to have forgotten its start has nearly always done so 32 rows later: checkpoints every 32 rows since the
+                // end of round 5 - every 64 before, and a refit's lane 0 filtered 64 rows where it now filters 32.)
                 uint32_t met = 0u, old_nfb = 0u;
-                if (ckpt && bb + 64u < last) {
-                    uint32_t* const ck = ckpt + (uint64_t)((bb - first) / 64u) * (uint32_t)(K + 1) * C + f;
+                if (ckpt && bb + CKR < last) {
+                    uint32_t* const ck = ckpt + (uint64_t)((bb - first) / CKR) * (uint32_t)(K + 1) * C + f;
                     met = 1u;
 #pragma unroll
                     for (int s = 0; s < K; ++s) {
@@ -502,7 +506,7 @@ HML_KERNEL __launch_bounds__(64) void hml_k_trellis_refit(const float2* __restri
                 sm_met[1] = old_nfb;
             }
             __syncthreads();
-            if (b < last) {
+            if (mine) {
                 const uint32_t t = b + 1u;
                 float row[K];
 #pragma unroll
@@ -517,13 +521,13 @@ HML_KERNEL __launch_bounds__(64) void hml_k_trellis_refit(const float2* __restri
             }
             __syncthreads();
             if (lane == 0)
-                for (uint32_t l = 0; l < 64u && bb + l < last; ++l) m = hml_map_compose<K>(m, sm_m[l]);
+                for (uint32_t l = 0; l < CKR && bb + l < last; ++l) m = hml_map_compose<K>(m, sm_m[l]);
             const bool met = sm_met[0] != 0u;
             __syncthreads();
             if (met) {   // workgroup-uniform
                 // the rest of the chunk stands: its maps (in memory) complete the chunk map, its end vector and the fallbacks
                 // counted behind the checkpoint stay
-                for (uint32_t b2 = bb + 64u; b2 < last; b2 += 64u) {
+                for (uint32_t b2 = bb + CKR; b2 < last; b2 += 64u) {
                     const uint32_t b = b2 + (uint32_t)lane;
                     unsigned long long mp = (b < last) ? hml_tre_load_cand<K>(cand, (uint64_t)b + 1u) : HML_MAP_IDENTITY;
 #pragma unroll

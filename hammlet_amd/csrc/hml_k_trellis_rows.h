@@ -490,11 +490,11 @@ void hml_k_trellis_rows(const float2* __restrict__ ia, const uint32_t* __restric
                         cmap = hml_tr2_compose<K>(cmap, cm);
                     }
                 }
-                // a checkpoint every 64 rows inside the chunk: the forward vector (and the fallbacks so far) a refit of this
+                // a checkpoint every HML_TRE_CKPT_ROWS rows inside the chunk: the forward vector (and the fallbacks so far) a refit of this
                 // chunk compares with - from where it meets them again, bit for bit, the rest of the chunk stands
                 // (hml_k_trellis_refit).  Plane-major, the chunk fastest: consecutive lanes write consecutive words.
-                if (rel0 >= 0 && ((rel0 + R) & 63) == 0 && rel0 + R < (int)L) {   // wave-uniform
-                    uint32_t* const ck = ckpt + (uint64_t)((uint32_t)(rel0 + R) / 64u - 1u) * (uint32_t)(K + 1) * C + f;
+                if (rel0 >= 0 && ((rel0 + R) & (HML_TRE_CKPT_ROWS - 1)) == 0 && rel0 + R < (int)L) {   // wave-uniform
+                    uint32_t* const ck = ckpt + (uint64_t)((uint32_t)(rel0 + R) / (uint32_t)HML_TRE_CKPT_ROWS - 1u) * (uint32_t)(K + 1) * C + f;
 #pragma unroll
                     for (int s = 0; s < K; ++s) ck[(uint64_t)s * C] = hml_f2u(alpha[s]);
                     ck[(uint64_t)K * C] = nfb;
