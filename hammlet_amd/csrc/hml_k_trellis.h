@@ -418,15 +418,15 @@ HML_KERNEL __launch_bounds__(64) void hml_k_trellis_refit(const float2* __restri
                                                           float* __restrict__ eprobe, float* __restrict__ aprobe,
                                                           const uint32_t* __restrict__ list, int list_is_a,
                                                           uint32_t* __restrict__ ckpt, uint32_t L) {
-    __shared__ float sm_e[K * 65];
-    __shared__ unsigned long long sm_m[64];
+    __shared__ float sm_e[K * 65];   // the batch's emission terms (all lanes) ...
+    __shared__ float sm_a[K * 65];   // ... and its rows (lane 0)
     __shared__ uint32_t sm_met[2];   // lane 0 met the checkpoint again | the fallbacks the old rows had counted up to it
     const uint32_t n = list_is_a ? mdl->fwd_mismatch : mdl->fwd_mismatch2;
     if (blockIdx.x == 0 && threadIdx.x == 0) {   // the other list is written next (hml_k_trellis_verify_list): empty it
         if (list_is_a) mdl->fwd_mismatch2 = 0u; else mdl->fwd_mismatch = 0u;
     }
     if (n == 0u) return;
-    // (one wavefront per workgroup, like hml_k_trellis_tile: sm_e / sm_m are exchanged without barriers)
+    // (one wavefront per workgroup, like hml_k_trellis_tile: sm_e / sm_a are exchanged between its lanes)
     if (blockDim.x != 64u) { if (threadIdx.x == 0) hml_raise(mdl, HML_DEVERR_LAUNCH_GEOMETRY, (float)blockDim.x); return; }
     const int lane = threadIdx.x;
     hml_emit_params<K> p;
@@ -474,15 +474,20 @@ HML_KERNEL __launch_bounds__(64) void hml_k_trellis_refit(const float2* __restri
             }
             __syncthreads();
             if (lane == 0) {
-                for (uint32_t l = 0; l < CKR && bb + l < last; ++l) {
+                // (the rows go to an array of their own: the reads of the next rows' terms do not wait behind these stores, and the
+                // loop is unrolled so that they are requested ahead of the step that needs them)
+                const uint32_t nrows = (last - bb < CKR) ? last - bb : CKR;
+#pragma unroll 4
+                for (uint32_t l = 0; l < nrows; ++l) {
                     float e[K];
 #pragma unroll
                     for (int s = 0; s < K; ++s) e[s] = sm_e[s * 65 + l];
                     if (hml_fwd_step<K>(cx, alpha, e)) nfb++;
 #pragma unroll
-                    for (int s = 0; s < K; ++s) {
-                        sm_e[s * 65 + l] = alpha[s];
-                        if (aprobe) aprobe[(uint64_t)(bb + l + 1u) * K + s] = alpha[s];
+                    for (int s = 0; s < K; ++s) sm_a[s * 65 + l] = alpha[s];
+                    if (aprobe) {
+#pragma unroll
+                        for (int s = 0; s < K; ++s) aprobe[(uint64_t)(bb + l + 1u) * K + s] = alpha[s];
                     }
                 }
                 // The first pass left its forward vector after every HML_TRE_CKPT_ROWS rows of the chunk (hml_k_trellis_rows).  Where the
@@ -506,37 +511,54 @@ HML_KERNEL __launch_bounds__(64) void hml_k_trellis_refit(const float2* __restri
                 sm_met[1] = old_nfb;
             }
             __syncthreads();
+            unsigned long long mb = HML_MAP_IDENTITY;
             if (mine) {
                 const uint32_t t = b + 1u;
                 float row[K];
 #pragma unroll
-                for (int s = 0; s < K; ++s) row[s] = sm_e[s * 65 + lane];
+                for (int s = 0; s < K; ++s) row[s] = sm_a[s * 65 + lane];
                 if (cx.self && t < B) {
 #pragma unroll
                     for (int s = 0; s < K; ++s) row[s] = row[s] * hml_expf(((float)nb - 1.0f) * p.logA[s]);   // (the first pass's table holds this very value)
                 }
-                const unsigned long long cm = hml_tre_cand<K>(row, cx.A, mdl, t, B, epoch, key);
-                hml_tre_store_cand<K>(cand, t, cm);
-                sm_m[lane] = cm;
+                mb = hml_tre_cand<K>(row, cx.A, mdl, t, B, epoch, key);
+                hml_tre_store_cand<K>(cand, t, mb);
             }
-            __syncthreads();
-            if (lane == 0)
-                for (uint32_t l = 0; l < CKR && bb + l < last; ++l) m = hml_map_compose<K>(m, sm_m[l]);
+            // the batch's maps composed in row order across the lanes (composition is associative: the same map as one lane's walk)
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                unsigned long long o = hml_shfl_down_u64(mb, d);
+                if (lane + d >= 64) o = HML_MAP_IDENTITY;
+                mb = hml_map_compose<K>(mb, o);
+            }
+            m = hml_map_compose<K>(m, mb);   // (lane 0's m is the chunk's map so far)
             const bool met = sm_met[0] != 0u;
             __syncthreads();
             if (met) {   // workgroup-uniform
                 // the rest of the chunk stands: its maps (in memory) complete the chunk map, its end vector and the fallbacks
                 // counted behind the checkpoint stay
-                for (uint32_t b2 = bb + CKR; b2 < last; b2 += 64u) {
-                    const uint32_t b = b2 + (uint32_t)lane;
-                    unsigned long long mp = (b < last) ? hml_tre_load_cand<K>(cand, (uint64_t)b + 1u) : HML_MAP_IDENTITY;
+                // (all of them requested before the first is composed - straight-line loads from clamped rows: one memory round trip
+                // for the rest of the chunk instead of one per 64 rows)
+                constexpr int NB = HML_TRE_MAX_L / 64;
+                unsigned long long rest[NB];
 #pragma unroll
-                    for (int d = 1; d < 64; d <<= 1) {
-                        unsigned long long o = hml_shfl_down_u64(mp, d);
-                        if (lane + d >= 64) o = HML_MAP_IDENTITY;
-                        mp = hml_map_compose<K>(mp, o);
+                for (int j = 0; j < NB; ++j) {
+                    const uint64_t b = (uint64_t)bb + CKR + (uint32_t)(j * 64 + lane);
+                    rest[j] = hml_tre_load_cand<K>(cand, (b < last ? b : (uint64_t)last - 1u) + 1u);
+                    if (!(b < last)) rest[j] = HML_MAP_IDENTITY;
+                }
+#pragma unroll
+                for (int j = 0; j < NB; ++j) {
+                    if ((uint64_t)bb + CKR + (uint32_t)(j * 64) < last) {   // workgroup-uniform
+                        unsigned long long mp = rest[j];
+#pragma unroll
+                        for (int d = 1; d < 64; d <<= 1) {
+                            unsigned long long o = hml_shfl_down_u64(mp, d);
+                            if (lane + d >= 64) o = HML_MAP_IDENTITY;
+                            mp = hml_map_compose<K>(mp, o);
+                        }
+                        m = hml_map_compose<K>(m, mp);   // (lane 0 holds the product of the 64 maps in row order)
                     }
-                    m = hml_map_compose<K>(m, mp);   // (lane 0 holds the product of the 64 maps in row order)
                 }
                 stopped = true;
                 break;
