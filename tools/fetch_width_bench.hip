@@ -29,6 +29,27 @@ __global__ __launch_bounds__(256) void k_read(const T* __restrict__ p, uint64_t 
     if (acc == 0x12345678u) sink[threadIdx.x] = acc;   // never true for the fill pattern; keeps the loads alive
 }
 
+// Stores of 2 bytes per lane over N bytes: FULL = a wavefront's store covers one whole 128-byte line; otherwise each half-wavefront writes a 64-byte run
+// into a line of its own and the other halves of those lines follow GAP iterations later (the states kernel of the weakly compressed sweep: 32 rows of a
+// chunk per batch, the neighbouring 32 rows one batch later).  Does the FETCH_SIZE counter see reads for such half-line stores?
+template <bool FULL, int GAP>
+__global__ __launch_bounds__(64) void k_write(uint16_t* __restrict__ p, uint64_t n_elems) {
+    const uint32_t lane = threadIdx.x;
+    const uint64_t lines = n_elems / 64u;                     // 128-byte lines
+    const uint64_t per = lines / gridDim.x;                   // lines per wavefront (contiguous range)
+    const uint64_t l0 = (uint64_t)blockIdx.x * per;
+    if (FULL) {
+        for (uint64_t l = 0; l < per; ++l) p[(l0 + l) * 64u + lane] = (uint16_t)(l + lane);
+    } else {
+        // pairs of lines (A, B): first the lower half of A (lanes 0-31) and of B (lanes 32-63), GAP pairs later their upper halves
+        const uint64_t pairs = per / 2u;
+        for (uint64_t i = 0; i < pairs + GAP; ++i) {
+            if (i < pairs) { const uint64_t line = l0 + 2u * i + (lane >> 5); p[line * 64u + (lane & 31u)] = (uint16_t)(i + lane); }
+            if (i >= (uint64_t)GAP) { const uint64_t j = i - GAP; const uint64_t line = l0 + 2u * j + (lane >> 5); p[line * 64u + 32u + (lane & 31u)] = (uint16_t)(j + lane); }
+        }
+    }
+}
+
 struct b16 { uint32_t x, y, z, w; };
 
 template <typename T>
@@ -58,6 +79,11 @@ int main() {
     run<uint32_t>("k_read<unsigned int>", d, bytes, sink);
     run<uint64_t>("k_read<unsigned long>", d, bytes, sink);
     run<b16>("k_read<b16>", d, bytes, sink);
+    for (int rep = 0; rep < 3; ++rep) {
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_write<true, 0>), dim3(8192), dim3(64), 0, 0, reinterpret_cast<uint16_t*>(d), bytes / 2);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_write<false, 1>), dim3(8192), dim3(64), 0, 0, reinterpret_cast<uint16_t*>(d), bytes / 2);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_write<false, 16>), dim3(8192), dim3(64), 0, 0, reinterpret_cast<uint16_t*>(d), bytes / 2);
+    }
     hipDeviceSynchronize();
     return 0;
 }
